@@ -1,0 +1,275 @@
+"""Oracle ops: torch-CPU restatement of the TF/Keras ops the reference invokes.
+
+TEST INFRASTRUCTURE (see oracle/__init__.py).  All tensors are channels-last
+like the reference: (N, H, W, C) / (N, D, H, W, C).  Kernels use the Keras
+layouts (kh, kw, cin, cout) / (kd, kh, kw, cin, cout) / Dense (in, out).
+[TF-2.1] marks semantics that live in tensorflow 2.1 (not vendored).
+"""
+import math
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+# ----------------------------------------------------------------------------
+# padding / conv   [TF-2.1] SAME padding rule R2
+# ----------------------------------------------------------------------------
+def same_pad(in_size, k, s):
+    """total = max((ceil(in/s)-1)*s + k - in, 0); lo = total//2; hi = total-lo."""
+    out = -(-in_size // s)
+    total = max((out - 1) * s + k - in_size, 0)
+    lo = total // 2
+    return lo, total - lo, out
+
+
+def _to_cf(x):   # channels-last -> channels-first
+    nd = x.dim() - 2
+    return x.permute(0, nd + 1, *range(1, nd + 1))
+
+
+def _to_cl(x):   # channels-first -> channels-last
+    nd = x.dim() - 2
+    return x.permute(0, *range(2, nd + 2), 1)
+
+
+def conv_same(x, w, b=None, stride=1):
+    """keras.layers.Conv2D/Conv3D(padding="same") -- cross-correlation, asymmetric
+    SAME padding (building_blocks.py:29,65,91; hologan_generator.py:50-56,101)."""
+    nd = x.dim() - 2
+    ks = w.shape[:nd]
+    spatial = x.shape[1:1 + nd]
+    pads = []
+    for i in reversed(range(nd)):            # F.pad wants last dim first
+        lo, hi, _ = same_pad(spatial[i], ks[i], stride)
+        pads += [lo, hi]
+    xc = F.pad(_to_cf(x), pads)
+    wc = w.permute(nd + 1, nd, *range(nd))   # (cout, cin, *k)
+    fn = F.conv2d if nd == 2 else F.conv3d
+    y = fn(xc, wc, b, stride=stride)
+    return _to_cl(y)
+
+
+def conv_valid_padded(x, w, b, stride, pad):
+    """ZeroPadding2D(pad) + Conv2D(padding="valid") (keras ResNet50 conv1)."""
+    xc = F.pad(_to_cf(x), [pad, pad, pad, pad])
+    wc = w.permute(3, 2, 0, 1)
+    return _to_cl(F.conv2d(xc, wc, b, stride=stride))
+
+
+def upsample2(x):
+    """keras UpSampling2D()/UpSampling3D(): size 2, nearest (R6)."""
+    nd = x.dim() - 2
+    for ax in range(1, 1 + nd):
+        x = x.repeat_interleave(2, dim=ax)
+    return x
+
+
+def leaky_relu(x, alpha):
+    """keras.layers.LeakyReLU() default alpha=0.3; tf.nn.leaky_relu default 0.2 (R1)."""
+    return torch.where(x > 0, x, x * alpha)
+
+
+def dense(x, w, b=None):
+    y = x @ w
+    return y if b is None else y + b
+
+
+def mlp_simple(x, weights, alpha, alpha_last=None):
+    """MLPSimple (building_blocks.py:152-173): (Dense -> nonlin) x (L-1), Dense."""
+    n_layers = len(weights) // 2
+    for i in range(n_layers):
+        x = dense(x, weights[2 * i], weights[2 * i + 1])
+        if i < n_layers - 1:
+            x = leaky_relu(x, alpha)
+        elif alpha_last is not None:
+            x = leaky_relu(x, alpha_last)
+    return x
+
+
+# ----------------------------------------------------------------------------
+# normalisation
+# ----------------------------------------------------------------------------
+def adain(x, z, mlp_weights, mlp_alpha=0.2):
+    """AdaIn (building_blocks.py:114-149): LayerNormalization over the spatial axes,
+    center=False, scale=False, eps 1e-3 [TF-2.1], biased variance, (x-mu)*rsqrt(var+eps);
+    then x*(s+1)+b with [s, b] = MLP(z) split as (N, 2, C)."""
+    nd = x.dim() - 2
+    axes = tuple(range(1, 1 + nd))
+    c = x.shape[-1]
+    sb = mlp_simple(z, mlp_weights, mlp_alpha)
+    sb = sb.reshape(-1, 2, *([1] * nd), c)
+    mu = x.mean(dim=axes, keepdim=True)
+    var = ((x - mu) ** 2).mean(dim=axes, keepdim=True)
+    xn = (x - mu) * torch.rsqrt(var + 1e-3)
+    return xn * (sb[:, 0] + 1) + sb[:, 1]
+
+
+def instance_norm(x, gamma, beta, eps=1e-3):
+    """InstanceNormalization(axis=-1) (instance_normalization.py:108-131): eps is
+    added to the *std*: (x-mean)/(std+eps)*gamma+beta, biased std."""
+    axes = tuple(range(1, x.dim() - 1))
+    mu = x.mean(dim=axes, keepdim=True)
+    std = torch.sqrt(((x - mu) ** 2).mean(dim=axes, keepdim=True)) + eps
+    return (x - mu) / std * gamma + beta
+
+
+def layer_style(x, eps=1e-6):
+    """get_layer_style (confignet_utils.py:147-159)."""
+    axes = tuple(range(1, x.dim() - 1))
+    mu = x.mean(dim=axes, keepdim=True)
+    std = torch.sqrt(((x - mu) ** 2).mean(dim=axes, keepdim=True) + eps)
+    return mu, std
+
+
+# ----------------------------------------------------------------------------
+# 3-D rotation
+# ----------------------------------------------------------------------------
+def euler_angles_to_matrix(angles):
+    """confignet_utils.py:122-145."""
+    a = angles.reshape(-1, 3)
+    s, c = torch.sin(a), torch.cos(a)
+    a11 = c[:, 2] * c[:, 1]
+    a12 = -s[:, 2]
+    a13 = c[:, 2] * s[:, 1]
+    a21 = s[:, 0] * s[:, 1] + c[:, 0] * c[:, 1] * s[:, 2]
+    a22 = c[:, 0] * c[:, 2]
+    a23 = c[:, 0] * s[:, 2] * s[:, 1] - c[:, 1] * s[:, 0]
+    a31 = c[:, 1] * s[:, 0] * s[:, 2] - c[:, 0] * s[:, 1]
+    a32 = c[:, 2] * s[:, 0]
+    a33 = c[:, 0] * c[:, 1] + s[:, 0] * s[:, 1] * s[:, 2]
+    return torch.stack([a11, a12, a13, a21, a22, a23, a31, a32, a33], dim=-1).reshape(-1, 3, 3)
+
+
+def transform_3d_grid(grid, transform):
+    """transform_3d_grid_tf (confignet_utils.py:63-120): rigid rotation about the grid
+    centre, clamp-to-edge, trilinear (x, then y, then z).  tf.floor has zero gradient;
+    tf.clip_by_value passes gradient strictly inside the interval (R12)."""
+    n, g = grid.shape[0], grid.shape[1]
+    assert grid.shape[1] == grid.shape[2] == grid.shape[3]
+    centre = (g - 1) / 2
+    ar = torch.arange(g, dtype=grid.dtype)
+    xs, ys, zs = torch.meshgrid(ar, ar, ar, indexing="ij")
+    coords = torch.stack([xs.reshape(-1), ys.reshape(-1), zs.reshape(-1)])      # (3, P)
+    tc = transform.to(grid.dtype) @ (coords - centre) + centre                  # (N, 3, P)
+    # clip_by_value: gradient 1 strictly inside, 0 outside/at the clamp
+    tc = torch.clamp(tc, 0, g - 1)
+    fl = torch.clamp(torch.floor(tc.detach()), 0, g - 1)
+    ce = torch.clamp(fl + 1, 0, g - 1)
+    fi, ci = fl.long(), ce.long()
+    bidx = torch.arange(n).reshape(n, 1).expand(n, g ** 3)
+
+    def gat(ix, iy, iz):
+        return grid[bidx, ix, iy, iz]                                            # (N, P, C)
+
+    x0, y0, z0 = fi[:, 0], fi[:, 1], fi[:, 2]
+    x1, y1, z1 = ci[:, 0], ci[:, 1], ci[:, 2]
+    c000, c100 = gat(x0, y0, z0), gat(x1, y0, z0)
+    c101, c001 = gat(x1, y0, z1), gat(x0, y0, z1)
+    c010, c110 = gat(x0, y1, z0), gat(x1, y1, z0)
+    c111, c011 = gat(x1, y1, z1), gat(x0, y1, z1)
+    d = (tc - fl).unsqueeze(-1)                                                  # (N, 3, P, 1)
+    dx, dy, dz = d[:, 0], d[:, 1], d[:, 2]
+    c00 = c000 * (1 - dx) + c100 * dx
+    c01 = c001 * (1 - dx) + c101 * dx
+    c10 = c010 * (1 - dx) + c110 * dx
+    c11 = c011 * (1 - dx) + c111 * dx
+    c0 = c00 * (1 - dy) + c10 * dy
+    c1 = c01 * (1 - dy) + c11 * dy
+    out = c0 * (1 - dz) + c1 * dz
+    return out.reshape(grid.shape)
+
+
+# ----------------------------------------------------------------------------
+# pooling / misc (keras.applications VGG / ResNet50)
+# ----------------------------------------------------------------------------
+def maxpool(x, k, s, pad=0):
+    """MaxPooling2D(k, strides=s) after an optional ZeroPadding2D(pad)."""
+    xc = _to_cf(x)
+    if pad:
+        xc = F.pad(xc, [pad, pad, pad, pad])     # zero padding, as ZeroPadding2D does
+    return _to_cl(F.max_pool2d(xc, k, s))
+
+
+def bn_inference(x, gamma, beta, mean, var, eps):
+    """BatchNormalization in inference mode (R9)."""
+    return (x - mean) * (gamma / torch.sqrt(var + eps)) + beta
+
+
+def caffe_preprocess(x_m11):
+    """(x+1)*127.5 -> keras preprocess_input mode "caffe" (R8): RGB->BGR flip of the
+    channel axis, subtract (103.939, 116.779, 123.68)  (perceptual_loss.py:52-61,
+    real_encoder.py:24-25)."""
+    x = (x_m11 + 1) * 127.5
+    x = x.flip(-1)
+    return x - torch.tensor([103.939, 116.779, 123.68], dtype=x.dtype)
+
+
+def vggface_preprocess(x_m11):
+    """perceptual_loss.py:53-56: subtract (93.5940, 104.7624, 129.1863), no flip."""
+    x = (x_m11 + 1) * 127.5
+    return x - torch.tensor([93.5940, 104.7624, 129.1863], dtype=x.dtype)
+
+
+# ----------------------------------------------------------------------------
+# losses (losses.py)
+# ----------------------------------------------------------------------------
+def gan_g_loss(scores):
+    """losses.py:7-8."""
+    return F.softplus(-scores).mean()
+
+
+def gan_d_loss(labels, scores):
+    """losses.py:10-11."""
+    return (labels * F.softplus(-scores) + (1.0 - labels) * F.softplus(scores)).mean()
+
+
+def eye_loss(gt, gen, masks):
+    """losses.py:13-18; masks uint8 (N,H,W)."""
+    m = masks.to(gt.dtype)
+    diff = (gt - gen) * m.unsqueeze(-1)
+    per = (diff ** 2).sum(dim=(1, 2, 3)) / (1 + m.sum(dim=(1, 2)))
+    return per.mean()
+
+
+def r1_penalty(out, x):
+    """gradient_regularization (losses.py:75-82): 10*0.5*mean_n sum (d sum(out)/dx)^2."""
+    (g,) = torch.autograd.grad(out.sum(), x, create_graph=True)
+    return 10 * 0.5 * (g ** 2).reshape(g.shape[0], -1).sum(dim=1).mean()
+
+
+# ----------------------------------------------------------------------------
+# optimizer [TF-2.1] Keras Adam (R10)
+# ----------------------------------------------------------------------------
+class KerasAdam:
+    """theta -= lr*sqrt(1-b2^t)/(1-b1^t) * m/(sqrt(v)+eps), eps=1e-7; ONE step counter
+    per optimizer object shared by every variable it updates."""
+
+    def __init__(self, lr=0.001, beta_1=0.9, beta_2=0.999, epsilon=1e-7, amsgrad=False):
+        assert not amsgrad
+        self.lr, self.b1, self.b2, self.eps = lr, beta_1, beta_2, epsilon
+        self.t = 0
+        self.state = {}
+
+    def apply_gradients(self, grads_and_vars):
+        self.t += 1
+        lr_t = self.lr * math.sqrt(1 - self.b2 ** self.t) / (1 - self.b1 ** self.t)
+        with torch.no_grad():
+            for g, p in grads_and_vars:
+                if g is None:
+                    continue
+                st = self.state.setdefault(id(p), [torch.zeros_like(p), torch.zeros_like(p)])
+                st[0].mul_(self.b1).add_(g, alpha=1 - self.b1)
+                st[1].mul_(self.b2).addcmul_(g, g, value=1 - self.b2)
+                p.sub_(lr_t * st[0] / (torch.sqrt(st[1]) + self.eps))
+
+
+def glorot_uniform(rng, shape):
+    """Keras default kernel initializer (R4): U(-l, l), l = sqrt(6/(fan_in+fan_out));
+    fan_in = prod(k)*cin, fan_out = prod(k)*cout."""
+    if len(shape) == 2:
+        fan_in, fan_out = shape
+    else:
+        rf = int(np.prod(shape[:-2]))
+        fan_in, fan_out = rf * shape[-2], rf * shape[-1]
+    lim = math.sqrt(6.0 / (fan_in + fan_out))
+    return rng.uniform(-lim, lim, size=shape).astype(np.float32)

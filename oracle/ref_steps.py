@@ -1,0 +1,128 @@
+"""Oracle training steps: restatement of the reference's step functions on explicit
+batches (the numpy batch sampling is done by the caller so the HIP path and the oracle
+see identical inputs).  TEST INFRASTRUCTURE (oracle/__init__.py).
+
+Weights are dicts name -> list of torch tensors (requires_grad=True leaves), names as in
+ConfigNetFirstStage.get_weights() minus the "_weights" suffix.
+"""
+import torch
+
+from . import ref_ops as O
+from . import ref_nets as R
+
+
+def discriminator_loss(d_w, real_imgs, fake_imgs):
+    """compute_discriminator_loss (losses.py:20-47)."""
+    real_imgs = real_imgs.detach().requires_grad_(True)
+    out_real = R.discriminator_forward(d_w, real_imgs)
+    out_fake = R.discriminator_forward(d_w, fake_imgs.detach())
+    losses = {}
+    ones = torch.ones(real_imgs.shape[0], 1, dtype=real_imgs.dtype)
+    zeros = torch.zeros(fake_imgs.shape[0], 1, dtype=real_imgs.dtype)
+    for i, o in enumerate(out_real.values()):
+        losses["GAN_loss_real_%d" % i] = O.gan_d_loss(ones, o)
+    for i, o in enumerate(out_fake.values()):
+        losses["GAN_loss_fake_%d" % i] = O.gan_d_loss(zeros, o)
+    for i, o in enumerate(out_real.values()):
+        losses["gp_loss_%d" % i] = O.r1_penalty(o, real_imgs)
+    losses["loss_sum"] = sum(losses.values())
+    return losses
+
+
+def latent_discriminator_loss(ld_w, real_latents, fake_latents):
+    """compute_latent_discriminator_loss (losses.py:49-73); MLP with LeakyReLU(0.3)."""
+    real_latents = real_latents.detach().requires_grad_(True)
+    out_real = O.mlp_simple(real_latents, ld_w, 0.3)
+    out_fake = O.mlp_simple(fake_latents.detach(), ld_w, 0.3)
+    n = real_latents.shape[0]
+    losses = {
+        "GAN_loss_real": O.gan_d_loss(torch.ones(n, 1, dtype=out_real.dtype), out_real),
+        "GAN_loss_fake": O.gan_d_loss(torch.zeros(n, 1, dtype=out_real.dtype), out_fake),
+        "gp_loss": O.r1_penalty(out_real, real_latents),
+    }
+    losses["loss_sum"] = sum(losses.values())
+    return losses
+
+
+def grads_of(loss, weight_list):
+    gs = torch.autograd.grad(loss, weight_list, allow_unused=True)
+    return [torch.zeros_like(w) if g is None else g for g, w in zip(gs, weight_list)]
+
+
+def first_stage_generator_loss(W, cfg, facemodel_params, synth_rot, gt_imgs, eye_masks,
+                               real_latents, real_rot, vgg_w):
+    """ConfigNetFirstStage.generator_training_step (confignet_first_stage.py:506-560),
+    the part inside the tape.  gt_imgs already scaled to [-1, 1]."""
+    res = cfg["output_shape"][0]
+    losses = {}
+    synth_latents = R.synthetic_encoder_forward(W["synthetic_encoder"], facemodel_params)
+    g_synth = R.generator_forward(W["generator"], synth_latents, synth_rot, res)
+    g_real = R.generator_forward(W["generator"], real_latents, real_rot, res)
+    losses["image_loss"] = cfg["image_loss_weight"] * R.perceptual_loss(vgg_w, gt_imgs, g_synth)
+    losses["eye_loss"] = cfg["eye_loss_weight"] * O.eye_loss(gt_imgs, g_synth, eye_masks)
+    for i, o in enumerate(R.discriminator_forward(W["synth_discriminator"], g_synth).values()):
+        losses["GAN_loss_synth_%d" % i] = O.gan_g_loss(o)
+    for i, o in enumerate(R.discriminator_forward(W["discriminator"], g_real).values()):
+        losses["GAN_loss_real_%d" % i] = O.gan_g_loss(o)
+    ld_out = O.mlp_simple(synth_latents, W["latent_discriminator"], 0.3)
+    losses["latent_GAN_loss"] = cfg["domain_adverserial_loss_weight"] * O.gan_g_loss(ld_out)
+    lat = torch.cat([synth_latents, real_latents], dim=0)
+    imgs = torch.cat([g_synth, g_real], dim=0)
+    rots = torch.cat([synth_rot, real_rot], dim=0)
+    labels = torch.cat([lat, cfg["latent_regressor_rot_weight"] * rots], dim=-1)
+    pred = R.latent_regressor_forward(W["latent_regressor"], imgs)
+    # tf.losses.mean_squared_error + reduce_mean == global mean (R7)
+    losses["latent_regression_loss"] = cfg["latent_regression_weight"] * ((labels - pred) ** 2).mean()
+    losses["loss_sum"] = sum(losses.values())
+    return losses, {"g_synth": g_synth, "g_real": g_real, "synth_latents": synth_latents}
+
+
+def normalized_latent_regression_loss(lr_w, cfg, gen_imgs, labels):
+    """ConfigNet.compute_normalized_latent_regression_loss (confignet_second_stage.py:93-107)."""
+    out = R.latent_regressor_forward(lr_w, gen_imgs)
+    den = torch.sqrt(labels.var(dim=0, unbiased=False, keepdim=True) + 1e-3)
+    den = torch.cat([den[:, :-3], torch.ones(1, 3, dtype=den.dtype)], dim=1)
+    out = out.mean(dim=0) + (out - out.mean(dim=0)) / den
+    labels = labels.mean(dim=0) + (labels - labels.mean(dim=0)) / den
+    return ((labels - out) ** 2).mean() * cfg["latent_regression_weight"]
+
+
+def second_stage_generator_loss(W, cfg, facemodel_params, synth_rot, synth_imgs, eye_masks,
+                                real_imgs, vgg_w):
+    """ConfigNet.generator_training_step (confignet_second_stage.py:149-218), inside the tape."""
+    res = cfg["output_shape"][0]
+    n_synth, n_real = synth_imgs.shape[0], real_imgs.shape[0]
+    losses = {}
+    synth_latents = R.synthetic_encoder_forward(W["synthetic_encoder"], facemodel_params)
+    g_synth = R.generator_forward(W["generator"], synth_latents, synth_rot, res)
+    real_latents, real_rot = R.real_encoder_forward(W["real_encoder"], real_imgs, cfg["rotation_ranges"])
+    g_real = R.generator_forward(W["generator"], real_latents, real_rot, res)
+    losses["image_loss_synth"] = cfg["image_loss_weight"] * R.perceptual_loss(vgg_w, synth_imgs, g_synth)
+    losses["image_loss_real"] = cfg["image_loss_weight"] * R.perceptual_loss(vgg_w, real_imgs, g_real)
+    losses["eye_loss"] = cfg["eye_loss_weight"] * O.eye_loss(synth_imgs, g_synth, eye_masks)
+    for i, o in enumerate(R.discriminator_forward(W["synth_discriminator"], g_synth).values()):
+        losses["GAN_loss_synth_%d" % i] = O.gan_g_loss(o)
+    for i, o in enumerate(R.discriminator_forward(W["discriminator"], g_real).values()):
+        losses["GAN_loss_real_%d" % i] = O.gan_g_loss(o)
+    ld_synth = O.mlp_simple(synth_latents, W["latent_discriminator"], 0.3)
+    ld_real = O.mlp_simple(real_latents, W["latent_discriminator"], 0.3)
+    ld_out = torch.cat([ld_real, ld_synth], dim=0)
+    dt = ld_out.dtype
+    dom_labels = torch.cat([torch.zeros(n_real, 1, dtype=dt), torch.ones(n_synth, 1, dtype=dt)], dim=0)
+    losses["latent_GAN_loss"] = cfg["domain_adverserial_loss_weight"] * O.gan_d_loss(dom_labels, ld_out)
+    if cfg["latent_regression_weight"] > 0.0:
+        lat = torch.cat([synth_latents, real_latents], dim=0)
+        imgs = torch.cat([g_synth, g_real], dim=0)
+        rots = torch.cat([synth_rot, real_rot], dim=0)
+        labels = torch.cat([lat, cfg["latent_regressor_rot_weight"] * rots], dim=-1)
+        losses["latent_regression_loss"] = normalized_latent_regression_loss(
+            W["latent_regressor"], cfg, imgs, labels)
+    losses["loss_sum"] = sum(losses.values())
+    return losses, {"g_synth": g_synth, "g_real": g_real}
+
+
+def ema_update(smoothed, training, alpha=0.999):
+    """update_smoothed_weights (confignet_first_stage.py:393-400)."""
+    with torch.no_grad():
+        for s, t in zip(smoothed, training):
+            s.mul_(alpha).add_(t, alpha=1 - alpha)

@@ -1,0 +1,166 @@
+"""Pins for the oracle: (1) torch restatement vs independent NumPy-loop restatement,
+(2) analytic known-answer tests that need no TensorFlow."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import np_ops as NP
+from oracle import ref_nets as R
+from oracle import ref_ops as O
+
+torch.manual_seed(0)
+
+
+def t(a, dt=torch.float64):
+    return torch.tensor(np.asarray(a), dtype=dt)
+
+
+@pytest.mark.parametrize("shape,k,s", [((2, 7, 6, 3), (4, 4), 1), ((2, 8, 8, 5), (3, 3), 2), ((1, 9, 7, 2), (3, 3), 2),
+                                       ((2, 5, 4, 6, 3), (3, 3, 3), 1), ((1, 6, 6, 4), (1, 1), 1), ((1, 11, 11, 3), (7, 7), 2)])
+def test_conv_same_double_implementation(shape, k, s):
+    rng = np.random.default_rng(1)
+    x = rng.normal(size=shape)
+    w = rng.normal(size=(*k, shape[-1], 5))
+    b = rng.normal(size=5)
+    y_t = O.conv_same(t(x), t(w), t(b), stride=s).numpy()
+    y_n = NP.conv_same(x, w, b, stride=s)
+    assert y_t.shape == y_n.shape
+    np.testing.assert_allclose(y_t, y_n, atol=1e-10)
+    # SAME output size = ceil(in/stride)
+    assert y_t.shape[1:-1] == tuple(math.ceil(d / s) for d in shape[1:-1])
+
+
+def test_same_pad_rules():
+    assert O.same_pad(16, 4, 1)[:2] == (1, 2)      # k4 s1 -> (1,2)
+    assert O.same_pad(256, 3, 2)[:2] == (0, 1)     # k3 s2 even input -> (0,1)
+    assert O.same_pad(32, 3, 1)[:2] == (1, 1)
+
+
+def test_norms_double_implementation():
+    rng = np.random.default_rng(2)
+    x = rng.normal(size=(2, 5, 6, 4)) * 3 + 1
+    g, b = rng.normal(size=4), rng.normal(size=4)
+    np.testing.assert_allclose(O.instance_norm(t(x), t(g), t(b)).numpy(), NP.instance_norm(x, g, b), atol=1e-12)
+    mu, sd = O.layer_style(t(x))
+    mu_n, sd_n = NP.layer_style(x)
+    np.testing.assert_allclose(mu.numpy(), mu_n, atol=1e-12)
+    np.testing.assert_allclose(sd.numpy(), sd_n, atol=1e-12)
+
+
+def test_adain_statistics():
+    """AdaIN output has per-(n,c) mean b and variance (s+1)^2 * var/(var+1e-3)."""
+    rng = np.random.default_rng(3)
+    x = t(rng.normal(size=(2, 4, 4, 4, 6)) * 2 + 0.5)
+    z = t(rng.normal(size=(2, 7)))
+    mlp = [t(rng.normal(size=s)) for s in [(7, 5), (5,), (5, 12), (12,)]]
+    y = O.adain(x, z, mlp)
+    sb = O.mlp_simple(z, mlp, 0.2).reshape(2, 2, 6)
+    var = x.var(dim=(1, 2, 3), unbiased=False)
+    np.testing.assert_allclose(y.mean(dim=(1, 2, 3)).numpy(), sb[:, 1].numpy(), atol=1e-10)
+    np.testing.assert_allclose(y.var(dim=(1, 2, 3), unbiased=False).numpy(),
+                               ((sb[:, 0] + 1) ** 2 * var / (var + 1e-3)).numpy(), atol=1e-10)
+    # vs NumPy layer norm
+    yn = NP.layer_norm_spatial(x.numpy()) * (sb[:, 0].numpy()[:, None, None, None] + 1) + sb[:, 1].numpy()[:, None, None, None]
+    np.testing.assert_allclose(y.numpy(), yn, atol=1e-10)
+
+
+def test_euler_and_rotation_kat():
+    assert np.allclose(O.euler_angles_to_matrix(torch.zeros(2, 3, dtype=torch.float64)).numpy(), np.eye(3))
+    a = t(np.random.default_rng(4).uniform(-0.5, 0.5, size=(3, 3)))
+    Rm = O.euler_angles_to_matrix(a)
+    np.testing.assert_allclose((Rm @ Rm.transpose(1, 2)).numpy(), np.tile(np.eye(3), (3, 1, 1)), atol=1e-12)
+    np.testing.assert_allclose(Rm.numpy(), NP.euler_angles_to_matrix(a.numpy()), atol=1e-12)
+    # identity rotation => exact identity resample
+    g = t(np.random.default_rng(5).normal(size=(2, 6, 6, 6, 3)))
+    np.testing.assert_array_equal(O.transform_3d_grid(g, torch.eye(3, dtype=torch.float64).expand(2, 3, 3)).numpy(), g.numpy())
+    # general rotation vs per-voxel loop
+    out = O.transform_3d_grid(g, Rm[:2])
+    np.testing.assert_allclose(out.numpy(), NP.transform_3d_grid(g.numpy(), Rm[:2].numpy()), atol=1e-12)
+
+
+def test_rotation_90deg_is_permutation_with_clamp():
+    """90 degrees about axis 0 maps voxel (i,j,k) <- source (i, c+(k-c)... ) exactly: a one-hot
+    voxel moves to the permuted index (interior => no clamping involved)."""
+    g = np.zeros((1, 4, 4, 4, 1))
+    g[0, 1, 2, 0, 0] = 1.0
+    Rm = NP.euler_angles_to_matrix([[math.pi / 2, 0, 0]])
+    out = O.transform_3d_grid(t(g), t(Rm)).numpy()
+    ref = NP.transform_3d_grid(g, Rm)
+    np.testing.assert_allclose(out, ref, atol=1e-12)
+    assert abs(out.sum() - 1.0) < 1e-9 and (out > 0.5).sum() == 1
+
+
+def test_gan_losses_and_r1_kat():
+    z = torch.zeros(5, 1, dtype=torch.float64)
+    assert abs(O.gan_g_loss(z).item() - math.log(2)) < 1e-12
+    assert abs(O.gan_d_loss(torch.ones_like(z), z).item() - math.log(2)) < 1e-12
+    # R1 of a linear discriminator out = x.w  is 5*||w||^2
+    w = t(np.random.default_rng(6).normal(size=(12,)))
+    x = t(np.random.default_rng(7).normal(size=(4, 12))).requires_grad_(True)
+    out = (x @ w).reshape(4, 1)
+    assert abs(O.r1_penalty(out, x).item() - 5 * (w ** 2).sum().item()) < 1e-10
+
+
+def test_keras_adam_first_step_and_shared_counter():
+    """First Keras-Adam step = lr*sign(g) when |g| >> eps (confirmed by the reference's finetune
+    fixture: rotation deltas of +-1.000e-4 at lr 1e-4); the step counter is per optimizer."""
+    p1 = torch.tensor([1.0, -2.0, 3.0], dtype=torch.float64)
+    p2 = torch.tensor([0.5], dtype=torch.float64)
+    opt = O.KerasAdam(lr=4e-4, beta_1=0.0, beta_2=0.9)
+    g1 = torch.tensor([0.3, -7.0, 1e-2], dtype=torch.float64)
+    before = p1.clone()
+    opt.apply_gradients([(g1, p1)])
+    np.testing.assert_allclose((before - p1).numpy(), 4e-4 * np.sign(g1.numpy()), rtol=1e-4)
+    # second apply on ANOTHER variable uses t=2: lr_t = lr*sqrt(1-0.9^2), v=(1-b2) g^2 -> step = lr_t/sqrt(0.1)
+    g2 = torch.tensor([2.0], dtype=torch.float64)
+    b2 = p2.clone()
+    opt.apply_gradients([(g2, p2)])
+    expect = 4e-4 * math.sqrt(1 - 0.9 ** 2) * 2.0 / (math.sqrt(0.1 * 4.0) + 1e-7)
+    assert abs((b2 - p2).item() - expect) < 1e-12
+
+
+def _rand_weights(shapes, seed, dt=torch.float64):
+    rng = np.random.default_rng(seed)
+    return [torch.tensor(O.glorot_uniform(rng, s) if len(s) > 1 else rng.normal(size=s) * 0.1, dtype=dt) for s in shapes]
+
+
+def test_learned_input_is_ones_and_kernel_grad_zero():
+    shapes = R.generator_weight_shapes(9, 128, n_mlp_units=8)
+    w = _rand_weights(shapes, 8)
+    w[0] = torch.zeros(1, 32768, dtype=torch.float64, requires_grad=True)
+    w[1] = torch.ones(32768, dtype=torch.float64, requires_grad=True)
+    z = t(np.random.default_rng(9).normal(size=(1, 9)))
+    img = R.generator_forward(w, z, torch.zeros(1, 3, dtype=torch.float64), 128)
+    assert img.shape == (1, 128, 128, 3) and img.abs().max() <= 1.0
+    gk, gb = torch.autograd.grad(img.sum(), [w[0], w[1]])
+    assert gk.abs().max().item() == 0.0 and gb.abs().max().item() > 0
+
+
+def test_discriminator_dict_order_and_shapes():
+    w = _rand_weights(R.discriminator_weight_shapes(64), 10)
+    out = R.discriminator_forward(w, t(np.random.default_rng(11).normal(size=(2, 64, 64, 3))))
+    assert list(out.keys()) == ["discr_style_%d" % i for i in range(5)] + ["discr_final"]
+    assert all(v.shape == (2, 1) for v in out.values())
+    lr = R.latent_regressor_forward(_rand_weights(R.latent_regressor_weight_shapes(9, 64), 12),
+                                    t(np.random.default_rng(13).normal(size=(2, 64, 64, 3))))
+    assert lr.shape == (2, 12)
+
+
+def test_reference_golden_weight_free_facts():
+    """What the reference's own goldens tell us without weights: the
+    fine-tune fixture moves exactly the blendshape slice 7..36 of the 144-d latent."""
+    import os
+    p = "/root/reference/tests/test_assets"
+    if not os.path.isdir(p):
+        pytest.skip("reference assets not present (GPU box)")
+    base = np.load(os.path.join(p, "confignet_basic_ref_256.npz"))
+    ft = np.load(os.path.join(p, "confignet_finetune_ref_256.npz"))
+    keys_b, keys_f = list(base.keys()), list(ft.keys())
+    emb_b = base["embedding"]
+    emb_f = ft[[k for k in keys_f if "embedding" in k][0]]
+    assert emb_b.shape == (1, 144)
+    moved = np.nonzero(emb_b[0] != emb_f[0])[0]
+    assert moved.min() == 7 and moved.max() == 36 and len(moved) == 30
+    np.testing.assert_allclose(np.abs(emb_b[0, moved] - emb_f[0, moved]), 1e-4, rtol=2e-2)
