@@ -161,6 +161,7 @@ def test_reference_golden_weight_free_facts():
     emb_b = base["embedding"]
     emb_f = ft[[k for k in keys_f if "embedding" in k][0]]
     assert emb_b.shape == (1, 144)
-    moved = np.nonzero(emb_b[0] != emb_f[0])[0]
+    # the other 114 entries agree to float noise (~1e-7: two separate encoder runs)
+    moved = np.nonzero(np.abs(emb_b[0] - emb_f[0]) > 1e-5)[0]
     assert moved.min() == 7 and moved.max() == 36 and len(moved) == 30
     np.testing.assert_allclose(np.abs(emb_b[0, moved] - emb_f[0, moved]), 1e-4, rtol=2e-2)
