@@ -1,0 +1,81 @@
+"""ctypes binding of libconfignet_hip.so (the C ABI declared in include/confignet_hip.h).
+
+The product path has no CPU fallback: importing this module without the built library, or
+calling an op without a GPU, raises."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libconfignet_hip.so")
+
+
+class CnConvGeom(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int) for n in (
+        "nd", "n", "in_d", "in_h", "in_w", "cin", "out_d", "out_h", "out_w", "cout",
+        "k_d", "k_h", "k_w", "s_d", "s_h", "s_w", "dl_d", "dl_h", "dl_w", "p_d", "p_h", "p_w", "up")]
+
+
+class ConfigNetHipError(RuntimeError):
+    pass
+
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        "confignet_amd: %s is missing -- build it with `python -m confignet_amd.build` "
+        "(or __graft_entry__.build()).  There is no CPU/PyTorch fallback." % LIB_PATH)
+
+lib = ctypes.CDLL(LIB_PATH)
+
+_p = ctypes.c_void_p
+_i = ctypes.c_int
+_f = ctypes.c_float
+_z = ctypes.c_size_t
+_G = ctypes.POINTER(CnConvGeom)
+
+# name -> argtypes (restype is int for all but cn_last_error_string); mirrors include/confignet_hip.h
+SIGNATURES = {
+    "cn_version": [],
+    "cn_conv_fwd": [_G, _p, _p, _p, _p, _i, _f, _p],
+    "cn_conv_weight_tflip": [_p, _p, _i, _i, _i, _p],
+    "cn_conv_dgrad": [_G, _p, _p, _p, _p],
+    "cn_conv_wgrad": [_G, _p, _p, _p, _p],
+    "cn_sumpool2": [_p, _p, _i, _i, _i, _i, _i, _i, _p],
+    "cn_gemm": [_i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _p, _i, _f, _p],
+    "cn_nc_reduce": [_p, _p, _p, _p, _i, _i, _i, _i, _f, _p],
+    "cn_nc_lin2": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p],
+    "cn_act_fwd": [_p, _p, _z, _i, _f, _p],
+    "cn_act_bwd": [_p, _p, _p, _z, _i, _f, _p],
+    "cn_axpby": [_p, _p, _p, _z, _f, _f, _p],
+    "cn_mul": [_p, _p, _p, _z, _p],
+    "cn_sqdiff_sum": [_p, _p, _p, _z, _f, _p],
+    "cn_row_sumsq": [_p, _p, _i, _z, _p],
+    "cn_row_scale": [_p, _p, _p, _i, _z, _f, _p],
+    "cn_masked_diff": [_p, _p, _p, _p, _z, _i, _p],
+    "cn_maxpool_fwd": [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
+    "cn_maxpool_bwd": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
+    "cn_chan_affine3_fwd": [_p, _p, _z, ctypes.POINTER(_i), _f, ctypes.POINTER(_f), _p],
+    "cn_chan_affine3_bwd": [_p, _p, _z, ctypes.POINTER(_i), _f, _p],
+    "cn_gan_loss_fwd": [_p, _p, _i, _f, _p],
+    "cn_gan_loss_bwd": [_p, _p, _p, _i, _f, _p],
+    "cn_rotate3d_fwd": [_p, _p, _p, _i, _i, _i, _p],
+    "cn_rotate3d_bwd": [_p, _p, _p, _p, _p, _i, _i, _i, _p],
+    "cn_adam_step": [_p, _p, _p, _p, _p, _z, _f, _f, _f, _f, _f, _p],
+    "cn_ema_step": [_p, _p, _z, _f, _p],
+    "cn_gather_images_u8": [_p, _p, _p, _p, _i, _i, _i, _i, _p],
+    "cn_to_uint8": [_p, _p, _z, _p],
+    "cn_prof_enable": [_i],
+    "cn_prof_reset": [],
+    "cn_prof_collect": [ctypes.POINTER(_i), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)],
+}
+
+for _name, _args in SIGNATURES.items():
+    _fn = getattr(lib, _name)          # AttributeError here == header/library mismatch
+    _fn.argtypes = _args
+    _fn.restype = ctypes.c_int
+lib.cn_last_error_string.argtypes = []
+lib.cn_last_error_string.restype = ctypes.c_char_p
+
+
+def check(code, what):
+    if code != 0:
+        raise ConfigNetHipError("%s failed (%d): %s" % (what, code, lib.cn_last_error_string().decode()))

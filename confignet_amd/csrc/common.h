@@ -1,0 +1,49 @@
+// common.h -- shared helpers of libconfignet_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/confignet_hip.h"
+
+void cn_set_error(const char* fmt, ...);
+
+#define CN_CHECK_ARG(cond, ...)            \
+    do {                                   \
+        if (!(cond)) {                     \
+            cn_set_error(__VA_ARGS__);     \
+            return CN_EINVAL;              \
+        }                                  \
+    } while (0)
+
+#define CN_HIP(expr)                                                              \
+    do {                                                                          \
+        hipError_t e__ = (expr);                                                  \
+        if (e__ != hipSuccess) {                                                  \
+            cn_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+            return CN_EHIP;                                                       \
+        }                                                                         \
+    } while (0)
+
+#define CN_LAUNCH_CHECK()                                                         \
+    do {                                                                          \
+        hipError_t e__ = hipGetLastError();                                       \
+        if (e__ != hipSuccess) {                                                  \
+            cn_set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(e__), __FILE__, __LINE__); \
+            return CN_EHIP;                                                       \
+        }                                                                         \
+    } while (0)
+
+// profiling hooks (prof.hip): bracket one launch of the dominant kernel class
+void cn_prof_begin(hipStream_t s, double flops);
+void cn_prof_end(hipStream_t s);
+
+__device__ __forceinline__ float cn_apply_act(float v, int act, float slope) {
+    switch (act) {
+        case CN_ACT_LRELU: return v > 0.f ? v : v * slope;
+        case CN_ACT_RELU: return v > 0.f ? v : 0.f;
+        case CN_ACT_TANH: return tanhf(v);
+        default: return v;
+    }
+}
+
+static inline int cn_cdiv(long a, long b) { return (int)((a + b - 1) / b); }

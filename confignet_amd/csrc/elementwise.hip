@@ -1,0 +1,488 @@
+// elementwise.hip -- HBM-bound kernels of the path: per-(sample,channel) statistics and affine
+// maps (LayerNorm/AdaIN, instance norm, style statistics, BN inference, bias gradients, global
+// average pool), activations, pooling, loss reductions, image pre/post-processing, Adam+EMA.
+// All are single-pass, float4-vectorised over the channel (fastest) axis where C % 4 == 0.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float lrelu(float v, float s) { return v > 0.f ? v : v * s; }
+__device__ __forceinline__ float4 lrelu4(float4 v, float s) {
+    return make_float4(lrelu(v.x, s), lrelu(v.y, s), lrelu(v.z, s), lrelu(v.w, s));
+}
+
+// ---- nc_reduce: (N,S,C) -> (N,C) sums.  grid (cblk, sblk, n); block (TX c-groups, TY rows) ----
+template <int V>   // V = 4: float4 channel groups, V = 1: scalar channels
+__global__ __launch_bounds__(256) void nc_reduce_kernel(const float* __restrict__ x1, const float* __restrict__ x2,
+                                                        float* __restrict__ s1, float* __restrict__ s2, int S, int C,
+                                                        int rows_per_block, int flags, float slope) {
+    const int CG = C / V;                          // channel groups
+    const int tx = threadIdx.x, ty = threadIdx.y, TX = blockDim.x, TY = blockDim.y;
+    const int cg = blockIdx.x * TX + tx;
+    const int n = blockIdx.z;
+    const int sbeg = blockIdx.y * rows_per_block, send = min(S, sbeg + rows_per_block);
+    float a1[V], a2[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) a1[e] = a2[e] = 0.f;
+    if (cg < CG) {
+        const long base = (long)n * S * C + (long)cg * V;
+        for (int s = sbeg + ty; s < send; s += TY) {
+            float a[V], b[V];
+            if (V == 4) {
+                float4 va = *reinterpret_cast<const float4*>(x1 + base + (long)s * C);
+                if (flags & 1) va = lrelu4(va, slope);
+                a[0] = va.x; a[1 % V] = va.y; a[2 % V] = va.z; a[3 % V] = va.w;
+                if (x2) {
+                    float4 vb = *reinterpret_cast<const float4*>(x2 + base + (long)s * C);
+                    if (flags & 2) vb = lrelu4(vb, slope);
+                    b[0] = vb.x; b[1 % V] = vb.y; b[2 % V] = vb.z; b[3 % V] = vb.w;
+                }
+            } else {
+                a[0] = x1[base + (long)s * C];
+                if (flags & 1) a[0] = lrelu(a[0], slope);
+                if (x2) {
+                    b[0] = x2[base + (long)s * C];
+                    if (flags & 2) b[0] = lrelu(b[0], slope);
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                a1[e] += a[e];
+                a2[e] += a[e] * (x2 ? b[e] : a[e]);
+            }
+        }
+    }
+    __shared__ float red[2][256 * V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+        red[0][(ty * TX + tx) * V + e] = a1[e];
+        red[1][(ty * TX + tx) * V + e] = a2[e];
+    }
+    __syncthreads();
+    if (ty == 0 && cg < CG) {
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            float t1 = 0.f, t2 = 0.f;
+            for (int y = 0; y < TY; ++y) {
+                t1 += red[0][(y * TX + tx) * V + e];
+                t2 += red[1][(y * TX + tx) * V + e];
+            }
+            const long o = (long)n * C + (long)cg * V + e;
+            if (s1) unsafeAtomicAdd(&s1[o], t1);
+            if (s2) unsafeAtomicAdd(&s2[o], t2);
+        }
+    }
+}
+
+// ---- nc_lin2: y = A1*f1(x1) + A2*f2(x2) + B ----
+template <int V>
+__global__ __launch_bounds__(256) void nc_lin2_kernel(const float* __restrict__ x1, const float* __restrict__ a1,
+                                                      const float* __restrict__ x2, const float* __restrict__ a2,
+                                                      const float* __restrict__ bb, float* __restrict__ y, long total_g,
+                                                      int S, int C, int cstride, int flags, float slope) {
+    const int CG = C / V;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total_g; i += (long)gridDim.x * blockDim.x) {
+        const int cg = (int)(i % CG);
+        const long row = i / CG;
+        const int n = (int)(row / S);
+        const long ci = (long)n * cstride + (long)cg * V;
+        float r[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) r[e] = bb ? bb[ci + e] : 0.f;
+        float raw2[V];
+        if (x1) {
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                float v = x1[i * V + e];
+                if (flags & 1) v = lrelu(v, slope);
+                r[e] += (a1 ? a1[ci + e] : 1.f) * v;
+            }
+        }
+        if (x2) {
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                raw2[e] = x2[i * V + e];
+                float v = raw2[e];
+                if (flags & 2) v = lrelu(v, slope);
+                if (a2) r[e] += a2[ci + e] * v;
+            }
+            if (flags & 4) {
+#pragma unroll
+                for (int e = 0; e < V; ++e) r[e] *= raw2[e] > 0.f ? 1.f : slope;
+            }
+        }
+        if (flags & 8) {
+#pragma unroll
+            for (int e = 0; e < V; ++e) r[e] = fmaxf(r[e], 0.f);
+        }
+        if (V == 4) *reinterpret_cast<float4*>(y + i * 4) = make_float4(r[0], r[1 % V], r[2 % V], r[3 % V]);
+        else y[i] = r[0];
+    }
+}
+
+__global__ void act_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n, int act, float slope) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        y[i] = cn_apply_act(x[i], act, slope);
+}
+
+__global__ void act_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ y, float* __restrict__ gx,
+                               size_t n, int act, float slope) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float o = y[i], g = gy[i];
+        float d = 1.f;
+        if (act == CN_ACT_LRELU) d = o > 0.f ? 1.f : slope;
+        else if (act == CN_ACT_RELU) d = o > 0.f ? 1.f : 0.f;
+        else if (act == CN_ACT_TANH) d = 1.f - o * o;
+        gx[i] = g * d;
+    }
+}
+
+__global__ void axpby_kernel(const float* __restrict__ x, const float* __restrict__ y, float* __restrict__ o, size_t n,
+                             float a, float b) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        o[i] = a * x[i] + (y ? b * y[i] : 0.f);
+}
+
+__global__ void mul_kernel(const float* __restrict__ x, const float* __restrict__ y, float* __restrict__ o, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        o[i] = x[i] * y[i];
+}
+
+__device__ __forceinline__ float block_sum(float v) {
+    __shared__ float sh[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sh[w] = v;
+    __syncthreads();
+    return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+__global__ __launch_bounds__(256) void sqdiff_sum_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                         float* __restrict__ out, size_t n, float scale) {
+    float acc = 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float d = a[i] - b[i];
+        acc += d * d;
+    }
+    const float t = block_sum(acc);
+    if (threadIdx.x == 0) unsafeAtomicAdd(out, t * scale);
+}
+
+// grid (blocks_per_row, n)
+__global__ __launch_bounds__(256) void row_sumsq_kernel(const float* __restrict__ x, float* __restrict__ out, size_t row) {
+    const float* p = x + (size_t)blockIdx.y * row;
+    float acc = 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < row; i += (size_t)gridDim.x * blockDim.x)
+        acc += p[i] * p[i];
+    const float t = block_sum(acc);
+    if (threadIdx.x == 0) unsafeAtomicAdd(&out[blockIdx.y], t);
+}
+
+__global__ void row_scale_kernel(const float* __restrict__ x, const float* __restrict__ s, float* __restrict__ o,
+                                 size_t row, float k) {
+    const float f = s[blockIdx.y] * k;
+    const size_t base = (size_t)blockIdx.y * row;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < row; i += (size_t)gridDim.x * blockDim.x)
+        o[base + i] = x[base + i] * f;
+}
+
+__global__ void masked_diff_kernel(const float* __restrict__ a, const float* __restrict__ b, const uint8_t* __restrict__ m,
+                                   float* __restrict__ o, size_t pixels, int c) {
+    for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < pixels; p += (size_t)gridDim.x * blockDim.x) {
+        const float mk = (float)m[p];
+        for (int e = 0; e < c; ++e) o[p * c + e] = (a[p * c + e] - (b ? b[p * c + e] : 0.f)) * mk;
+    }
+}
+
+__global__ void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int n, int h, int w, int c,
+                                   int oh, int ow, int k, int s, int pad) {
+    const long total = (long)n * oh * ow * c;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % c);
+        long t = i / c;
+        const int ox = (int)(t % ow);
+        t /= ow;
+        const int oy = (int)(t % oh);
+        const int b = (int)(t / oh);
+        float best = -INFINITY;
+        for (int dy = 0; dy < k; ++dy)
+            for (int dx = 0; dx < k; ++dx) {
+                const int iy = oy * s - pad + dy, ix = ox * s - pad + dx;
+                const float v = (iy >= 0 && iy < h && ix >= 0 && ix < w) ? x[(((long)b * h + iy) * w + ix) * c + ch] : 0.f;
+                if ((iy >= 0 && iy < h && ix >= 0 && ix < w) || pad > 0) best = fmaxf(best, v);
+            }
+        y[i] = best;
+    }
+}
+
+// gradient goes to the first maximum of the window in row-major window order
+__global__ void maxpool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gy, float* __restrict__ gx,
+                                   int n, int h, int w, int c, int oh, int ow, int k, int s, int pad) {
+    const long total = (long)n * oh * ow * c;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % c);
+        long t = i / c;
+        const int ox = (int)(t % ow);
+        t /= ow;
+        const int oy = (int)(t % oh);
+        const int b = (int)(t / oh);
+        float best = -INFINITY;
+        long arg = -1;
+        for (int dy = 0; dy < k; ++dy)
+            for (int dx = 0; dx < k; ++dx) {
+                const int iy = oy * s - pad + dy, ix = ox * s - pad + dx;
+                const bool in = iy >= 0 && iy < h && ix >= 0 && ix < w;
+                if (!in && pad == 0) continue;
+                const float v = in ? x[(((long)b * h + iy) * w + ix) * c + ch] : 0.f;
+                if (v > best) {
+                    best = v;
+                    arg = in ? (((long)b * h + iy) * w + ix) * c + ch : -1;
+                }
+            }
+        if (arg >= 0) unsafeAtomicAdd(&gx[arg], gy[i]);
+    }
+}
+
+__global__ void chan_affine3_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, size_t pixels, int p0, int p1,
+                                        int p2, float scale, float o0, float o1, float o2) {
+    for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < pixels; p += (size_t)gridDim.x * blockDim.x) {
+        const float v0 = x[p * 3 + 0], v1 = x[p * 3 + 1], v2 = x[p * 3 + 2];
+        const float v[3] = {v0, v1, v2};
+        y[p * 3 + 0] = scale * v[p0] + o0;
+        y[p * 3 + 1] = scale * v[p1] + o1;
+        y[p * 3 + 2] = scale * v[p2] + o2;
+    }
+}
+
+__global__ void chan_affine3_bwd_kernel(const float* __restrict__ gy, float* __restrict__ gx, size_t pixels, int p0,
+                                        int p1, int p2, float scale) {
+    for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < pixels; p += (size_t)gridDim.x * blockDim.x) {
+        float g[3];
+        g[p0] = scale * gy[p * 3 + 0];
+        g[p1] = scale * gy[p * 3 + 1];
+        g[p2] = scale * gy[p * 3 + 2];
+        gx[p * 3 + 0] = g[0];
+        gx[p * 3 + 1] = g[1];
+        gx[p * 3 + 2] = g[2];
+    }
+}
+
+__device__ __forceinline__ float softplus_f(float x) { return fmaxf(x, 0.f) + log1pf(expf(-fabsf(x))); }
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + expf(-x)); }
+
+__global__ __launch_bounds__(256) void gan_loss_fwd_kernel(const float* __restrict__ s, float* __restrict__ out, int n,
+                                                           float label) {
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) acc += label * softplus_f(-s[i]) + (1.f - label) * softplus_f(s[i]);
+    const float t = block_sum(acc);
+    if (threadIdx.x == 0) out[0] = t / (float)n;
+}
+
+__global__ void gan_loss_bwd_kernel(const float* __restrict__ s, const float* __restrict__ gout, float* __restrict__ gs,
+                                    int n, float label) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) gs[i] = gout[0] * (-label * sigmoid_f(-s[i]) + (1.f - label) * sigmoid_f(s[i])) / (float)n;
+}
+
+__global__ void adam_kernel(float* __restrict__ th, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, float* __restrict__ ema, size_t n, float lr_t, float b1, float b2,
+                            float eps, float alpha) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float gi = g[i];
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        const float t = th[i] - lr_t * mi / (sqrtf(vi) + eps);
+        m[i] = mi;
+        v[i] = vi;
+        th[i] = t;
+        if (ema) ema[i] = alpha * ema[i] + (1.f - alpha) * t;
+    }
+}
+
+__global__ void ema_kernel(float* __restrict__ ema, const float* __restrict__ th, size_t n, float alpha) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        ema[i] = alpha * ema[i] + (1.f - alpha) * th[i];
+}
+
+__global__ void gather_u8_kernel(const uint8_t* __restrict__ pool, const int64_t* __restrict__ idx,
+                                 const uint8_t* __restrict__ flip, float* __restrict__ out, int n, int h, int w, int c) {
+    const long per = (long)h * w * c;
+    const long total = (long)n * per;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int b = (int)(i / per);
+        const long r = i % per;
+        const int ch = (int)(r % c);
+        const int x = (int)((r / c) % w);
+        const int y = (int)(r / ((long)c * w));
+        const int sx = (flip && flip[b]) ? w - 1 - x : x;
+        const uint8_t v = pool[(size_t)idx[b] * per + ((long)y * w + sx) * c + ch];
+        out[i] = (float)v / 127.5f - 1.0f;
+    }
+}
+
+__global__ void to_uint8_kernel(const float* __restrict__ x, uint8_t* __restrict__ o, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float v = fminf(fmaxf(x[i], -1.f), 1.f);
+        o[i] = (uint8_t)((v + 1.f) * 127.5f);   // numpy astype(uint8) truncates toward zero
+    }
+}
+
+inline int ew_blocks(size_t n) {
+    size_t b = (n + 255) / 256;
+    return (int)(b > 8192 ? 8192 : (b ? b : 1));
+}
+
+}  // namespace
+
+extern "C" int cn_nc_reduce(const float* x1, const float* x2, float* s1, float* s2, int n, int s, int c, int flags,
+                            float slope, void* stream) {
+    CN_CHECK_ARG(x1 && (s1 || s2) && n > 0 && s > 0 && c > 0, "nc_reduce: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    if (s1) CN_HIP(hipMemsetAsync(s1, 0, sizeof(float) * (size_t)n * c, st));
+    if (s2) CN_HIP(hipMemsetAsync(s2, 0, sizeof(float) * (size_t)n * c, st));
+    const int V = (c % 4 == 0) ? 4 : 1;
+    const int CG = c / V;
+    int TX = 1;
+    while (TX < CG && TX < 64) TX <<= 1;
+    const int TY = 256 / TX;
+    const int cblk = cn_cdiv(CG, TX);
+    // ~2048 workgroups in total, at least 4*TY rows each
+    long want = 2048 / ((long)cblk * n);
+    if (want < 1) want = 1;
+    long rpb = (s + want - 1) / want;
+    if (rpb < 4 * TY) rpb = 4 * TY;
+    const int sblk = cn_cdiv(s, rpb);
+    dim3 grid(cblk, sblk, n), block(TX, TY);
+    if (V == 4) hipLaunchKernelGGL(nc_reduce_kernel<4>, grid, block, 0, st, x1, x2, s1, s2, s, c, (int)rpb, flags, slope);
+    else hipLaunchKernelGGL(nc_reduce_kernel<1>, grid, block, 0, st, x1, x2, s1, s2, s, c, (int)rpb, flags, slope);
+    CN_LAUNCH_CHECK();
+    return CN_OK;
+}
+
+extern "C" int cn_nc_lin2(const float* x1, const float* a1, const float* x2, const float* a2, const float* bb, float* y,
+                          int n, int s, int c, int cstride, int flags, float slope, void* stream) {
+    CN_CHECK_ARG(y && n > 0 && s > 0 && c > 0 && (cstride == 0 || cstride == c), "nc_lin2: bad args");
+    CN_CHECK_ARG(x1 || x2 || bb, "nc_lin2: nothing to compute");
+    const int V = (c % 4 == 0) ? 4 : 1;
+    const long total = (long)n * s * (c / V);
+    hipStream_t st = (hipStream_t)stream;
+    if (V == 4) hipLaunchKernelGGL(nc_lin2_kernel<4>, dim3(ew_blocks(total)), dim3(256), 0, st, x1, a1, x2, a2, bb, y, total, s, c, cstride, flags, slope);
+    else hipLaunchKernelGGL(nc_lin2_kernel<1>, dim3(ew_blocks(total)), dim3(256), 0, st, x1, a1, x2, a2, bb, y, total, s, c, cstride, flags, slope);
+    CN_LAUNCH_CHECK();
+    return CN_OK;
+}
+
+#define EW_LAUNCH(kernel, n, ...)                                                                              \
+    hipLaunchKernelGGL(kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__);             \
+    CN_LAUNCH_CHECK();                                                                                         \
+    return CN_OK;
+
+extern "C" int cn_act_fwd(const float* x, float* y, size_t numel, int act, float slope, void* stream) {
+    CN_CHECK_ARG(x && y, "act_fwd: NULL");
+    if (!numel) return CN_OK;
+    EW_LAUNCH(act_fwd_kernel, numel, x, y, numel, act, slope)
+}
+extern "C" int cn_act_bwd(const float* gy, const float* y, float* gx, size_t numel, int act, float slope, void* stream) {
+    CN_CHECK_ARG(gy && y && gx, "act_bwd: NULL");
+    if (!numel) return CN_OK;
+    EW_LAUNCH(act_bwd_kernel, numel, gy, y, gx, numel, act, slope)
+}
+extern "C" int cn_axpby(const float* x, const float* y, float* out, size_t numel, float a, float b, void* stream) {
+    CN_CHECK_ARG(x && out, "axpby: NULL");
+    if (!numel) return CN_OK;
+    EW_LAUNCH(axpby_kernel, numel, x, y, out, numel, a, b)
+}
+extern "C" int cn_mul(const float* x, const float* y, float* out, size_t numel, void* stream) {
+    CN_CHECK_ARG(x && y && out, "mul: NULL");
+    if (!numel) return CN_OK;
+    EW_LAUNCH(mul_kernel, numel, x, y, out, numel)
+}
+extern "C" int cn_sqdiff_sum(const float* a, const float* b, float* out, size_t numel, float scale, void* stream) {
+    CN_CHECK_ARG(a && b && out, "sqdiff_sum: NULL");
+    if (!numel) return CN_OK;
+    const int blocks = ew_blocks(numel) > 2048 ? 2048 : ew_blocks(numel);
+    hipLaunchKernelGGL(sqdiff_sum_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, b, out, numel, scale);
+    CN_LAUNCH_CHECK();
+    return CN_OK;
+}
+extern "C" int cn_row_sumsq(const float* x, float* out, int n, size_t row, void* stream) {
+    CN_CHECK_ARG(x && out && n > 0 && row > 0, "row_sumsq: bad args");
+    CN_HIP(hipMemsetAsync(out, 0, sizeof(float) * n, (hipStream_t)stream));
+    int bpr = (int)((row + 256 * 16 - 1) / (256 * 16));
+    if (bpr > 256) bpr = 256;
+    hipLaunchKernelGGL(row_sumsq_kernel, dim3(bpr, n), dim3(256), 0, (hipStream_t)stream, x, out, row);
+    CN_LAUNCH_CHECK();
+    return CN_OK;
+}
+extern "C" int cn_row_scale(const float* x, const float* s, float* out, int n, size_t row, float k, void* stream) {
+    CN_CHECK_ARG(x && s && out && n > 0 && row > 0, "row_scale: bad args");
+    int bpr = (int)((row + 256 * 8 - 1) / (256 * 8));
+    if (bpr > 512) bpr = 512;
+    hipLaunchKernelGGL(row_scale_kernel, dim3(bpr, n), dim3(256), 0, (hipStream_t)stream, x, s, out, row, k);
+    CN_LAUNCH_CHECK();
+    return CN_OK;
+}
+extern "C" int cn_masked_diff(const float* a, const float* b, const uint8_t* mask, float* out, size_t pixels, int c, void* stream) {
+    CN_CHECK_ARG(a && mask && out && c > 0, "masked_diff: bad args");
+    if (!pixels) return CN_OK;
+    EW_LAUNCH(masked_diff_kernel, pixels, a, b, mask, out, pixels, c)
+}
+extern "C" int cn_maxpool_fwd(const float* x, float* y, int n, int h, int w, int c, int k, int s, int pad, void* stream) {
+    CN_CHECK_ARG(x && y && n > 0 && h > 0 && w > 0 && c > 0 && k > 0 && s > 0 && pad >= 0, "maxpool: bad args");
+    const int oh = (h + 2 * pad - k) / s + 1, ow = (w + 2 * pad - k) / s + 1;
+    const size_t total = (size_t)n * oh * ow * c;
+    EW_LAUNCH(maxpool_fwd_kernel, total, x, y, n, h, w, c, oh, ow, k, s, pad)
+}
+extern "C" int cn_maxpool_bwd(const float* x, const float* gy, float* gx, int n, int h, int w, int c, int k, int s, int pad, void* stream) {
+    CN_CHECK_ARG(x && gy && gx && n > 0 && h > 0 && w > 0 && c > 0 && k > 0 && s > 0 && pad >= 0, "maxpool_bwd: bad args");
+    const int oh = (h + 2 * pad - k) / s + 1, ow = (w + 2 * pad - k) / s + 1;
+    CN_HIP(hipMemsetAsync(gx, 0, sizeof(float) * (size_t)n * h * w * c, (hipStream_t)stream));
+    const size_t total = (size_t)n * oh * ow * c;
+    EW_LAUNCH(maxpool_bwd_kernel, total, x, gy, gx, n, h, w, c, oh, ow, k, s, pad)
+}
+extern "C" int cn_chan_affine3_fwd(const float* x, float* y, size_t pixels, const int* perm, float scale, const float* off, void* stream) {
+    CN_CHECK_ARG(x && y && perm && off, "chan_affine3: NULL");
+    for (int i = 0; i < 3; ++i) CN_CHECK_ARG(perm[i] >= 0 && perm[i] < 3, "chan_affine3: bad perm");
+    EW_LAUNCH(chan_affine3_fwd_kernel, pixels, x, y, pixels, perm[0], perm[1], perm[2], scale, off[0], off[1], off[2])
+}
+extern "C" int cn_chan_affine3_bwd(const float* gy, float* gx, size_t pixels, const int* perm, float scale, void* stream) {
+    CN_CHECK_ARG(gy && gx && perm, "chan_affine3_bwd: NULL");
+    for (int i = 0; i < 3; ++i) CN_CHECK_ARG(perm[i] >= 0 && perm[i] < 3, "chan_affine3: bad perm");
+    EW_LAUNCH(chan_affine3_bwd_kernel, pixels, gy, gx, pixels, perm[0], perm[1], perm[2], scale)
+}
+extern "C" int cn_gan_loss_fwd(const float* s, float* out, int n, float label, void* stream) {
+    CN_CHECK_ARG(s && out && n > 0, "gan_loss: bad args");
+    hipLaunchKernelGGL(gan_loss_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, s, out, n, label);
+    CN_LAUNCH_CHECK();
+    return CN_OK;
+}
+extern "C" int cn_gan_loss_bwd(const float* s, const float* gout, float* gs, int n, float label, void* stream) {
+    CN_CHECK_ARG(s && gout && gs && n > 0, "gan_loss_bwd: bad args");
+    hipLaunchKernelGGL(gan_loss_bwd_kernel, dim3(cn_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, s, gout, gs, n, label);
+    CN_LAUNCH_CHECK();
+    return CN_OK;
+}
+extern "C" int cn_adam_step(float* theta, const float* grad, float* m, float* v, float* ema, size_t numel, float lr_t,
+                            float beta1, float beta2, float eps, float ema_alpha, void* stream) {
+    CN_CHECK_ARG(theta && grad && m && v, "adam: NULL");
+    if (!numel) return CN_OK;
+    EW_LAUNCH(adam_kernel, numel, theta, grad, m, v, ema, numel, lr_t, beta1, beta2, eps, ema_alpha)
+}
+extern "C" int cn_ema_step(float* ema, const float* theta, size_t numel, float alpha, void* stream) {
+    CN_CHECK_ARG(ema && theta, "ema: NULL");
+    if (!numel) return CN_OK;
+    EW_LAUNCH(ema_kernel, numel, ema, theta, numel, alpha)
+}
+extern "C" int cn_gather_images_u8(const uint8_t* pool, const int64_t* idx, const uint8_t* flip, float* out, int n, int h,
+                                   int w, int c, void* stream) {
+    CN_CHECK_ARG(pool && idx && out && n > 0, "gather_images: bad args");
+    const size_t total = (size_t)n * h * w * c;
+    EW_LAUNCH(gather_u8_kernel, total, pool, idx, flip, out, n, h, w, c)
+}
+extern "C" int cn_to_uint8(const float* x, uint8_t* out, size_t numel, void* stream) {
+    CN_CHECK_ARG(x && out, "to_uint8: NULL");
+    if (!numel) return CN_OK;
+    EW_LAUNCH(to_uint8_kernel, numel, x, out, numel)
+}

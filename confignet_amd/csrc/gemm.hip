@@ -1,0 +1,129 @@
+// gemm.hip -- dense GEMM  C = act(op(A) op(B) + bias)  for the Keras Dense layers of the path
+// (AdaIN MLPs, discriminator heads, latent regressor head, latent discriminator, synthetic
+// encoder, RealEncoder heads, LatentGAN).  Arbitrary M/N/K/ld (e.g. latent_dim = 145), so the
+// loaders are guarded scalar loads; the multiply is the same 32x32x2 f32 MFMA tile as the
+// convolutions (64x64 tile, 4 waves).  Skinny problems with a long K (32768 -> 148 at M = batch)
+// are split over K across workgroups and combined with fp32 atomics.
+#include "common.h"
+#include "mma_tile.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void gemm_kernel(int ta, int tb, int M, int N, int K, const float* __restrict__ A,
+                                                   int lda, const float* __restrict__ B, int ldb, float* __restrict__ C,
+                                                   int ldc, const float* __restrict__ bias, int act, float slope,
+                                                   int k_per_split, int splitk) {
+    constexpr int BM = 64, BN = 64, LDA = BM + 4, LDB = BN + 4;
+    __shared__ float As[2][BK][LDA];
+    __shared__ float Bs[2][BK][LDB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, half = lane >> 5, l31 = lane & 31;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int kbeg = blockIdx.z * k_per_split, kend = min(K, kbeg + k_per_split);
+    if (kbeg >= kend) return;
+
+    f32x16 acc[1][1];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
+    float ra[4], rb[4];
+    const int q4 = tid & 3, r64 = tid >> 2;      // (4 consecutive k, row) mapping
+    const int q16 = tid & 15, r16 = tid >> 4;    // (4 consecutive m/n, k row) mapping
+
+    auto load_tiles = [&](int k0) {
+        if (!ta) {
+            const int m = m0 + r64;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int k = k0 + q4 * 4 + e;
+                ra[e] = (m < M && k < kend) ? A[(long)m * lda + k] : 0.f;
+            }
+        } else {
+            const int k = k0 + r16;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int m = m0 + q16 * 4 + e;
+                ra[e] = (m < M && k < kend) ? A[(long)k * lda + m] : 0.f;
+            }
+        }
+        if (!tb) {
+            const int k = k0 + r16;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int n = n0 + q16 * 4 + e;
+                rb[e] = (n < N && k < kend) ? B[(long)k * ldb + n] : 0.f;
+            }
+        } else {
+            const int n = n0 + r64;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int k = k0 + q4 * 4 + e;
+                rb[e] = (n < N && k < kend) ? B[(long)n * ldb + k] : 0.f;
+            }
+        }
+    };
+    auto store_tiles = [&](int buf) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (!ta) As[buf][q4 * 4 + e][r64] = ra[e];
+            else As[buf][r16][q16 * 4 + e] = ra[e];
+            if (!tb) Bs[buf][r16][q16 * 4 + e] = rb[e];
+            else Bs[buf][q4 * 4 + e][r64] = rb[e];
+        }
+    };
+
+    const int nks = (kend - kbeg + BK - 1) / BK;
+    load_tiles(kbeg);
+    store_tiles(0);
+    __syncthreads();
+    for (int ks = 0; ks < nks; ++ks) {
+        const int buf = ks & 1;
+        if (ks + 1 < nks) load_tiles(kbeg + (ks + 1) * BK);
+        mma_step<1, 1, LDA, LDB>(As[buf], Bs[buf], acc, wm * 32 + l31, wn * 32 + l31, half);
+        if (ks + 1 < nks) store_tiles(buf ^ 1);
+        __syncthreads();
+    }
+
+    const int col = n0 + wn * 32 + l31;
+    if (col >= N) return;
+    const float bv = (bias && blockIdx.z == 0) ? bias[col] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 32 + 4 * half + (r & 3) + 8 * (r >> 2);
+        if (row >= M) continue;
+        const float v = acc[0][0][r] + bv;
+        if (splitk > 1) unsafeAtomicAdd(&C[(long)row * ldc + col], v);
+        else C[(long)row * ldc + col] = cn_apply_act(v, act, slope);
+    }
+}
+
+__global__ void zero_rows_kernel(float* C, int M, int N, int ldc) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < (long)M * N) C[(i / N) * ldc + i % N] = 0.f;
+}
+
+}  // namespace
+
+extern "C" int cn_gemm(int ta, int tb, int m, int n, int k, const float* a, int lda, const float* b, int ldb, float* c,
+                       int ldc, const float* bias, int act, float slope, void* stream) {
+    CN_CHECK_ARG(m > 0 && n > 0 && k > 0 && a && b && c, "gemm: bad args m=%d n=%d k=%d", m, n, k);
+    CN_CHECK_ARG(lda >= (ta ? m : k) && ldb >= (tb ? k : n) && ldc >= n, "gemm: leading dimension too small");
+    hipStream_t s = (hipStream_t)stream;
+    const long tiles = (long)cn_cdiv(m, 64) * cn_cdiv(n, 64);
+    int splitk = 1;
+    if (act == CN_ACT_NONE && tiles < 128 && k >= 1024) {
+        splitk = (int)((256 + tiles - 1) / tiles);
+        if (splitk > k / 256) splitk = k / 256;
+        if (splitk < 1) splitk = 1;
+    }
+    int kps = (k + splitk - 1) / splitk;
+    kps = (kps + BK - 1) / BK * BK;
+    splitk = (k + kps - 1) / kps;
+    if (splitk > 1) {
+        hipLaunchKernelGGL(zero_rows_kernel, dim3(cn_cdiv((long)m * n, 256)), dim3(256), 0, s, c, m, n, ldc);
+        CN_LAUNCH_CHECK();
+    }
+    dim3 grid(cn_cdiv(m, 64), cn_cdiv(n, 64), splitk);
+    hipLaunchKernelGGL(gemm_kernel, grid, dim3(256), 0, s, ta, tb, m, n, k, a, lda, b, ldb, c, ldc, bias, act, slope, kps, splitk);
+    CN_LAUNCH_CHECK();
+    return CN_OK;
+}

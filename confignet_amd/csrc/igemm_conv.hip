@@ -1,0 +1,584 @@
+// igemm_conv.hip -- N-d convolution family as implicit GEMM on the CDNA4 matrix cores.
+//
+// fp32 in / fp32 accumulate on v_mfma_f32_32x32x2_f32 (exact f32, 157 TF peak on MI355X).
+// One 256-thread workgroup (4 wave64, 2x2) owns a (64*TM) x (64*TN) output tile; each wave
+// owns TM x TN 32x32 MFMA tiles.  K is walked in steps of 16: the gathered activation tile
+// and the filter tile are prefetched from HBM/L2 into registers while the previous step is
+// multiplied out of LDS (two LDS buffers, one barrier per step).  Both LDS tiles are
+// "k-major" ([k][m] / [k][n], row pitch +4 floats) so every MFMA operand read is a
+// conflict-free ds_read_b32 of 32 consecutive floats per half-wave.
+//
+// Layouts: activations channels-last (N,[D,]H,W,C); filters Keras (kd,kh,kw,cin,cout) ==
+// row-major [K = taps*cin][cout], i.e. already the B matrix of the GEMM.  The x2 nearest
+// upsample that precedes most generator convolutions (hologan_generator.py:139-170) is folded
+// into the gather (index >> 1); SAME padding ([TF-2.1] asymmetric, low = total//2) and the
+// zero-stuffing of strided data-gradients are predicates of the gather.
+#include "common.h"
+
+#include "mma_tile.h"
+
+namespace {
+
+struct RowInfo {
+    int nbase, vd, vh, vw;
+    bool ok;
+};
+
+__device__ __forceinline__ RowInfo decode_row(const CnConvGeom& g, int m, int M) {
+    RowInfo r;
+    r.ok = m < M;
+    if (!r.ok) m = 0;
+    int ow = m % g.out_w;
+    int t = m / g.out_w;
+    int oh = t % g.out_h;
+    t /= g.out_h;
+    int od = t % g.out_d;
+    int n = t / g.out_d;
+    r.nbase = n * g.in_d;
+    r.vd = od * g.s_d - g.p_d;
+    r.vh = oh * g.s_h - g.p_h;
+    r.vw = ow * g.s_w - g.p_w;
+    return r;
+}
+
+__device__ __forceinline__ bool map1(int v, int dl, int ext, int up, int& q) {
+    if (v < 0) return false;
+    if (dl > 1) {
+        if (v % dl) return false;
+        v /= dl;
+    }
+    if (v >= ext) return false;
+    q = v >> up;
+    return true;
+}
+
+// element offset (channel 0) of the stored input element read by row r at tap (kd,kh,kw), or -1
+__device__ __forceinline__ int src_off(const CnConvGeom& g, const RowInfo& r, int kd, int kh, int kw) {
+    int qd, qh, qw;
+    if (!r.ok) return -1;
+    if (!map1(r.vd + kd, g.dl_d, g.in_d << g.up, g.up, qd)) return -1;
+    if (!map1(r.vh + kh, g.dl_h, g.in_h << g.up, g.up, qh)) return -1;
+    if (!map1(r.vw + kw, g.dl_w, g.in_w << g.up, g.up, qw)) return -1;
+    return (((r.nbase + qd) * g.in_h + qh) * g.in_w + qw) * g.cin;
+}
+
+__device__ __forceinline__ void tap_decode(const CnConvGeom& g, int tap, int& kd, int& kh, int& kw) {
+    kw = tap % g.k_w;
+    int t = tap / g.k_w;
+    kh = t % g.k_h;
+    kd = t / g.k_h;
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward / data-gradient:  Y[m, co] = act( sum_{t,ci} X[src(m,t), ci] * W[t, ci, co] + bias[co] )
+// ---------------------------------------------------------------------------------------------
+template <int WM, int WN, int TM, int TN, bool VEC>
+__global__ __launch_bounds__(256) void igemm_fwd_kernel(CnConvGeom g, const float* __restrict__ X,
+                                                        const float* __restrict__ W, const float* __restrict__ bias,
+                                                        float* __restrict__ Y, int act, float slope) {
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+    constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN, LDA = BM + 4, LDB = BN + 4;
+    constexpr int AP = BM / 64, BP = (BN + 63) / 64;   // float4 loads per thread per K step
+    __shared__ float As[2][BK][LDA];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK][LDB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN, half = lane >> 5, l31 = lane & 31;
+    const int M = g.n * g.out_d * g.out_h * g.out_w;
+    const int T = g.k_d * g.k_h * g.k_w;
+    const int Ktot = T * g.cin;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+
+    const int kq = tid & 3, arow = tid >> 2;
+    RowInfo ri[AP];
+#pragma unroll
+    for (int i = 0; i < AP; ++i) ri[i] = decode_row(g, m0 + arow + 64 * i, M);
+    int aoff[AP];
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float4 ra[AP], rb[BP];
+    const int cpb = VEC ? g.cin / BK : 1;
+    const int nks = VEC ? T * cpb : (Ktot + BK - 1) / BK;
+
+    auto load_tiles = [&](int ks) {
+        if (VEC) {
+            const int tap = ks / cpb;
+            const int c0 = (ks - tap * cpb) * BK;
+            if (c0 == 0) {
+                int kd, kh, kw;
+                tap_decode(g, tap, kd, kh, kw);
+#pragma unroll
+                for (int i = 0; i < AP; ++i) aoff[i] = src_off(g, ri[i], kd, kh, kw);
+            }
+#pragma unroll
+            for (int i = 0; i < AP; ++i)
+                ra[i] = aoff[i] >= 0 ? *reinterpret_cast<const float4*>(X + aoff[i] + c0 + kq * 4)
+                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int j = 0; j < BP; ++j) {
+                const int idx = tid + 256 * j;
+                const int brow = idx / (BN / 4), col = n0 + (idx % (BN / 4)) * 4;
+                const long kg = (long)tap * g.cin + c0 + brow;
+                rb[j] = (col < g.cout && idx < BK * BN / 4) ? *reinterpret_cast<const float4*>(W + kg * g.cout + col)
+                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < AP; ++i) {
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int k = ks * BK + kq * 4 + e;
+                    v[e] = 0.f;
+                    if (k < Ktot) {
+                        const int tap = k / g.cin, ci = k - tap * g.cin;
+                        int kd, kh, kw;
+                        tap_decode(g, tap, kd, kh, kw);
+                        const int off = src_off(g, ri[i], kd, kh, kw);
+                        if (off >= 0) v[e] = X[off + ci];
+                    }
+                }
+                ra[i] = make_float4(v[0], v[1], v[2], v[3]);
+            }
+#pragma unroll
+            for (int j = 0; j < BP; ++j) {
+                const int idx = tid + 256 * j;
+                const int brow = idx / (BN / 4), col = n0 + (idx % (BN / 4)) * 4;
+                const long kg = (long)ks * BK + brow;
+                rb[j] = (col < g.cout && kg < Ktot && idx < BK * BN / 4) ? *reinterpret_cast<const float4*>(W + kg * g.cout + col)
+                                                    : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    };
+    auto store_tiles = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < AP; ++i) {
+            const int r = arow + 64 * i;
+            As[buf][kq * 4 + 0][r] = ra[i].x;
+            As[buf][kq * 4 + 1][r] = ra[i].y;
+            As[buf][kq * 4 + 2][r] = ra[i].z;
+            As[buf][kq * 4 + 3][r] = ra[i].w;
+        }
+#pragma unroll
+        for (int j = 0; j < BP; ++j) {
+            const int idx = tid + 256 * j;
+            const int brow = idx / (BN / 4), bcol = (idx % (BN / 4)) * 4;
+            if (idx < BK * BN / 4) *reinterpret_cast<float4*>(&Bs[buf][brow][bcol]) = rb[j];
+        }
+    };
+
+    load_tiles(0);
+    store_tiles(0);
+    __syncthreads();
+    const int a_col = wm * 32 * TM + l31, b_col = wn * 32 * TN + l31;
+    for (int ks = 0; ks < nks; ++ks) {
+        const int buf = ks & 1;
+        if (ks + 1 < nks) load_tiles(ks + 1);
+        mma_step<TM, TN, LDA, LDB>(As[buf], Bs[buf], acc, a_col, b_col, half);
+        if (ks + 1 < nks) store_tiles(buf ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = n0 + wn * 32 * TN + 32 * j + l31;
+        if (col >= g.cout) continue;
+        const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int rbase = m0 + wm * 32 * TM + 32 * i + 4 * half;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = rbase + (r & 3) + 8 * (r >> 2);
+                if (row < M) Y[(long)row * g.cout + col] = cn_apply_act(acc[i][j][r] + bv, act, slope);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// filter gradient:  GW[(t,ci), co] = sum_m X[src(m,t), ci] * GY[m, co]   (split over m, fp32 atomics)
+// ---------------------------------------------------------------------------------------------
+template <int WM, int WN, int TM, int TN, bool VEC, bool BVEC>
+__global__ __launch_bounds__(256) void igemm_wgrad_kernel(CnConvGeom g, const float* __restrict__ X,
+                                                          const float* __restrict__ GY, float* __restrict__ GW,
+                                                          int rows_per_split) {
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+    constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN, LDA = BM + 4, LDB = BN + 4;
+    constexpr int AP = BM / 64, BP = (BN + 63) / 64;
+    __shared__ __attribute__((aligned(16))) float As[2][BK][LDA];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK][LDB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN, half = lane >> 5, l31 = lane & 31;
+    const int M = g.n * g.out_d * g.out_h * g.out_w;
+    const int T = g.k_d * g.k_h * g.k_w;
+    const int Ktot = T * g.cin;
+    const int i0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int mbeg = blockIdx.z * rows_per_split;
+    const int mend = min(M, mbeg + rows_per_split);
+    if (mbeg >= mend) return;
+
+    // A loader: float4 along i = (tap, ci); fixed per thread across the whole m loop
+    int a_krow[AP], a_col[AP], a_ci[AP][4], a_kd[AP][4], a_kh[AP][4], a_kw[AP][4];
+    bool a_ok[AP][4];
+#pragma unroll
+    for (int ii = 0; ii < AP; ++ii) {
+        const int idx = tid + 256 * ii;
+        a_krow[ii] = idx / (BM / 4);
+        a_col[ii] = (idx % (BM / 4)) * 4;
+#pragma unroll
+        for (int e = 0; e < (VEC ? 1 : 4); ++e) {
+            const int i = i0 + a_col[ii] + e;
+            a_ok[ii][e] = i < Ktot;
+            const int tap = a_ok[ii][e] ? i / g.cin : 0;
+            a_ci[ii][e] = a_ok[ii][e] ? i - tap * g.cin : 0;
+            tap_decode(g, tap, a_kd[ii][e], a_kh[ii][e], a_kw[ii][e]);
+        }
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float4 ra[AP], rb[BP];
+    const int nks = (mend - mbeg + BK - 1) / BK;
+
+    auto load_tiles = [&](int ks) {
+#pragma unroll
+        for (int ii = 0; ii < AP; ++ii) {
+            const int m = mbeg + ks * BK + a_krow[ii];
+            const RowInfo r = decode_row(g, m, mend);
+            if (VEC) {
+                const int off = a_ok[ii][0] ? src_off(g, r, a_kd[ii][0], a_kh[ii][0], a_kw[ii][0]) : -1;
+                ra[ii] = off >= 0 ? *reinterpret_cast<const float4*>(X + off + a_ci[ii][0])
+                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+            } else {
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int off = a_ok[ii][e] ? src_off(g, r, a_kd[ii][e], a_kh[ii][e], a_kw[ii][e]) : -1;
+                    v[e] = off >= 0 ? X[off + a_ci[ii][e]] : 0.f;
+                }
+                ra[ii] = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < BP; ++j) {
+            const int idx = tid + 256 * j;
+            const int krow = idx / (BN / 4), col = n0 + (idx % (BN / 4)) * 4;
+            const int m = mbeg + ks * BK + krow;
+            const bool ok = m < mend && idx < BK * BN / 4;
+            if (BVEC) {
+                rb[j] = (ok && col < g.cout) ? *reinterpret_cast<const float4*>(GY + (long)m * g.cout + col)
+                                             : make_float4(0.f, 0.f, 0.f, 0.f);
+            } else {
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = (ok && col + e < g.cout) ? GY[(long)m * g.cout + col + e] : 0.f;
+                rb[j] = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        }
+    };
+    auto store_tiles = [&](int buf) {
+#pragma unroll
+        for (int ii = 0; ii < AP; ++ii) *reinterpret_cast<float4*>(&As[buf][a_krow[ii]][a_col[ii]]) = ra[ii];
+#pragma unroll
+        for (int j = 0; j < BP; ++j) {
+            const int idx = tid + 256 * j;
+            if (idx < BK * BN / 4) *reinterpret_cast<float4*>(&Bs[buf][idx / (BN / 4)][(idx % (BN / 4)) * 4]) = rb[j];
+        }
+    };
+
+    load_tiles(0);
+    store_tiles(0);
+    __syncthreads();
+    const int ac = wm * 32 * TM + l31, bc = wn * 32 * TN + l31;
+    for (int ks = 0; ks < nks; ++ks) {
+        const int buf = ks & 1;
+        if (ks + 1 < nks) load_tiles(ks + 1);
+        mma_step<TM, TN, LDA, LDB>(As[buf], Bs[buf], acc, ac, bc, half);
+        if (ks + 1 < nks) store_tiles(buf ^ 1);
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = n0 + wn * 32 * TN + 32 * j + l31;
+        if (col >= g.cout) continue;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int rbase = i0 + wm * 32 * TM + 32 * i + 4 * half;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = rbase + (r & 3) + 8 * (r >> 2);
+                if (row < Ktot) unsafeAtomicAdd(&GW[(long)row * g.cout + col], acc[i][j][r]);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// thin-output direct convolution (cout <= 4): HBM-bound, one thread per output position.
+// Used for map_final (32->3, hologan_generator.py:101), the 1x1 3->3 from-RGB conv
+// (hologan_discriminator.py:20) and the data-gradient of every 3-channel-input conv.
+// ---------------------------------------------------------------------------------------------
+template <int CO, bool VEC>
+__global__ __launch_bounds__(256) void thin_conv_kernel(CnConvGeom g, const float* __restrict__ X,
+                                                        const float* __restrict__ W, const float* __restrict__ bias,
+                                                        float* __restrict__ Y, int act, float slope) {
+    const int M = g.n * g.out_d * g.out_h * g.out_w;
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= M) return;
+    const RowInfo r = decode_row(g, m, M);
+    float acc[CO];
+#pragma unroll
+    for (int c = 0; c < CO; ++c) acc[c] = bias ? bias[c] : 0.f;
+    int tap = 0;
+    for (int kd = 0; kd < g.k_d; ++kd)
+        for (int kh = 0; kh < g.k_h; ++kh)
+            for (int kw = 0; kw < g.k_w; ++kw, ++tap) {
+                const int off = src_off(g, r, kd, kh, kw);
+                if (off < 0) continue;
+                const float* __restrict__ wp = W + (long)tap * g.cin * CO;
+                if (VEC) {
+                    for (int ci = 0; ci < g.cin; ci += 4) {
+                        const float4 xv = *reinterpret_cast<const float4*>(X + off + ci);
+#pragma unroll
+                        for (int c = 0; c < CO; ++c)
+                            acc[c] += xv.x * wp[(ci + 0) * CO + c] + xv.y * wp[(ci + 1) * CO + c] +
+                                      xv.z * wp[(ci + 2) * CO + c] + xv.w * wp[(ci + 3) * CO + c];
+                    }
+                } else {
+                    for (int ci = 0; ci < g.cin; ++ci) {
+                        const float xv = X[off + ci];
+#pragma unroll
+                        for (int c = 0; c < CO; ++c) acc[c] += xv * wp[ci * CO + c];
+                    }
+                }
+            }
+#pragma unroll
+    for (int c = 0; c < CO; ++c) Y[(long)m * CO + c] = cn_apply_act(acc[c], act, slope);
+}
+
+__global__ void weight_tflip_kernel(const float* __restrict__ W, float* __restrict__ Wt, int T, int cin, int cout) {
+    const long total = (long)T * cin * cout;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        // i indexes Wt[t'][co][ci]
+        const int ci = (int)(i % cin);
+        const long r = i / cin;
+        const int co = (int)(r % cout);
+        const int tp = (int)(r / cout);
+        Wt[i] = W[((long)(T - 1 - tp) * cin + ci) * cout + co];
+    }
+}
+
+template <int ND>
+__global__ void sumpool2_kernel(const float* __restrict__ GU, float* __restrict__ GX, int n, int d, int h, int w, int c4) {
+    const long total = (long)n * d * h * w * c4;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int cc = (int)(i % c4);
+    long t = i / c4;
+    const int x = (int)(t % w);
+    t /= w;
+    const int y = (int)(t % h);
+    t /= h;
+    const int z = (int)(t % d);
+    const int b = (int)(t / d);
+    const int H2 = 2 * h, W2 = 2 * w, D2 = ND == 3 ? 2 * d : 1;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4* src = reinterpret_cast<const float4*>(GU);
+#pragma unroll
+    for (int dz = 0; dz < (ND == 3 ? 2 : 1); ++dz)
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                const int zz = ND == 3 ? 2 * z + dz : 0;
+                const float4 v = src[((((long)b * D2 + zz) * H2 + 2 * y + dy) * W2 + 2 * x + dx) * c4 + cc];
+                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            }
+    reinterpret_cast<float4*>(GX)[i] = s;
+}
+
+// exact number of (output position, tap) pairs that touch a stored element, per spatial axis
+double valid_pairs_1d(int out, int k, int s, int dl, int p, int in, int up) {
+    long cnt = 0;
+    for (int o = 0; o < out; ++o)
+        for (int kk = 0; kk < k; ++kk) {
+            int v = o * s - p + kk;
+            if (v < 0 || v % dl) continue;
+            if (v / dl >= (in << up)) continue;
+            ++cnt;
+        }
+    return (double)cnt;
+}
+
+double conv_flops(const CnConvGeom& g) {
+    return 2.0 * g.n * valid_pairs_1d(g.out_d, g.k_d, g.s_d, g.dl_d, g.p_d, g.in_d, g.up) *
+           valid_pairs_1d(g.out_h, g.k_h, g.s_h, g.dl_h, g.p_h, g.in_h, g.up) *
+           valid_pairs_1d(g.out_w, g.k_w, g.s_w, g.dl_w, g.p_w, g.in_w, g.up) * g.cin * g.cout;
+}
+
+int check_geom(const CnConvGeom* g) {
+    CN_CHECK_ARG(g != nullptr, "geom is NULL");
+    CN_CHECK_ARG(g->nd == 2 || g->nd == 3, "nd must be 2 or 3 (got %d)", g->nd);
+    CN_CHECK_ARG(g->n > 0 && g->cin > 0 && g->cout > 0, "empty batch/channels");
+    CN_CHECK_ARG(g->in_d > 0 && g->in_h > 0 && g->in_w > 0 && g->out_d > 0 && g->out_h > 0 && g->out_w > 0, "empty extent");
+    CN_CHECK_ARG(g->k_d > 0 && g->k_h > 0 && g->k_w > 0 && g->s_d > 0 && g->s_h > 0 && g->s_w > 0, "bad kernel/stride");
+    CN_CHECK_ARG(g->dl_d > 0 && g->dl_h > 0 && g->dl_w > 0, "bad dilation divisor");
+    CN_CHECK_ARG(g->up == 0 || g->up == 1, "up must be 0/1");
+    CN_CHECK_ARG(g->nd == 3 || (g->in_d == 1 && g->out_d == 1 && g->k_d == 1), "2-D geometry must have depth 1");
+    const double in_el = (double)g->n * g->in_d * g->in_h * g->in_w * g->cin;
+    const double out_el = (double)g->n * g->out_d * g->out_h * g->out_w * g->cout;
+    CN_CHECK_ARG(in_el < 2147483647.0 && out_el < 2147483647.0, "tensor exceeds 2^31 elements (32-bit offsets)");
+    return CN_OK;
+}
+
+template <int WM, int WN, int TM, int TN>
+int launch_fwd(const CnConvGeom& g, bool vec, const float* x, const float* w, const float* bias, float* y, int act,
+               float slope, hipStream_t s) {
+    const long M = (long)g.n * g.out_d * g.out_h * g.out_w;
+    dim3 grid(cn_cdiv(M, 32 * WM * TM), cn_cdiv(g.cout, 32 * WN * TN));
+    if (vec)
+        hipLaunchKernelGGL((igemm_fwd_kernel<WM, WN, TM, TN, true>), grid, dim3(256), 0, s, g, x, w, bias, y, act, slope);
+    else
+        hipLaunchKernelGGL((igemm_fwd_kernel<WM, WN, TM, TN, false>), grid, dim3(256), 0, s, g, x, w, bias, y, act, slope);
+    CN_LAUNCH_CHECK();
+    return CN_OK;
+}
+
+template <int WM, int WN, int TM, int TN>
+int launch_wgrad(const CnConvGeom& g, const float* x, const float* gy, float* gw, hipStream_t s) {
+    constexpr int BMt = 32 * WM * TM, BNt = 32 * WN * TN;
+    const long M = (long)g.n * g.out_d * g.out_h * g.out_w;
+    const long Ktot = (long)g.k_d * g.k_h * g.k_w * g.cin;
+    const long tiles = (long)cn_cdiv(Ktot, BMt) * cn_cdiv(g.cout, BNt);
+    long splits = (1024 + tiles - 1) / tiles;
+    long rows = (M + splits - 1) / splits;
+    if (rows < 256) rows = 256;
+    rows = (rows + BK - 1) / BK * BK;
+    splits = (M + rows - 1) / rows;
+    dim3 grid(cn_cdiv(Ktot, BMt), cn_cdiv(g.cout, BNt), (unsigned)splits);
+    const bool avec = g.cin % 4 == 0, bvec = g.cout % 4 == 0;
+#define WG(A, B) hipLaunchKernelGGL((igemm_wgrad_kernel<WM, WN, TM, TN, A, B>), grid, dim3(256), 0, s, g, x, gy, gw, (int)rows)
+    if (avec && bvec) WG(true, true);
+    else if (avec) WG(true, false);
+    else if (bvec) WG(false, true);
+    else WG(false, false);
+#undef WG
+    CN_LAUNCH_CHECK();
+    return CN_OK;
+}
+
+}  // namespace
+
+extern "C" int cn_conv_fwd(const CnConvGeom* gp, const float* x, const float* w, const float* bias, float* y, int act,
+                           float slope, void* stream) {
+    if (int e = check_geom(gp)) return e;
+    CN_CHECK_ARG(x && w && y, "NULL tensor");
+    const CnConvGeom g = *gp;
+    hipStream_t s = (hipStream_t)stream;
+    const long M = (long)g.n * g.out_d * g.out_h * g.out_w;
+    if (g.cout <= 4) {
+        const bool vec = g.cin % 4 == 0;
+        dim3 grid(cn_cdiv(M, 256));
+#define THIN(CO)                                                                                               \
+    if (vec)                                                                                                   \
+        hipLaunchKernelGGL((thin_conv_kernel<CO, true>), grid, dim3(256), 0, s, g, x, w, bias, y, act, slope); \
+    else                                                                                                       \
+        hipLaunchKernelGGL((thin_conv_kernel<CO, false>), grid, dim3(256), 0, s, g, x, w, bias, y, act, slope);
+        switch (g.cout) {
+            case 1: THIN(1); break;
+            case 2: THIN(2); break;
+            case 3: THIN(3); break;
+            default: THIN(4); break;
+        }
+#undef THIN
+        CN_LAUNCH_CHECK();
+        return CN_OK;
+    }
+    CN_CHECK_ARG(g.cout % 4 == 0, "cout=%d: implicit-GEMM path needs cout %% 4 == 0", g.cout);
+    const bool vec = g.cin % BK == 0;
+    // tile choice: the biggest tile that still gives >= 2 workgroups per CU (256 CUs)
+    const long t128 = (long)cn_cdiv(M, 128) * cn_cdiv(g.cout, 128);
+    const long t128x64 = (long)cn_cdiv(M, 128) * cn_cdiv(g.cout, 64);
+    cn_prof_begin(s, conv_flops(g));
+    int e;
+    if (g.cout <= 32)
+        e = launch_fwd<4, 1, 1, 1>(g, vec, x, w, bias, y, act, slope, s);      // 128 x 32
+    else if (g.cout > 64 && t128 >= 512)
+        e = launch_fwd<2, 2, 2, 2>(g, vec, x, w, bias, y, act, slope, s);      // 128 x 128
+    else if (t128x64 >= 512)
+        e = launch_fwd<2, 2, 2, 1>(g, vec, x, w, bias, y, act, slope, s);      // 128 x 64
+    else
+        e = launch_fwd<2, 2, 1, 1>(g, vec, x, w, bias, y, act, slope, s);      // 64 x 64
+    cn_prof_end(s);
+    return e;
+}
+
+extern "C" int cn_conv_weight_tflip(const float* w, float* wt, int taps, int cin, int cout, void* stream) {
+    CN_CHECK_ARG(w && wt && taps > 0 && cin > 0 && cout > 0, "bad tflip args");
+    const long total = (long)taps * cin * cout;
+    const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    hipLaunchKernelGGL(weight_tflip_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, wt, taps, cin, cout);
+    CN_LAUNCH_CHECK();
+    return CN_OK;
+}
+
+extern "C" int cn_conv_dgrad(const CnConvGeom* gp, const float* gy, const float* w_tflip, float* gu, void* stream) {
+    if (int e = check_geom(gp)) return e;
+    CN_CHECK_ARG(gp->dl_d == 1 && gp->dl_h == 1 && gp->dl_w == 1, "dgrad of a dilated-input geometry is not defined here");
+    CnConvGeom d = *gp;
+    d.in_d = gp->out_d; d.in_h = gp->out_h; d.in_w = gp->out_w; d.cin = gp->cout;
+    d.out_d = gp->in_d << gp->up; d.out_h = gp->in_h << gp->up; d.out_w = gp->in_w << gp->up;
+    if (gp->nd == 2) d.out_d = 1;
+    d.cout = gp->cin;
+    d.s_d = d.s_h = d.s_w = 1;
+    d.dl_d = gp->s_d; d.dl_h = gp->s_h; d.dl_w = gp->s_w;
+    d.p_d = gp->k_d - 1 - gp->p_d; d.p_h = gp->k_h - 1 - gp->p_h; d.p_w = gp->k_w - 1 - gp->p_w;
+    d.up = 0;
+    return cn_conv_fwd(&d, gy, w_tflip, nullptr, gu, CN_ACT_NONE, 0.f, stream);
+}
+
+extern "C" int cn_conv_wgrad(const CnConvGeom* gp, const float* x, const float* gy, float* gw, void* stream) {
+    if (int e = check_geom(gp)) return e;
+    CN_CHECK_ARG(x && gy && gw, "NULL tensor");
+    const CnConvGeom g = *gp;
+    hipStream_t s = (hipStream_t)stream;
+    const long Ktot = (long)g.k_d * g.k_h * g.k_w * g.cin;
+    CN_HIP(hipMemsetAsync(gw, 0, sizeof(float) * Ktot * g.cout, s));
+    cn_prof_begin(s, conv_flops(g));
+    int e;
+    if (g.cout <= 32)
+        e = launch_wgrad<4, 1, 1, 1>(g, x, gy, gw, s);       // 128 (tap,ci) x 32 co
+    else if (Ktot >= 128 && g.cout >= 128)
+        e = launch_wgrad<2, 2, 2, 2>(g, x, gy, gw, s);       // 128 x 128
+    else
+        e = launch_wgrad<2, 2, 1, 1>(g, x, gy, gw, s);       // 64 x 64
+    cn_prof_end(s);
+    return e;
+}
+
+extern "C" int cn_sumpool2(const float* gu, float* gx, int nd, int n, int d, int h, int w, int c, void* stream) {
+    CN_CHECK_ARG(gu && gx && (nd == 2 || nd == 3) && c % 4 == 0, "sumpool2: bad args (c must be a multiple of 4)");
+    if (nd == 2) d = 1;
+    const long total = (long)n * d * h * w * (c / 4);
+    if (nd == 3)
+        hipLaunchKernelGGL(sumpool2_kernel<3>, dim3(cn_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, gu, gx, n, d, h, w, c / 4);
+    else
+        hipLaunchKernelGGL(sumpool2_kernel<2>, dim3(cn_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, gu, gx, n, d, h, w, c / 4);
+    CN_LAUNCH_CHECK();
+    return CN_OK;
+}

@@ -1,0 +1,75 @@
+// prof.hip -- error string + HIP-event profiling of the dominant kernel class.
+#include "common.h"
+#include <stdarg.h>
+#include <mutex>
+#include <vector>
+
+static thread_local char g_err[512] = "no error";
+
+void cn_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* cn_last_error_string(void) { return g_err; }
+extern "C" int cn_version(void) { return 1; }
+
+namespace {
+struct Rec { hipEvent_t a, b; double flops; };
+std::mutex g_mu;
+bool g_on = false;
+std::vector<Rec> g_pool;      // allocated event pairs
+size_t g_used = 0;            // pairs used since the last reset
+}  // namespace
+
+void cn_prof_begin(hipStream_t s, double flops) {
+    if (!g_on) return;
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g_used == g_pool.size()) {
+        Rec r;
+        r.flops = 0;
+        if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
+        g_pool.push_back(r);
+    }
+    g_pool[g_used].flops = flops;
+    (void)hipEventRecord(g_pool[g_used].a, s);
+}
+
+void cn_prof_end(hipStream_t s) {
+    if (!g_on) return;
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g_used < g_pool.size()) {
+        (void)hipEventRecord(g_pool[g_used].b, s);
+        ++g_used;
+    }
+}
+
+extern "C" int cn_prof_enable(int on) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_on = on != 0;
+    return CN_OK;
+}
+
+extern "C" int cn_prof_reset(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_used = 0;
+    return CN_OK;
+}
+
+extern "C" int cn_prof_collect(int* launches, double* total_ms, double* total_flops) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    double ms = 0, fl = 0;
+    for (size_t i = 0; i < g_used; ++i) {
+        CN_HIP(hipEventSynchronize(g_pool[i].b));
+        float t = 0;
+        CN_HIP(hipEventElapsedTime(&t, g_pool[i].a, g_pool[i].b));
+        ms += t;
+        fl += g_pool[i].flops;
+    }
+    if (launches) *launches = (int)g_used;
+    if (total_ms) *total_ms = ms;
+    if (total_flops) *total_flops = fl;
+    return CN_OK;
+}

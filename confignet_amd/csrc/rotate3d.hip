@@ -1,0 +1,156 @@
+// rotate3d.hip -- rigid 3-D resample of the (N,G,G,G,C) feature volume about its centre
+// (transform_3d_grid_tf, confignet_utils.py:63-120): q = R (p - ctr) + ctr, clamp to [0,G-1],
+// trilinear (x, then y, then z).  Coordinates are computed in-kernel from the 3x3 matrix; no
+// coordinate tensors and no materialised gathers.  HBM-bound: 8 taps/voxel mostly from L2.
+#include "common.h"
+
+namespace {
+
+struct Taps {
+    int x0, x1, y0, y1, z0, z1;
+    float dx, dy, dz;
+    bool px, py, pz;   // clip_by_value passes the gradient (raw coordinate inside [0, G-1])
+};
+
+__device__ __forceinline__ Taps make_taps(const float* __restrict__ R, int p, int G) {
+    const float ctr = 0.5f * (float)(G - 1);
+    const int k = p % G, j = (p / G) % G, i = p / (G * G);
+    const float px = (float)i - ctr, py = (float)j - ctr, pz = (float)k - ctr;
+    float q[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) q[a] = R[a * 3 + 0] * px + R[a * 3 + 1] * py + R[a * 3 + 2] * pz + ctr;
+    Taps t;
+    const float hi = (float)(G - 1);
+    t.px = q[0] >= 0.f && q[0] <= hi;
+    t.py = q[1] >= 0.f && q[1] <= hi;
+    t.pz = q[2] >= 0.f && q[2] <= hi;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) q[a] = fminf(fmaxf(q[a], 0.f), hi);
+    const float fx = floorf(q[0]), fy = floorf(q[1]), fz = floorf(q[2]);
+    t.x0 = (int)fx; t.y0 = (int)fy; t.z0 = (int)fz;
+    t.x1 = min(t.x0 + 1, G - 1); t.y1 = min(t.y0 + 1, G - 1); t.z1 = min(t.z0 + 1, G - 1);
+    t.dx = q[0] - fx; t.dy = q[1] - fy; t.dz = q[2] - fz;
+    return t;
+}
+
+__device__ __forceinline__ float4 lerp4(float4 a, float4 b, float t) {
+    const float s = 1.f - t;
+    return make_float4(a.x * s + b.x * t, a.y * s + b.y * t, a.z * s + b.z * t, a.w * s + b.w * t);
+}
+__device__ __forceinline__ float4 sub4(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+__device__ __forceinline__ float dot4(float4 a, float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+
+// grid (ceil(P*C4/256), N)
+__global__ __launch_bounds__(256) void rotate3d_fwd_kernel(const float* __restrict__ grid, const float* __restrict__ rot,
+                                                           float* __restrict__ out, int G, int C4) {
+    const int n = blockIdx.y;
+    const int P = G * G * G;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P * C4) return;
+    const int c = i % C4, p = i / C4;
+    const Taps t = make_taps(rot + n * 9, p, G);
+    const float4* g4 = reinterpret_cast<const float4*>(grid) + (long)n * P * C4;
+    auto at = [&](int x, int y, int z) { return g4[((long)(x * G + y) * G + z) * C4 + c]; };
+    const float4 c00 = lerp4(at(t.x0, t.y0, t.z0), at(t.x1, t.y0, t.z0), t.dx);
+    const float4 c01 = lerp4(at(t.x0, t.y0, t.z1), at(t.x1, t.y0, t.z1), t.dx);
+    const float4 c10 = lerp4(at(t.x0, t.y1, t.z0), at(t.x1, t.y1, t.z0), t.dx);
+    const float4 c11 = lerp4(at(t.x0, t.y1, t.z1), at(t.x1, t.y1, t.z1), t.dx);
+    const float4 c0 = lerp4(c00, c10, t.dy);
+    const float4 c1 = lerp4(c01, c11, t.dy);
+    reinterpret_cast<float4*>(out)[((long)n * P + p) * C4 + c] = lerp4(c0, c1, t.dz);
+}
+
+__device__ __forceinline__ void atomic_add4(float* p, float4 v, float w) {
+    unsafeAtomicAdd(p + 0, v.x * w);
+    unsafeAtomicAdd(p + 1, v.y * w);
+    unsafeAtomicAdd(p + 2, v.z * w);
+    unsafeAtomicAdd(p + 3, v.w * w);
+}
+
+// grid (ceil(P/256), N): one thread per output voxel, loop over channel groups
+__global__ __launch_bounds__(256) void rotate3d_bwd_kernel(const float* __restrict__ grid, const float* __restrict__ rot,
+                                                           const float* __restrict__ gout, float* __restrict__ ggrid,
+                                                           float* __restrict__ grot, int G, int C4) {
+    const int n = blockIdx.y;
+    const int P = G * G * G;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    float gq[3] = {0.f, 0.f, 0.f};
+    float pc[3] = {0.f, 0.f, 0.f};
+    if (p < P) {
+        const Taps t = make_taps(rot + n * 9, p, G);
+        const float ctr = 0.5f * (float)(G - 1);
+        pc[0] = (float)(p / (G * G)) - ctr; pc[1] = (float)((p / G) % G) - ctr; pc[2] = (float)(p % G) - ctr;
+        const float4* g4 = reinterpret_cast<const float4*>(grid) + (long)n * P * C4;
+        float* gg = ggrid + (long)n * P * C4 * 4;
+        const float4* go4 = reinterpret_cast<const float4*>(gout) + ((long)n * P + p) * C4;
+        const float wx0 = 1.f - t.dx, wy0 = 1.f - t.dy, wz0 = 1.f - t.dz;
+        const long o000 = ((long)(t.x0 * G + t.y0) * G + t.z0) * C4, o100 = ((long)(t.x1 * G + t.y0) * G + t.z0) * C4;
+        const long o001 = ((long)(t.x0 * G + t.y0) * G + t.z1) * C4, o101 = ((long)(t.x1 * G + t.y0) * G + t.z1) * C4;
+        const long o010 = ((long)(t.x0 * G + t.y1) * G + t.z0) * C4, o110 = ((long)(t.x1 * G + t.y1) * G + t.z0) * C4;
+        const long o011 = ((long)(t.x0 * G + t.y1) * G + t.z1) * C4, o111 = ((long)(t.x1 * G + t.y1) * G + t.z1) * C4;
+        for (int c = 0; c < C4; ++c) {
+            const float4 go = go4[c];
+            atomic_add4(gg + (o000 + c) * 4, go, wx0 * wy0 * wz0);
+            atomic_add4(gg + (o100 + c) * 4, go, t.dx * wy0 * wz0);
+            atomic_add4(gg + (o001 + c) * 4, go, wx0 * wy0 * t.dz);
+            atomic_add4(gg + (o101 + c) * 4, go, t.dx * wy0 * t.dz);
+            atomic_add4(gg + (o010 + c) * 4, go, wx0 * t.dy * wz0);
+            atomic_add4(gg + (o110 + c) * 4, go, t.dx * t.dy * wz0);
+            atomic_add4(gg + (o011 + c) * 4, go, wx0 * t.dy * t.dz);
+            atomic_add4(gg + (o111 + c) * 4, go, t.dx * t.dy * t.dz);
+            if (grot) {
+                const float4 c000 = g4[o000 + c], c100 = g4[o100 + c], c001 = g4[o001 + c], c101 = g4[o101 + c];
+                const float4 c010 = g4[o010 + c], c110 = g4[o110 + c], c011 = g4[o011 + c], c111 = g4[o111 + c];
+                const float4 c00 = lerp4(c000, c100, t.dx), c01 = lerp4(c001, c101, t.dx);
+                const float4 c10 = lerp4(c010, c110, t.dx), c11 = lerp4(c011, c111, t.dx);
+                const float4 c0 = lerp4(c00, c10, t.dy), c1 = lerp4(c01, c11, t.dy);
+                gq[2] += dot4(go, sub4(c1, c0));
+                gq[1] += dot4(go, lerp4(sub4(c10, c00), sub4(c11, c01), t.dz));
+                const float4 ex0 = lerp4(sub4(c100, c000), sub4(c110, c010), t.dy);
+                const float4 ex1 = lerp4(sub4(c101, c001), sub4(c111, c011), t.dy);
+                gq[0] += dot4(go, lerp4(ex0, ex1, t.dz));
+            }
+        }
+        if (!t.px) gq[0] = 0.f;
+        if (!t.py) gq[1] = 0.f;
+        if (!t.pz) gq[2] = 0.f;
+    }
+    if (!grot) return;
+    // block reduction of the 9 outer-product entries gq[a] * pc[b]
+    __shared__ float sh[4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            float v = gq[a] * pc[b];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+            __syncthreads();
+            if (lane == 0) sh[w] = v;
+            __syncthreads();
+            if (threadIdx.x == 0) unsafeAtomicAdd(&grot[n * 9 + a * 3 + b], sh[0] + sh[1] + sh[2] + sh[3]);
+        }
+}
+
+}  // namespace
+
+extern "C" int cn_rotate3d_fwd(const float* grid, const float* rot, float* out, int n, int g, int c, void* stream) {
+    CN_CHECK_ARG(grid && rot && out && n > 0 && g > 1 && c > 0 && c % 4 == 0, "rotate3d: bad args (c %% 4 == 0 required)");
+    const long work = (long)g * g * g * (c / 4);
+    hipLaunchKernelGGL(rotate3d_fwd_kernel, dim3(cn_cdiv(work, 256), n), dim3(256), 0, (hipStream_t)stream, grid, rot, out, g, c / 4);
+    CN_LAUNCH_CHECK();
+    return CN_OK;
+}
+
+extern "C" int cn_rotate3d_bwd(const float* grid, const float* rot, const float* gout, float* ggrid, float* grot, int n,
+                               int g, int c, void* stream) {
+    CN_CHECK_ARG(grid && rot && gout && ggrid && n > 0 && g > 1 && c > 0 && c % 4 == 0, "rotate3d_bwd: bad args");
+    hipStream_t s = (hipStream_t)stream;
+    const long P = (long)g * g * g;
+    CN_HIP(hipMemsetAsync(ggrid, 0, sizeof(float) * n * P * c, s));
+    if (grot) CN_HIP(hipMemsetAsync(grot, 0, sizeof(float) * n * 9, s));
+    hipLaunchKernelGGL(rotate3d_bwd_kernel, dim3(cn_cdiv(P, 256), n), dim3(256), 0, s, grid, rot, gout, ggrid, grot, g, c / 4);
+    CN_LAUNCH_CHECK();
+    return CN_OK;
+}

@@ -1,0 +1,300 @@
+"""Raw (non-differentiable) wrappers: torch CUDA tensors in, C-ABI call on the current HIP
+stream, torch tensors out.  torch only allocates memory and provides the stream here."""
+import ctypes
+import math
+
+import torch
+
+from ._lib import CnConvGeom, check, lib
+
+ACT_NONE, ACT_LRELU, ACT_RELU, ACT_TANH = 0, 1, 2, 3
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    assert t.is_cuda and t.dtype in (torch.float32, torch.uint8, torch.int64) and t.is_contiguous(), \
+        "confignet_amd ops need contiguous CUDA tensors (got %s %s contiguous=%s)" % (t.device, t.dtype, t.is_contiguous())
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# ---------------------------------------------------------------------------------------------
+# convolution geometry ([TF-2.1] SAME rule R2: total = max((ceil(e/s)-1)*s + k - e, 0), lo = total//2)
+# ---------------------------------------------------------------------------------------------
+class ConvSpec:
+    """Static description of one conv layer call: spatial kernel, stride, folded x2 upsample,
+    optional explicit symmetric padding (ZeroPadding2D + 'valid')."""
+
+    def __init__(self, kernel, stride=1, up=0, explicit_pad=None):
+        self.kernel = tuple(kernel)
+        self.stride, self.up, self.explicit_pad = stride, up, explicit_pad
+
+    def geom(self, x_shape, cout):
+        nd = len(self.kernel)
+        assert len(x_shape) == nd + 2
+        n, cin = x_shape[0], x_shape[-1]
+        sp = list(x_shape[1:-1])
+        ins, outs, pads = [1, 1, 1], [1, 1, 1], [0, 0, 0]
+        ks = [1, 1, 1]
+        for i in range(nd):
+            a = 3 - nd + i
+            e = sp[i] << self.up
+            k, s = self.kernel[i], self.stride
+            if self.explicit_pad is None:
+                o = -(-e // s)
+                total = max((o - 1) * s + k - e, 0)
+                lo = total // 2
+            else:
+                lo = self.explicit_pad
+                o = (e + 2 * lo - k) // s + 1
+            ins[a], outs[a], pads[a], ks[a] = sp[i], o, lo, k
+        g = CnConvGeom()
+        g.nd, g.n = nd, n
+        g.in_d, g.in_h, g.in_w, g.cin = ins[0], ins[1], ins[2], cin
+        g.out_d, g.out_h, g.out_w, g.cout = outs[0], outs[1], outs[2], cout
+        g.k_d, g.k_h, g.k_w = ks
+        s = self.stride
+        g.s_d, g.s_h, g.s_w = (s if nd == 3 else 1), s, s
+        g.dl_d = g.dl_h = g.dl_w = 1
+        g.p_d, g.p_h, g.p_w = pads
+        g.up = self.up
+        return g
+
+
+def geom_out_shape(g):
+    return (g.n, g.out_d, g.out_h, g.out_w, g.cout) if g.nd == 3 else (g.n, g.out_h, g.out_w, g.cout)
+
+
+def geom_in_shape(g, upsampled=False):
+    u = g.up if upsampled else 0
+    if g.nd == 3:
+        return (g.n, g.in_d << u, g.in_h << u, g.in_w << u, g.cin)
+    return (g.n, g.in_h << u, g.in_w << u, g.cin)
+
+
+def conv_fwd(x, w, bias, g, act=ACT_NONE, slope=0.0):
+    y = torch.empty(geom_out_shape(g), device=x.device, dtype=torch.float32)
+    check(lib.cn_conv_fwd(ctypes.byref(g), _ptr(x), _ptr(w), _ptr(bias), _ptr(y), act, slope, _stream()), "cn_conv_fwd")
+    return y
+
+
+def weight_tflip(w):
+    taps = int(math.prod(w.shape[:-2]))
+    wt = torch.empty(w.shape[:-2] + (w.shape[-1], w.shape[-2]), device=w.device, dtype=torch.float32)
+    check(lib.cn_conv_weight_tflip(_ptr(w), _ptr(wt), taps, w.shape[-2], w.shape[-1], _stream()), "cn_conv_weight_tflip")
+    return wt
+
+
+def conv_dgrad(gy, wt, g):
+    """Gradient w.r.t. the (virtually upsampled) input of the conv described by g."""
+    gu = torch.empty(geom_in_shape(g, upsampled=True), device=gy.device, dtype=torch.float32)
+    check(lib.cn_conv_dgrad(ctypes.byref(g), _ptr(gy), _ptr(wt), _ptr(gu), _stream()), "cn_conv_dgrad")
+    return gu
+
+
+def conv_wgrad(x, gy, g, w_shape):
+    gw = torch.empty(w_shape, device=x.device, dtype=torch.float32)
+    check(lib.cn_conv_wgrad(ctypes.byref(g), _ptr(x), _ptr(gy), _ptr(gw), _stream()), "cn_conv_wgrad")
+    return gw
+
+
+def sumpool2(gu):
+    nd = gu.dim() - 2
+    sp = [s // 2 for s in gu.shape[1:-1]]
+    gx = torch.empty((gu.shape[0], *sp, gu.shape[-1]), device=gu.device, dtype=torch.float32)
+    d, h, w = ([1] + sp) if nd == 2 else sp
+    check(lib.cn_sumpool2(_ptr(gu), _ptr(gx), nd, gu.shape[0], d, h, w, gu.shape[-1], _stream()), "cn_sumpool2")
+    return gx
+
+
+# ---------------------------------------------------------------------------------------------
+def gemm(a, b, trans_a=False, trans_b=False, bias=None, act=ACT_NONE, slope=0.0):
+    """C = act(op(a) @ op(b) + bias); a, b 2-D row-major."""
+    m = a.shape[1] if trans_a else a.shape[0]
+    k = a.shape[0] if trans_a else a.shape[1]
+    n = b.shape[0] if trans_b else b.shape[1]
+    kb = b.shape[1] if trans_b else b.shape[0]
+    assert k == kb, "gemm inner dims %d vs %d" % (k, kb)
+    c = torch.empty((m, n), device=a.device, dtype=torch.float32)
+    check(lib.cn_gemm(int(trans_a), int(trans_b), m, n, k, _ptr(a), a.shape[1], _ptr(b), b.shape[1], _ptr(c), n,
+                      _ptr(bias), act, slope, _stream()), "cn_gemm")
+    return c
+
+
+def _nsc(x):
+    n, c = x.shape[0], x.shape[-1]
+    return n, x.numel() // (n * c), c
+
+
+def nc_reduce(x1, x2=None, want_sum=True, want_dot=True, flags=0, slope=0.0, per_channel=False):
+    """(sum_s f1(x1), sum_s f1(x1)*f2(x2 or x1)) per (n, c); per_channel folds n into s."""
+    n, s, c = _nsc(x1)
+    if per_channel:
+        n, s = 1, n * s
+    s1 = torch.empty((n, c), device=x1.device, dtype=torch.float32) if want_sum else None
+    s2 = torch.empty((n, c), device=x1.device, dtype=torch.float32) if want_dot else None
+    check(lib.cn_nc_reduce(_ptr(x1), _ptr(x2), _ptr(s1), _ptr(s2), n, s, c, flags, slope, _stream()), "cn_nc_reduce")
+    return s1, s2
+
+
+def nc_lin2(shape, x1=None, a1=None, x2=None, a2=None, b=None, flags=0, slope=0.0, per_channel=False):
+    """y = a1*f1(x1) + a2*f2(x2) + b with (n,c) [or (c,)] coefficients broadcast over space."""
+    n, c = shape[0], shape[-1]
+    s = int(math.prod(shape)) // (n * c)
+    ref = x1 if x1 is not None else (x2 if x2 is not None else b)
+    y = torch.empty(shape, device=ref.device, dtype=torch.float32)
+    check(lib.cn_nc_lin2(_ptr(x1), _ptr(a1), _ptr(x2), _ptr(a2), _ptr(b), _ptr(y), n, s, c, 0 if per_channel else c,
+                         flags, slope, _stream()), "cn_nc_lin2")
+    return y
+
+
+def act_fwd(x, act, slope=0.0):
+    y = torch.empty_like(x)
+    check(lib.cn_act_fwd(_ptr(x), _ptr(y), x.numel(), act, slope, _stream()), "cn_act_fwd")
+    return y
+
+
+def act_bwd(gy, y, act, slope=0.0):
+    gx = torch.empty_like(gy)
+    check(lib.cn_act_bwd(_ptr(gy), _ptr(y), _ptr(gx), gy.numel(), act, slope, _stream()), "cn_act_bwd")
+    return gx
+
+
+def axpby(x, y, a, b):
+    out = torch.empty_like(x)
+    check(lib.cn_axpby(_ptr(x), _ptr(y), _ptr(out), x.numel(), a, b, _stream()), "cn_axpby")
+    return out
+
+
+def mul(x, y):
+    out = torch.empty_like(x)
+    check(lib.cn_mul(_ptr(x), _ptr(y), _ptr(out), x.numel(), _stream()), "cn_mul")
+    return out
+
+
+def sqdiff_sum(a, b, scale):
+    out = torch.zeros((1,), device=a.device, dtype=torch.float32)
+    check(lib.cn_sqdiff_sum(_ptr(a), _ptr(b), _ptr(out), a.numel(), scale, _stream()), "cn_sqdiff_sum")
+    return out
+
+
+def row_sumsq(x):
+    n = x.shape[0]
+    out = torch.empty((n,), device=x.device, dtype=torch.float32)
+    check(lib.cn_row_sumsq(_ptr(x), _ptr(out), n, x.numel() // n, _stream()), "cn_row_sumsq")
+    return out
+
+
+def row_scale(x, s, k):
+    out = torch.empty_like(x)
+    check(lib.cn_row_scale(_ptr(x), _ptr(s), _ptr(out), x.shape[0], x.numel() // x.shape[0], k, _stream()), "cn_row_scale")
+    return out
+
+
+def masked_diff(a, b, mask):
+    out = torch.empty_like(a)
+    check(lib.cn_masked_diff(_ptr(a), _ptr(b), _ptr(mask), _ptr(out), mask.numel(), a.shape[-1], _stream()), "cn_masked_diff")
+    return out
+
+
+def maxpool_fwd(x, k, s, pad):
+    n, h, w, c = x.shape
+    oh, ow = (h + 2 * pad - k) // s + 1, (w + 2 * pad - k) // s + 1
+    y = torch.empty((n, oh, ow, c), device=x.device, dtype=torch.float32)
+    check(lib.cn_maxpool_fwd(_ptr(x), _ptr(y), n, h, w, c, k, s, pad, _stream()), "cn_maxpool_fwd")
+    return y
+
+
+def maxpool_bwd(x, gy, k, s, pad):
+    n, h, w, c = x.shape
+    gx = torch.empty_like(x)
+    check(lib.cn_maxpool_bwd(_ptr(x), _ptr(gy), _ptr(gx), n, h, w, c, k, s, pad, _stream()), "cn_maxpool_bwd")
+    return gx
+
+
+def chan_affine3_fwd(x, perm, scale, off):
+    y = torch.empty_like(x)
+    check(lib.cn_chan_affine3_fwd(_ptr(x), _ptr(y), x.numel() // 3, (ctypes.c_int * 3)(*perm), scale,
+                                  (ctypes.c_float * 3)(*off), _stream()), "cn_chan_affine3_fwd")
+    return y
+
+
+def chan_affine3_bwd(gy, perm, scale):
+    gx = torch.empty_like(gy)
+    check(lib.cn_chan_affine3_bwd(_ptr(gy), _ptr(gx), gy.numel() // 3, (ctypes.c_int * 3)(*perm), scale, _stream()),
+          "cn_chan_affine3_bwd")
+    return gx
+
+
+def gan_loss_fwd(s, label):
+    out = torch.empty((1,), device=s.device, dtype=torch.float32)
+    check(lib.cn_gan_loss_fwd(_ptr(s), _ptr(out), s.numel(), label, _stream()), "cn_gan_loss_fwd")
+    return out
+
+
+def gan_loss_bwd(s, gout, label):
+    gs = torch.empty_like(s)
+    check(lib.cn_gan_loss_bwd(_ptr(s), _ptr(gout), _ptr(gs), s.numel(), label, _stream()), "cn_gan_loss_bwd")
+    return gs
+
+
+def rotate3d_fwd(grid, rot):
+    out = torch.empty_like(grid)
+    n, g, c = grid.shape[0], grid.shape[1], grid.shape[-1]
+    check(lib.cn_rotate3d_fwd(_ptr(grid), _ptr(rot), _ptr(out), n, g, c, _stream()), "cn_rotate3d_fwd")
+    return out
+
+
+def rotate3d_bwd(grid, rot, gout, need_rot):
+    n, g, c = grid.shape[0], grid.shape[1], grid.shape[-1]
+    ggrid = torch.empty_like(grid)
+    grot = torch.empty((n, 3, 3), device=grid.device, dtype=torch.float32) if need_rot else None
+    check(lib.cn_rotate3d_bwd(_ptr(grid), _ptr(rot), _ptr(gout), _ptr(ggrid), _ptr(grot), n, g, c, _stream()),
+          "cn_rotate3d_bwd")
+    return ggrid, grot
+
+
+def adam_step(theta, grad, m, v, ema, lr_t, beta1, beta2, eps, ema_alpha=0.999):
+    check(lib.cn_adam_step(_ptr(theta), _ptr(grad), _ptr(m), _ptr(v), _ptr(ema), theta.numel(), lr_t, beta1, beta2,
+                           eps, ema_alpha, _stream()), "cn_adam_step")
+
+
+def ema_step(ema, theta, alpha):
+    check(lib.cn_ema_step(_ptr(ema), _ptr(theta), theta.numel(), alpha, _stream()), "cn_ema_step")
+
+
+def gather_images_u8(pool, idx, flip):
+    n = idx.numel()
+    _, h, w, c = pool.shape
+    out = torch.empty((n, h, w, c), device=pool.device, dtype=torch.float32)
+    check(lib.cn_gather_images_u8(_ptr(pool), _ptr(idx), _ptr(flip), _ptr(out), n, h, w, c, _stream()),
+          "cn_gather_images_u8")
+    return out
+
+
+def to_uint8(x):
+    out = torch.empty(x.shape, device=x.device, dtype=torch.uint8)
+    check(lib.cn_to_uint8(_ptr(x), _ptr(out), x.numel(), _stream()), "cn_to_uint8")
+    return out
+
+
+def prof_enable(on):
+    check(lib.cn_prof_enable(int(on)), "cn_prof_enable")
+
+
+def prof_reset():
+    check(lib.cn_prof_reset(), "cn_prof_reset")
+
+
+def prof_collect():
+    n, ms, fl = ctypes.c_int(0), ctypes.c_double(0), ctypes.c_double(0)
+    check(lib.cn_prof_collect(ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl)), "cn_prof_collect")
+    return n.value, ms.value, fl.value

@@ -1,0 +1,146 @@
+/* confignet_hip.h -- C ABI of libconfignet_hip.so (MI355X / gfx950 only).
+ *
+ * The reference (microsoft/ConfigNet) has no FFI boundary: its per-layer arithmetic is
+ * reached through tensorflow.keras calls (tensorflow-gpu==2.1.0).  Each entry point below
+ * replaces the TF op(s) issued by the cited reference line(s); paths are relative to the
+ * reference root.  All pointers are DEVICE pointers owned by the caller, fp32, channels-last
+ * (N, [D,] H, W, C); kernels use the Keras layouts (kd,kh,kw,cin,cout) / Dense (in,out).
+ * Every call enqueues on `stream` (a hipStream_t passed as void*) and returns 0 on success
+ * or a negative CN_E* code; cn_last_error_string() describes the last failure of the
+ * calling thread.  No exceptions cross the ABI.  No global state except a profiling event
+ * pool (cn_prof_*).
+ */
+#ifndef CONFIGNET_HIP_H
+#define CONFIGNET_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CN_OK 0
+#define CN_EINVAL (-1)   /* bad argument / unsupported geometry */
+#define CN_EHIP (-2)     /* HIP runtime error */
+
+/* activation codes for fused epilogues */
+#define CN_ACT_NONE 0
+#define CN_ACT_LRELU 1   /* keras LeakyReLU(alpha) / tf.nn.leaky_relu */
+#define CN_ACT_RELU 2
+#define CN_ACT_TANH 3
+
+/* Geometry of one N-d convolution read as an implicit GEMM.  2-D uses nd=2, *_d = 1 (k_d=1,
+ * s_d=1, dl_d=1, p_d=0).  Output position o, tap k reads v = o*s - p + k of the (virtually
+ * x2-upsampled when up=1) input; it is valid iff 0 <= v, v % dl == 0, v/dl < (in << up);
+ * the stored element is (v/dl) >> up.  dl > 1 expresses the data-gradient of a strided
+ * convolution; up=1 folds keras UpSampling2D/3D (hologan_generator.py:139,143,160-170)
+ * into the gather. */
+typedef struct CnConvGeom {
+    int nd, n;
+    int in_d, in_h, in_w, cin;      /* stored input extent */
+    int out_d, out_h, out_w, cout;
+    int k_d, k_h, k_w;
+    int s_d, s_h, s_w;
+    int dl_d, dl_h, dl_w;
+    int p_d, p_h, p_w;              /* low-side padding ([TF-2.1] SAME: total//2) */
+    int up;
+} CnConvGeom;
+
+const char* cn_last_error_string(void);
+int cn_version(void);
+
+/* ---- convolution family (implicit GEMM on v_mfma_f32_32x32x2_f32) -------------------------
+ * Replaces keras.layers.Conv3D/Conv2D forward (+bias +activation):
+ *   building_blocks.py:29,65,91 ; hologan_generator.py:50-56,101 ; hologan_discriminator.py:20,77 ;
+ *   keras.applications VGG19/VGG16/ResNet50 convs (perceptual_loss.py:19,35 ; real_encoder.py:13). */
+int cn_conv_fwd(const CnConvGeom* g, const float* x, const float* w, const float* bias,
+                float* y, int act, float slope, void* stream);
+/* w_tflip[T-1-t][co][ci] = w[t][ci][co]: the operand of the data-gradient GEMM. */
+int cn_conv_weight_tflip(const float* w, float* w_tflip, int taps, int cin, int cout, void* stream);
+/* Data gradient of cn_conv_fwd(g) w.r.t. its (virtually upsampled) input: gu has extent
+ * (in << up).  Replaces the Conv*DBackpropInput ops tf.GradientTape issues
+ * (confignet_first_stage.py:473,485,557 ; losses.py:76). */
+int cn_conv_dgrad(const CnConvGeom* g, const float* gy, const float* w_tflip, float* gu, void* stream);
+/* Filter gradient (Conv*DBackpropFilter): gw[(t,ci),co] = sum_m x[src(m,t),ci]*gy[m,co]; gw is
+ * overwritten. */
+int cn_conv_wgrad(const CnConvGeom* g, const float* x, const float* gy, float* gw, void* stream);
+/* Backward of the folded nearest x2 upsample: out[n,p,c] = sum of the 2^nd children of p. */
+int cn_sumpool2(const float* gu, float* gx, int nd, int n, int d, int h, int w, int c, void* stream);
+
+/* ---- dense GEMM: C = act(op(A) op(B) + bias) (keras Dense: building_blocks.py:152-173,
+ * hologan_discriminator.py:34,46,97 ; real_encoder.py:16,18 ; latent_gan.py:88-109) ---------*/
+int cn_gemm(int trans_a, int trans_b, int m, int n, int k, const float* a, int lda,
+            const float* b, int ldb, float* c, int ldc, const float* bias, int act, float slope,
+            void* stream);
+
+/* ---- per-(sample,channel) statistics and affine maps on (N, S, C) tensors ------------------
+ * Building blocks of LayerNormalization/AdaIn (building_blocks.py:132-144), InstanceNormalization
+ * (instance_normalization.py:108-131), get_layer_style (confignet_utils.py:147-159), BN inference
+ * (keras ResNet50), global average pooling and every bias gradient.
+ *   a = f1(x1), b = x2 ? f2(x2) : a ;  sum1[n,c] = sum_s a ; sum2[n,c] = sum_s a*b
+ *   flags: bit0 leaky-relu(slope) on x1, bit1 leaky-relu(slope) on x2.  Outputs are overwritten. */
+int cn_nc_reduce(const float* x1, const float* x2, float* sum1, float* sum2, int n, int s, int c,
+                 int flags, float slope, void* stream);
+/* y = A1*f1(x1) + A2*f2(x2) + B, coefficient tensors indexed [n*cstride + c] (cstride = c, or 0 for
+ * per-channel coefficients).  flags: bit0/bit1 as above, bit2: multiply the result by lrelu'(x2),
+ * bit3: relu on the result.  x1/A1, x2/A2 and B are each optional (NULL). */
+int cn_nc_lin2(const float* x1, const float* a1, const float* x2, const float* a2, const float* bb,
+               float* y, int n, int s, int c, int cstride, int flags, float slope, void* stream);
+
+/* ---- elementwise / small ops ------------------------------------------------------------------*/
+int cn_act_fwd(const float* x, float* y, size_t numel, int act, float slope, void* stream);
+/* gx = gy * act'(.) evaluated from the activation OUTPUT (lrelu/relu: sign of y; tanh: 1-y^2). */
+int cn_act_bwd(const float* gy, const float* y, float* gx, size_t numel, int act, float slope, void* stream);
+int cn_axpby(const float* x, const float* y, float* out, size_t numel, float a, float b, void* stream);
+int cn_mul(const float* x, const float* y, float* out, size_t numel, void* stream);
+/* out[0] += scale * sum (a-b)^2  (perceptual_loss.py:74-80); out must be initialised by the caller */
+int cn_sqdiff_sum(const float* a, const float* b, float* out, size_t numel, float scale, void* stream);
+/* out[n] = sum_row x^2 (R1: losses.py:77-79 ; eye loss: losses.py:16) */
+int cn_row_sumsq(const float* x, float* out, int n, size_t row, void* stream);
+/* out[n,:] = x[n,:] * s[n] * k */
+int cn_row_scale(const float* x, const float* s, float* out, int n, size_t row, float k, void* stream);
+/* out = (a - b) * mask[n,h,w] broadcast over c (b optional) (losses.py:14) */
+int cn_masked_diff(const float* a, const float* b, const uint8_t* mask, float* out, size_t pixels, int c, void* stream);
+/* 2-D max pooling, zero padding (keras MaxPooling2D after ZeroPadding2D) */
+int cn_maxpool_fwd(const float* x, float* y, int n, int h, int w, int c, int k, int s, int pad, void* stream);
+int cn_maxpool_bwd(const float* x, const float* gy, float* gx, int n, int h, int w, int c, int k, int s, int pad, void* stream);
+/* y[...,j] = scale * x[...,perm[j]] + off[j] on 3-channel images: (x+1)*127.5 + "caffe"/VGGFace
+ * preprocessing (perceptual_loss.py:52-61 ; real_encoder.py:24-25); bwd scatters back. */
+int cn_chan_affine3_fwd(const float* x, float* y, size_t pixels, const int* perm, float scale, const float* off, void* stream);
+int cn_chan_affine3_bwd(const float* gy, float* gx, size_t pixels, const int* perm, float scale, void* stream);
+/* softplus means of losses.py:7-11 on (n) scores: out[0] = mean(l*softplus(-s) + (1-l)*softplus(s)),
+ * label l constant; bwd: gs = gout * (-(l)*sigmoid(-s) + (1-l)*sigmoid(s)) / n */
+int cn_gan_loss_fwd(const float* s, float* out, int n, float label, void* stream);
+int cn_gan_loss_bwd(const float* s, const float* gout, float* gs, int n, float label, void* stream);
+
+/* ---- 3-D rigid resample (confignet_utils.py:63-120): trilinear, clamp to edge ---------------*/
+int cn_rotate3d_fwd(const float* grid, const float* rot /* (N,3,3) */, float* out, int n, int g, int c, void* stream);
+/* ggrid (overwritten) and grot (N,3,3) (overwritten; through `diffs` only, l.105) */
+int cn_rotate3d_bwd(const float* grid, const float* rot, const float* gout, float* ggrid, float* grot,
+                    int n, int g, int c, void* stream);
+
+/* ---- optimizer: Keras Adam + EMA in one pass (confignet_first_stage.py:393-400,601-602) -----
+ * theta -= lr_t * m/(sqrt(v)+eps) with lr_t supplied by the host (shared step counter rule);
+ * if ema != NULL: ema = ema_alpha*ema + (1-ema_alpha)*theta_new. */
+int cn_adam_step(float* theta, const float* grad, float* m, float* v, float* ema, size_t numel,
+                 float lr_t, float beta1, float beta2, float eps, float ema_alpha, void* stream);
+int cn_ema_step(float* ema, const float* theta, size_t numel, float alpha, void* stream);
+
+/* ---- data path: batch assembly on device (confignet_first_stage.py:438-450 ;
+ * confignet_utils.py:198-204): out[i] = flip?(pool[idx[i]]) / 127.5 - 1 ----------------------*/
+int cn_gather_images_u8(const uint8_t* pool, const int64_t* idx, const uint8_t* flip, float* out,
+                        int n, int h, int w, int c, void* stream);
+/* uint8 image from generator output: clip(-1,1), (x+1)*127.5 (confignet_first_stage.py:636-637) */
+int cn_to_uint8(const float* x, uint8_t* out, size_t numel, void* stream);
+
+/* ---- profiling of the dominant kernel class (implicit-GEMM convolutions) with HIP events
+ * recorded on the launch stream (bench.py roofline object) -----------------------------------*/
+int cn_prof_enable(int on);
+int cn_prof_reset(void);
+/* synchronises the recorded events; returns launches, summed kernel ms and algorithmic flops */
+int cn_prof_collect(int* launches, double* total_ms, double* total_flops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CONFIGNET_HIP_H */

@@ -1,0 +1,45 @@
+"""CPU checks of the drop-in boundary: the C-ABI library loads and exports every symbol
+include/confignet_hip.h declares (no compute calls without a GPU)."""
+import ctypes
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "confignet_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(cn_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from confignet_amd import _lib
+    names = _declared()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(_lib.lib, n), "libconfignet_hip.so does not export %s" % n
+    assert _lib.lib.cn_version() >= 1
+    # every declared int-returning function has a ctypes signature (binding == header)
+    assert set(_lib.SIGNATURES) | {"cn_last_error_string"} == set(names)
+
+
+def test_bad_arguments_return_error_codes_not_crashes():
+    from confignet_amd import _lib
+    g = _lib.CnConvGeom()
+    rc = _lib.lib.cn_conv_fwd(ctypes.byref(g), None, None, None, None, 0, 0.0, None)
+    assert rc == -1
+    assert b"nd must be" in _lib.lib.cn_last_error_string()
+    assert _lib.lib.cn_gemm(0, 0, 0, 1, 1, None, 1, None, 1, None, 1, None, 0, 0.0, None) == -1
+
+
+def test_geometry_same_padding_rules():
+    from confignet_amd.ops import ConvSpec
+    g = ConvSpec((4, 4), up=1).geom((2, 16, 16, 64), 32)
+    assert (g.out_h, g.out_w, g.p_h, g.p_w, g.up) == (32, 32, 1, 1, 1)
+    g = ConvSpec((3, 3), stride=2).geom((2, 256, 256, 3), 48)
+    assert (g.out_h, g.p_h, g.s_h) == (128, 0, 2)
+    g = ConvSpec((3, 3, 3), up=1).geom((2, 4, 4, 4, 512), 256)
+    assert (g.out_d, g.out_h, g.out_w, g.p_d) == (8, 8, 8, 1)
+    g = ConvSpec((7, 7), stride=2, explicit_pad=3).geom((1, 256, 256, 3), 64)
+    assert (g.out_h, g.p_h) == (128, 3)

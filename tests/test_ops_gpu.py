@@ -1,0 +1,240 @@
+"""GPU parity of the raw HIP ops (through the C ABI) against the CPU oracle (float64)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import ref_ops as O
+
+
+def dev(a):
+    return torch.as_tensor(np.asarray(a, dtype=np.float32)).cuda().contiguous()
+
+
+def t64(a):
+    return torch.tensor(np.asarray(a), dtype=torch.float64)
+
+
+def close(got, ref, tol=2e-4, what=""):
+    got = got.detach().cpu().double().numpy()
+    ref = ref.detach().double().numpy() if torch.is_tensor(ref) else np.asarray(ref, np.float64)
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    scale = max(1.0, np.abs(ref).max())
+    err = np.abs(got - ref).max()
+    assert err <= tol * scale, "%s: max abs err %.3e (scale %.3e)" % (what, err, scale)
+
+
+CONV_CASES = [
+    # (x shape, kernel, cout, stride, up, explicit_pad, act, slope)
+    ((2, 16, 16, 64), (4, 4), 32, 1, 1, None, 1, 0.3),        # k4 + folded upsample, 128x32 tile
+    ((2, 16, 16, 512), (4, 4), 256, 1, 0, None, 1, 0.3),      # map_2d_0
+    ((2, 4, 4, 4, 512), (3, 3, 3), 256, 1, 1, None, 1, 0.3),  # map_3d_0 with folded upsample
+    ((1, 8, 8, 8, 64), (3, 3, 3), 64, 1, 0, None, 1, 0.3),    # map_3d_post
+    ((3, 16, 16, 1024), (1, 1), 512, 1, 0, None, 1, 0.2),     # projection conv
+    ((2, 64, 64, 3), (3, 3), 48, 2, 0, None, 0, 0.0),         # D block 0 (scalar gather, stride 2)
+    ((2, 32, 32, 48), (3, 3), 96, 2, 0, None, 0, 0.0),        # D block 1
+    ((2, 17, 13, 48), (3, 3), 96, 2, 0, None, 0, 0.0),        # ragged odd extents
+    ((2, 32, 32, 3), (3, 3), 64, 1, 0, None, 2, 0.0),         # VGG conv1_1 + relu
+    ((1, 64, 64, 3), (7, 7), 64, 2, 0, 3, 0, 0.0),            # ResNet conv1 (pad 3, valid)
+    ((2, 32, 32, 32), (4, 4), 3, 1, 1, None, 3, 0.0),         # map_final: thin cout + tanh + upsample
+    ((2, 32, 32, 3), (1, 1), 3, 1, 0, None, 0, 0.0),          # from-RGB 1x1
+    ((4, 8, 8, 256), (3, 3), 512, 1, 0, None, 2, 0.0),        # VGG block4 shape, 64x64 tiles
+    ((1, 8, 8, 128), (1, 1), 512, 2, 0, None, 0, 0.0),        # ResNet strided 1x1
+]
+
+
+def _oracle_conv(x, w, b, stride, up, explicit_pad, act, slope):
+    if up:
+        x = O.upsample2(x)
+    if explicit_pad is not None:
+        y = O.conv_valid_padded(x, w, b, stride, explicit_pad)
+    else:
+        y = O.conv_same(x, w, b, stride=stride)
+    if act == 1:
+        y = O.leaky_relu(y, slope)
+    elif act == 2:
+        y = torch.relu(y)
+    elif act == 3:
+        y = torch.tanh(y)
+    return y
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[str(i) for i in range(len(CONV_CASES))])
+def test_conv_fwd_dgrad_wgrad(case):
+    from confignet_amd import ops
+    xs, k, cout, stride, up, epad, act, slope = case
+    rng = np.random.default_rng(hash(case) % 2 ** 31)
+    cin = xs[-1]
+    x = rng.normal(size=xs)
+    w = rng.normal(size=(*k, cin, cout)) / math.sqrt(np.prod(k) * cin)
+    b = rng.normal(size=cout)
+    spec = ops.ConvSpec(k, stride=stride, up=up, explicit_pad=epad)
+    g = spec.geom(xs, cout)
+    y = ops.conv_fwd(dev(x), dev(w), dev(b), g, act, slope)
+    xr = t64(x).requires_grad_(True)
+    wr = t64(w).requires_grad_(True)
+    # reference on the upsampled tensor so dgrad can be compared at the upsampled extent
+    xu = O.upsample2(xr) if up else xr
+    xu.retain_grad()
+    yr = _oracle_conv(xu, wr, t64(b), stride, 0, epad, act, slope)
+    close(y, yr, what="fwd")
+    # backward of the pre-activation (act none) for dgrad / wgrad
+    yr0 = _oracle_conv(xu, wr, None, stride, 0, epad, 0, 0.0)
+    gy = rng.normal(size=tuple(yr0.shape))
+    (yr0 * t64(gy)).sum().backward()
+    gu = ops.conv_dgrad(dev(gy), ops.weight_tflip(dev(w)), g)
+    close(gu, xu.grad, what="dgrad")
+    if up:
+        close(ops.sumpool2(gu), xr.grad, what="sumpool2(dgrad)")
+    gw = ops.conv_wgrad(dev(x), dev(gy), g, tuple(w.shape))
+    close(gw, wr.grad, tol=5e-4, what="wgrad")
+
+
+@pytest.mark.parametrize("m,n,k,ta,tb", [(16, 148, 32768, 0, 0), (16, 1, 32768, 0, 0), (8, 145, 145, 0, 0), (4096, 217, 145, 0, 0),
+                                         (16, 32768, 148, 0, 1), (32768, 148, 16, 1, 0), (7, 5, 3, 1, 1), (130, 70, 33, 0, 1)])
+def test_gemm(m, n, k, ta, tb):
+    from confignet_amd import ops
+    rng = np.random.default_rng(m * 7 + n)
+    a = rng.normal(size=(k, m) if ta else (m, k))
+    b = rng.normal(size=(n, k) if tb else (k, n)) / math.sqrt(k)
+    bias = rng.normal(size=n)
+    ref = (t64(a).T if ta else t64(a)) @ (t64(b).T if tb else t64(b)) + t64(bias)
+    close(ops.gemm(dev(a), dev(b), bool(ta), bool(tb), dev(bias)), ref, what="gemm")
+    if k < 1000:
+        close(ops.gemm(dev(a), dev(b), bool(ta), bool(tb), dev(bias), act=1, slope=0.3), O.leaky_relu(ref, 0.3), what="gemm+lrelu")
+
+
+@pytest.mark.parametrize("shape", [(2, 16, 16, 48), (3, 8, 8, 8, 128), (2, 128, 128, 32), (2, 5, 7, 3), (4, 1, 1, 2048)])
+def test_nc_reduce_and_lin2(shape):
+    from confignet_amd import ops
+    rng = np.random.default_rng(sum(shape))
+    x1, x2 = rng.normal(size=shape), rng.normal(size=shape)
+    n, c = shape[0], shape[-1]
+    axes = tuple(range(1, len(shape) - 1))
+    s1, s2 = ops.nc_reduce(dev(x1), dev(x2))
+    close(s1, t64(x1).sum(dim=axes), tol=1e-4, what="sum")
+    close(s2, (t64(x1) * t64(x2)).sum(dim=axes), tol=1e-4, what="dot")
+    s1, s2 = ops.nc_reduce(dev(x1), None, flags=1, slope=0.3)
+    a = O.leaky_relu(t64(x1), 0.3)
+    close(s1, a.sum(dim=axes), tol=1e-4, what="sum lrelu")
+    close(s2, (a * a).sum(dim=axes), tol=1e-4, what="sumsq lrelu")
+    s1, _ = ops.nc_reduce(dev(x1), None, want_dot=False, per_channel=True)
+    close(s1, t64(x1).sum(dim=(0,) + axes).reshape(1, c), tol=1e-4, what="colsum")
+    A1, A2, B = rng.normal(size=(n, c)), rng.normal(size=(n, c)), rng.normal(size=(n, c))
+    bc = lambda v: t64(v).reshape(n, *([1] * len(axes)), c)
+    y = ops.nc_lin2(shape, dev(x1), dev(A1), dev(x2), dev(A2), dev(B))
+    close(y, bc(A1) * t64(x1) + bc(A2) * t64(x2) + bc(B), what="lin2")
+    y = ops.nc_lin2(shape, dev(x1), dev(A1), dev(x2), dev(A2), dev(B), flags=2 | 4, slope=0.3)
+    ref = (bc(A1) * t64(x1) + bc(A2) * O.leaky_relu(t64(x2), 0.3) + bc(B)) * torch.where(t64(x2) > 0, 1.0, 0.3)
+    close(y, ref, what="lin2 flags")
+    y = ops.nc_lin2(shape, dev(x1), dev(A1[0]), None, None, dev(B[0]), flags=8, per_channel=True)
+    close(y, torch.relu(t64(A1[0]) * t64(x1) + t64(B[0])), what="lin2 per-channel relu")
+    y = ops.nc_lin2(shape, None, None, None, None, dev(B))
+    close(y, bc(B).expand(shape), what="lin2 broadcast")
+
+
+def test_elementwise_and_losses():
+    from confignet_amd import ops
+    rng = np.random.default_rng(5)
+    x, y = rng.normal(size=(3, 9, 11, 5)), rng.normal(size=(3, 9, 11, 5))
+    for act, f in [(1, lambda v: O.leaky_relu(v, 0.3)), (2, torch.relu), (3, torch.tanh)]:
+        out = ops.act_fwd(dev(x), act, 0.3)
+        close(out, f(t64(x)), what="act")
+        xr = t64(x).requires_grad_(True)
+        (f(xr) * t64(y)).sum().backward()
+        close(ops.act_bwd(dev(y), out, act, 0.3), xr.grad, what="act_bwd")
+    close(ops.axpby(dev(x), dev(y), 2.0, -0.5), 2 * t64(x) - 0.5 * t64(y))
+    close(ops.mul(dev(x), dev(y)), t64(x) * t64(y))
+    close(ops.sqdiff_sum(dev(x), dev(y), 0.25), (0.25 * ((t64(x) - t64(y)) ** 2).sum()).reshape(1), tol=1e-4)
+    close(ops.row_sumsq(dev(x)), (t64(x) ** 2).reshape(3, -1).sum(1), tol=1e-4)
+    s = rng.normal(size=3)
+    close(ops.row_scale(dev(x), dev(s), 2.0), t64(x) * 2.0 * t64(s).reshape(3, 1, 1, 1))
+    mask = (rng.uniform(size=(3, 9, 11)) > 0.5).astype(np.uint8)
+    close(ops.masked_diff(dev(x), dev(y), torch.as_tensor(mask).cuda()), (t64(x) - t64(y)) * t64(mask).unsqueeze(-1))
+    sc = rng.normal(size=(16, 1)) * 3
+    for label in (0.0, 1.0):
+        sr = t64(sc).requires_grad_(True)
+        ref = O.gan_d_loss(torch.full((16, 1), label, dtype=torch.float64), sr)
+        close(ops.gan_loss_fwd(dev(sc), label), ref.reshape(1), tol=1e-5)
+        ref.backward()
+        close(ops.gan_loss_bwd(dev(sc), dev([1.0]), label), sr.grad, tol=1e-5)
+
+
+def test_pools_preproc_uint8():
+    from confignet_amd import ops
+    rng = np.random.default_rng(6)
+    x = rng.normal(size=(2, 16, 16, 8))
+    for k, s, pad in [(2, 2, 0), (3, 2, 1)]:
+        xr = t64(np.maximum(x, 0) if pad else x).requires_grad_(True)
+        ref = O.maxpool(xr, k, s, pad)
+        close(ops.maxpool_fwd(dev(xr.detach().numpy()), k, s, pad), ref, what="maxpool")
+        gy = rng.normal(size=tuple(ref.shape))
+        (ref * t64(gy)).sum().backward()
+        close(ops.maxpool_bwd(dev(xr.detach().numpy()), dev(gy), k, s, pad), xr.grad, what="maxpool_bwd")
+    img = rng.uniform(-1, 1, size=(2, 8, 8, 3))
+    close(ops.chan_affine3_fwd(dev(img), (2, 1, 0), 127.5, (127.5 - 103.939, 127.5 - 116.779, 127.5 - 123.68)),
+          O.caffe_preprocess(t64(img)), tol=1e-5)
+    close(ops.chan_affine3_fwd(dev(img), (0, 1, 2), 127.5, (127.5 - 93.5940, 127.5 - 104.7624, 127.5 - 129.1863)),
+          O.vggface_preprocess(t64(img)), tol=1e-5)
+    ir = t64(img).requires_grad_(True)
+    gy = rng.normal(size=img.shape)
+    (O.caffe_preprocess(ir) * t64(gy)).sum().backward()
+    close(ops.chan_affine3_bwd(dev(gy), (2, 1, 0), 127.5), ir.grad, tol=1e-5)
+    big = rng.uniform(-1.3, 1.3, size=(2, 8, 8, 3)).astype(np.float32)
+    ref = ((np.clip(big, -1.0, 1.0) + 1) * 127.5).astype(np.uint8)
+    got = ops.to_uint8(dev(big)).cpu().numpy()
+    assert np.abs(got.astype(int) - ref.astype(int)).max() <= 1 and (got != ref).mean() < 1e-2
+    pool = rng.integers(0, 256, size=(10, 8, 8, 3), dtype=np.uint8)
+    idx = np.array([3, 9, 0, 3])
+    flip = np.array([0, 1, 1, 0], dtype=np.uint8)
+    out = ops.gather_images_u8(torch.as_tensor(pool).cuda(), torch.as_tensor(idx).cuda(), torch.as_tensor(flip).cuda())
+    ref = pool[idx].astype(np.float32) / 127.5 - 1.0
+    for i in range(4):
+        if flip[i]:
+            ref[i] = np.fliplr(ref[i])
+    np.testing.assert_allclose(out.cpu().numpy(), ref, atol=1e-6)
+
+
+@pytest.mark.parametrize("g,c,n", [(4, 8, 2), (16, 128, 2)])
+def test_rotate3d(g, c, n):
+    from confignet_amd import ops
+    rng = np.random.default_rng(g)
+    grid = rng.normal(size=(n, g, g, g, c))
+    ang = rng.uniform(-0.5, 0.5, size=(n, 3))
+    ang[:, 2] = 0
+    gr = t64(grid).requires_grad_(True)
+    ar = t64(ang).requires_grad_(True)
+    Rm = O.euler_angles_to_matrix(ar)
+    Rm.retain_grad()
+    ref = O.transform_3d_grid(gr, Rm)
+    out = ops.rotate3d_fwd(dev(grid), dev(Rm.detach().numpy()))
+    close(out, ref, tol=2e-4, what="rotate fwd")
+    gout = rng.normal(size=grid.shape)
+    (ref * t64(gout)).sum().backward()
+    gg, grot = ops.rotate3d_bwd(dev(grid), dev(Rm.detach().numpy()), dev(gout), True)
+    close(gg, gr.grad, tol=5e-4, what="rotate ggrid")
+    close(grot, Rm.grad, tol=2e-3, what="rotate grot")
+    # identity rotation is an exact identity
+    eye = torch.eye(3).expand(n, 3, 3).contiguous().cuda()
+    assert torch.equal(ops.rotate3d_fwd(dev(grid), eye), dev(grid))
+
+
+def test_adam_ema():
+    from confignet_amd import ops
+    rng = np.random.default_rng(9)
+    th, g = rng.normal(size=1000), rng.normal(size=1000)
+    p = t64(th).clone()
+    opt = O.KerasAdam(lr=4e-4, beta_1=0.0, beta_2=0.9)
+    dth, m, v, ema = dev(th), torch.zeros(1000).cuda(), torch.zeros(1000).cuda(), dev(th)
+    ema_ref = t64(th).clone()
+    for t in range(1, 5):
+        gt = g * t
+        opt.apply_gradients([(t64(gt), p)])
+        ema_ref = 0.999 * ema_ref + 0.001 * p
+        lr_t = 4e-4 * math.sqrt(1 - 0.9 ** t) / (1 - 0.0 ** t)
+        ops.adam_step(dth, dev(gt), m, v, ema, lr_t, 0.0, 0.9, 1e-7, 0.999)
+    close(dth, p, tol=1e-6)
+    close(ema, ema_ref, tol=1e-6)
