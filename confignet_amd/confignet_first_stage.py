@@ -1,0 +1,444 @@
+"""ConfigNetFirstStage (reference: confignet/confignet_first_stage.py): same config dict, attributes,
+step functions, persistence format and inference API, with every network on HIP kernels.
+
+Out of scope here: FID/KID/controllability metrics, image-grid checkpoints,
+TensorBoard/AzureML logging.  `train()` keeps the reference's iteration structure and timing."""
+import contextlib
+import json
+import os
+import pickle
+import time
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import confignet_utils, ops, optim
+from .dnn_models.building_blocks import MLPSimple
+from .dnn_models.hologan_discriminator import HologanDiscriminator, HologanLatentRegressor
+from .dnn_models.hologan_generator import HologanGenerator
+from .dnn_models.synthetic_encoder import SyntheticDataEncoder
+from .losses import (GAN_G_loss, compute_discriminator_loss, compute_latent_discriminator_loss,
+                     compute_latent_regression_loss, eye_loss)
+from .nn import require_gpu
+from .perceptual_loss import PerceptualLoss
+
+DEFAULT_CONFIG = {
+    "model_type": None,
+    "latent_dim": 128,
+    "output_shape": (128, 128, 3),
+    "const_input_shape": (4, 4, 4, 512),
+    "n_adain_mlp_layers": 2,
+    "n_adain_mlp_units": 128,
+    "gen_output_activation": "tanh",
+    "n_discr_features_at_layer_0": 48,
+    "max_discr_filters": 512,
+    "n_discr_layers": 5,
+    "discr_conv_kernel_size": 3,
+    "latent_regression_weight": 10.0,
+    "use_style_discriminator": True,
+    "rotation_ranges": ((-30, 30), (-10, 10), (0, 0)),
+    "relu_before_in": True,
+    "initial_from_rgb_layer_in_discr": True,
+    "adain_on_learned_input": False,
+    "latent_regressor_rot_weight": 5.0,
+    "optimizer": {"lr": 0.0004, "beta_1": 0.0, "beta_2": 0.9, "amsgrad": False},
+    "batch_size": 24,
+    "n_discriminator_updates": 1,
+    "n_generator_updates": 1,
+    "latent_distribution": "normal",
+    "metrics_checkpoint_period": 1000,
+    "image_checkpoint_period": 500,
+    "facemodel_inputs": {
+        "texture_embedding": (None, 30),
+        "geometry_identity_params": (None, 30),
+        "blendshape_values": (None, 30),
+        "beard_style_embedding": (None, 7),
+        "eyebrow_style_embedding": (None, 7),
+        "lower_eyelash_style": (None, 2),
+        "upper_eyelash_style": (None, 2),
+        "head_hair_style_embedding": (None, 9),
+        "eye_color": (None, 3),
+        "head_hair_color": (None, 3),
+        "hdri_embedding": (None, 20),
+        "bone_rotations:left_eye": (None, 2),
+    },
+    "num_synth_encoder_layers": 2,
+    "n_latent_discr_layers": 4,
+    "image_loss_weight": 0.00005,
+    "eye_loss_weight": 5,
+    "domain_adverserial_loss_weight": 5.0,
+}
+
+
+@contextlib.contextmanager
+def frozen(*nets):
+    """Networks whose weights are not in the step's trainable list: no filter gradients are computed."""
+    for n in nets:
+        n.requires_grad_(False)
+    try:
+        yield
+    finally:
+        for n in nets:
+            n.requires_grad_(True)
+
+
+class ConfigNetFirstStage:
+    def __init__(self, config, initialize=True, seed=None):
+        self.config = confignet_utils.merge_configs(DEFAULT_CONFIG, config)
+        self.config["model_type"] = "ConfigNetFirstStage"
+        self.device = require_gpu()
+        self._rng = np.random.default_rng(seed)
+
+        self.generator = None
+        self.generator_smoothed = None
+        self.discriminator = None
+        self.latent_regressor = None
+        self.latent_discriminator = None
+        self.synth_discriminator = None
+
+        self.g_losses, self.d_losses, self.metrics = {}, {}, {}
+        self.synth_d_losses, self.latent_d_losses = {}, {}
+
+        # Remove the inputs that do not have a defined input dimension; sort by name (l.114-116)
+        fm = {k: tuple(v) for k, v in self.config["facemodel_inputs"].items() if v[0] is not None}
+        self.config["facemodel_inputs"] = OrderedDict(sorted(fm.items(), key=lambda t: t[0]))
+        self.config["latent_dim"] = sum(v[1] for v in self.config["facemodel_inputs"].values())   # l.118-120
+
+        self.synthetic_encoder = None
+        self.facemodel_param_distributions = None
+        self.perceptual_loss = PerceptualLoss(self.config["output_shape"], model_type="imagenet")
+
+        if initialize:
+            self.initialize_network()
+
+    # ---- weights / persistence (confignet_first_stage.py:129-206) ---------------------------------
+    def get_weights(self, return_tensors=False):
+        return {
+            "generator_weights": self.generator.get_weights(),
+            "generator_smoothed_weights": self.generator_smoothed.get_weights(),
+            "discriminator_weights": self.discriminator.get_weights(),
+            "latent_regressor_weights": self.latent_regressor.get_weights(),
+            "synthetic_encoder_weights": self.synthetic_encoder.get_weights(),
+            "latent_discriminator_weights": self.latent_discriminator.get_weights(),
+            "synth_discriminator_weights": self.synth_discriminator.get_weights(),
+        }
+
+    def set_weights(self, weights):
+        self.generator.set_weights(weights["generator_weights"])
+        self.generator_smoothed.set_weights(weights["generator_smoothed_weights"])
+        self.discriminator.set_weights(weights["discriminator_weights"])
+        self.latent_regressor.set_weights(weights["latent_regressor_weights"])
+        self.synthetic_encoder.set_weights(weights["synthetic_encoder_weights"])
+        self.latent_discriminator.set_weights(weights["latent_discriminator_weights"])
+        self.synth_discriminator.set_weights(weights["synth_discriminator_weights"])
+
+    def get_training_step_number(self):
+        return 0 if "loss_sum" not in self.g_losses else len(self.g_losses["loss_sum"]) - 1
+
+    def get_batch_size(self):
+        return self.config["batch_size"]
+
+    def get_log_dict(self):
+        return {"g_losses": self.g_losses, "d_losses": self.d_losses, "metrics": self.metrics}
+
+    def set_logs(self, log_dict):
+        self.g_losses, self.d_losses, self.metrics = log_dict["g_losses"], log_dict["d_losses"], log_dict["metrics"]
+
+    @staticmethod
+    def _weights_to_npz(weights):
+        out = {}
+        for k, lst in weights.items():
+            arr = np.empty(len(lst), dtype=object)
+            arr[:] = lst
+            out[k] = arr
+        return out
+
+    def save(self, output_dir, output_filename):
+        """<name>.npz (one object array of the Keras-ordered weight list per network), <name>.json,
+        <name>_facemodel_distr.pck -- the reference's layout (l.173-180)."""
+        os.makedirs(output_dir, exist_ok=True)
+        np.savez(os.path.join(output_dir, output_filename + ".npz"), **self._weights_to_npz(self.get_weights()))
+        with open(os.path.join(output_dir, output_filename + ".json"), "w") as fp:
+            json.dump(self.config, fp, indent=4)
+        with open(os.path.join(output_dir, output_filename + "_facemodel_distr.pck"), "wb") as fp:
+            pickle.dump(self.facemodel_param_distributions, fp)
+
+    @classmethod
+    def load(cls, file_path):
+        with open(file_path, "r") as fp:
+            config = json.load(fp)
+        model = cls(config)
+        weights = np.load(os.path.splitext(file_path)[0] + ".npz", allow_pickle=True)
+        model.set_weights(weights)
+        log_file = os.path.splitext(file_path)[0] + "_log.json"
+        if os.path.exists(log_file):
+            with open(log_file, "r") as fp:
+                model.set_logs(json.load(fp))
+        distr = os.path.splitext(file_path)[0] + "_facemodel_distr.pck"
+        if os.path.exists(distr):
+            with open(distr, "rb") as fp:
+                model.facemodel_param_distributions = pickle.load(fp)
+        else:
+            print("WARNING: facemodel param distributions not loaded")
+        return model
+
+    @property
+    def facemodel_input_dim(self):
+        return sum(d for d, _ in self.config["facemodel_inputs"].values())
+
+    def get_facemodel_param_idxs_in_latent(self, param_name):
+        dims = list(self.config["facemodel_inputs"].values())
+        names = list(self.config["facemodel_inputs"].keys())
+        i = names.index(param_name)
+        start = int(np.sum([x[1] for x in dims[:i]]))
+        return range(start, start + dims[i][1])
+
+    def set_facemodel_param_in_latents(self, latents, param_name, param_value):
+        param_value = np.array(param_value)
+        if len(param_value.shape) == 1:
+            param_value = param_value[np.newaxis]
+        latents_for_param = self.synthetic_encoder.per_facemodel_input_mlps[param_name].predict(param_value)
+        new_latents = np.copy(latents)
+        new_latents[:, self.get_facemodel_param_idxs_in_latent(param_name)] = latents_for_param
+        return new_latents
+
+    def _get_generator_kwargs(self):
+        return {
+            "latent_dim": self.config["latent_dim"],
+            "output_shape": tuple(self.config["output_shape"][:2]),
+            "n_adain_mlp_units": self.config["n_adain_mlp_units"],
+            "n_adain_mlp_layers": self.config["n_adain_mlp_layers"],
+            "gen_output_activation": self.config["gen_output_activation"],
+        }
+
+    def initialize_network(self):
+        """confignet_first_stage.py:251-287."""
+        rng = self._rng
+        self.synthetic_encoder = SyntheticDataEncoder(self.config["facemodel_inputs"],
+                                                      self.config["num_synth_encoder_layers"], rng=rng)
+        dargs = {
+            "img_shape": tuple(self.config["output_shape"][:2]),
+            "num_resample": self.config["n_discr_layers"],
+            "disc_kernel_size": self.config["discr_conv_kernel_size"],
+            "disc_expansion_factor": self.config["n_discr_features_at_layer_0"],
+            "disc_max_feature_maps": self.config["max_discr_filters"],
+            "initial_from_rgb_layer_in_discr": self.config["initial_from_rgb_layer_in_discr"],
+        }
+        self.discriminator = HologanDiscriminator(rng=rng, **dargs)
+        self.synth_discriminator = HologanDiscriminator(rng=rng, **dargs)
+        L = self.config["latent_dim"]
+        self.latent_discriminator = MLPSimple(self.config["n_latent_discr_layers"], L, L, 1, rng=rng)
+        self.latent_regressor = HologanLatentRegressor(L, rng=rng, **dargs)
+        self.generator = HologanGenerator(rng=rng, **self._get_generator_kwargs())
+        self.generator_smoothed = HologanGenerator(rng=rng, **self._get_generator_kwargs())
+        self.generator_smoothed.copy_weights_from(self.generator)
+
+    def all_networks(self):
+        return [self.generator, self.generator_smoothed, self.discriminator, self.synth_discriminator,
+                self.latent_discriminator, self.latent_regressor, self.synthetic_encoder]
+
+    # ---- training code ----------------------------------------------------------------------------
+    def update_smoothed_weights(self, smoother_alpha=0.999):
+        """w_bar = a*w_bar + (1-a)*w over the whole generator arena in one launch (l.393-400; the
+        reference round-trips every weight through numpy)."""
+        ops.ema_step(self.generator_smoothed.arena, self.generator.arena, smoother_alpha)
+
+    def sample_rotations(self, n_samples, axes=[0, 1, 2]):
+        r = np.zeros((n_samples, 3))
+        for axis in axes:
+            lo, hi = self.config["rotation_ranges"][axis]
+            r[:, axis] = np.pi * np.random.uniform(lo, hi, n_samples) / 180
+        return r.astype(np.float32)
+
+    def sample_latent_vector(self, n_samples):
+        if self.config["latent_distribution"] == "normal":
+            return np.random.normal(0, 1, (n_samples, self.config["latent_dim"]))
+        elif self.config["latent_distribution"] == "uniform":
+            return np.random.uniform(-1, 1, (n_samples, self.config["latent_dim"]))
+
+    def sample_facemodel_params(self, n_samples):
+        return [self.facemodel_param_distributions[name].sample(n_samples)[0]
+                for name in self.config["facemodel_inputs"].keys()]
+
+    def sample_synthetic_dataset(self, dataset, n_samples):
+        """Host (numpy) sampler with the reference's return contract (l.425-435)."""
+        idx = np.random.randint(0, dataset.imgs.shape[0], n_samples)
+        params = [dataset.metadata_inputs[name][idx] for name in self.config["facemodel_inputs"].keys()]
+        rot = dataset.metadata_inputs["rotations"][idx].astype(np.float32)
+        return params, rot, np.copy(dataset.imgs[idx]).astype(np.float32), np.copy(dataset.eye_masks[idx])
+
+    # device-resident pools: the uint8 image pool lives in HBM, batches are gathered/normalised/flipped
+    # by one kernel (data path row of SURVEY.md 8f); the RNG calls mirror the reference's order.
+    def _pool(self, dataset):
+        cache = getattr(dataset, "_cn_device_pool", None)
+        if cache is None or cache["device"] != self.device:
+            cache = {
+                "device": self.device,
+                "imgs": torch.as_tensor(np.ascontiguousarray(dataset.imgs)).to(self.device),
+                "eye_masks": (torch.as_tensor(np.ascontiguousarray(dataset.eye_masks)).to(self.device)
+                              if getattr(dataset, "eye_masks", None) is not None else None),
+            }
+            dataset._cn_device_pool = cache
+        return cache
+
+    def _gather_images(self, dataset, idx, flip=None):
+        pool = self._pool(dataset)["imgs"]
+        idx_t = torch.as_tensor(idx, dtype=torch.int64).to(self.device)
+        flip_t = torch.as_tensor(flip.astype(np.uint8)).to(self.device) if flip is not None else None
+        return ops.gather_images_u8(pool, idx_t, flip_t)
+
+    def _sample_real_batch(self, dataset, n):
+        idx = np.random.randint(0, dataset.imgs.shape[0], n)
+        flip = np.random.randint(0, 2, size=n)                # flip_random_subset_of_images
+        return self._gather_images(dataset, idx, flip)
+
+    def _sample_synthetic_batch(self, dataset, n):
+        idx = np.random.randint(0, dataset.imgs.shape[0], n)
+        params = [self._dev(dataset.metadata_inputs[name][idx]) for name in self.config["facemodel_inputs"].keys()]
+        rot = self._dev(dataset.metadata_inputs["rotations"][idx])
+        imgs = self._gather_images(dataset, idx)
+        masks = self._pool(dataset)["eye_masks"][torch.as_tensor(idx, dtype=torch.int64).to(self.device)].contiguous()
+        return params, rot, imgs, masks
+
+    def _dev(self, a):
+        return torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32)).to(self.device)
+
+    def get_discriminator_batch(self, training_set):
+        real_imgs = self._sample_real_batch(training_set, self.get_batch_size())
+        latent_vector = self.sample_latent_vector(self.get_batch_size())
+        random_rotation = self.sample_rotations(self.get_batch_size())
+        with torch.no_grad():
+            fake_imgs = self.generator([latent_vector, random_rotation])
+        return real_imgs, fake_imgs
+
+    def get_synth_discriminator_batch(self, training_set):
+        real_imgs = self._sample_real_batch(training_set, self.get_batch_size())
+        params, rotations, _, _ = self._sample_synthetic_batch(training_set, self.get_batch_size())
+        with torch.no_grad():
+            fake_imgs = self.generator([self.synthetic_encoder(params), rotations])
+        return real_imgs, fake_imgs
+
+    def _discriminator_update(self, net, real_imgs, fake_imgs, optimizer):
+        net.zero_grad()
+        losses = compute_discriminator_loss(net, real_imgs, fake_imgs)
+        torch.autograd.backward(losses["loss_sum"], inputs=net.trainable_weights)
+        optimizer.apply_gradients(net)
+        return losses
+
+    def discriminator_training_step(self, training_set, optimizer):
+        real_imgs, fake_imgs = self.get_discriminator_batch(training_set)
+        return self._discriminator_update(self.discriminator, real_imgs, fake_imgs, optimizer)
+
+    def synth_discriminator_training_step(self, synth_training_set, optimizer):
+        real_imgs, fake_imgs = self.get_synth_discriminator_batch(synth_training_set)
+        return self._discriminator_update(self.synth_discriminator, real_imgs, fake_imgs, optimizer)
+
+    def _latent_discriminator_update(self, real_latents, fake_latents, optimizer):
+        net = self.latent_discriminator
+        net.zero_grad()
+        losses = compute_latent_discriminator_loss(net, real_latents, fake_latents)
+        torch.autograd.backward(losses["loss_sum"], inputs=net.trainable_weights)
+        optimizer.apply_gradients(net)
+        return losses
+
+    def latent_discriminator_training_step(self, synth_training_set, optimizer):
+        real_latents = self._dev(self.sample_latent_vector(self.get_batch_size()))
+        params, _, _, _ = self._sample_synthetic_batch(synth_training_set, self.get_batch_size())
+        with torch.no_grad():
+            fake_latents = self.synthetic_encoder(params)
+        return self._latent_discriminator_update(real_latents, fake_latents, optimizer)
+
+    def _generator_loss(self, facemodel_params, synth_rotations, gt_imgs, eye_masks, real_latents, real_rotations):
+        """The taped part of generator_training_step (l.518-554)."""
+        cfg = self.config
+        losses = {}
+        synth_latents = self.synthetic_encoder(facemodel_params)
+        generator_output_synth = self.generator((synth_latents, synth_rotations))
+        generator_output_real = self.generator((real_latents, real_rotations))
+        losses["image_loss"] = cfg["image_loss_weight"] * self.perceptual_loss.loss(gt_imgs, generator_output_synth)
+        losses["eye_loss"] = cfg["eye_loss_weight"] * eye_loss(gt_imgs, generator_output_synth, eye_masks)
+        for i, o in enumerate(self.synth_discriminator(generator_output_synth).values()):
+            losses["GAN_loss_synth_" + str(i)] = GAN_G_loss(o)
+        for i, o in enumerate(self.discriminator(generator_output_real).values()):
+            losses["GAN_loss_real_" + str(i)] = GAN_G_loss(o)
+        latent_discriminator_output = self.latent_discriminator(synth_latents)
+        losses["latent_GAN_loss"] = cfg["domain_adverserial_loss_weight"] * GAN_G_loss(latent_discriminator_output)
+        stacked_latents = torch.cat((synth_latents, real_latents), dim=0)
+        stacked_imgs = torch.cat((generator_output_synth, generator_output_real), dim=0)
+        stacked_rotations = torch.cat((synth_rotations, real_rotations), dim=0)
+        labels = torch.cat((stacked_latents, cfg["latent_regressor_rot_weight"] * stacked_rotations), dim=-1)
+        reg = compute_latent_regression_loss(stacked_imgs, labels, self.latent_regressor)
+        losses["latent_regression_loss"] = cfg["latent_regression_weight"] * reg
+        losses["loss_sum"] = sum(losses.values())
+        return losses
+
+    def _generator_update(self, losses, nets, optimizer):
+        params = [p for n in nets for p in n.trainable_weights]
+        torch.autograd.backward(losses["loss_sum"], inputs=params)
+        optimizer.apply_gradients(nets)
+
+    def generator_training_step(self, real_training_set, synth_training_set, optimizer):
+        n_synth = self.get_batch_size() // 2
+        n_real = self.get_batch_size() - n_synth
+        params, synth_rot, gt_imgs, eye_masks = self._sample_synthetic_batch(synth_training_set, n_synth)
+        real_latents = self._dev(self.sample_latent_vector(n_real))
+        real_rot = self._dev(self.sample_rotations(n_real))
+        nets = [self.generator, self.latent_regressor, self.synthetic_encoder]
+        for n in nets:
+            n.zero_grad()
+        with frozen(self.discriminator, self.synth_discriminator, self.latent_discriminator):
+            losses = self._generator_loss(params, synth_rot, gt_imgs, eye_masks, real_latents, real_rot)
+            self._generator_update(losses, nets, optimizer)
+        return losses
+
+    def setup_training(self, log_dir, synth_training_set, n_samples_for_metrics, real_training_set=None):
+        self.facemodel_param_distributions = synth_training_set.metadata_input_distributions   # l.587
+
+    def train(self, real_training_set, synth_training_set, output_dir, log_dir, n_steps=100000,
+              n_samples_for_metrics=1000, aml_run=None):
+        """confignet_first_stage.py:597-626 (checkpoint images / metrics are out of scope)."""
+        self.setup_training(log_dir, synth_training_set, n_samples_for_metrics, real_training_set=real_training_set)
+        start_step = self.get_training_step_number()
+        discriminator_optimizer = optim.Adam(**self.config["optimizer"])
+        generator_optimizer = optim.Adam(**self.config["optimizer"])
+        for _ in range(start_step, n_steps):
+            t0 = time.perf_counter()
+            for _ in range(self.config["n_discriminator_updates"]):
+                d_loss = self.discriminator_training_step(real_training_set, discriminator_optimizer)
+                synth_d_loss = self.synth_discriminator_training_step(synth_training_set, discriminator_optimizer)
+                latent_d_loss = self.latent_discriminator_training_step(synth_training_set, discriminator_optimizer)
+            for _ in range(self.config["n_generator_updates"]):
+                g_loss = self.generator_training_step(real_training_set, synth_training_set, generator_optimizer)
+            self.update_smoothed_weights()
+            torch.cuda.synchronize()
+            self.last_iteration_time = time.perf_counter() - t0
+            print("[D loss: %f] [synth_D loss: %f] [latent_D_loss: %f] [G loss: %f]" %
+                  (d_loss["loss_sum"], synth_d_loss["loss_sum"], latent_d_loss["loss_sum"], g_loss["loss_sum"]))
+            confignet_utils.update_loss_dict(self.g_losses, g_loss)
+            confignet_utils.update_loss_dict(self.d_losses, d_loss)
+            confignet_utils.update_loss_dict(self.synth_d_losses, synth_d_loss)
+            confignet_utils.update_loss_dict(self.latent_d_losses, latent_d_loss)
+            step = self.get_training_step_number()
+            if output_dir is not None and step % self.config["metrics_checkpoint_period"] == 0 and step > 0:
+                self.save(os.path.join(output_dir, "checkpoints"), str(step).zfill(6))
+
+    # ---- evaluation code ----------------------------------------------------------------------------
+    def _generate_images_with(self, generator, latent_vector, rotations):
+        inp = self.generator.build_input_dict(latent_vector, rotations)
+        n = len(inp["rotation"])
+        outs = []
+        with torch.no_grad():
+            for s in range(0, n, 32):                                       # keras predict batch 32 (R11)
+                chunk = {k: (v[s:s + 32] if not isinstance(v, list) else v) for k, v in inp.items()}
+                outs.append(ops.to_uint8(generator(chunk)).cpu().numpy())   # clip + (x+1)*127.5 -> uint8
+        return np.concatenate(outs, axis=0)
+
+    def generate_images(self, latent_vector, rotations):
+        """confignet_first_stage.py:633-639."""
+        return self._generate_images_with(self.generator_smoothed, latent_vector, rotations)
+
+    def generate_images_from_facemodel(self, facemodel_params, rotations):
+        with torch.no_grad():
+            latents = self.synthetic_encoder(facemodel_params).cpu().numpy()
+        return self.generate_images(latents, rotations)

@@ -1,0 +1,238 @@
+"""ConfigNet second stage (reference: confignet/confignet_second_stage.py): adds the ResNet-50 real
+encoder trained end-to-end, the normalised latent-regression loss and one-shot fine-tuning."""
+import time
+import os
+
+import numpy as np
+import torch
+
+from . import confignet_utils, ops, optim
+from .confignet_first_stage import DEFAULT_CONFIG, ConfigNetFirstStage, frozen
+from .dnn_models.hologan_generator import HologanGenerator
+from .dnn_models.real_encoder import RealEncoder
+from .losses import GAN_D_loss, GAN_G_loss, compute_latent_discriminator_loss, eye_loss, mean_squared_error
+from .nn import Net
+from .perceptual_loss import PerceptualLoss
+
+
+class _Variables(Net):
+    """A handful of free tensors optimised next to a network (the tf.Variables of fine_tune_on_img)."""
+
+    def __init__(self, arrays):
+        super().__init__()
+        for i, a in enumerate(arrays):
+            self.add_weight("var%d" % i, a)
+        self.finalize()
+
+
+class ConfigNet(ConfigNetFirstStage):
+    def __init__(self, config, initialize=True, seed=None):
+        self.config = confignet_utils.merge_configs(DEFAULT_CONFIG, config)
+        super(ConfigNet, self).__init__(self.config, initialize=False, seed=seed)
+        self.config["model_type"] = "ConfigNet"
+        self.encoder = None
+        self.generator_fine_tuned = None
+        self.perceptual_loss_face_reco = PerceptualLoss(self.config["output_shape"], model_type="VGGFace")
+        if initialize:
+            self.initialize_network()
+
+    def get_weights(self):
+        weights = super().get_weights()
+        weights["real_encoder_weights"] = self.encoder.get_weights()
+        return weights
+
+    def set_weights(self, weights):
+        super().set_weights(weights)
+        self.encoder.set_weights(weights["real_encoder_weights"])
+
+    def initialize_network(self):
+        super(ConfigNet, self).initialize_network()
+        self.encoder = RealEncoder(self.config["latent_dim"], self.config["output_shape"],
+                                   self.config["rotation_ranges"], rng=self._rng)
+
+    def all_networks(self):
+        return super().all_networks() + [self.encoder]
+
+    # ---- training code ----------------------------------------------------------------------------
+    def face_reco_loss(self, gt_imgs, gen_imgs):
+        return self.perceptual_loss_face_reco.loss(gen_imgs, gt_imgs)
+
+    def compute_normalized_latent_regression_loss(self, generator_outputs, labels):
+        """confignet_second_stage.py:93-107.  The (N, L+3) batch statistics are latent-vector algebra
+        (host-side plumbing); the latent regressor itself runs on HIP kernels."""
+        out = self.latent_regressor(generator_outputs)
+        den = torch.sqrt(labels.var(dim=0, unbiased=False, keepdim=True) + 1e-3)
+        den = torch.cat((den[:, :-3], torch.ones((1, 3), device=den.device)), dim=1)
+        out = out.mean(dim=0) + (out - out.mean(dim=0)) / den
+        labels = labels.mean(dim=0) + (labels - labels.mean(dim=0)) / den
+        return mean_squared_error(labels, out) * self.config["latent_regression_weight"]
+
+    def sample_random_batch_of_images(self, dataset, batch_size=None):
+        return self._sample_real_batch(dataset, self.get_batch_size() if batch_size is None else batch_size)
+
+    def get_discriminator_batch(self, training_set):
+        real_imgs = self.sample_random_batch_of_images(training_set)
+        idx = np.random.randint(0, training_set.imgs.shape[0], self.get_batch_size())
+        input_imgs = self._gather_images(training_set, idx)
+        with torch.no_grad():
+            latent_vector, rotation = self.encoder(input_imgs)
+            fake_imgs = self.generator([latent_vector, rotation])
+        return real_imgs, fake_imgs
+
+    def latent_discriminator_training_step(self, real_training_set, synth_training_set, optimizer):
+        real_imgs = self.sample_random_batch_of_images(real_training_set)
+        with torch.no_grad():
+            real_latents, _ = self.encoder(real_imgs)
+        params, _, _, _ = self._sample_synthetic_batch(synth_training_set, self.get_batch_size())
+        with torch.no_grad():
+            fake_latents = self.synthetic_encoder(params)
+        return self._latent_discriminator_update(real_latents, fake_latents, optimizer)
+
+    def _generator_loss(self, facemodel_params, synth_rotations, synth_imgs, eye_masks, real_imgs):
+        """The taped part of ConfigNet.generator_training_step (l.167-211)."""
+        cfg = self.config
+        n_synth, n_real = synth_imgs.shape[0], real_imgs.shape[0]
+        losses = {}
+        synth_latents = self.synthetic_encoder(facemodel_params)
+        generator_output_synth = self.generator((synth_latents, synth_rotations))
+        real_latents, real_rotations = self.encoder(real_imgs)
+        generator_output_real = self.generator((real_latents, real_rotations))
+        losses["image_loss_synth"] = cfg["image_loss_weight"] * self.perceptual_loss.loss(synth_imgs, generator_output_synth)
+        losses["image_loss_real"] = cfg["image_loss_weight"] * self.perceptual_loss.loss(real_imgs, generator_output_real)
+        losses["eye_loss"] = cfg["eye_loss_weight"] * eye_loss(synth_imgs, generator_output_synth, eye_masks)
+        for i, o in enumerate(self.synth_discriminator(generator_output_synth).values()):
+            losses["GAN_loss_synth_" + str(i)] = GAN_G_loss(o)
+        for i, o in enumerate(self.discriminator(generator_output_real).values()):
+            losses["GAN_loss_real_" + str(i)] = GAN_G_loss(o)
+        out_synth = self.latent_discriminator(synth_latents)
+        out_real = self.latent_discriminator(real_latents)
+        # labels: real -> 0, synth -> 1 (l.160-163,195-197); mean over the concatenation
+        latent_gan_loss = (n_real * GAN_D_loss(0.0, out_real) + n_synth * GAN_D_loss(1.0, out_synth)) / (n_real + n_synth)
+        losses["latent_GAN_loss"] = cfg["domain_adverserial_loss_weight"] * latent_gan_loss
+        if cfg["latent_regression_weight"] > 0.0:
+            stacked_latents = torch.cat((synth_latents, real_latents), dim=0)
+            stacked_imgs = torch.cat((generator_output_synth, generator_output_real), dim=0)
+            stacked_rotations = torch.cat((synth_rotations, real_rotations), dim=0)
+            labels = torch.cat((stacked_latents, cfg["latent_regressor_rot_weight"] * stacked_rotations), dim=-1)
+            losses["latent_regression_loss"] = self.compute_normalized_latent_regression_loss(stacked_imgs, labels)
+        losses["loss_sum"] = sum(losses.values())
+        return losses
+
+    def generator_training_step(self, real_training_set, synth_training_set, optimizer):
+        n_synth = self.get_batch_size() // 2
+        n_real = self.get_batch_size() - n_synth
+        params, synth_rot, synth_imgs, eye_masks = self._sample_synthetic_batch(synth_training_set, n_synth)
+        real_imgs = self.sample_random_batch_of_images(real_training_set, n_real)
+        nets = [self.generator, self.latent_regressor, self.synthetic_encoder, self.encoder]
+        for n in nets:
+            n.zero_grad()
+        with frozen(self.discriminator, self.synth_discriminator, self.latent_discriminator):
+            losses = self._generator_loss(params, synth_rot, synth_imgs, eye_masks, real_imgs)
+            self._generator_update(losses, nets, optimizer)
+        return losses
+
+    def training_iteration(self, real_training_set, synth_training_set, discriminator_optimizer, generator_optimizer):
+        """One reference training iteration (confignet_second_stage.py:277-288): D, synth-D, latent-D,
+        G, EMA.  Returns the four loss dicts (device scalars; no host sync here)."""
+        for _ in range(self.config["n_discriminator_updates"]):
+            d_loss = self.discriminator_training_step(real_training_set, discriminator_optimizer)
+            synth_d_loss = self.synth_discriminator_training_step(synth_training_set, discriminator_optimizer)
+            latent_d_loss = self.latent_discriminator_training_step(real_training_set, synth_training_set,
+                                                                    discriminator_optimizer)
+        for _ in range(self.config["n_generator_updates"]):
+            g_loss = self.generator_training_step(real_training_set, synth_training_set, generator_optimizer)
+        self.update_smoothed_weights()
+        return d_loss, synth_d_loss, latent_d_loss, g_loss
+
+    def setup_training(self, log_dir, synth_training_set, n_samples_for_metrics, attribute_classifier=None,
+                       real_training_set=None, validation_set=None):
+        super(ConfigNet, self).setup_training(log_dir, synth_training_set, n_samples_for_metrics, real_training_set)
+
+    def train(self, real_training_set, synth_training_set, validation_set, attribute_classifier, output_dir, log_dir,
+              n_steps=100000, n_samples_for_metrics=1000, aml_run=None):
+        """confignet_second_stage.py:268-299 (metrics / image checkpoints are out of scope)."""
+        self.setup_training(log_dir, synth_training_set, n_samples_for_metrics, attribute_classifier,
+                            real_training_set=real_training_set, validation_set=validation_set)
+        start_step = self.get_training_step_number()
+        discriminator_optimizer = optim.Adam(**self.config["optimizer"])
+        generator_optimizer = optim.Adam(**self.config["optimizer"])
+        for _ in range(start_step, n_steps):
+            t0 = time.perf_counter()
+            d_loss, synth_d_loss, latent_d_loss, g_loss = self.training_iteration(
+                real_training_set, synth_training_set, discriminator_optimizer, generator_optimizer)
+            torch.cuda.synchronize()
+            self.last_iteration_time = time.perf_counter() - t0
+            print("[D loss: %f] [synth_D loss: %f] [latent_D_loss: %f] [G loss: %f]" %
+                  (d_loss["loss_sum"], synth_d_loss["loss_sum"], latent_d_loss["loss_sum"], g_loss["loss_sum"]))
+            confignet_utils.update_loss_dict(self.g_losses, g_loss)
+            confignet_utils.update_loss_dict(self.d_losses, d_loss)
+            confignet_utils.update_loss_dict(self.synth_d_losses, synth_d_loss)
+            confignet_utils.update_loss_dict(self.latent_d_losses, latent_d_loss)
+            step = self.get_training_step_number()
+            if output_dir is not None and step % self.config["metrics_checkpoint_period"] == 0 and step > 0:
+                self.save(os.path.join(output_dir, "checkpoints"), str(step).zfill(6))
+
+    # ---- inference ----------------------------------------------------------------------------------
+    def encode_images(self, input_images):
+        """confignet_second_stage.py:301-308."""
+        if not torch.is_tensor(input_images) and input_images.dtype == np.uint8:
+            input_images = input_images.astype(np.float32) / 127.5 - 1.0
+        return self.encoder.predict(np.asarray(input_images, dtype=np.float32))
+
+    def generate_images(self, latent_vectors, rotations):
+        """confignet_second_stage.py:310-319."""
+        g = self.generator_fine_tuned if self.generator_fine_tuned is not None else self.generator_smoothed
+        return self._generate_images_with(g, latent_vectors, rotations)
+
+    def fine_tune_on_img(self, input_images, n_iters=50, img_output_dir=None, force_neutral_expression=False):
+        """confignet_second_stage.py:321-403: Adam(lr 1e-4) on the fine-tuned generator copy, the
+        pre/post-expression embeddings (batch mean, tiled), the expression slice and the rotations."""
+        if input_images.dtype == np.uint8:
+            input_images = (input_images / 127.5) - 1.0
+        if len(input_images.shape) == 3:
+            input_images = input_images[np.newaxis]
+        input_images = np.asarray(input_images, dtype=np.float32)
+        emb, rot = self.encoder.predict(input_images)
+        if force_neutral_expression:
+            n_bs = self.config["facemodel_inputs"]["blendshape_values"][0]
+            emb = self.set_facemodel_param_in_latents(emb, "blendshape_values", np.zeros((1, n_bs), np.float32))
+        if self.generator_fine_tuned is None:
+            self.generator_fine_tuned = HologanGenerator(rng=self._rng, **self._get_generator_kwargs())
+        self.generator_fine_tuned.copy_weights_from(self.generator_smoothed)
+        gen = self.generator_fine_tuned
+
+        expr_idxs = self.get_facemodel_param_idxs_in_latent("blendshape_values")
+        mean_emb = np.mean(emb, axis=0, keepdims=True)
+        var = _Variables([mean_emb[:, :expr_idxs[0]], emb[:, expr_idxs], mean_emb[:, expr_idxs[-1] + 1:], rot])
+        pre, expr, post, rotations = var.weights
+        if force_neutral_expression:
+            expr.requires_grad_(False)
+        n_imgs = input_images.shape[0]
+        imgs_dev = gen.to_device(input_images)
+        optimizer = optim.Adam(lr=0.0001)
+        w = self.config
+        for step_number in range(n_iters):
+            gen.zero_grad()
+            var.zero_grad()
+            losses = {}
+            with frozen(self.discriminator, self.latent_discriminator, self.latent_regressor):
+                pre_t, post_t = pre.repeat(n_imgs, 1), post.repeat(n_imgs, 1)
+                embeddings = torch.cat((pre_t, expr, post_t), dim=1)
+                out = gen((embeddings, rotations))
+                losses["image_loss_real"] = 0.5 * w["image_loss_weight"] * self.perceptual_loss.loss(imgs_dev, out)
+                losses["face_reco_loss"] = 0.5 * w["image_loss_weight"] * self.face_reco_loss(imgs_dev, out)
+                for i, o in enumerate(self.discriminator(out).values()):
+                    losses["GAN_loss_real_" + str(i)] = GAN_G_loss(o)
+                latent_gan_loss = GAN_D_loss(1.0, self.latent_discriminator(embeddings))
+                losses["latent_GAN_loss"] = w["domain_adverserial_loss_weight"] * latent_gan_loss
+                labels = torch.cat((embeddings, w["latent_regressor_rot_weight"] * rotations), dim=-1)
+                losses["latent_regression_loss"] = self.compute_normalized_latent_regression_loss(out, labels)
+                losses["loss_sum"] = sum(losses.values())
+                params = gen.trainable_weights + [p for p in var.weights if p.requires_grad]
+                torch.autograd.backward(losses["loss_sum"], inputs=params)
+            stale = torch.cat((pre_t, expr, post_t), dim=1).detach().clone()   # pre/post tiled BEFORE the step
+            optimizer.apply_gradients([gen, var])
+        # the reference returns pre/post tiled before the last optimizer step with the updated expr (l.402)
+        result = stale.cpu().numpy()
+        result[:, list(expr_idxs)] = expr.detach().cpu().numpy()
+        return result, rotations.detach().cpu().numpy()

@@ -1,0 +1,52 @@
+"""Config / bookkeeping helpers (reference: confignet/confignet_utils.py:14-61,198-212)."""
+import json
+import sys
+
+import numpy as np
+
+
+def merge_configs(default_config, input_config):
+    """Recursively merge configuration dictionaries (confignet_utils.py:39-61)."""
+    result = {}
+    for name in default_config:
+        lhs = default_config[name]
+        if name in input_config:
+            rhs = input_config[name]
+            if isinstance(lhs, dict):
+                assert isinstance(rhs, dict)
+                result[name] = merge_configs(lhs, rhs)
+            else:
+                result[name] = rhs
+        else:
+            result[name] = lhs
+    for name in input_config:
+        rhs = input_config[name]
+        if isinstance(rhs, dict) and name in default_config.keys():
+            continue
+        result[name] = rhs
+    return result
+
+
+def load_confignet(model_path):
+    """Dispatch on config["model_type"] (confignet_utils.py:14-21)."""
+    with open(model_path, "r") as fp:
+        metadata = json.load(fp)
+    cls = getattr(sys.modules["confignet_amd"], metadata["model_type"])
+    return cls.load(model_path)
+
+
+def flip_random_subset_of_images(images):
+    """Host version kept for API parity (confignet_utils.py:198-204); the training path draws the same
+    flip flags and applies them on device while gathering the batch."""
+    flip_or_not = np.random.randint(0, 2, size=images.shape[0])
+    for i, flip in enumerate(flip_or_not):
+        if flip == 1:
+            images[i] = np.fliplr(images[i])
+    return images
+
+
+def update_loss_dict(main_loss_dict, new_loss_dict):
+    """confignet_utils.py:206-212."""
+    for key, val in new_loss_dict.items():
+        val = float(val)
+        main_loss_dict.setdefault(key, []).append(val)

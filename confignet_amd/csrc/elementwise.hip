@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void nc_lin2_kernel(const float* __restrict__ 
                 raw2[e] = x2[i * V + e];
                 float v = raw2[e];
                 if (flags & 2) v = lrelu(v, slope);
-                if (a2) r[e] += a2[ci + e] * v;
+                r[e] += (a2 ? a2[ci + e] : 1.f) * v;
             }
             if (flags & 4) {
 #pragma unroll

@@ -1,0 +1,586 @@
+"""Differentiable ops: torch.autograd.Function wrappers whose forward AND backward are calls
+into libconfignet_hip.so.  torch.autograd is only the tape driver (the reference uses
+tf.GradientTape the same way); no torch compute kernel runs on activation-sized tensors.
+
+Double backward (the R1 penalty, losses.py:75-82, differentiates an input-gradient) is obtained
+by writing every backward in terms of other Functions of this module: the sets
+{conv, conv_dgrad, conv_wgrad}, {matmul}, {nc_sumdot, nc_lin} and {lrelu, lrelu_mask_mul} are
+each closed under differentiation.
+"""
+import contextlib
+
+import torch
+from torch.autograd import Function
+
+from . import ops
+from .ops import ACT_LRELU, ACT_NONE, ACT_RELU, ACT_TANH, ConvSpec  # noqa: F401
+
+_INPUT_GRADS_ONLY = False
+
+
+@contextlib.contextmanager
+def input_grads_only():
+    """Inside this context backward passes skip parameter gradients (used while taking
+    d out / d input for the R1 penalty, where tf's tape.gradient(out, real_imgs) computes
+    nothing else either)."""
+    global _INPUT_GRADS_ONLY
+    prev, _INPUT_GRADS_ONLY = _INPUT_GRADS_ONLY, True
+    try:
+        yield
+    finally:
+        _INPUT_GRADS_ONLY = prev
+
+
+def _cg(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _tflip_cached(w):
+    """weight_tflip(w), cached on the tensor until it is modified in place."""
+    ver = w._version
+    c = getattr(w, "_cn_tflip", None)
+    if c is not None and c[0] == ver and c[2] == w.data_ptr():
+        return c[1]
+    wt = ops.weight_tflip(w.detach())
+    try:
+        w._cn_tflip = (ver, wt, w.data_ptr())
+    except Exception:
+        pass
+    return wt
+
+
+# =============================================================================================
+# convolution family
+# =============================================================================================
+class ConvFn(Function):
+    """y = act(conv(x [upsampled x2], w) + bias)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, spec, act, slope):
+        x, w = _cg(x), _cg(w)
+        g = spec.geom(tuple(x.shape), w.shape[-1])
+        y = ops.conv_fwd(x, w, bias, g, act, slope)
+        ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
+        ctx.g, ctx.act, ctx.slope, ctx.has_bias = g, act, slope, bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w, y = ctx.saved_tensors
+        gy = _cg(gy)
+        if ctx.act != ACT_NONE:
+            if torch.is_grad_enabled():
+                raise RuntimeError("double backward through a fused-activation conv is not supported; "
+                                   "use conv(..., act=ACT_NONE) + lrelu()")
+            gy = ops.act_bwd(gy, y, ctx.act, ctx.slope)
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = ConvDgradFn.apply(gy, w, ctx.g)
+        if not _INPUT_GRADS_ONLY:
+            if ctx.needs_input_grad[1]:
+                gw = ConvWgradFn.apply(x, gy, ctx.g, tuple(w.shape))
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                gb = ops.nc_reduce(gy.detach(), None, want_dot=False, per_channel=True)[0].reshape(-1)
+        return gx, gw, gb, None, None, None
+
+
+class ConvDgradFn(Function):
+    """gx = d conv / d x applied to gy (includes the 2^nd-child sum of a folded upsample)."""
+
+    @staticmethod
+    def forward(ctx, gy, w, g):
+        gy = _cg(gy)
+        gu = ops.conv_dgrad(gy, _tflip_cached(w), g)
+        ctx.save_for_backward(gy, w)
+        ctx.g = g
+        return ops.sumpool2(gu) if g.up else gu
+
+    @staticmethod
+    def backward(ctx, ggx):
+        gy, w = ctx.saved_tensors
+        ggx = _cg(ggx)
+        g_gy = g_w = None
+        if ctx.needs_input_grad[0]:
+            g_gy = ConvNoBiasFromGeomFn.apply(ggx, w, ctx.g)
+        if ctx.needs_input_grad[1]:
+            g_w = ConvWgradFn.apply(ggx, gy, ctx.g, tuple(w.shape))
+        return g_gy, g_w, None
+
+
+class ConvNoBiasFromGeomFn(Function):
+    """conv(x, w) for an already-built geometry (the adjoint of ConvDgradFn)."""
+
+    @staticmethod
+    def forward(ctx, x, w, g):
+        x = _cg(x)
+        ctx.save_for_backward(x, w)
+        ctx.g = g
+        return ops.conv_fwd(x, _cg(w), None, g, ACT_NONE, 0.0)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gy = _cg(gy)
+        gx = ConvDgradFn.apply(gy, w, ctx.g) if ctx.needs_input_grad[0] else None
+        gw = ConvWgradFn.apply(x, gy, ctx.g, tuple(w.shape)) if ctx.needs_input_grad[1] else None
+        return gx, gw, None
+
+
+class ConvWgradFn(Function):
+    @staticmethod
+    def forward(ctx, x, gy, g, w_shape):
+        x, gy = _cg(x), _cg(gy)
+        ctx.save_for_backward(x, gy)
+        ctx.g, ctx.w_shape = g, w_shape
+        return ops.conv_wgrad(x, gy, g, w_shape)
+
+    @staticmethod
+    def backward(ctx, ggw):
+        x, gy = ctx.saved_tensors
+        ggw = _cg(ggw)
+        gx = ConvDgradFn.apply(gy, ggw, ctx.g) if ctx.needs_input_grad[0] else None
+        ggy = ConvNoBiasFromGeomFn.apply(x, ggw, ctx.g) if ctx.needs_input_grad[1] else None
+        return gx, ggy, None, None
+
+
+def conv(x, w, bias, spec, act=ACT_NONE, slope=0.0):
+    return ConvFn.apply(x, w, bias, spec, act, slope)
+
+
+# =============================================================================================
+# dense
+# =============================================================================================
+class MatmulFn(Function):
+    """op(a) @ op(b); closed under differentiation."""
+
+    @staticmethod
+    def forward(ctx, a, b, ta, tb):
+        a, b = _cg(a), _cg(b)
+        ctx.save_for_backward(a, b)
+        ctx.ta, ctx.tb = ta, tb
+        return ops.gemm(a, b, ta, tb)
+
+    @staticmethod
+    def backward(ctx, gc):
+        a, b = ctx.saved_tensors
+        ta, tb = ctx.ta, ctx.tb
+        ga = gb = None
+        if ctx.needs_input_grad[0]:
+            # C = op(a) op(b): d/d op(a) = gc op(b)^T ; transpose back if ta
+            ga = MatmulFn.apply(b, gc, tb, True) if ta else MatmulFn.apply(gc, b, False, not tb)
+        if ctx.needs_input_grad[1] and not (_INPUT_GRADS_ONLY and b.is_leaf):
+            gb = MatmulFn.apply(gc, a, True, ta) if tb else MatmulFn.apply(a, gc, not ta, False)
+        return ga, gb, None, None
+
+
+class LinearFn(Function):
+    """Keras Dense without activation: y = x @ W + b (bias fused into the GEMM epilogue)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x, w = _cg(x), _cg(w)
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        return ops.gemm(x, w, False, False, b)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gy = _cg(gy)
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = MatmulFn.apply(gy, w, False, True)
+        if not _INPUT_GRADS_ONLY:
+            if ctx.needs_input_grad[1]:
+                gw = MatmulFn.apply(x, gy, True, False)
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                gb = ops.nc_reduce(gy.detach(), None, want_dot=False, per_channel=True)[0].reshape(-1)
+        return gx, gw, gb
+
+
+class LinearActFn(Function):
+    """Dense + fused activation; first-order only (generator / encoder MLPs)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, act, slope):
+        x, w = _cg(x), _cg(w)
+        y = ops.gemm(x, w, False, False, b, act, slope)
+        ctx.save_for_backward(x, w, y)
+        ctx.act, ctx.slope, ctx.has_bias = act, slope, b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        if torch.is_grad_enabled():
+            raise RuntimeError("LinearActFn is first-order only; use linear() + lrelu()")
+        x, w, y = ctx.saved_tensors
+        g = ops.act_bwd(_cg(gy), y, ctx.act, ctx.slope)
+        gx = ops.gemm(g, w, False, True) if ctx.needs_input_grad[0] else None
+        gw = ops.gemm(x, g, True, False) if ctx.needs_input_grad[1] else None
+        gb = None
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = ops.nc_reduce(g, None, want_dot=False, per_channel=True)[0].reshape(-1)
+        return gx, gw, gb, None, None
+
+
+def linear(x, w, b=None, act=ACT_NONE, slope=0.0):
+    if act == ACT_NONE:
+        return LinearFn.apply(x, w, b)
+    return LinearActFn.apply(x, w, b, act, slope)
+
+
+# =============================================================================================
+# activations
+# =============================================================================================
+class LreluFn(Function):
+    @staticmethod
+    def forward(ctx, x, slope):
+        y = ops.act_fwd(_cg(x), ACT_LRELU, slope)
+        ctx.save_for_backward(y)
+        ctx.slope = slope
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (y,) = ctx.saved_tensors
+        return LreluMaskMulFn.apply(gy, y, ctx.slope), None
+
+
+class LreluMaskMulFn(Function):
+    """g * lrelu'(.) with the mask taken from the sign of y (sign(y) == sign(x), slope > 0)."""
+
+    @staticmethod
+    def forward(ctx, g, y, slope):
+        ctx.save_for_backward(y)
+        ctx.slope = slope
+        return ops.act_bwd(_cg(g), y, ACT_LRELU, slope)
+
+    @staticmethod
+    def backward(ctx, gg):
+        (y,) = ctx.saved_tensors
+        return LreluMaskMulFn.apply(gg, y, ctx.slope), None, None
+
+
+def lrelu(x, slope):
+    return LreluFn.apply(x, slope)
+
+
+# =============================================================================================
+# per-(sample, channel) statistics / affine maps on channels-last tensors
+# =============================================================================================
+class NcSumDotFn(Function):
+    """(sum_s a, sum_s a*b) per (n, c) [per c when per_channel]; b=None means b = a."""
+
+    @staticmethod
+    def forward(ctx, a, b, per_channel):
+        a = _cg(a)
+        b = _cg(b) if b is not None else None
+        ctx.save_for_backward(a, b)
+        ctx.per_channel = per_channel
+        s1, s2 = ops.nc_reduce(a, b, per_channel=per_channel)
+        return s1, s2
+
+    @staticmethod
+    def backward(ctx, g1, g2):
+        a, b = ctx.saved_tensors
+        pc = ctx.per_channel
+        ga = gb = None
+        g1 = _cg(g1) if g1 is not None else None
+        g2 = _cg(g2) if g2 is not None else None
+        if b is None:
+            if ctx.needs_input_grad[0]:
+                ga = NcLinFn.apply(a, None if g2 is None else 2.0 * g2, None, None, g1, pc) if g2 is not None else \
+                    NcLinFn.apply(None, None, None, None, g1, pc, tuple(a.shape))
+        else:
+            if ctx.needs_input_grad[0]:
+                ga = NcLinFn.apply(b, g2, None, None, g1, pc) if g2 is not None else \
+                    NcLinFn.apply(None, None, None, None, g1, pc, tuple(a.shape))
+            if ctx.needs_input_grad[1] and g2 is not None:
+                gb = NcLinFn.apply(a, g2, None, None, None, pc)
+        return ga, gb, None
+
+
+class NcLinFn(Function):
+    """y = a1*x1 + a2*x2 + b, coefficients (n, c) [or (1, c) when per_channel] broadcast over space.
+    Any of (x1,a1), (x2,a2), b may be None; a missing coefficient of a present x means 1."""
+
+    @staticmethod
+    def forward(ctx, x1, a1, x2, a2, b, per_channel, shape=None):
+        x1 = _cg(x1) if x1 is not None else None
+        x2 = _cg(x2) if x2 is not None else None
+        a1 = _cg(a1) if a1 is not None else None
+        a2 = _cg(a2) if a2 is not None else None
+        b = _cg(b) if b is not None else None
+        if shape is None:
+            shape = tuple((x1 if x1 is not None else x2).shape)
+        ctx.save_for_backward(x1, a1, x2, a2)
+        ctx.per_channel, ctx.has_b = per_channel, b is not None
+        return ops.nc_lin2(shape, x1, a1, x2, a2, b, per_channel=per_channel)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x1, a1, x2, a2 = ctx.saved_tensors
+        pc = ctx.per_channel
+        gy = _cg(gy)
+        gx1 = ga1 = gx2 = ga2 = gb = None
+        need_b = ctx.has_b and ctx.needs_input_grad[4]
+        sum_gy = None
+        if x1 is not None and ctx.needs_input_grad[0]:
+            gx1 = NcLinFn.apply(gy, a1, None, None, None, pc)
+        if a1 is not None and ctx.needs_input_grad[1]:
+            sum_gy, ga1 = NcSumDotFn.apply(gy, x1, pc)
+        if x2 is not None and ctx.needs_input_grad[2]:
+            gx2 = NcLinFn.apply(gy, a2, None, None, None, pc)
+        if a2 is not None and ctx.needs_input_grad[3]:
+            sum_gy2, ga2 = NcSumDotFn.apply(gy, x2, pc)
+            sum_gy = sum_gy if sum_gy is not None else sum_gy2
+        if need_b:
+            gb = sum_gy if sum_gy is not None else NcSumDotFn.apply(gy, None, pc)[0]
+        return gx1, ga1, gx2, ga2, gb, None, None
+
+
+def nc_stats(x, per_channel=False):
+    """(sum x, sum x^2) in one pass."""
+    return NcSumDotFn.apply(x, None, per_channel)
+
+
+def nc_lin(x1, a1=None, x2=None, a2=None, b=None, per_channel=False):
+    return NcLinFn.apply(x1, a1, x2, a2, b, per_channel)
+
+
+def _spatial(x):
+    return x.numel() // (x.shape[0] * x.shape[-1])
+
+
+def adain(x, scale_bias):
+    """AdaIn.call (building_blocks.py:135-149): LayerNormalization over the spatial axes (eps 1e-3,
+    no affine) then x*(s+1)+b; scale_bias (N, 2C) = [s | b] from the MLP of z."""
+    c = x.shape[-1]
+    s_, b_ = scale_bias[:, :c], scale_bias[:, c:]
+    inv = 1.0 / _spatial(x)
+    s1, s2 = nc_stats(x)
+    mu = s1 * inv
+    var = s2 * inv - mu * mu
+    a = torch.rsqrt(var + 1e-3) * (s_ + 1.0)
+    return nc_lin(x, a, None, None, b_ - mu * a)
+
+
+def instance_norm(x, gamma, beta, eps=1e-3):
+    """InstanceNormalization (instance_normalization.py:108-131): (x-mean)/(std+eps)*gamma+beta."""
+    inv = 1.0 / _spatial(x)
+    s1, s2 = nc_stats(x)
+    mu = s1 * inv
+    var = torch.clamp(s2 * inv - mu * mu, min=0.0)
+    a = gamma.unsqueeze(0) / (torch.sqrt(var) + eps)
+    return nc_lin(x, a, None, None, beta.unsqueeze(0) - mu * a)
+
+
+def layer_style(x, eps=1e-6):
+    """get_layer_style (confignet_utils.py:147-159) flattened as DiscrBlock does: (N, 2C) = [mu | std]."""
+    inv = 1.0 / _spatial(x)
+    s1, s2 = nc_stats(x)
+    mu = s1 * inv
+    var = torch.clamp(s2 * inv - mu * mu, min=0.0)
+    return torch.cat([mu, torch.sqrt(var + eps)], dim=1)
+
+
+def global_avg_pool(x):
+    return nc_stats(x)[0] * (1.0 / _spatial(x))
+
+
+class ChannelAffineActFn(Function):
+    """y = relu?(x*a[c] + b[c] (+ res)): BatchNormalization in inference mode folded to a per-channel
+    affine (keras ResNet50; R9), optional residual add and ReLU.  First-order only."""
+
+    @staticmethod
+    def forward(ctx, x, a, b, res, relu):
+        x = _cg(x)
+        res = _cg(res) if res is not None else None
+        y = ops.nc_lin2(tuple(x.shape), x, _cg(a), res, None, _cg(b), flags=8 if relu else 0, per_channel=True)
+        ctx.save_for_backward(x, a, y if relu else None)
+        ctx.relu, ctx.has_res = relu, res is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        if torch.is_grad_enabled():
+            raise RuntimeError("ChannelAffineActFn is first-order only")
+        x, a, y = ctx.saved_tensors
+        g = _cg(gy)
+        if ctx.relu:
+            g = ops.act_bwd(g, y, ACT_RELU)
+        gx = ga = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = ops.nc_lin2(tuple(x.shape), g, a, per_channel=True)
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            gb, ga = ops.nc_reduce(g, x, per_channel=True)
+            gb, ga = gb.reshape(-1), ga.reshape(-1)
+        return gx, ga, gb, (g if ctx.has_res else None), None
+
+
+def channel_affine_act(x, a, b, res=None, relu=False):
+    return ChannelAffineActFn.apply(x, a, b, res, relu)
+
+
+# =============================================================================================
+# pooling, pre-processing, rotation, loss reductions
+# =============================================================================================
+class MaxPoolFn(Function):
+    @staticmethod
+    def forward(ctx, x, k, s, pad):
+        x = _cg(x)
+        ctx.save_for_backward(x)
+        ctx.cfg = (k, s, pad)
+        return ops.maxpool_fwd(x, k, s, pad)
+
+    @staticmethod
+    def backward(ctx, gy):
+        (x,) = ctx.saved_tensors
+        return ops.maxpool_bwd(x, _cg(gy), *ctx.cfg), None, None, None
+
+
+def maxpool(x, k, s, pad=0):
+    return MaxPoolFn.apply(x, k, s, pad)
+
+
+class ChanAffine3Fn(Function):
+    @staticmethod
+    def forward(ctx, x, perm, scale, off):
+        ctx.perm, ctx.scale = perm, scale
+        return ops.chan_affine3_fwd(_cg(x), perm, scale, off)
+
+    @staticmethod
+    def backward(ctx, gy):
+        return ops.chan_affine3_bwd(_cg(gy), ctx.perm, ctx.scale), None, None, None
+
+
+def caffe_preprocess(x):
+    """(x+1)*127.5, RGB<->BGR flip, subtract (103.939, 116.779, 123.68) (R8)."""
+    return ChanAffine3Fn.apply(x, (2, 1, 0), 127.5, (127.5 - 103.939, 127.5 - 116.779, 127.5 - 123.68))
+
+
+def vggface_preprocess(x):
+    """(x+1)*127.5 - (93.5940, 104.7624, 129.1863), no flip (perceptual_loss.py:53-56)."""
+    return ChanAffine3Fn.apply(x, (0, 1, 2), 127.5, (127.5 - 93.5940, 127.5 - 104.7624, 127.5 - 129.1863))
+
+
+class Rotate3dFn(Function):
+    @staticmethod
+    def forward(ctx, grid, rot):
+        grid, rot = _cg(grid), _cg(rot)
+        ctx.save_for_backward(grid, rot)
+        return ops.rotate3d_fwd(grid, rot)
+
+    @staticmethod
+    def backward(ctx, gout):
+        grid, rot = ctx.saved_tensors
+        ggrid, grot = ops.rotate3d_bwd(grid, rot, _cg(gout), ctx.needs_input_grad[1])
+        return ggrid, grot
+
+
+def euler_angles_to_matrix(angles):
+    """confignet_utils.py:122-145 on an (N, 3) tensor (9 scalars per sample: host-side plumbing)."""
+    a = angles.reshape(-1, 3)
+    s, c = torch.sin(a), torch.cos(a)
+    rows = [c[:, 2] * c[:, 1], -s[:, 2], c[:, 2] * s[:, 1],
+            s[:, 0] * s[:, 1] + c[:, 0] * c[:, 1] * s[:, 2], c[:, 0] * c[:, 2],
+            c[:, 0] * s[:, 2] * s[:, 1] - c[:, 1] * s[:, 0],
+            c[:, 1] * s[:, 0] * s[:, 2] - c[:, 0] * s[:, 1], c[:, 2] * s[:, 0],
+            c[:, 0] * c[:, 1] + s[:, 0] * s[:, 1] * s[:, 2]]
+    return torch.stack(rows, dim=-1).reshape(-1, 3, 3)
+
+
+def rotate3d(grid, angles):
+    return Rotate3dFn.apply(grid, euler_angles_to_matrix(angles))
+
+
+class SqDiffSumFn(Function):
+    """scale * sum (a-b)^2 ; gradient only to `a` (b is the ground-truth branch)."""
+
+    @staticmethod
+    def forward(ctx, a, b, scale):
+        a, b = _cg(a), _cg(b)
+        ctx.save_for_backward(a, b)
+        ctx.scale = scale
+        return ops.sqdiff_sum(a, b, scale).reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        d = ops.axpby(a, b, 1.0, -1.0)
+        return ops.row_scale(d.reshape(1, -1), _cg(g.reshape(1)), 2.0 * ctx.scale).reshape(a.shape), None, None
+
+
+def mse_sum(a, b):
+    """mean((a-b)^2) over all elements (one perceptual-loss term, perceptual_loss.py:74-80)."""
+    return SqDiffSumFn.apply(a, b.detach(), 1.0 / a.numel())
+
+
+class RowSumSqFn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _cg(x)
+        ctx.save_for_backward(x)
+        return ops.row_sumsq(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        return RowScaleFn.apply(x, g, 2.0)
+
+
+class RowScaleFn(Function):
+    @staticmethod
+    def forward(ctx, x, s, k):
+        x, s = _cg(x), _cg(s)
+        ctx.save_for_backward(x, s)
+        ctx.k = k
+        return ops.row_scale(x, s, k)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, s = ctx.saved_tensors
+        gx = RowScaleFn.apply(g, s, ctx.k) if ctx.needs_input_grad[0] else None
+        gs = None
+        if ctx.needs_input_grad[1]:
+            gs = ctx.k * (ops.mul(_cg(g), x).reshape(x.shape[0], -1).sum(dim=1))
+        return gx, gs, None
+
+
+def row_sumsq(x):
+    return RowSumSqFn.apply(x)
+
+
+class MaskedDiffFn(Function):
+    """(gt - gen) * mask; gradient to gen only (losses.py:14)."""
+
+    @staticmethod
+    def forward(ctx, gen, gt, mask):
+        ctx.save_for_backward(mask)
+        return ops.masked_diff(_cg(gt), _cg(gen), mask)
+
+    @staticmethod
+    def backward(ctx, g):
+        (mask,) = ctx.saved_tensors
+        gm = ops.masked_diff(_cg(g), None, mask)
+        return ops.axpby(gm, None, -1.0, 0.0), None, None
+
+
+class GanLossFn(Function):
+    """mean(l*softplus(-s) + (1-l)*softplus(s)) for a constant label l (losses.py:7-11)."""
+
+    @staticmethod
+    def forward(ctx, scores, label):
+        scores = _cg(scores)
+        ctx.save_for_backward(scores)
+        ctx.label = label
+        return ops.gan_loss_fwd(scores, label).reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (s,) = ctx.saved_tensors
+        return ops.gan_loss_bwd(s, _cg(g.reshape(1)), ctx.label).reshape(s.shape), None
+
+
+def gan_loss(scores, label):
+    return GanLossFn.apply(scores, float(label))

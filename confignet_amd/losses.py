@@ -1,0 +1,85 @@
+"""Losses (reference: confignet/losses.py) on HIP kernels."""
+import numpy as np
+import torch
+
+from . import functional as F
+
+
+def GAN_G_loss(scores):
+    """mean(softplus(-scores)) (losses.py:7-8)."""
+    return F.gan_loss(scores, 1.0)
+
+
+def GAN_D_loss(labels, scores):
+    """mean(labels*softplus(-s) + (1-labels)*softplus(s)) (losses.py:10-11).  `labels` is a python
+    scalar or an array of 0/1 values (the reference only ever passes those)."""
+    if np.isscalar(labels):
+        return F.gan_loss(scores, float(labels))
+    lab = np.asarray(labels).reshape(-1)
+    vals = np.unique(lab)
+    if len(vals) == 1:
+        return F.gan_loss(scores, float(vals[0]))
+    total = 0
+    for v in vals:
+        idx = torch.as_tensor(np.nonzero(lab == v)[0], device=scores.device)
+        total = total + F.gan_loss(scores.reshape(-1)[idx].reshape(-1, 1), float(v)) * (len(idx) / len(lab))
+    return total
+
+
+def eye_loss(gt_imgs, gen_imgs, eye_masks):
+    """mean_n( sum_hwc ((gt-gen)*mask)^2 / (1 + sum_hw mask) ) (losses.py:13-18); masks uint8 (N,H,W)."""
+    if not torch.is_tensor(eye_masks):
+        eye_masks = torch.as_tensor(np.ascontiguousarray(eye_masks)).to(gen_imgs.device)
+    diff = F.MaskedDiffFn.apply(gen_imgs, gt_imgs, eye_masks.contiguous())
+    den = 1.0 + eye_masks.reshape(eye_masks.shape[0], -1).sum(dim=1).to(torch.float32)
+    return (F.row_sumsq(diff) / den).mean()
+
+
+def gradient_regularization(real_out, real_in):
+    """R1 (losses.py:75-82): 10*0.5*mean_n sum (d sum(real_out) / d real_in)^2; the input-gradient pass
+    is itself recorded (create_graph) so the penalty can be differentiated w.r.t. the weights."""
+    with F.input_grads_only():
+        (g,) = torch.autograd.grad(real_out, real_in, grad_outputs=torch.ones_like(real_out), create_graph=True)
+    return 10 * 0.5 * F.row_sumsq(g).mean()
+
+
+def compute_discriminator_loss(discriminator, real_imgs, fake_imgs):
+    """losses.py:20-47."""
+    real_imgs = real_imgs.detach().requires_grad_(True)
+    out_real = discriminator(real_imgs)
+    out_fake = discriminator(fake_imgs.detach())
+    losses = {}
+    for i, o in enumerate(out_real.values()):
+        losses["GAN_loss_real_" + str(i)] = GAN_D_loss(1.0, o)
+    for i, o in enumerate(out_fake.values()):
+        losses["GAN_loss_fake_" + str(i)] = GAN_D_loss(0.0, o)
+    for i, o in enumerate(out_real.values()):
+        losses["gp_loss_" + str(i)] = gradient_regularization(o, real_imgs)
+    losses["loss_sum"] = sum(losses.values())
+    return losses
+
+
+def compute_latent_discriminator_loss(latent_discriminator, real_latents, fake_latents):
+    """losses.py:49-73."""
+    real_latents = real_latents.detach().requires_grad_(True)
+    out_real = latent_discriminator(real_latents, twice_differentiable=True)
+    out_fake = latent_discriminator(fake_latents.detach())
+    losses = {
+        "GAN_loss_real": GAN_D_loss(1.0, out_real),
+        "GAN_loss_fake": GAN_D_loss(0.0, out_fake),
+        "gp_loss": gradient_regularization(out_real, real_latents),
+    }
+    losses["loss_sum"] = sum(losses.values())
+    return losses
+
+
+def mean_squared_error(labels, outputs):
+    """reduce_mean(tf.losses.mean_squared_error(a, b)) == global mean (R7).  Only ever applied to
+    (N, latent_dim+3) tensors (<= a few thousand floats, gradients on BOTH sides through the encoders):
+    latent-vector algebra of this size is host-side plumbing, not a kernel."""
+    return ((labels - outputs) ** 2).mean()
+
+
+def compute_latent_regression_loss(generator_outputs, labels, latent_regressor):
+    """losses.py:85-90."""
+    return mean_squared_error(labels, latent_regressor(generator_outputs))

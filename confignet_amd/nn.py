@@ -1,0 +1,118 @@
+"""Network container: Keras-ordered weight lists stored in one flat HBM arena per network.
+
+Mirrors the protocol the reference's callers use on keras Models: `net(inputs)`,
+`.predict(ndarray)`, `.get_weights()`, `.set_weights(list)`, `.trainable_weights`.  All
+trainable tensors of a network are views into ONE contiguous fp32 arena with a matching
+gradient arena, so the optimizer is one kernel launch and the data-parallel gradient exchange
+is one RCCL all-reduce per network."""
+import math
+
+import numpy as np
+import torch
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise RuntimeError("confignet_amd needs an MI355X GPU: the hot path is HIP-only (no CPU fallback)")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def glorot_uniform(rng, shape):
+    """Keras default kernel initializer (R4)."""
+    if len(shape) == 2:
+        fan_in, fan_out = shape
+    else:
+        rf = int(np.prod(shape[:-2]))
+        fan_in, fan_out = rf * shape[-2], rf * shape[-1]
+    lim = math.sqrt(6.0 / (fan_in + fan_out))
+    return rng.uniform(-lim, lim, size=shape).astype(np.float32)
+
+
+def he_normal(rng, shape):
+    """Stand-in init for the pretrained keras.applications stacks (no imagenet weights offline):
+    keeps activation magnitudes stable through 10-50 ReLU layers."""
+    rf = int(np.prod(shape[:-2])) if len(shape) > 2 else 1
+    return (rng.standard_normal(size=shape) * math.sqrt(2.0 / (rf * shape[-2]))).astype(np.float32)
+
+
+class Net:
+    def __init__(self):
+        self._entries = []          # (name, np array, trainable)
+        self.weights = []           # torch tensors, Keras get_weights() order
+        self._trainable_idx = []
+        self.arena = None           # flat parameters
+        self.grad_arena = None
+        self.device = None
+
+    # ---- construction -----------------------------------------------------------------------
+    def add_weight(self, name, array, trainable=True):
+        self._entries.append((name, np.ascontiguousarray(array, dtype=np.float32), trainable))
+        return len(self._entries) - 1
+
+    def finalize(self):
+        self.device = require_gpu()
+        n_train = sum(e[1].size for e in self._entries if e[2])
+        # 16-byte aligned slots so every view supports float4 access
+        offs, cur = [], 0
+        for _, a, tr in self._entries:
+            if tr:
+                offs.append(cur)
+                cur += (a.size + 3) // 4 * 4
+            else:
+                offs.append(-1)
+        self.arena = torch.zeros(max(cur, 4), device=self.device, dtype=torch.float32)
+        self.grad_arena = torch.zeros_like(self.arena)
+        self.weights, self._trainable_idx = [], []
+        for i, ((name, a, tr), off) in enumerate(zip(self._entries, offs)):
+            if tr:
+                p = self.arena[off:off + a.size].view(a.shape)
+                p.copy_(torch.from_numpy(a))
+                p.requires_grad_(True)
+                p.grad = self.grad_arena[off:off + a.size].view(a.shape)
+                self._trainable_idx.append(i)
+            else:
+                p = torch.from_numpy(a).to(self.device)
+            self.weights.append(p)
+        self.n_trainable = n_train
+        return self
+
+    # ---- keras-like protocol ----------------------------------------------------------------
+    @property
+    def trainable_weights(self):
+        return [self.weights[i] for i in self._trainable_idx]
+
+    def get_weights(self):
+        return [w.detach().cpu().numpy().copy() for w in self.weights]
+
+    def set_weights(self, weights):
+        weights = list(weights)
+        assert len(weights) == len(self.weights), "expected %d arrays, got %d" % (len(self.weights), len(weights))
+        with torch.no_grad():
+            for w, a in zip(self.weights, weights):
+                a = np.asarray(a, dtype=np.float32)
+                assert tuple(a.shape) == tuple(w.shape), "shape mismatch %s vs %s" % (a.shape, tuple(w.shape))
+                w.copy_(torch.from_numpy(np.ascontiguousarray(a)))
+
+    def copy_weights_from(self, other):
+        with torch.no_grad():
+            self.arena.copy_(other.arena)
+            for w, o in zip(self.weights, other.weights):
+                if not w.requires_grad:
+                    w.copy_(o)
+
+    def zero_grad(self):
+        self.grad_arena.zero_()
+
+    def requires_grad_(self, flag):
+        for i in self._trainable_idx:
+            self.weights[i].requires_grad_(flag)
+        return self
+
+    def to_device(self, x, dtype=torch.float32):
+        if torch.is_tensor(x):
+            return x.to(device=self.device, dtype=dtype)
+        return torch.as_tensor(np.ascontiguousarray(x)).to(device=self.device, dtype=dtype)
+
+    def predict(self, x, batch_size=32):
+        """keras Model.predict: batches of 32, numpy out (R11)."""
+        raise NotImplementedError

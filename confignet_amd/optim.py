@@ -1,0 +1,37 @@
+"""Keras-form Adam on flat parameter arenas ([TF-2.1] R10):
+theta -= lr*sqrt(1-b2^t)/(1-b1^t) * m/(sqrt(v)+eps), eps = 1e-7, with ONE iteration counter per
+optimizer object shared by every network it updates (confignet_first_stage.py:601-610: the same
+discriminator_optimizer serves D, synth-D and latent-D in turn, so t advances 3x per iteration)."""
+import math
+
+import torch
+
+from . import ops
+from . import parallel
+
+
+class Adam:
+    def __init__(self, lr=0.001, beta_1=0.9, beta_2=0.999, epsilon=1e-7, amsgrad=False, **_):
+        assert not amsgrad, "amsgrad is False everywhere in the reference"
+        self.lr, self.beta_1, self.beta_2, self.epsilon = lr, beta_1, beta_2, epsilon
+        self.iterations = 0
+        self._state = {}
+
+    def lr_t(self):
+        t = self.iterations
+        return self.lr * math.sqrt(1.0 - self.beta_2 ** t) / (1.0 - self.beta_1 ** t)
+
+    def apply_gradients(self, nets):
+        """One Keras apply_gradients call over the flat arenas of `nets` (a Net or a list of Nets):
+        data-parallel gradient all-reduce first, then one fused Adam launch per arena."""
+        if not isinstance(nets, (list, tuple)):
+            nets = [nets]
+        parallel.allreduce_gradients(nets)
+        self.iterations += 1
+        lr_t = self.lr_t()
+        for net in nets:
+            st = self._state.get(id(net))
+            if st is None:
+                st = (torch.zeros_like(net.arena), torch.zeros_like(net.arena))
+                self._state[id(net)] = st
+            ops.adam_step(net.arena, net.grad_arena, st[0], st[1], None, lr_t, self.beta_1, self.beta_2, self.epsilon)

@@ -1,0 +1,45 @@
+"""PerceptualLoss (reference: confignet/perceptual_loss.py) on HIP kernels."""
+import torch
+
+from . import functional as F
+from .dnn_models.vgg import VGG16_CFG, VGG16_TAPS, VGG19_CFG, VGG19_TAPS, VGGFeatures
+
+
+class PerceptualLoss:
+    def __init__(self, input_shape, model_type="imagenet", rng=None):
+        self.input_shape, self.model_type = input_shape, model_type
+        if model_type == "VGGFace":
+            self._pretrained_dnn_activations = VGGFeatures(VGG16_CFG, VGG16_TAPS, rng)
+        elif model_type == "imagenet":
+            self._pretrained_dnn_activations = VGGFeatures(VGG19_CFG, VGG19_TAPS, rng)
+        else:
+            raise ValueError(model_type)
+
+    def _preprocess_input(self, img):
+        return F.vggface_preprocess(img) if self.model_type == "VGGFace" else F.caffe_preprocess(img)
+
+    def _activations(self, img, need_grad):
+        net = self._pretrained_dnn_activations
+        img = net.to_device(img)
+        if img.dim() == 3:
+            img = img.unsqueeze(0)
+        if need_grad:
+            return net(self._preprocess_input(img))
+        with torch.no_grad():
+            return net(self._preprocess_input(img))
+
+    def loss(self, predicted, data):
+        """sum over the 4 tapped layers of mean((phi(predicted)-phi(data))^2) (perceptual_loss.py:43-82).
+        Symmetric; the side that carries gradient (the generated image) keeps its activations."""
+        p_grad = torch.is_tensor(predicted) and predicted.requires_grad
+        d_grad = torch.is_tensor(data) and data.requires_grad
+        if p_grad and not d_grad:
+            live, const = predicted, data
+        else:
+            live, const = data, predicted
+        fl = self._activations(live, torch.is_tensor(live) and live.requires_grad)
+        fc = self._activations(const, torch.is_tensor(const) and const.requires_grad)
+        total = 0
+        for a, b in zip(fl, fc):
+            total = total + F.mse_sum(a, b)
+        return total

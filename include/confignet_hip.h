@@ -83,7 +83,8 @@ int cn_nc_reduce(const float* x1, const float* x2, float* sum1, float* sum2, int
                  int flags, float slope, void* stream);
 /* y = A1*f1(x1) + A2*f2(x2) + B, coefficient tensors indexed [n*cstride + c] (cstride = c, or 0 for
  * per-channel coefficients).  flags: bit0/bit1 as above, bit2: multiply the result by lrelu'(x2),
- * bit3: relu on the result.  x1/A1, x2/A2 and B are each optional (NULL). */
+ * bit3: relu on the result.  x1, x2 and B are each optional (NULL); a NULL coefficient of a present
+ * x means 1. */
 int cn_nc_lin2(const float* x1, const float* a1, const float* x2, const float* a2, const float* bb,
                float* y, int n, int s, int c, int cstride, int flags, float slope, void* stream);
 

@@ -1,0 +1,344 @@
+"""GPU parity of the networks, losses and training steps (HIP path through the C ABI) against the
+CPU oracle in float64 on identical seeded weights and inputs.  Tolerance: outputs / loss scalars
+1e-3 max-abs (north_star), gradients 2e-3 of the tensor's max magnitude."""
+from collections import OrderedDict
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import ref_nets as R
+from oracle import ref_ops as O
+from oracle import ref_steps as S
+
+FM = OrderedDict([("beard_style_embedding", (9, 7)), ("blendshape_values", (62, 30)), ("eye_color", (8, 3)),
+                  ("head_hair_color", (3, 3))])          # latent_dim 43
+
+
+def w64(net, grad=True):
+    return [torch.tensor(w, dtype=torch.float64, requires_grad=grad) for w in net.get_weights()]
+
+
+def t64(a):
+    if torch.is_tensor(a):
+        a = a.detach().cpu().numpy()
+    return torch.tensor(np.asarray(a), dtype=torch.float64)
+
+
+def close(got, ref, tol=1e-3, what="", rel=False):
+    got = got.detach().cpu().double().numpy() if torch.is_tensor(got) else np.asarray(got, np.float64)
+    ref = ref.detach().double().numpy() if torch.is_tensor(ref) else np.asarray(ref, np.float64)
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    scale = max(np.abs(ref).max(), 1e-30) if rel else max(1.0, np.abs(ref).max())
+    err = np.abs(got - ref).max()
+    assert np.isfinite(got).all(), what + ": non-finite"
+    assert err <= tol * scale, "%s: max abs err %.3e vs scale %.3e" % (what, err, scale)
+
+
+def close_grads(net, ref_grads, what, tol=2e-3):
+    for i, (p, g) in enumerate(zip(net.weights, ref_grads)):
+        if not p.requires_grad:
+            continue
+        if g is None:
+            g = torch.zeros(tuple(p.shape), dtype=torch.float64)
+        close(p.grad, g, tol=tol, what="%s grad[%d] %s" % (what, i, tuple(p.shape)), rel=True)
+
+
+def randomize(net, seed, scale=0.1):
+    """Biases / gammas / betas are zero/one-initialised: perturb them so their gradients matter."""
+    rng = np.random.default_rng(seed)
+    ws = net.get_weights()
+    for i, w in enumerate(ws):
+        if w.ndim == 1:
+            ws[i] = (w + rng.normal(size=w.shape) * scale).astype(np.float32)
+    ws_ok = ws
+    net.set_weights(ws_ok)
+
+
+@pytest.mark.parametrize("res,n", [(128, 2), (256, 1)])
+def test_generator_forward_backward(res, n):
+    from confignet_amd.dnn_models.hologan_generator import HologanGenerator
+    rng = np.random.default_rng(res)
+    g = HologanGenerator(43, (res, res), 128, 2, "tanh", rng=rng)
+    randomize(g, 1)
+    z = rng.normal(size=(n, 43))
+    rot = rng.uniform(-0.5, 0.5, size=(n, 3)).astype(np.float32)
+    rot[:, 2] = 0
+    rot_t = torch.tensor(rot, device="cuda", requires_grad=True)
+    img = g((z, rot_t))
+    wr = w64(g)
+    rot_r = t64(rot).requires_grad_(True)
+    ref = R.generator_forward(wr, t64(z), rot_r, res)
+    close(img, ref, what="generator image")
+    cot = rng.normal(size=tuple(ref.shape))
+    g.zero_grad()
+    torch.autograd.backward((img * torch.tensor(cot, device="cuda", dtype=torch.float32)).sum(),
+                            inputs=g.trainable_weights + [rot_t])
+    grads = torch.autograd.grad((ref * t64(cot)).sum(), wr + [rot_r], allow_unused=True)
+    close_grads(g, grads[:-1], "generator")
+    close(rot_t.grad, grads[-1], tol=5e-3, what="d/d rotation", rel=True)
+    # predict() == eager call, numpy out; learned_input kernel gradient is identically zero
+    np.testing.assert_allclose(g.predict({**g.build_input_dict(z, rot)}), img.detach().cpu().numpy(), atol=1e-6)
+    assert float(g.weights[0].grad.abs().max()) == 0.0
+
+
+def test_discriminator_loss_with_r1_double_backward():
+    from confignet_amd.dnn_models.hologan_discriminator import HologanDiscriminator
+    from confignet_amd.losses import compute_discriminator_loss
+    rng = np.random.default_rng(7)
+    res, n = 64, 3
+    d = HologanDiscriminator((res, res), 5, 512, 3, 48, True, rng=rng)
+    randomize(d, 2)
+    real = rng.uniform(-1, 1, size=(n, res, res, 3))
+    fake = rng.uniform(-1, 1, size=(n, res, res, 3))
+    out = d(real)
+    wr = w64(d)
+    ref_out = R.discriminator_forward(wr, t64(real))
+    assert list(out.keys()) == list(ref_out.keys())
+    for k in out:
+        close(out[k], ref_out[k], what=k)
+    d.zero_grad()
+    losses = compute_discriminator_loss(d, d.to_device(real), d.to_device(fake))
+    torch.autograd.backward(losses["loss_sum"], inputs=d.trainable_weights)
+    ref_losses = S.discriminator_loss(wr, t64(real), t64(fake))
+    assert list(losses.keys()) == list(ref_losses.keys())
+    for k in losses:
+        close(losses[k], ref_losses[k], what=k)
+    close_grads(d, S.grads_of(ref_losses["loss_sum"], wr), "discriminator (R1)")
+
+
+def test_latent_regressor_and_latent_discriminator():
+    from confignet_amd.dnn_models.building_blocks import MLPSimple
+    from confignet_amd.dnn_models.hologan_discriminator import HologanLatentRegressor
+    from confignet_amd.losses import compute_latent_discriminator_loss
+    rng = np.random.default_rng(8)
+    lr = HologanLatentRegressor(43, (64, 64), 5, 512, 3, 48, True, rng=rng)
+    randomize(lr, 3)
+    img = rng.uniform(-1, 1, size=(2, 64, 64, 3))
+    wr = w64(lr)
+    out = lr(img)
+    ref = R.latent_regressor_forward(wr, t64(img))
+    close(out, ref, what="latent regressor")
+    lr.zero_grad()
+    torch.autograd.backward((out ** 2).sum(), inputs=lr.trainable_weights)
+    close_grads(lr, S.grads_of((ref ** 2).sum(), wr), "latent regressor")
+
+    ld = MLPSimple(4, 43, 43, 1, rng=rng)
+    randomize(ld, 4)
+    a, b = rng.normal(size=(16, 43)), rng.normal(size=(16, 43))
+    wr = w64(ld)
+    ld.zero_grad()
+    losses = compute_latent_discriminator_loss(ld, ld.to_device(a), ld.to_device(b))
+    torch.autograd.backward(losses["loss_sum"], inputs=ld.trainable_weights)
+    ref_losses = S.latent_discriminator_loss(wr, t64(a), t64(b))
+    for k in losses:
+        close(losses[k], ref_losses[k], what="latent D " + k)
+    close_grads(ld, S.grads_of(ref_losses["loss_sum"], wr), "latent discriminator (R1)")
+
+
+@pytest.mark.parametrize("model_type", ["imagenet", "VGGFace"])
+def test_perceptual_loss(model_type):
+    from confignet_amd.perceptual_loss import PerceptualLoss
+    rng = np.random.default_rng(9)
+    pl = PerceptualLoss((64, 64, 3), model_type)
+    gt = rng.uniform(-1, 1, size=(2, 64, 64, 3))
+    gen = rng.uniform(-1, 1, size=(2, 64, 64, 3))
+    gen_t = torch.tensor(gen, device="cuda", dtype=torch.float32, requires_grad=True)
+    loss = pl.loss(gt, gen_t)
+    (g,) = torch.autograd.grad(loss, gen_t)
+    vw = w64(pl._pretrained_dnn_activations, grad=False)
+    gen_r = t64(gen).requires_grad_(True)
+    ref = R.perceptual_loss(vw, t64(gt), gen_r, model_type)
+    (gr,) = torch.autograd.grad(ref, gen_r)
+    close(loss, ref, tol=1e-3, what="perceptual loss", rel=True)
+    close(g, gr, tol=2e-3, what="d perceptual / d image", rel=True)
+
+
+def test_real_encoder():
+    from confignet_amd.dnn_models.real_encoder import RealEncoder
+    rng = np.random.default_rng(10)
+    enc = RealEncoder(43, (64, 64, 3), ((-30, 30), (-10, 10), (0, 0)), rng=rng)
+    randomize(enc, 5, 0.05)
+    img = rng.uniform(-1, 1, size=(2, 64, 64, 3))
+    wr = w64(enc)
+    emb, rot = enc(img)
+    emb_r, rot_r = R.real_encoder_forward(wr, t64(img))
+    close(emb, emb_r, what="encoder embedding", rel=True)
+    close(rot, rot_r, what="encoder rotation")
+    enc.zero_grad()
+    torch.autograd.backward((emb ** 2).sum() + (rot ** 2).sum() * 10, inputs=enc.trainable_weights)
+    grads = torch.autograd.grad((emb_r ** 2).sum() + (rot_r ** 2).sum() * 10, wr, allow_unused=True)
+    close_grads(enc, grads, "real encoder", tol=3e-3)
+    e2, r2 = enc.predict(img.astype(np.float32))
+    np.testing.assert_allclose(e2, emb.detach().cpu().numpy(), atol=1e-5)
+
+
+def _make_model(cls, res, batch, seed=0):
+    cfg = {"output_shape": (res, res, 3), "batch_size": batch, "facemodel_inputs": dict(FM)}
+    np.random.seed(seed)
+    m = cls(cfg, seed=seed)
+    for i, net in enumerate(m.all_networks()):
+        if net is not m.generator_smoothed:
+            randomize(net, 100 + i, 0.05)
+    m.generator_smoothed.copy_weights_from(m.generator)
+    return m
+
+
+def _oracle_weights(m):
+    names = {"generator": m.generator, "discriminator": m.discriminator, "synth_discriminator": m.synth_discriminator,
+             "latent_discriminator": m.latent_discriminator, "latent_regressor": m.latent_regressor,
+             "synthetic_encoder": m.synthetic_encoder}
+    if getattr(m, "encoder", None) is not None:
+        names["real_encoder"] = m.encoder
+    return {k: w64(v) for k, v in names.items()}
+
+
+def _batch(m, res, n_synth, n_real, rng):
+    params = [rng.normal(size=(n_synth, d[0])) for d in m.config["facemodel_inputs"].values()]
+    rot = rng.uniform(-0.4, 0.4, size=(n_synth + n_real, 3))
+    rot[:, 2] = 0
+    imgs = rng.uniform(-1, 1, size=(n_synth + n_real, res, res, 3))
+    masks = np.zeros((n_synth, res, res), np.uint8)
+    masks[:, 20:30, 30:45] = 1
+    return params, rot, imgs, masks
+
+
+def test_first_stage_generator_step_and_adam():
+    from confignet_amd import ConfigNetFirstStage, optim
+    res, ns, nr = 128, 1, 1
+    m = _make_model(ConfigNetFirstStage, res, ns + nr)
+    rng = np.random.default_rng(11)
+    params, rot, imgs, masks = _batch(m, res, ns, nr, rng)
+    z_real = rng.normal(size=(nr, m.config["latent_dim"]))
+    W = _oracle_weights(m)
+    vgg_w = w64(m.perceptual_loss._pretrained_dnn_activations, grad=False)
+    dev = m._dev
+    nets = [m.generator, m.latent_regressor, m.synthetic_encoder]
+    for n in nets:
+        n.zero_grad()
+    from confignet_amd.confignet_first_stage import frozen
+    opt = optim.Adam(**m.config["optimizer"])
+    with frozen(m.discriminator, m.synth_discriminator, m.latent_discriminator):
+        losses = m._generator_loss([dev(p) for p in params], dev(rot[:ns]), dev(imgs[:ns]),
+                                   torch.as_tensor(masks).cuda(), dev(z_real), dev(rot[ns:]))
+        torch.autograd.backward(losses["loss_sum"], inputs=[p for n in nets for p in n.trainable_weights])
+    ref, _ = S.first_stage_generator_loss(W, m.config, [t64(p) for p in params], t64(rot[:ns]), t64(imgs[:ns]),
+                                          torch.as_tensor(masks), t64(z_real), t64(rot[ns:]), vgg_w)
+    assert list(losses.keys()) == list(ref.keys())
+    for k in losses:
+        close(losses[k], ref[k], what="G step " + k)
+    allw = W["generator"] + W["latent_regressor"] + W["synthetic_encoder"]
+    grads = S.grads_of(ref["loss_sum"], allw)
+    ng, nl = len(W["generator"]), len(W["latent_regressor"])
+    close_grads(m.generator, grads[:ng], "G step: generator")
+    close_grads(m.latent_regressor, grads[ng:ng + nl], "G step: latent regressor")
+    close_grads(m.synthetic_encoder, grads[ng + nl:], "G step: synthetic encoder")
+    # Keras Adam (shared counter) + EMA on the arenas vs the oracle
+    ropt = O.KerasAdam(**m.config["optimizer"])
+    ropt.apply_gradients(list(zip(grads, allw)))
+    opt.apply_gradients(nets)
+    for net, ws in ((m.generator, W["generator"]), (m.latent_regressor, W["latent_regressor"])):
+        for p, r in zip(net.weights, ws):
+            close(p, r, tol=2e-5, what="adam-updated weight")
+    sm = [w.detach().clone() for w in w64(m.generator_smoothed, grad=False)]
+    S.ema_update(sm, W["generator"])
+    m.update_smoothed_weights()
+    for p, r in zip(m.generator_smoothed.weights, sm):
+        close(p, r, tol=1e-5, what="EMA weight")
+
+
+def test_second_stage_generator_step():
+    from confignet_amd import ConfigNet
+    from confignet_amd.confignet_first_stage import frozen
+    res, ns, nr = 128, 1, 1
+    m = _make_model(ConfigNet, res, ns + nr, seed=1)
+    rng = np.random.default_rng(12)
+    params, rot, imgs, masks = _batch(m, res, ns, nr, rng)
+    W = _oracle_weights(m)
+    vgg_w = w64(m.perceptual_loss._pretrained_dnn_activations, grad=False)
+    dev = m._dev
+    nets = [m.generator, m.latent_regressor, m.synthetic_encoder, m.encoder]
+    for n in nets:
+        n.zero_grad()
+    with frozen(m.discriminator, m.synth_discriminator, m.latent_discriminator):
+        losses = m._generator_loss([dev(p) for p in params], dev(rot[:ns]), dev(imgs[:ns]),
+                                   torch.as_tensor(masks).cuda(), dev(imgs[ns:]))
+        torch.autograd.backward(losses["loss_sum"], inputs=[p for n in nets for p in n.trainable_weights])
+    ref, _ = S.second_stage_generator_loss(W, m.config, [t64(p) for p in params], t64(rot[:ns]), t64(imgs[:ns]),
+                                           torch.as_tensor(masks), t64(imgs[ns:]), vgg_w)
+    assert list(losses.keys()) == list(ref.keys())
+    for k in losses:
+        close(losses[k], ref[k], what="stage-2 G step " + k)
+    allw = W["generator"] + W["latent_regressor"] + W["synthetic_encoder"] + W["real_encoder"]
+    grads = torch.autograd.grad(ref["loss_sum"], allw, allow_unused=True)
+    ng, nl, ne = len(W["generator"]), len(W["latent_regressor"]), len(W["synthetic_encoder"])
+    close_grads(m.generator, grads[:ng], "stage-2: generator")
+    close_grads(m.latent_regressor, grads[ng:ng + nl], "stage-2: latent regressor")
+    close_grads(m.synthetic_encoder, grads[ng + nl:ng + nl + ne], "stage-2: synthetic encoder")
+    close_grads(m.encoder, grads[ng + nl + ne:], "stage-2: real encoder", tol=5e-3)
+
+
+def test_full_iteration_runs_and_api(tmp_path):
+    """One whole second-stage iteration through the reference-shaped API on a synthetic dataset;
+    save/load round trip in the reference's npz/json layout; generate_images uint8 contract."""
+    from confignet_amd import ConfigNet, SyntheticFaceDataset, load_confignet, optim
+    from confignet_amd.confignet_first_stage import DEFAULT_CONFIG
+    from confignet_amd.confignet_utils import merge_configs
+    np.random.seed(0)
+    ds = SyntheticFaceDataset(16, 128, seed=3)
+    cfg = merge_configs(DEFAULT_CONFIG, {"batch_size": 4, "output_shape": (128, 128, 3)})
+    ds.process_metadata(cfg, True)
+    m = ConfigNet(cfg, seed=0)
+    assert m.config["latent_dim"] == 145
+    m.setup_training(None, ds, 0, real_training_set=ds)
+    dopt, gopt = optim.Adam(**m.config["optimizer"]), optim.Adam(**m.config["optimizer"])
+    before = m.generator.arena.clone()
+    for _ in range(2):
+        d, sd, ld, g = m.training_iteration(ds, ds, dopt, gopt)
+    assert dopt.iterations == 6 and gopt.iterations == 2            # shared-counter rule (R10)
+    for losses in (d, sd, ld, g):
+        assert np.isfinite(float(losses["loss_sum"]))
+    assert set(d.keys()) == {"GAN_loss_real_%d" % i for i in range(6)} | {"GAN_loss_fake_%d" % i for i in range(6)} | \
+        {"gp_loss_%d" % i for i in range(6)} | {"loss_sum"}
+    assert not torch.equal(before, m.generator.arena)
+    imgs = m.generate_images(m.sample_latent_vector(3), m.sample_rotations(3))
+    assert imgs.shape == (3, 128, 128, 3) and imgs.dtype == np.uint8
+    emb, rot = m.encode_images(ds.imgs[:2])
+    assert emb.shape == (2, 145) and rot.shape == (2, 3)
+    lat2 = m.set_facemodel_param_in_latents(emb, "blendshape_values", np.zeros(62, np.float32))
+    assert lat2.shape == emb.shape and np.array_equal(np.nonzero((lat2 != emb).any(0))[0], np.arange(7, 37))
+    m.save(str(tmp_path), "model")
+    m2 = load_confignet(str(tmp_path / "model.json"))
+    assert type(m2).__name__ == "ConfigNet"
+    np.testing.assert_array_equal(m2.generate_images(emb, rot), m.generate_images(emb, rot))
+    e3, r3 = m.fine_tune_on_img(ds.imgs[:1], n_iters=2)
+    assert e3.shape == (1, 145) and np.isfinite(e3).all()
+    # only the expression slice differs from a stale pre/post return after the steps
+    assert m.generator_fine_tuned is not None
+
+
+def test_latent_gan_step():
+    from confignet_amd import LatentGAN, optim
+    np.random.seed(0)
+    gan = LatentGAN({"latent_dim": 145, "batch_size": 256}, seed=0)
+    opt = optim.Adam(**gan.config["optimizer"])
+    emb = np.random.normal(size=(1000, 145)).astype(np.float32)
+    # parity of the discriminator loss incl. R1 with the oracle
+    real, fake = emb[:64], emb[64:128] * 0.5
+    from oracle.ref_steps import latent_discriminator_loss, grads_of
+    wr = w64(gan.discriminator)
+    gan.discriminator.zero_grad()
+    losses = gan._discriminator_loss(gan.discriminator.to_device(real), gan.discriminator.to_device(fake))
+    torch.autograd.backward(losses["loss_sum"], inputs=gan.discriminator.trainable_weights)
+    ref = latent_discriminator_loss(wr, t64(real), t64(fake))
+    for k in losses:
+        close(losses[k], ref[k], what="LatentGAN D " + k)
+    close_grads(gan.discriminator, grads_of(ref["loss_sum"], wr), "LatentGAN D")
+    for _ in range(2):
+        d = gan.discriminator_training_step(emb, opt)
+        g = gan.generator_training_step(opt)
+        gan.update_smoothed_weights()
+    assert np.isfinite(float(d["loss_sum"])) and np.isfinite(float(g["loss_sum"]))
+    assert gan.generate_latents(5).shape == (5, 145)
