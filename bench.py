@@ -1,0 +1,131 @@
+#!/usr/bin/env python
+"""bench.py -- train-step images/sec at 256x256 (BASELINE.json metric).
+
+One "step" = one whole reference training iteration of the SECOND stage (discriminator step +
+synthetic-domain discriminator step + latent-discriminator step + generator step + EMA update,
+reference confignet_second_stage.py:277-288) at 256x256, batch 16 per GPU, fp32, on synthetic
+FFHQ-shaped uint8 pools that are resident in HBM before the timed region (BASELINE.json configs[1]).
+images/sec = global batch / iteration time, the reference's own instrument
+(confignet_first_stage.py:605-625).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+N > 1: one process per GPU, same per-GPU batch (weak scaling), gradient arenas all-reduced with RCCL.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=16, help="images per GPU per step function")
+    ap.add_argument("--res", type=int, default=256)
+    ap.add_argument("--pool", type=int, default=512, help="images in each synthetic uint8 pool")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=4)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from confignet_amd import ConfigNet, SyntheticFaceDataset, ops, optim, parallel
+    from confignet_amd.confignet_first_stage import DEFAULT_CONFIG
+    from confignet_amd.confignet_utils import merge_configs
+
+    world = parallel.init_from_env()
+    rank = parallel.rank()
+    assert world == args.gpus or world == 1 and args.gpus == 1, "WORLD_SIZE=%d but --gpus %d" % (world, args.gpus)
+    if world == 1:
+        torch.cuda.set_device(0)
+
+    np.random.seed(1234 + rank)                       # per-rank batch sampling stream
+    real_set = SyntheticFaceDataset(args.pool, args.res, seed=1)
+    synth_set = SyntheticFaceDataset(args.pool, args.res, seed=2)
+    cfg = merge_configs(DEFAULT_CONFIG, {"batch_size": args.batch, "output_shape": (args.res, args.res, 3)})
+    synth_set.process_metadata(cfg, True)
+    cfg["image_loss_weight"] *= 10                    # second stage (train_confignet.py:67)
+    model = ConfigNet(cfg, seed=0)                    # identical seeded weights on every rank
+    parallel.broadcast_weights(model.all_networks())
+    model.setup_training(None, synth_set, 0, real_training_set=real_set)
+    d_opt, g_opt = optim.Adam(**cfg["optimizer"]), optim.Adam(**cfg["optimizer"])
+    model._pool(real_set), model._pool(synth_set)     # uint8 pools -> HBM before timing
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        model.training_iteration(real_set, synth_set, d_opt, g_opt)
+    sync()
+    ops.prof_reset()
+    ops.prof_enable(True)                             # HIP events around every implicit-GEMM conv launch
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        losses = model.training_iteration(real_set, synth_set, d_opt, g_opt)
+    sync()
+    elapsed = time.perf_counter() - t0
+    ops.prof_enable(False)
+    launches, kernel_ms, kernel_flops = ops.prof_collect()
+    finite = all(np.isfinite(float(l["loss_sum"])) for l in losses)
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / args.steps
+        value = args.batch * world / (elapsed / args.steps)
+        achieved = kernel_flops / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
+        out = {
+            "metric": "train-step images/sec at 256x256 (G+D fwd+bwd)",
+            "value": round(value, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "ConfigNet second-stage iteration (D + synth-D + latent-D + G + EMA), %dx%d, "
+                                   "batch %d per GPU, fp32, Keras-Adam" % (args.res, args.res, args.batch),
+                       "global_batch": args.batch * world, "resolution": args.res, "latent_dim": cfg_latent(model),
+                       "parallelism": "dp%d" % world, "losses_finite": bool(finite)},
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                         "kernel": "igemm_fwd/igemm_wgrad (implicit-GEMM conv, v_mfma_f32_32x32x2_f32)",
+                         "launches_per_step": launches / max(args.steps, 1),
+                         "kernel_ms_per_step": round(kernel_ms / max(args.steps, 1), 3),
+                         "algorithmic_gflop_per_step": round(kernel_flops / max(args.steps, 1) / 1e9, 2)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import cpu_baseline
+            v, sec, cores = cpu_baseline.time_second_stage_iteration(args.res, args.cpu_batch)
+            out["cpu_baseline"] = {
+                "value": round(v, 4), "unit": "images/sec", "cores": cores, "kind": "port",
+                "sample": "1 second-stage iteration at %dx%d, batch %d (%.1f s), torch-CPU fp32 restatement of the "
+                          "reference (oracle/); TensorFlow 2.1 itself is not installable here" % (args.res, args.res, args.cpu_batch, sec)}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cfg_latent(model):
+    return int(model.config["latent_dim"])
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,115 @@
+"""Timed CPU baseline for bench.py: the oracle's restatement of ONE whole second-stage training
+iteration (torch-CPU fp32, eager, op for op with the reference) on a bounded batch.
+TEST/BENCH INFRASTRUCTURE (oracle/__init__.py): this is a port of the reference's arithmetic, not
+TensorFlow 2.1 (which cannot be installed here)."""
+import os
+import time
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import ref_nets as R
+from . import ref_ops as O
+from . import ref_steps as S
+
+FACEMODEL_IO = OrderedDict(sorted({
+    "beard_style_embedding": (9, 7), "blendshape_values": (62, 30), "bone_rotations:left_eye": (3, 2),
+    "eye_color": (8, 3), "eyebrow_style_embedding": (44, 7), "geometry_identity_params": (53, 30),
+    "hdri_embedding": (50, 20), "head_hair_color": (3, 3), "head_hair_style_embedding": (18, 9),
+    "lower_eyelash_style": (4, 2), "texture_embedding": (50, 30), "upper_eyelash_style": (4, 2)}.items()))
+
+
+def _init(shapes, rng, he=False, dtype=torch.float32, grad=True):
+    out = []
+    for s in shapes:
+        if len(s) == 1:
+            a = np.zeros(s, np.float32)
+        elif he:
+            rf = int(np.prod(s[:-2])) if len(s) > 2 else 1
+            a = (rng.standard_normal(size=s) * np.sqrt(2.0 / (rf * s[-2]))).astype(np.float32)
+        else:
+            a = O.glorot_uniform(rng, s)
+        out.append(torch.tensor(a, dtype=dtype, requires_grad=grad))
+    return out
+
+
+def build_weights(res, latent_dim, rng, dtype=torch.float32):
+    W = {
+        "generator": _init(R.generator_weight_shapes(latent_dim, res), rng, dtype=dtype),
+        "discriminator": _init(R.discriminator_weight_shapes(res), rng, dtype=dtype),
+        "synth_discriminator": _init(R.discriminator_weight_shapes(res), rng, dtype=dtype),
+        "latent_discriminator": _init(R.mlp_weight_shapes(4, latent_dim, latent_dim, 1), rng, dtype=dtype),
+        "latent_regressor": _init(R.latent_regressor_weight_shapes(latent_dim, res), rng, dtype=dtype),
+        "synthetic_encoder": _init(R.synthetic_encoder_weight_shapes(list(FACEMODEL_IO.values())), rng, dtype=dtype),
+    }
+    with torch.no_grad():
+        W["generator"][1].fill_(1.0)           # learned_input bias = ones
+        W["generator"][0].zero_()
+        for k in ("discriminator", "synth_discriminator", "latent_regressor"):
+            shapes = R.discriminator_weight_shapes(res) if k != "latent_regressor" else R.latent_regressor_weight_shapes(latent_dim, res)
+            for i in range(5):
+                W[k][2 + 4 * i + 2].fill_(1.0)  # instance-norm gamma = 1
+    enc = []
+    for i, s in enumerate(R.real_encoder_weight_shapes(latent_dim)):
+        # per conv-bn group: kernel, bias, gamma, beta, moving_mean, moving_var
+        enc.append(s)
+    ew = _init(enc, rng, he=True, dtype=dtype)
+    n_bn = (len(ew) - 4) // 6
+    with torch.no_grad():
+        for j in range(n_bn):
+            ew[6 * j + 2].fill_(1.0)
+            ew[6 * j + 5].fill_(1.0)
+            ew[6 * j + 4].requires_grad_(False)
+            ew[6 * j + 5].requires_grad_(False)
+    W["real_encoder"] = ew
+    W["generator_smoothed"] = [w.detach().clone() for w in W["generator"]]
+    vgg = _init(R.vgg_weight_shapes(R.VGG19_CFG), rng, he=True, dtype=dtype, grad=False)
+    return W, vgg
+
+
+def make_batch(res, b, rng, dtype=torch.float32):
+    t = lambda a: torch.tensor(np.asarray(a), dtype=dtype)
+    img = lambda n: t(rng.uniform(-1, 1, size=(n, res, res, 3)))
+    par = lambda n: [t(rng.standard_normal(size=(n, d[0]))) for d in FACEMODEL_IO.values()]
+
+    def rot(n):
+        r = np.zeros((n, 3))
+        r[:, 0] = np.pi * rng.uniform(-30, 30, n) / 180
+        r[:, 1] = np.pi * rng.uniform(-10, 10, n) / 180
+        return t(r)
+    ns, nr = b // 2, b - b // 2
+    masks = np.zeros((ns, res, res), np.uint8)
+    masks[:, res // 3:res // 3 + res // 12, res // 3:res // 3 + res // 12] = 1
+    return {"real_d": img(b), "enc_in_d": img(b), "real_sd": img(b), "params_sd": par(b), "rot_sd": rot(b),
+            "real_ld": img(b), "params_ld": par(b), "params_g": par(ns), "rot_g": rot(ns), "synth_imgs_g": img(ns),
+            "eye_masks_g": torch.as_tensor(masks), "real_imgs_g": img(nr)}
+
+
+def time_second_stage_iteration(res=256, batch=2, repeats=1, threads=None):
+    """Returns (images_per_sec, seconds_per_iteration, cores_used)."""
+    threads = threads or os.cpu_count()
+    torch.set_num_threads(threads)
+    rng = np.random.default_rng(0)
+    latent_dim = sum(v[1] for v in FACEMODEL_IO.values())
+    cfg = {"output_shape": (res, res, 3), "rotation_ranges": ((-30, 30), (-10, 10), (0, 0)),
+           "image_loss_weight": 5e-4, "eye_loss_weight": 5, "domain_adverserial_loss_weight": 5.0,
+           "latent_regression_weight": 10.0, "latent_regressor_rot_weight": 5.0}
+    W, vgg = build_weights(res, latent_dim, rng)
+    d_opt = O.KerasAdam(lr=4e-4, beta_1=0.0, beta_2=0.9)
+    g_opt = O.KerasAdam(lr=4e-4, beta_1=0.0, beta_2=0.9)
+    times = []
+    for _ in range(repeats):
+        b = make_batch(res, batch, rng)
+        t0 = time.perf_counter()
+        S.second_stage_iteration(W, cfg, b, d_opt, g_opt, vgg)
+        times.append(time.perf_counter() - t0)
+    sec = float(np.median(times))
+    return batch / sec, sec, threads
+
+
+if __name__ == "__main__":
+    import sys
+    b = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+    r = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+    print(time_second_stage_iteration(r, b))

@@ -126,3 +126,44 @@ def ema_update(smoothed, training, alpha=0.999):
     with torch.no_grad():
         for s, t in zip(smoothed, training):
             s.mul_(alpha).add_(t, alpha=1 - alpha)
+
+
+def second_stage_iteration(W, cfg, batch, d_opt, g_opt, vgg_w):
+    """One whole reference training iteration (confignet_second_stage.py:277-288) on explicit
+    batches: D step, synth-D step, latent-D step, G step, EMA.  `batch` holds, for a batch size B:
+    real_d, enc_in_d (B images each), real_sd, params_sd, rot_sd, real_ld, params_ld, and for the G step
+    params_g, rot_g, synth_imgs_g, eye_masks_g (B//2) and real_imgs_g (B - B//2).
+    Used by tests and as bench.py's timed CPU baseline."""
+    res = cfg["output_shape"][0]
+    out = {}
+    # (1) discriminator step (confignet_first_stage.py:466-476 ; batch: second_stage:119-130)
+    with torch.no_grad():
+        lat, rot = R.real_encoder_forward(W["real_encoder"], batch["enc_in_d"], cfg["rotation_ranges"])
+        fake = R.generator_forward(W["generator"], lat, rot, res)
+    losses = discriminator_loss(W["discriminator"], batch["real_d"], fake)
+    d_opt.apply_gradients(list(zip(grads_of(losses["loss_sum"], W["discriminator"]), W["discriminator"])))
+    out["d"] = losses
+    # (2) synthetic-domain discriminator step (confignet_first_stage.py:478-488,452-464)
+    with torch.no_grad():
+        lat = R.synthetic_encoder_forward(W["synthetic_encoder"], batch["params_sd"])
+        fake = R.generator_forward(W["generator"], lat, batch["rot_sd"], res)
+    losses = discriminator_loss(W["synth_discriminator"], batch["real_sd"], fake)
+    d_opt.apply_gradients(list(zip(grads_of(losses["loss_sum"], W["synth_discriminator"]), W["synth_discriminator"])))
+    out["synth_d"] = losses
+    # (3) latent discriminator step (confignet_second_stage.py:132-147)
+    with torch.no_grad():
+        real_lat, _ = R.real_encoder_forward(W["real_encoder"], batch["real_ld"], cfg["rotation_ranges"])
+        fake_lat = R.synthetic_encoder_forward(W["synthetic_encoder"], batch["params_ld"])
+    losses = latent_discriminator_loss(W["latent_discriminator"], real_lat, fake_lat)
+    d_opt.apply_gradients(list(zip(grads_of(losses["loss_sum"], W["latent_discriminator"]), W["latent_discriminator"])))
+    out["latent_d"] = losses
+    # (4) generator step (confignet_second_stage.py:149-218)
+    losses, _ = second_stage_generator_loss(W, cfg, batch["params_g"], batch["rot_g"], batch["synth_imgs_g"],
+                                            batch["eye_masks_g"], batch["real_imgs_g"], vgg_w)
+    allw = W["generator"] + W["latent_regressor"] + W["synthetic_encoder"] + \
+        [w for w in W["real_encoder"] if w.requires_grad]
+    g_opt.apply_gradients(list(zip(grads_of(losses["loss_sum"], allw), allw)))
+    out["g"] = losses
+    # (5) EMA (confignet_first_stage.py:393-400)
+    ema_update(W["generator_smoothed"], W["generator"])
+    return out
