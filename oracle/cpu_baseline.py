@@ -88,7 +88,9 @@ def make_batch(res, b, rng, dtype=torch.float32):
 
 def time_second_stage_iteration(res=256, batch=2, repeats=1, threads=None):
     """Returns (images_per_sec, seconds_per_iteration, cores_used)."""
-    threads = threads or os.cpu_count()
+    # torch-CPU eager on these op sizes stops scaling (and collapses from oversubscription) beyond a few
+    # dozen threads: use at most 16 of the host's cores and report that number as `cores`
+    threads = threads or min(os.cpu_count() or 1, 16)
     torch.set_num_threads(threads)
     rng = np.random.default_rng(0)
     latent_dim = sum(v[1] for v in FACEMODEL_IO.values())
@@ -109,7 +111,9 @@ def time_second_stage_iteration(res=256, batch=2, repeats=1, threads=None):
 
 
 if __name__ == "__main__":
+    import json
     import sys
     b = int(sys.argv[1]) if len(sys.argv) > 1 else 2
     r = int(sys.argv[2]) if len(sys.argv) > 2 else 256
-    print(time_second_stage_iteration(r, b))
+    v, sec, cores = time_second_stage_iteration(r, b)
+    print(json.dumps({"value": v, "seconds": sec, "cores": cores, "host_cores": os.cpu_count()}))
