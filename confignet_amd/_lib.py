@@ -21,7 +21,7 @@ class ConfigNetHipError(RuntimeError):
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
-        "confignet_amd: %s is missing -- build it with `python -m confignet_amd.build` "
+        "confignet_amd: %s is missing -- build it with `python confignet_amd/build.py` "
         "(or __graft_entry__.build()).  There is no CPU/PyTorch fallback." % LIB_PATH)
 
 lib = ctypes.CDLL(LIB_PATH)
@@ -42,7 +42,9 @@ SIGNATURES = {
     "cn_sumpool2": [_p, _p, _i, _i, _i, _i, _i, _i, _p],
     "cn_gemm": [_i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _p, _i, _f, _p],
     "cn_nc_reduce": [_p, _p, _p, _p, _i, _i, _i, _i, _f, _p],
-    "cn_nc_lin2": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p],
+    "cn_nc_lin2": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p],
+    "cn_norm_coef_fwd": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _p],
+    "cn_norm_coef_bwd": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _p],
     "cn_act_fwd": [_p, _p, _z, _i, _f, _p],
     "cn_act_bwd": [_p, _p, _p, _z, _i, _f, _p],
     "cn_axpby": [_p, _p, _p, _z, _f, _f, _p],

@@ -1,5 +1,5 @@
 """Builds libconfignet_hip.so (gfx950) in-tree with hipcc.  Used by __graft_entry__.build()
-and `python -m confignet_amd.build`.  No cmake, no JIT cache: the .so sits next to the sources
+and `python confignet_amd/build.py`.  No cmake, no JIT cache: the .so sits next to the sources
 so it travels to the GPU box with the repo snapshot."""
 import os
 import subprocess
@@ -7,7 +7,7 @@ import sys
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libconfignet_hip.so")
-SOURCES = ["prof.hip", "igemm_conv.hip", "gemm.hip", "elementwise.hip", "rotate3d.hip"]
+SOURCES = ["prof.hip", "igemm_conv.hip", "gemm.hip", "elementwise.hip", "norm_coef.hip", "rotate3d.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wall"]
 
 

@@ -78,7 +78,8 @@ __global__ __launch_bounds__(256) void nc_reduce_kernel(const float* __restrict_
 template <int V>
 __global__ __launch_bounds__(256) void nc_lin2_kernel(const float* __restrict__ x1, const float* __restrict__ a1,
                                                       const float* __restrict__ x2, const float* __restrict__ a2,
-                                                      const float* __restrict__ bb, float* __restrict__ y, long total_g,
+                                                      const float* __restrict__ bb, const float* __restrict__ a3,
+                                                      const float* __restrict__ b3, float* __restrict__ y, long total_g,
                                                       int S, int C, int cstride, int flags, float slope) {
     const int CG = C / V;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total_g; i += (long)gridDim.x * blockDim.x) {
@@ -110,6 +111,10 @@ __global__ __launch_bounds__(256) void nc_lin2_kernel(const float* __restrict__ 
 #pragma unroll
                 for (int e = 0; e < V; ++e) r[e] *= raw2[e] > 0.f ? 1.f : slope;
             }
+            if (a3) {
+#pragma unroll
+                for (int e = 0; e < V; ++e) r[e] += a3[ci + e] * raw2[e] + (b3 ? b3[ci + e] : 0.f);
+            }
         }
         if (flags & 8) {
 #pragma unroll
@@ -120,7 +125,7 @@ __global__ __launch_bounds__(256) void nc_lin2_kernel(const float* __restrict__ 
     }
 }
 
-__global__ void act_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n, int act, float slope) {
+__global__ void act_fwd_kernel(const float* x, float* y, size_t n, int act, float slope) {   // may run in place
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
         y[i] = cn_apply_act(x[i], act, slope);
 }
@@ -361,15 +366,16 @@ extern "C" int cn_nc_reduce(const float* x1, const float* x2, float* s1, float* 
     return CN_OK;
 }
 
-extern "C" int cn_nc_lin2(const float* x1, const float* a1, const float* x2, const float* a2, const float* bb, float* y,
-                          int n, int s, int c, int cstride, int flags, float slope, void* stream) {
+extern "C" int cn_nc_lin2(const float* x1, const float* a1, const float* x2, const float* a2, const float* bb,
+                          const float* a3, const float* b3, float* y, int n, int s, int c, int cstride, int flags,
+                          float slope, void* stream) {
     CN_CHECK_ARG(y && n > 0 && s > 0 && c > 0 && (cstride == 0 || cstride == c), "nc_lin2: bad args");
     CN_CHECK_ARG(x1 || x2 || bb, "nc_lin2: nothing to compute");
     const int V = (c % 4 == 0) ? 4 : 1;
     const long total = (long)n * s * (c / V);
     hipStream_t st = (hipStream_t)stream;
-    if (V == 4) hipLaunchKernelGGL(nc_lin2_kernel<4>, dim3(ew_blocks(total)), dim3(256), 0, st, x1, a1, x2, a2, bb, y, total, s, c, cstride, flags, slope);
-    else hipLaunchKernelGGL(nc_lin2_kernel<1>, dim3(ew_blocks(total)), dim3(256), 0, st, x1, a1, x2, a2, bb, y, total, s, c, cstride, flags, slope);
+    if (V == 4) hipLaunchKernelGGL(nc_lin2_kernel<4>, dim3(ew_blocks(total)), dim3(256), 0, st, x1, a1, x2, a2, bb, a3, b3, y, total, s, c, cstride, flags, slope);
+    else hipLaunchKernelGGL(nc_lin2_kernel<1>, dim3(ew_blocks(total)), dim3(256), 0, st, x1, a1, x2, a2, bb, a3, b3, y, total, s, c, cstride, flags, slope);
     CN_LAUNCH_CHECK();
     return CN_OK;
 }

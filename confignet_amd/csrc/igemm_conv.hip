@@ -41,6 +41,38 @@ __device__ __forceinline__ RowInfo decode_row(const CnConvGeom& g, int m, int M)
     return r;
 }
 
+// Parity-class row order for the data-gradient of a strided convolution (dl > 1, stride 1 on the output
+// side, out % dl == 0): rows are enumerated class-major, class = (od % dl_d, oh % dl_h, ow % dl_w), so
+// that all rows of a tile hit the zero-stuffed positions for the SAME taps and those taps are skipped as a
+// whole (4x fewer MFMAs for the 2-D stride-2 discriminator blocks).  Returns the true output row.
+__device__ __forceinline__ int par_row(const CnConvGeom& g, int mp, int M, int& cls) {
+    const int qd = g.out_d / g.dl_d, qh = g.out_h / g.dl_h, qw = g.out_w / g.dl_w;
+    const int per = g.n * qd * qh * qw;
+    if (mp >= M) { cls = -1; return M; }
+    cls = mp / per;
+    int rem = mp - cls * per;
+    const int cw = cls % g.dl_w, ch = (cls / g.dl_w) % g.dl_h, cd = cls / (g.dl_w * g.dl_h);
+    const int xw = rem % qw; rem /= qw;
+    const int xh = rem % qh; rem /= qh;
+    const int xd = rem % qd;
+    const int n = rem / qd;
+    return ((n * g.out_d + xd * g.dl_d + cd) * g.out_h + xh * g.dl_h + ch) * g.out_w + xw * g.dl_w + cw;
+}
+
+__device__ __forceinline__ unsigned long long par_tap_mask(const CnConvGeom& g, int cls) {
+    const int cw = cls % g.dl_w, ch = (cls / g.dl_w) % g.dl_h, cd = cls / (g.dl_w * g.dl_h);
+    unsigned long long mask = 0ull;
+    int tap = 0;
+    for (int kd = 0; kd < g.k_d; ++kd)
+        for (int kh = 0; kh < g.k_h; ++kh)
+            for (int kw = 0; kw < g.k_w; ++kw, ++tap) {
+                const int vd = cd - g.p_d + kd, vh = ch - g.p_h + kh, vw = cw - g.p_w + kw;
+                const bool ok = ((vd % g.dl_d) == 0) && ((vh % g.dl_h) == 0) && ((vw % g.dl_w) == 0);
+                if (ok) mask |= 1ull << tap;
+            }
+    return mask;
+}
+
 __device__ __forceinline__ bool map1(int v, int dl, int ext, int up, int& q) {
     if (v < 0) return false;
     if (dl > 1) {
@@ -75,12 +107,13 @@ __device__ __forceinline__ void tap_decode(const CnConvGeom& g, int tap, int& kd
 template <int WM, int WN, int TM, int TN, bool VEC>
 __global__ __launch_bounds__(256) void igemm_fwd_kernel(CnConvGeom g, const float* __restrict__ X,
                                                         const float* __restrict__ W, const float* __restrict__ bias,
-                                                        float* __restrict__ Y, int act, float slope) {
+                                                        float* __restrict__ Y, int act, float slope, int par) {
     static_assert(WM * WN == 4, "4 waves per workgroup");
     constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN, LDA = BM + 4, LDB = BN + 4;
     constexpr int AP = BM / 64, BP = (BN + 63) / 64;   // float4 loads per thread per K step
     __shared__ float As[2][BK][LDA];
     __shared__ __attribute__((aligned(16))) float Bs[2][BK][LDB];
+    __shared__ int rowmap[BM];                          // tile row -> output row (or -1)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN, half = lane >> 5, l31 = lane & 31;
     const int M = g.n * g.out_d * g.out_h * g.out_w;
@@ -90,8 +123,23 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(CnConvGeom g, const floa
 
     const int kq = tid & 3, arow = tid >> 2;
     RowInfo ri[AP];
+    unsigned long long tapmask = T >= 64 ? ~0ull : ((1ull << T) - 1ull);
 #pragma unroll
-    for (int i = 0; i < AP; ++i) ri[i] = decode_row(g, m0 + arow + 64 * i, M);
+    for (int i = 0; i < AP; ++i) {
+        int mrow = m0 + arow + 64 * i;
+        if (par) {
+            int cls;
+            mrow = par_row(g, mrow, M, cls);
+        }
+        ri[i] = decode_row(g, mrow, M);
+        if (kq == 0) rowmap[arow + 64 * i] = ri[i].ok ? mrow : -1;
+    }
+    if (par) {
+        int c0, c1;
+        par_row(g, m0, M, c0);
+        par_row(g, min(m0 + BM, M) - 1, M, c1);
+        if (c0 == c1) tapmask = par_tap_mask(g, c0);   // whole tile in one parity class: skip dead taps
+    }
     int aoff[AP];
 
     f32x16 acc[TM][TN];
@@ -104,18 +152,27 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(CnConvGeom g, const floa
 
     float4 ra[AP], rb[BP];
     const int cpb = VEC ? g.cin / BK : 1;
-    const int nks = VEC ? T * cpb : (Ktot + BK - 1) / BK;
+    const int nks_all = VEC ? __popcll(tapmask) * cpb : (Ktot + BK - 1) / BK;
+    // split-K over gridDim.z (small-M problems): this workgroup walks K steps [ks_beg, ks_end)
+    const int per_z = (nks_all + gridDim.z - 1) / gridDim.z;
+    const int ks_beg = blockIdx.z * per_z, ks_end = min(nks_all, ks_beg + per_z);
+    int cur_ord = -1, cur_tap = -1;                     // ordinal among live taps / tap index
 
     auto load_tiles = [&](int ks) {
         if (VEC) {
-            const int tap = ks / cpb;
-            const int c0 = (ks - tap * cpb) * BK;
-            if (c0 == 0) {
+            const int ord = ks / cpb;
+            const int c0 = (ks - ord * cpb) * BK;
+            if (ord != cur_ord) {
+                while (cur_ord < ord) {
+                    cur_tap += __ffsll((long long)(tapmask >> (cur_tap + 1)));
+                    ++cur_ord;
+                }
                 int kd, kh, kw;
-                tap_decode(g, tap, kd, kh, kw);
+                tap_decode(g, cur_tap, kd, kh, kw);
 #pragma unroll
                 for (int i = 0; i < AP; ++i) aoff[i] = src_off(g, ri[i], kd, kh, kw);
             }
+            const int tap = cur_tap;
 #pragma unroll
             for (int i = 0; i < AP; ++i)
                 ra[i] = aoff[i] >= 0 ? *reinterpret_cast<const float4*>(X + aoff[i] + c0 + kq * 4)
@@ -126,7 +183,7 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(CnConvGeom g, const floa
                 const int brow = idx / (BN / 4), col = n0 + (idx % (BN / 4)) * 4;
                 const long kg = (long)tap * g.cin + c0 + brow;
                 rb[j] = (col < g.cout && idx < BK * BN / 4) ? *reinterpret_cast<const float4*>(W + kg * g.cout + col)
-                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+                                                            : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         } else {
 #pragma unroll
@@ -151,8 +208,9 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(CnConvGeom g, const floa
                 const int idx = tid + 256 * j;
                 const int brow = idx / (BN / 4), col = n0 + (idx % (BN / 4)) * 4;
                 const long kg = (long)ks * BK + brow;
-                rb[j] = (col < g.cout && kg < Ktot && idx < BK * BN / 4) ? *reinterpret_cast<const float4*>(W + kg * g.cout + col)
-                                                    : make_float4(0.f, 0.f, 0.f, 0.f);
+                rb[j] = (col < g.cout && kg < Ktot && idx < BK * BN / 4)
+                            ? *reinterpret_cast<const float4*>(W + kg * g.cout + col)
+                            : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
     };
@@ -173,31 +231,37 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(CnConvGeom g, const floa
         }
     };
 
-    load_tiles(0);
-    store_tiles(0);
-    __syncthreads();
     const int a_col = wm * 32 * TM + l31, b_col = wn * 32 * TN + l31;
-    for (int ks = 0; ks < nks; ++ks) {
-        const int buf = ks & 1;
-        if (ks + 1 < nks) load_tiles(ks + 1);
+    if (ks_beg < ks_end) {
+        load_tiles(ks_beg);
+        store_tiles(0);
+    }
+    __syncthreads();
+    for (int ks = ks_beg; ks < ks_end; ++ks) {
+        const int buf = (ks - ks_beg) & 1;
+        if (ks + 1 < ks_end) load_tiles(ks + 1);
         mma_step<TM, TN, LDA, LDB>(As[buf], Bs[buf], acc, a_col, b_col, half);
-        if (ks + 1 < nks) store_tiles(buf ^ 1);
+        if (ks + 1 < ks_end) store_tiles(buf ^ 1);
         __syncthreads();
     }
 
     // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const bool split = gridDim.z > 1;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int col = n0 + wn * 32 * TN + 32 * j + l31;
         if (col >= g.cout) continue;
-        const float bv = bias ? bias[col] : 0.f;
+        const float bv = (bias && blockIdx.z == 0) ? bias[col] : 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            const int rbase = m0 + wm * 32 * TM + 32 * i + 4 * half;
+            const int rbase = wm * 32 * TM + 32 * i + 4 * half;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = rbase + (r & 3) + 8 * (r >> 2);
-                if (row < M) Y[(long)row * g.cout + col] = cn_apply_act(acc[i][j][r] + bv, act, slope);
+                const int row = rowmap[rbase + (r & 3) + 8 * (r >> 2)];
+                if (row < 0) continue;
+                const float v = acc[i][j][r] + bv;
+                if (split) unsafeAtomicAdd(&Y[(long)row * g.cout + col], v);
+                else Y[(long)row * g.cout + col] = cn_apply_act(v, act, slope);
             }
         }
     }
@@ -336,10 +400,21 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(CnConvGeom g, const fl
 template <int CO, bool VEC>
 __global__ __launch_bounds__(256) void thin_conv_kernel(CnConvGeom g, const float* __restrict__ X,
                                                         const float* __restrict__ W, const float* __restrict__ bias,
-                                                        float* __restrict__ Y, int act, float slope) {
+                                                        float* __restrict__ Y, int act, float slope, int par) {
+    extern __shared__ __attribute__((aligned(16))) float wsh[];     // [taps*cin][4] filter, broadcast reads
     const int M = g.n * g.out_d * g.out_h * g.out_w;
-    const int m = blockIdx.x * 256 + threadIdx.x;
+    const int Ktot = g.k_d * g.k_h * g.k_w * g.cin;
+    for (int i = threadIdx.x; i < Ktot; i += 256) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) wsh[i * 4 + c] = c < CO ? W[(long)i * CO + c] : 0.f;
+    }
+    __syncthreads();
+    int m = blockIdx.x * 256 + threadIdx.x;
     if (m >= M) return;
+    if (par) {
+        int cls;
+        m = par_row(g, m, M, cls);
+    }
     const RowInfo r = decode_row(g, m, M);
     float acc[CO];
 #pragma unroll
@@ -350,25 +425,66 @@ __global__ __launch_bounds__(256) void thin_conv_kernel(CnConvGeom g, const floa
             for (int kw = 0; kw < g.k_w; ++kw, ++tap) {
                 const int off = src_off(g, r, kd, kh, kw);
                 if (off < 0) continue;
-                const float* __restrict__ wp = W + (long)tap * g.cin * CO;
+                const float4* wp = reinterpret_cast<const float4*>(wsh) + tap * g.cin;
                 if (VEC) {
                     for (int ci = 0; ci < g.cin; ci += 4) {
                         const float4 xv = *reinterpret_cast<const float4*>(X + off + ci);
+                        const float4 w0 = wp[ci], w1 = wp[ci + 1], w2 = wp[ci + 2], w3 = wp[ci + 3];
+                        const float wv[4][4] = {{w0.x, w0.y, w0.z, w0.w}, {w1.x, w1.y, w1.z, w1.w},
+                                                {w2.x, w2.y, w2.z, w2.w}, {w3.x, w3.y, w3.z, w3.w}};
 #pragma unroll
                         for (int c = 0; c < CO; ++c)
-                            acc[c] += xv.x * wp[(ci + 0) * CO + c] + xv.y * wp[(ci + 1) * CO + c] +
-                                      xv.z * wp[(ci + 2) * CO + c] + xv.w * wp[(ci + 3) * CO + c];
+                            acc[c] += xv.x * wv[0][c] + xv.y * wv[1][c] + xv.z * wv[2][c] + xv.w * wv[3][c];
                     }
                 } else {
                     for (int ci = 0; ci < g.cin; ++ci) {
                         const float xv = X[off + ci];
+                        const float4 w0 = wp[ci];
+                        const float wv[4] = {w0.x, w0.y, w0.z, w0.w};
 #pragma unroll
-                        for (int c = 0; c < CO; ++c) acc[c] += xv * wp[ci * CO + c];
+                        for (int c = 0; c < CO; ++c) acc[c] += xv * wv[c];
                     }
                 }
             }
 #pragma unroll
     for (int c = 0; c < CO; ++c) Y[(long)m * CO + c] = cn_apply_act(acc[c], act, slope);
+}
+
+// filter gradient of a 1x1 convolution between thin tensors (cin, cout <= 4: the from-RGB conv,
+// hologan_discriminator.py:20): a plain HBM-bound reduction gw[ci][co] = sum_m x[m][ci] gy[m][co]
+__global__ __launch_bounds__(256) void tiny_wgrad_1x1_kernel(const float* __restrict__ X, const float* __restrict__ GY,
+                                                             float* __restrict__ GW, long M, int cin, int cout) {
+    float acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+    for (long m = (long)blockIdx.x * 256 + threadIdx.x; m < M; m += (long)gridDim.x * 256) {
+        float xv[4] = {0.f, 0.f, 0.f, 0.f}, gv[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < cin; ++i) xv[i] = X[m * cin + i];
+        for (int j = 0; j < cout; ++j) gv[j] = GY[m * cout + j];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] += xv[i] * gv[j];
+    }
+    __shared__ float sh[4][16];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float v = acc[i][j];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+            if (lane == 0) sh[w][i * 4 + j] = v;
+        }
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        const int i = threadIdx.x >> 2, j = threadIdx.x & 3;
+        if (i < cin && j < cout)
+            unsafeAtomicAdd(&GW[i * cout + j], sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+    }
 }
 
 __global__ void weight_tflip_kernel(const float* __restrict__ W, float* __restrict__ Wt, int T, int cin, int cout) {
@@ -431,6 +547,13 @@ double conv_flops(const CnConvGeom& g) {
            valid_pairs_1d(g.out_w, g.k_w, g.s_w, g.dl_w, g.p_w, g.in_w, g.up) * g.cin * g.cout;
 }
 
+// parity-class row order applies to data-gradient geometries of strided convolutions
+bool parity_ordered(const CnConvGeom& g) {
+    if (g.s_d != 1 || g.s_h != 1 || g.s_w != 1 || g.up) return false;
+    if (g.dl_d * g.dl_h * g.dl_w == 1) return false;
+    return g.out_d % g.dl_d == 0 && g.out_h % g.dl_h == 0 && g.out_w % g.dl_w == 0;
+}
+
 int check_geom(const CnConvGeom* g) {
     CN_CHECK_ARG(g != nullptr, "geom is NULL");
     CN_CHECK_ARG(g->nd == 2 || g->nd == 3, "nd must be 2 or 3 (got %d)", g->nd);
@@ -447,14 +570,14 @@ int check_geom(const CnConvGeom* g) {
 }
 
 template <int WM, int WN, int TM, int TN>
-int launch_fwd(const CnConvGeom& g, bool vec, const float* x, const float* w, const float* bias, float* y, int act,
-               float slope, hipStream_t s) {
+int launch_fwd(const CnConvGeom& g, bool vec, int par, int splits, const float* x, const float* w, const float* bias,
+               float* y, int act, float slope, hipStream_t s) {
     const long M = (long)g.n * g.out_d * g.out_h * g.out_w;
-    dim3 grid(cn_cdiv(M, 32 * WM * TM), cn_cdiv(g.cout, 32 * WN * TN));
+    dim3 grid(cn_cdiv(M, 32 * WM * TM), cn_cdiv(g.cout, 32 * WN * TN), splits);
     if (vec)
-        hipLaunchKernelGGL((igemm_fwd_kernel<WM, WN, TM, TN, true>), grid, dim3(256), 0, s, g, x, w, bias, y, act, slope);
+        hipLaunchKernelGGL((igemm_fwd_kernel<WM, WN, TM, TN, true>), grid, dim3(256), 0, s, g, x, w, bias, y, act, slope, par);
     else
-        hipLaunchKernelGGL((igemm_fwd_kernel<WM, WN, TM, TN, false>), grid, dim3(256), 0, s, g, x, w, bias, y, act, slope);
+        hipLaunchKernelGGL((igemm_fwd_kernel<WM, WN, TM, TN, false>), grid, dim3(256), 0, s, g, x, w, bias, y, act, slope, par);
     CN_LAUNCH_CHECK();
     return CN_OK;
 }
@@ -493,12 +616,15 @@ extern "C" int cn_conv_fwd(const CnConvGeom* gp, const float* x, const float* w,
     const long M = (long)g.n * g.out_d * g.out_h * g.out_w;
     if (g.cout <= 4) {
         const bool vec = g.cin % 4 == 0;
+        const int par = parity_ordered(g);
+        const size_t lds = sizeof(float) * 4 * (size_t)g.k_d * g.k_h * g.k_w * g.cin;
+        CN_CHECK_ARG(lds <= 64 * 1024, "thin conv: filter of %zu bytes does not fit the LDS stage", lds);
         dim3 grid(cn_cdiv(M, 256));
-#define THIN(CO)                                                                                               \
-    if (vec)                                                                                                   \
-        hipLaunchKernelGGL((thin_conv_kernel<CO, true>), grid, dim3(256), 0, s, g, x, w, bias, y, act, slope); \
-    else                                                                                                       \
-        hipLaunchKernelGGL((thin_conv_kernel<CO, false>), grid, dim3(256), 0, s, g, x, w, bias, y, act, slope);
+#define THIN(CO)                                                                                                      \
+    if (vec)                                                                                                          \
+        hipLaunchKernelGGL((thin_conv_kernel<CO, true>), grid, dim3(256), lds, s, g, x, w, bias, y, act, slope, par); \
+    else                                                                                                              \
+        hipLaunchKernelGGL((thin_conv_kernel<CO, false>), grid, dim3(256), lds, s, g, x, w, bias, y, act, slope, par);
         switch (g.cout) {
             case 1: THIN(1); break;
             case 2: THIN(2); break;
@@ -511,20 +637,38 @@ extern "C" int cn_conv_fwd(const CnConvGeom* gp, const float* x, const float* w,
     }
     CN_CHECK_ARG(g.cout % 4 == 0, "cout=%d: implicit-GEMM path needs cout %% 4 == 0", g.cout);
     const bool vec = g.cin % BK == 0;
+    const int par = parity_ordered(g) && vec;
     // tile choice: the biggest tile that still gives >= 2 workgroups per CU (256 CUs)
     const long t128 = (long)cn_cdiv(M, 128) * cn_cdiv(g.cout, 128);
     const long t128x64 = (long)cn_cdiv(M, 128) * cn_cdiv(g.cout, 64);
+    int cfg;
+    long tiles;
+    if (g.cout <= 32) { cfg = 3; tiles = (long)cn_cdiv(M, 128) * cn_cdiv(g.cout, 32); }
+    else if (g.cout > 64 && t128 >= 512) { cfg = 0; tiles = t128; }
+    else if (t128x64 >= 512) { cfg = 1; tiles = t128x64; }
+    else { cfg = 2; tiles = (long)cn_cdiv(M, 64) * cn_cdiv(g.cout, 64); }
+    // split-K for small outputs with a long reduction (ResNet stage 4/5, Conv3D at 4^3->8^3)
+    int splits = 1;
+    if (vec && tiles < 256) {
+        long nks = (long)g.k_d * g.k_h * g.k_w * (g.cin / BK);
+        if (par) nks /= (long)g.dl_d * g.dl_h * g.dl_w;
+        long want = (512 + tiles - 1) / tiles;
+        if (want > 16) want = 16;
+        if (want > nks / 8) want = nks / 8;
+        if (want > 1) splits = (int)want;
+    }
+    const int kact = splits > 1 ? CN_ACT_NONE : act;
+    if (splits > 1) CN_HIP(hipMemsetAsync(y, 0, sizeof(float) * M * g.cout, s));
     cn_prof_begin(s, conv_flops(g));
     int e;
-    if (g.cout <= 32)
-        e = launch_fwd<4, 1, 1, 1>(g, vec, x, w, bias, y, act, slope, s);      // 128 x 32
-    else if (g.cout > 64 && t128 >= 512)
-        e = launch_fwd<2, 2, 2, 2>(g, vec, x, w, bias, y, act, slope, s);      // 128 x 128
-    else if (t128x64 >= 512)
-        e = launch_fwd<2, 2, 2, 1>(g, vec, x, w, bias, y, act, slope, s);      // 128 x 64
-    else
-        e = launch_fwd<2, 2, 1, 1>(g, vec, x, w, bias, y, act, slope, s);      // 64 x 64
+    switch (cfg) {
+        case 3: e = launch_fwd<4, 1, 1, 1>(g, vec, par, splits, x, w, bias, y, kact, slope, s); break;   // 128 x 32
+        case 0: e = launch_fwd<2, 2, 2, 2>(g, vec, par, splits, x, w, bias, y, kact, slope, s); break;   // 128 x 128
+        case 1: e = launch_fwd<2, 2, 2, 1>(g, vec, par, splits, x, w, bias, y, kact, slope, s); break;   // 128 x 64
+        default: e = launch_fwd<2, 2, 1, 1>(g, vec, par, splits, x, w, bias, y, kact, slope, s); break;  // 64 x 64
+    }
     cn_prof_end(s);
+    if (e == CN_OK && splits > 1 && act != CN_ACT_NONE) e = cn_act_fwd(y, y, (size_t)M * g.cout, act, slope, stream);
     return e;
 }
 
@@ -559,6 +703,14 @@ extern "C" int cn_conv_wgrad(const CnConvGeom* gp, const float* x, const float* 
     hipStream_t s = (hipStream_t)stream;
     const long Ktot = (long)g.k_d * g.k_h * g.k_w * g.cin;
     CN_HIP(hipMemsetAsync(gw, 0, sizeof(float) * Ktot * g.cout, s));
+    if (Ktot <= 4 && g.cout <= 4 && g.k_d * g.k_h * g.k_w == 1 && g.s_h == 1 && g.s_w == 1 && g.s_d == 1 && !g.up &&
+        g.p_h == 0 && g.p_w == 0 && g.p_d == 0) {
+        const long M = (long)g.n * g.out_d * g.out_h * g.out_w;
+        const int blocks = (int)(cn_cdiv(M, 256) > 1024 ? 1024 : cn_cdiv(M, 256));
+        hipLaunchKernelGGL(tiny_wgrad_1x1_kernel, dim3(blocks), dim3(256), 0, s, x, gy, gw, M, g.cin, g.cout);
+        CN_LAUNCH_CHECK();
+        return CN_OK;
+    }
     cn_prof_begin(s, conv_flops(g));
     int e;
     if (g.cout <= 32)

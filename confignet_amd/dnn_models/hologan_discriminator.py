@@ -46,7 +46,7 @@ class HologanDiscriminator(Net):
         self.add_weight("disc_map/bias", np.zeros(1, np.float32))
         self.finalize()
 
-    def __call__(self, input_img):
+    def __call__(self, input_img, twice_differentiable=False):
         """Returns the insertion-ordered dict discr_style_0..n-1, discr_final (l.48-64)."""
         w = self.weights
         nr = self.num_resample
@@ -54,7 +54,7 @@ class HologanDiscriminator(Net):
         heads = 2 + 4 * nr
         out = OrderedDict()
         for i in range(nr):
-            x, st = discr_block(x, w[2 + 4 * i:6 + 4 * i], True)
+            x, st = discr_block(x, w[2 + 4 * i:6 + 4 * i], True, twice_differentiable)
             out["discr_style_%d" % i] = F.linear(st, w[heads + 2 * i], w[heads + 2 * i + 1])
         x = x.reshape(x.shape[0], -1)
         out["discr_final"] = F.linear(x, w[-2], w[-1])

@@ -352,9 +352,39 @@ def _spatial(x):
     return x.numel() // (x.shape[0] * x.shape[-1])
 
 
+class AdaInFn(Function):
+    """AdaIn.call (building_blocks.py:135-149) fused: statistics pass, one coefficient kernel, one
+    normalise+modulate pass; backward = one reduction pass + one coefficient kernel + one pass.
+    First-order only (the generator is never differentiated twice)."""
+
+    @staticmethod
+    def forward(ctx, x, scale_bias):
+        x, sb = _cg(x), _cg(scale_bias)
+        sp = _spatial(x)
+        s1, s2 = ops.nc_reduce(x)
+        a, b, mean, r = ops.norm_coef_fwd(ops.NORM_ADAIN, s1, s2, sb, None, sp, 1e-3)
+        ctx.save_for_backward(x, sb, mean, r)
+        return ops.nc_lin2(tuple(x.shape), x, a, b=b)
+
+    @staticmethod
+    def backward(ctx, gy):
+        if torch.is_grad_enabled():
+            raise RuntimeError("AdaInFn is first-order only; use adain_composite()")
+        x, sb, mean, r = ctx.saved_tensors
+        gy = _cg(gy)
+        t1, t2 = ops.nc_reduce(gy, x)
+        c1, c2, c0, gsb, _ = ops.norm_coef_bwd(ops.NORM_ADAIN, t1, t2, mean, r, sb, _spatial(x), 1e-3)
+        return ops.nc_lin2(tuple(x.shape), gy, c1, x, c2, c0), gsb
+
+
 def adain(x, scale_bias):
     """AdaIn.call (building_blocks.py:135-149): LayerNormalization over the spatial axes (eps 1e-3,
     no affine) then x*(s+1)+b; scale_bias (N, 2C) = [s | b] from the MLP of z."""
+    return AdaInFn.apply(x, scale_bias)
+
+
+def adain_composite(x, scale_bias):
+    """Same maths from twice-differentiable primitives (kept as a cross-check of AdaInFn)."""
     c = x.shape[-1]
     s_, b_ = scale_bias[:, :c], scale_bias[:, c:]
     inv = 1.0 / _spatial(x)
@@ -363,6 +393,44 @@ def adain(x, scale_bias):
     var = s2 * inv - mu * mu
     a = torch.rsqrt(var + 1e-3) * (s_ + 1.0)
     return nc_lin(x, a, None, None, b_ - mu * a)
+
+
+class DiscrTailFn(Function):
+    """Tail of DiscrBlock.call (building_blocks.py:100-106) fused, first-order only: style statistics of the
+    pre-activation tensor, LeakyReLU, instance normalisation.  x is read by two reduction passes and one
+    normalise pass; the backward pass is one reduction pass + one pass that also adds the style gradient."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, want_style, slope):
+        x, gamma, beta = _cg(x), _cg(gamma), _cg(beta)
+        sp = _spatial(x)
+        style = smean = ssd = None
+        if want_style:
+            s1, s2 = ops.nc_reduce(x)
+            style, _, smean, ssd = ops.norm_coef_fwd(ops.NORM_STYLE, s1, s2, None, None, sp, 1e-6)
+        a1, a2 = ops.nc_reduce(x, flags=1, slope=slope)
+        a, b, mean, q = ops.norm_coef_fwd(ops.NORM_INSTANCE, a1, a2, gamma, beta, sp, 1e-3)
+        y = ops.nc_lin2(tuple(x.shape), x, a, b=b, flags=1, slope=slope)
+        ctx.save_for_backward(x, gamma, mean, q, smean, ssd)
+        ctx.slope, ctx.want_style = slope, want_style
+        if want_style:
+            return y, style
+        return y
+
+    @staticmethod
+    def backward(ctx, gy, gstyle=None):
+        if torch.is_grad_enabled():
+            raise RuntimeError("DiscrTailFn is first-order only; use the composite discr_block path")
+        x, gamma, mean, q, smean, ssd = ctx.saved_tensors
+        gy = _cg(gy)
+        sp = _spatial(x)
+        t1, t2 = ops.nc_reduce(gy, x, flags=2, slope=ctx.slope)
+        c1, c2, c0, ggamma, gbeta = ops.norm_coef_bwd(ops.NORM_INSTANCE, t1, t2, mean, q, gamma, sp, 1e-3)
+        d2 = d0 = None
+        if ctx.want_style and gstyle is not None:
+            _, d2, d0, _, _ = ops.norm_coef_bwd(ops.NORM_STYLE, _cg(gstyle), None, smean, ssd, None, sp, 1e-6)
+        gx = ops.nc_lin2(tuple(x.shape), gy, c1, x, c2, c0, flags=2 | 4, slope=ctx.slope, a3=d2, b3=d0)
+        return gx, ggamma, gbeta, None, None
 
 
 def instance_norm(x, gamma, beta, eps=1e-3):

@@ -46,7 +46,7 @@ def gradient_regularization(real_out, real_in):
 def compute_discriminator_loss(discriminator, real_imgs, fake_imgs):
     """losses.py:20-47."""
     real_imgs = real_imgs.detach().requires_grad_(True)
-    out_real = discriminator(real_imgs)
+    out_real = discriminator(real_imgs, twice_differentiable=True)
     out_fake = discriminator(fake_imgs.detach())
     losses = {}
     for i, o in enumerate(out_real.values()):

@@ -145,15 +145,46 @@ def nc_reduce(x1, x2=None, want_sum=True, want_dot=True, flags=0, slope=0.0, per
     return s1, s2
 
 
-def nc_lin2(shape, x1=None, a1=None, x2=None, a2=None, b=None, flags=0, slope=0.0, per_channel=False):
+def nc_lin2(shape, x1=None, a1=None, x2=None, a2=None, b=None, flags=0, slope=0.0, per_channel=False, a3=None, b3=None):
     """y = a1*f1(x1) + a2*f2(x2) + b with (n,c) [or (c,)] coefficients broadcast over space."""
     n, c = shape[0], shape[-1]
     s = int(math.prod(shape)) // (n * c)
     ref = x1 if x1 is not None else (x2 if x2 is not None else b)
     y = torch.empty(shape, device=ref.device, dtype=torch.float32)
-    check(lib.cn_nc_lin2(_ptr(x1), _ptr(a1), _ptr(x2), _ptr(a2), _ptr(b), _ptr(y), n, s, c, 0 if per_channel else c,
-                         flags, slope, _stream()), "cn_nc_lin2")
+    check(lib.cn_nc_lin2(_ptr(x1), _ptr(a1), _ptr(x2), _ptr(a2), _ptr(b), _ptr(a3), _ptr(b3), _ptr(y), n, s, c,
+                         0 if per_channel else c, flags, slope, _stream()), "cn_nc_lin2")
     return y
+
+
+NORM_ADAIN, NORM_INSTANCE, NORM_STYLE = 0, 1, 2
+
+
+def norm_coef_fwd(mode, s1, s2, p1, p2, spatial, eps):
+    n, c = s1.shape
+    A = torch.empty((n, 2 * c) if mode == NORM_STYLE else (n, c), device=s1.device, dtype=torch.float32)
+    B = torch.empty((n, c), device=s1.device, dtype=torch.float32) if mode != NORM_STYLE else None
+    mean = torch.empty((n, c), device=s1.device, dtype=torch.float32)
+    r = torch.empty((n, c), device=s1.device, dtype=torch.float32)
+    check(lib.cn_norm_coef_fwd(mode, _ptr(s1), _ptr(s2), _ptr(p1), _ptr(p2), _ptr(A), _ptr(B), _ptr(mean), _ptr(r),
+                               n, c, spatial, eps, _stream()), "cn_norm_coef_fwd")
+    return A, B, mean, r
+
+
+def norm_coef_bwd(mode, t1, t2, mean, r, p1, spatial, eps):
+    n, c = mean.shape
+    dev = mean.device
+    c1 = torch.empty((n, c), device=dev, dtype=torch.float32) if mode != NORM_STYLE else None
+    c2 = torch.empty((n, c), device=dev, dtype=torch.float32)
+    c0 = torch.empty((n, c), device=dev, dtype=torch.float32)
+    gp1 = gp2 = None
+    if mode == NORM_ADAIN:
+        gp1 = torch.empty((n, 2 * c), device=dev, dtype=torch.float32)
+    elif mode == NORM_INSTANCE:
+        gp1 = torch.empty((c,), device=dev, dtype=torch.float32)
+        gp2 = torch.empty((c,), device=dev, dtype=torch.float32)
+    check(lib.cn_norm_coef_bwd(mode, _ptr(t1), _ptr(t2), _ptr(mean), _ptr(r), _ptr(p1), _ptr(c1), _ptr(c2), _ptr(c0),
+                               _ptr(gp1), _ptr(gp2), n, c, spatial, eps, _stream()), "cn_norm_coef_bwd")
+    return c1, c2, c0, gp1, gp2
 
 
 def act_fwd(x, act, slope=0.0):

@@ -84,9 +84,27 @@ int cn_nc_reduce(const float* x1, const float* x2, float* sum1, float* sum2, int
 /* y = A1*f1(x1) + A2*f2(x2) + B, coefficient tensors indexed [n*cstride + c] (cstride = c, or 0 for
  * per-channel coefficients).  flags: bit0/bit1 as above, bit2: multiply the result by lrelu'(x2),
  * bit3: relu on the result.  x1, x2 and B are each optional (NULL); a NULL coefficient of a present
- * x means 1. */
+ * x means 1.  If a3 != NULL, a3*x2 + b3 (raw x2) is added after the bit2 mask -- the style-statistics
+ * gradient that joins the instance-norm gradient in DiscrBlock (building_blocks.py:100-106). */
 int cn_nc_lin2(const float* x1, const float* a1, const float* x2, const float* a2, const float* bb,
-               float* y, int n, int s, int c, int cstride, int flags, float slope, void* stream);
+               const float* a3, const float* b3, float* y, int n, int s, int c, int cstride, int flags,
+               float slope, void* stream);
+
+/* Per-(n,c) coefficient kernels of the normalisation layers (tiny: N*C threads).
+ * mode 0 AdaIN (building_blocks.py:132-144): p1 = [s|b] (N,2C); mu = s1/S, var = s2/S - mu^2,
+ *        r = rsqrt(var+eps); A = r*(s+1), B = b - mu*A.
+ * mode 1 InstanceNormalization (instance_normalization.py:117-130): p1 = gamma (C), p2 = beta (C);
+ *        q = 1/(sqrt(var)+eps); A = gamma*q, B = beta - mu*A.
+ * mode 2 get_layer_style (confignet_utils.py:147-159): A is (N,2C) = [mu | sqrt(var+eps)], B unused.
+ * save_mean / save_r (N,C) keep mu and r|q|std for the backward pass. */
+int cn_norm_coef_fwd(int mode, const float* s1, const float* s2, const float* p1, const float* p2, float* A,
+                     float* B, float* save_mean, float* save_r, int n, int c, int S, float eps, void* stream);
+/* Backward coefficients: the input gradient is gx = c1*gy + c2*x + c0 (x = the normalised tensor, after
+ * LeakyReLU for mode 1).  t1 = sum_s gy, t2 = sum_s gy*x.  mode 0: gp1 = d[s|b] (N,2C).  mode 1: gp1 = dgamma,
+ * gp2 = dbeta (C), reduced over n.  mode 2: t1 = d[mu|std] (N,2C), t2 unused; c1 unused, gx = c2*x + c0. */
+int cn_norm_coef_bwd(int mode, const float* t1, const float* t2, const float* save_mean, const float* save_r,
+                     const float* p1, float* c1, float* c2, float* c0, float* gp1, float* gp2, int n, int c,
+                     int S, float eps, void* stream);
 
 /* ---- elementwise / small ops ------------------------------------------------------------------*/
 int cn_act_fwd(const float* x, float* y, size_t numel, int act, float slope, void* stream);

@@ -374,3 +374,49 @@ def test_latent_gan_step():
         gan.update_smoothed_weights()
     assert np.isfinite(float(d["loss_sum"])) and np.isfinite(float(g["loss_sum"]))
     assert gan.generate_latents(5).shape == (5, 145)
+
+
+def test_fused_norm_functions_match_composites_and_oracle():
+    """AdaInFn / DiscrTailFn (fused, first order) == the twice-differentiable composites == the oracle."""
+    from confignet_amd import functional as F
+    rng = np.random.default_rng(21)
+    x = rng.normal(size=(3, 8, 8, 8, 32)) * 2 + 0.3
+    sb = rng.normal(size=(3, 64))
+    cot = rng.normal(size=x.shape)
+
+    def run(fn):
+        xt = torch.tensor(x, device="cuda", dtype=torch.float32, requires_grad=True)
+        st = torch.tensor(sb, device="cuda", dtype=torch.float32, requires_grad=True)
+        y = fn(xt, st)
+        gx, gs = torch.autograd.grad((y * torch.tensor(cot, device="cuda", dtype=torch.float32)).sum(), [xt, st])
+        return y, gx, gs
+    yf, gxf, gsf = run(F.adain)
+    yc, gxc, gsc = run(F.adain_composite)
+    xr, sr = t64(x).requires_grad_(True), t64(sb).requires_grad_(True)
+    mu = xr.mean(dim=(1, 2, 3), keepdim=True)
+    var = ((xr - mu) ** 2).mean(dim=(1, 2, 3), keepdim=True)
+    yr = (xr - mu) * torch.rsqrt(var + 1e-3) * (sr[:, :32].reshape(3, 1, 1, 1, 32) + 1) + sr[:, 32:].reshape(3, 1, 1, 1, 32)
+    gxr, gsr = torch.autograd.grad((yr * t64(cot)).sum(), [xr, sr])
+    for got, ref, what in ((yf, yr, "adain y"), (gxf, gxr, "adain gx"), (gsf, gsr, "adain gsb"),
+                           (yc, yr, "composite y"), (gxc, gxr, "composite gx"), (gsc, gsr, "composite gsb")):
+        close(got, ref, tol=2e-4, what=what, rel=True)
+
+    # DiscrBlock tail: style + LeakyReLU + instance norm
+    x = rng.normal(size=(2, 16, 16, 48))
+    gamma, beta = rng.normal(size=48) * 0.2 + 1, rng.normal(size=48) * 0.2
+    cy, cs = rng.normal(size=x.shape), rng.normal(size=(2, 96))
+    xt = torch.tensor(x, device="cuda", dtype=torch.float32, requires_grad=True)
+    gt = torch.tensor(gamma, device="cuda", dtype=torch.float32, requires_grad=True)
+    bt = torch.tensor(beta, device="cuda", dtype=torch.float32, requires_grad=True)
+    y, st = F.DiscrTailFn.apply(xt, gt, bt, True, 0.3)
+    loss = (y * torch.tensor(cy, device="cuda", dtype=torch.float32)).sum() + (st * torch.tensor(cs, device="cuda", dtype=torch.float32)).sum()
+    g = torch.autograd.grad(loss, [xt, gt, bt])
+    xr, gr, br = t64(x).requires_grad_(True), t64(gamma).requires_grad_(True), t64(beta).requires_grad_(True)
+    mu, sd = O.layer_style(xr)
+    st_r = torch.cat([mu, sd], dim=-1).reshape(2, -1)
+    y_r = O.instance_norm(O.leaky_relu(xr, 0.3), gr, br)
+    g_r = torch.autograd.grad((y_r * t64(cy)).sum() + (st_r * t64(cs)).sum(), [xr, gr, br])
+    close(y, y_r, tol=2e-4, what="tail y", rel=True)
+    close(st, st_r, tol=2e-4, what="tail style", rel=True)
+    for a, b, what in zip(g, g_r, ("tail gx", "tail ggamma", "tail gbeta")):
+        close(a, b, tol=5e-4, what=what, rel=True)
