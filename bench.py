@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--res", type=int, default=256)
     ap.add_argument("--pool", type=int, default=512, help="images in each synthetic uint8 pool")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graphs", action="store_true", help="dispatch every kernel eagerly (no HIP graph replay)")
     ap.add_argument("--cpu-batch", type=int, default=4)
     args = ap.parse_args()
 
@@ -71,19 +72,30 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    # Single GPU: every step's device half is one captured HIP graph (confignet_amd/graphs.py); N > 1 keeps
+    # eager dispatch around the RCCL all-reduces.  Warm-up covers the eager call + the capture of each graph.
+    model.use_graphs = (world == 1) and not args.no_graphs
+    for _ in range(max(args.warmup, 2 if model.use_graphs else 0)):
         model.training_iteration(real_set, synth_set, d_opt, g_opt)
     sync()
-    ops.prof_reset()
-    ops.prof_enable(True)                             # HIP events around every implicit-GEMM conv launch
     t0 = time.perf_counter()
     for _ in range(args.steps):
         losses = model.training_iteration(real_set, synth_set, d_opt, g_opt)
     sync()
     elapsed = time.perf_counter() - t0
+    finite = all(np.isfinite(float(l["loss_sum"].detach())) for l in losses)
+
+    # Roofline of the dominant kernel class, measured live with HIP events recorded on the launch stream
+    # around every implicit-GEMM convolution launch of the SAME K iterations dispatched eagerly right after the
+    # timed region (event records cannot sit inside a replayed graph; the kernels and shapes are identical).
+    model.use_graphs = False
+    ops.prof_reset()
+    ops.prof_enable(True)
+    for _ in range(args.steps):
+        model.training_iteration(real_set, synth_set, d_opt, g_opt)
+    sync()
     ops.prof_enable(False)
     launches, kernel_ms, kernel_flops = ops.prof_collect()
-    finite = all(np.isfinite(float(l["loss_sum"])) for l in losses)
 
     t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
     if world > 1:
@@ -102,7 +114,8 @@ def main():
             "config": {"workload": "ConfigNet second-stage iteration (D + synth-D + latent-D + G + EMA), %dx%d, "
                                    "batch %d per GPU, fp32, Keras-Adam" % (args.res, args.res, args.batch),
                        "global_batch": args.batch * world, "resolution": args.res, "latent_dim": cfg_latent(model),
-                       "parallelism": "dp%d" % world, "losses_finite": bool(finite)},
+                       "parallelism": "dp%d" % world, "losses_finite": bool(finite),
+                       "dispatch": "hip-graph replay per step function" if (world == 1 and not args.no_graphs) else "eager"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
                          "kernel": "igemm_fwd/igemm_wgrad (implicit-GEMM conv, v_mfma_f32_32x32x2_f32)",

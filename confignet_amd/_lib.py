@@ -61,7 +61,7 @@ SIGNATURES = {
     "cn_gan_loss_bwd": [_p, _p, _p, _i, _f, _p],
     "cn_rotate3d_fwd": [_p, _p, _p, _i, _i, _i, _p],
     "cn_rotate3d_bwd": [_p, _p, _p, _p, _p, _i, _i, _i, _p],
-    "cn_adam_step": [_p, _p, _p, _p, _p, _z, _f, _f, _f, _f, _f, _p],
+    "cn_adam_step": [_p, _p, _p, _p, _p, _z, _p, _f, _f, _f, _f, _p],
     "cn_ema_step": [_p, _p, _z, _f, _p],
     "cn_gather_images_u8": [_p, _p, _p, _p, _i, _i, _i, _i, _p],
     "cn_to_uint8": [_p, _p, _z, _p],

@@ -89,6 +89,10 @@ class ConfigNetFirstStage:
         self.config["model_type"] = "ConfigNetFirstStage"
         self.device = require_gpu()
         self._rng = np.random.default_rng(seed)
+        from .graphs import StaticBuffers
+        self._bufs = StaticBuffers(self.device)
+        self._graphs = {}
+        self.use_graphs = False       # capture each step's device half into a HIP graph (single-GPU runs)
 
         self.generator = None
         self.generator_smoothed = None
@@ -268,8 +272,9 @@ class ConfigNetFirstStage:
         rot = dataset.metadata_inputs["rotations"][idx].astype(np.float32)
         return params, rot, np.copy(dataset.imgs[idx]).astype(np.float32), np.copy(dataset.eye_masks[idx])
 
-    # device-resident pools: the uint8 image pool lives in HBM, batches are gathered/normalised/flipped
-    # by one kernel (data path row of SURVEY.md 8f); the RNG calls mirror the reference's order.
+    # ---- step machinery: host half (sampling + upload into static buffers) / device half (graph-capturable) --
+    # The uint8 image pools live in HBM; batches are gathered/normalised/flipped by one kernel (data-path row of
+    # SURVEY.md 8f).  The numpy RNG calls mirror the reference's order.
     def _pool(self, dataset):
         cache = getattr(dataset, "_cn_device_pool", None)
         if cache is None or cache["device"] != self.device:
@@ -282,72 +287,118 @@ class ConfigNetFirstStage:
             dataset._cn_device_pool = cache
         return cache
 
-    def _gather_images(self, dataset, idx, flip=None):
-        pool = self._pool(dataset)["imgs"]
-        idx_t = torch.as_tensor(idx, dtype=torch.int64).to(self.device)
-        flip_t = torch.as_tensor(flip.astype(np.uint8)).to(self.device) if flip is not None else None
-        return ops.gather_images_u8(pool, idx_t, flip_t)
-
-    def _sample_real_batch(self, dataset, n):
-        idx = np.random.randint(0, dataset.imgs.shape[0], n)
-        flip = np.random.randint(0, 2, size=n)                # flip_random_subset_of_images
-        return self._gather_images(dataset, idx, flip)
-
-    def _sample_synthetic_batch(self, dataset, n):
-        idx = np.random.randint(0, dataset.imgs.shape[0], n)
-        params = [self._dev(dataset.metadata_inputs[name][idx]) for name in self.config["facemodel_inputs"].keys()]
-        rot = self._dev(dataset.metadata_inputs["rotations"][idx])
-        imgs = self._gather_images(dataset, idx)
-        masks = self._pool(dataset)["eye_masks"][torch.as_tensor(idx, dtype=torch.int64).to(self.device)].contiguous()
-        return params, rot, imgs, masks
-
     def _dev(self, a):
         return torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32)).to(self.device)
 
-    def get_discriminator_batch(self, training_set):
-        real_imgs = self._sample_real_batch(training_set, self.get_batch_size())
-        latent_vector = self.sample_latent_vector(self.get_batch_size())
-        random_rotation = self.sample_rotations(self.get_batch_size())
-        with torch.no_grad():
-            fake_imgs = self.generator([latent_vector, random_rotation])
-        return real_imgs, fake_imgs
+    def _stage(self, key, arr, dtype=torch.float32):
+        return self._bufs.stage(key, arr, dtype)
 
-    def get_synth_discriminator_batch(self, training_set):
-        real_imgs = self._sample_real_batch(training_set, self.get_batch_size())
-        params, rotations, _, _ = self._sample_synthetic_batch(training_set, self.get_batch_size())
-        with torch.no_grad():
-            fake_imgs = self.generator([self.synthetic_encoder(params), rotations])
-        return real_imgs, fake_imgs
+    def _stage_real(self, key, dataset, n):
+        """Host half of a real-image batch: indices + flip flags (flip_random_subset_of_images)."""
+        self._stage(key + "/idx", np.random.randint(0, dataset.imgs.shape[0], n), torch.int64)
+        self._stage(key + "/flip", np.random.randint(0, 2, size=n), torch.uint8)
+
+    def _real_imgs(self, key, dataset):
+        return ops.gather_images_u8(self._pool(dataset)["imgs"], self._bufs[key + "/idx"], self._bufs[key + "/flip"])
+
+    def _stage_synth(self, key, dataset, n):
+        idx = np.random.randint(0, dataset.imgs.shape[0], n)
+        self._stage(key + "/idx", idx, torch.int64)
+        for name in self.config["facemodel_inputs"].keys():
+            self._stage(key + "/p/" + name, dataset.metadata_inputs[name][idx])
+        self._stage(key + "/rot", dataset.metadata_inputs["rotations"][idx])
+
+    def _synth_batch(self, key, dataset, imgs=True):
+        params = [self._bufs[key + "/p/" + name] for name in self.config["facemodel_inputs"].keys()]
+        rot = self._bufs[key + "/rot"]
+        if not imgs:
+            return params, rot, None, None
+        idx = self._bufs[key + "/idx"]
+        pool = self._pool(dataset)
+        return params, rot, ops.gather_images_u8(pool["imgs"], idx, None), pool["eye_masks"][idx].contiguous()
+
+    def _run_step(self, name, datasets, optimizer, device_fn):
+        """optimizer.advance() on the host, then the device half -- eagerly, or as a captured HIP graph."""
+        optimizer.advance()
+        if not self.use_graphs:
+            return device_fn()
+        key = (name, tuple(id(d) for d in datasets), id(optimizer), self._bufs.generation)
+        g = self._graphs.get(key)
+        if g is None:
+            from .graphs import StepGraph
+            self._graphs = {k: v for k, v in self._graphs.items() if k[3] == self._bufs.generation}
+            g = self._graphs[key] = StepGraph(device_fn)
+        return g()
 
     def _discriminator_update(self, net, real_imgs, fake_imgs, optimizer):
         net.zero_grad()
         losses = compute_discriminator_loss(net, real_imgs, fake_imgs)
         torch.autograd.backward(losses["loss_sum"], inputs=net.trainable_weights)
-        optimizer.apply_gradients(net)
+        optimizer.apply_gradients(net, advance=False)
         return losses
 
+    def get_discriminator_batch(self, training_set):
+        """Reference-shaped helper (confignet_first_stage.py:438-450): returns (real_imgs, fake_imgs)."""
+        self._stage_d_batch(training_set)
+        return self._d_batch(training_set)
+
+    def _stage_d_batch(self, training_set):
+        n = self.get_batch_size()
+        self._stage_real("d", training_set, n)
+        self._stage("d/z", self.sample_latent_vector(n))
+        self._stage("d/rot", self.sample_rotations(n))
+
+    def _d_batch(self, training_set):
+        real_imgs = self._real_imgs("d", training_set)
+        with torch.no_grad():
+            fake_imgs = self.generator([self._bufs["d/z"], self._bufs["d/rot"]])
+        return real_imgs, fake_imgs
+
     def discriminator_training_step(self, training_set, optimizer):
-        real_imgs, fake_imgs = self.get_discriminator_batch(training_set)
-        return self._discriminator_update(self.discriminator, real_imgs, fake_imgs, optimizer)
+        self._stage_d_batch(training_set)
+        return self._run_step("d", (training_set,), optimizer, lambda: self._discriminator_update(
+            self.discriminator, *self._d_batch(training_set), optimizer))
+
+    def get_synth_discriminator_batch(self, training_set):
+        self._stage_sd_batch(training_set)
+        return self._sd_batch(training_set)
+
+    def _stage_sd_batch(self, training_set):
+        n = self.get_batch_size()
+        self._stage_real("sd", training_set, n)
+        self._stage_synth("sd", training_set, n)
+
+    def _sd_batch(self, training_set):
+        real_imgs = self._real_imgs("sd", training_set)
+        params, rotations, _, _ = self._synth_batch("sd", training_set, imgs=False)
+        with torch.no_grad():
+            fake_imgs = self.generator([self.synthetic_encoder(params), rotations])
+        return real_imgs, fake_imgs
 
     def synth_discriminator_training_step(self, synth_training_set, optimizer):
-        real_imgs, fake_imgs = self.get_synth_discriminator_batch(synth_training_set)
-        return self._discriminator_update(self.synth_discriminator, real_imgs, fake_imgs, optimizer)
+        self._stage_sd_batch(synth_training_set)
+        return self._run_step("sd", (synth_training_set,), optimizer, lambda: self._discriminator_update(
+            self.synth_discriminator, *self._sd_batch(synth_training_set), optimizer))
 
     def _latent_discriminator_update(self, real_latents, fake_latents, optimizer):
         net = self.latent_discriminator
         net.zero_grad()
         losses = compute_latent_discriminator_loss(net, real_latents, fake_latents)
         torch.autograd.backward(losses["loss_sum"], inputs=net.trainable_weights)
-        optimizer.apply_gradients(net)
+        optimizer.apply_gradients(net, advance=False)
         return losses
 
     def latent_discriminator_training_step(self, synth_training_set, optimizer):
-        real_latents = self._dev(self.sample_latent_vector(self.get_batch_size()))
-        params, _, _, _ = self._sample_synthetic_batch(synth_training_set, self.get_batch_size())
-        with torch.no_grad():
-            fake_latents = self.synthetic_encoder(params)
-        return self._latent_discriminator_update(real_latents, fake_latents, optimizer)
+        n = self.get_batch_size()
+        self._stage("ld/z", self.sample_latent_vector(n))
+        self._stage_synth("ld", synth_training_set, n)
+
+        def device():
+            params, _, _, _ = self._synth_batch("ld", synth_training_set, imgs=False)
+            with torch.no_grad():
+                fake_latents = self.synthetic_encoder(params)
+            return self._latent_discriminator_update(self._bufs["ld/z"], fake_latents, optimizer)
+        return self._run_step("ld", (synth_training_set,), optimizer, device)
 
     def _generator_loss(self, facemodel_params, synth_rotations, gt_imgs, eye_masks, real_latents, real_rotations):
         """The taped part of generator_training_step (l.518-554)."""
@@ -376,21 +427,25 @@ class ConfigNetFirstStage:
     def _generator_update(self, losses, nets, optimizer):
         params = [p for n in nets for p in n.trainable_weights]
         torch.autograd.backward(losses["loss_sum"], inputs=params)
-        optimizer.apply_gradients(nets)
+        optimizer.apply_gradients(nets, advance=False)
 
     def generator_training_step(self, real_training_set, synth_training_set, optimizer):
         n_synth = self.get_batch_size() // 2
         n_real = self.get_batch_size() - n_synth
-        params, synth_rot, gt_imgs, eye_masks = self._sample_synthetic_batch(synth_training_set, n_synth)
-        real_latents = self._dev(self.sample_latent_vector(n_real))
-        real_rot = self._dev(self.sample_rotations(n_real))
+        self._stage_synth("g", synth_training_set, n_synth)
+        self._stage("g/z", self.sample_latent_vector(n_real))
+        self._stage("g/rot_real", self.sample_rotations(n_real))
         nets = [self.generator, self.latent_regressor, self.synthetic_encoder]
-        for n in nets:
-            n.zero_grad()
-        with frozen(self.discriminator, self.synth_discriminator, self.latent_discriminator):
-            losses = self._generator_loss(params, synth_rot, gt_imgs, eye_masks, real_latents, real_rot)
-            self._generator_update(losses, nets, optimizer)
-        return losses
+
+        def device():
+            params, synth_rot, gt_imgs, eye_masks = self._synth_batch("g", synth_training_set)
+            for n in nets:
+                n.zero_grad()
+            with frozen(self.discriminator, self.synth_discriminator, self.latent_discriminator):
+                losses = self._generator_loss(params, synth_rot, gt_imgs, eye_masks, self._bufs["g/z"], self._bufs["g/rot_real"])
+                self._generator_update(losses, nets, optimizer)
+            return losses
+        return self._run_step("g", (real_training_set, synth_training_set), optimizer, device)
 
     def setup_training(self, log_dir, synth_training_set, n_samples_for_metrics, real_training_set=None):
         self.facemodel_param_distributions = synth_training_set.metadata_input_distributions   # l.587

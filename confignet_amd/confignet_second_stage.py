@@ -68,25 +68,36 @@ class ConfigNet(ConfigNetFirstStage):
         return mean_squared_error(labels, out) * self.config["latent_regression_weight"]
 
     def sample_random_batch_of_images(self, dataset, batch_size=None):
-        return self._sample_real_batch(dataset, self.get_batch_size() if batch_size is None else batch_size)
+        """confignet_second_stage.py:109-117 (device gather of the staged indices/flips)."""
+        self._stage_real("rand", dataset, self.get_batch_size() if batch_size is None else batch_size)
+        return self._real_imgs("rand", dataset)
 
-    def get_discriminator_batch(self, training_set):
-        real_imgs = self.sample_random_batch_of_images(training_set)
-        idx = np.random.randint(0, training_set.imgs.shape[0], self.get_batch_size())
-        input_imgs = self._gather_images(training_set, idx)
+    def _stage_d_batch(self, training_set):
+        n = self.get_batch_size()
+        self._stage_real("d", training_set, n)
+        self._stage("d/enc_idx", np.random.randint(0, training_set.imgs.shape[0], n), torch.int64)
+
+    def _d_batch(self, training_set):
+        """confignet_second_stage.py:119-130: fakes are generated from encoded (unflipped) real images."""
+        real_imgs = self._real_imgs("d", training_set)
         with torch.no_grad():
+            input_imgs = ops.gather_images_u8(self._pool(training_set)["imgs"], self._bufs["d/enc_idx"], None)
             latent_vector, rotation = self.encoder(input_imgs)
             fake_imgs = self.generator([latent_vector, rotation])
         return real_imgs, fake_imgs
 
     def latent_discriminator_training_step(self, real_training_set, synth_training_set, optimizer):
-        real_imgs = self.sample_random_batch_of_images(real_training_set)
-        with torch.no_grad():
-            real_latents, _ = self.encoder(real_imgs)
-        params, _, _, _ = self._sample_synthetic_batch(synth_training_set, self.get_batch_size())
-        with torch.no_grad():
-            fake_latents = self.synthetic_encoder(params)
-        return self._latent_discriminator_update(real_latents, fake_latents, optimizer)
+        n = self.get_batch_size()
+        self._stage_real("ld", real_training_set, n)
+        self._stage_synth("ld", synth_training_set, n)
+
+        def device():
+            with torch.no_grad():
+                real_latents, _ = self.encoder(self._real_imgs("ld", real_training_set))
+                params, _, _, _ = self._synth_batch("ld", synth_training_set, imgs=False)
+                fake_latents = self.synthetic_encoder(params)
+            return self._latent_discriminator_update(real_latents, fake_latents, optimizer)
+        return self._run_step("ld", (real_training_set, synth_training_set), optimizer, device)
 
     def _generator_loss(self, facemodel_params, synth_rotations, synth_imgs, eye_masks, real_imgs):
         """The taped part of ConfigNet.generator_training_step (l.167-211)."""
@@ -121,15 +132,20 @@ class ConfigNet(ConfigNetFirstStage):
     def generator_training_step(self, real_training_set, synth_training_set, optimizer):
         n_synth = self.get_batch_size() // 2
         n_real = self.get_batch_size() - n_synth
-        params, synth_rot, synth_imgs, eye_masks = self._sample_synthetic_batch(synth_training_set, n_synth)
-        real_imgs = self.sample_random_batch_of_images(real_training_set, n_real)
+        self._stage_synth("g", synth_training_set, n_synth)
+        self._stage_real("g", real_training_set, n_real)
         nets = [self.generator, self.latent_regressor, self.synthetic_encoder, self.encoder]
-        for n in nets:
-            n.zero_grad()
-        with frozen(self.discriminator, self.synth_discriminator, self.latent_discriminator):
-            losses = self._generator_loss(params, synth_rot, synth_imgs, eye_masks, real_imgs)
-            self._generator_update(losses, nets, optimizer)
-        return losses
+
+        def device():
+            params, synth_rot, synth_imgs, eye_masks = self._synth_batch("g", synth_training_set)
+            real_imgs = self._real_imgs("g", real_training_set)
+            for n in nets:
+                n.zero_grad()
+            with frozen(self.discriminator, self.synth_discriminator, self.latent_discriminator):
+                losses = self._generator_loss(params, synth_rot, synth_imgs, eye_masks, real_imgs)
+                self._generator_update(losses, nets, optimizer)
+            return losses
+        return self._run_step("g", (real_training_set, synth_training_set), optimizer, device)
 
     def training_iteration(self, real_training_set, synth_training_set, discriminator_optimizer, generator_optimizer):
         """One reference training iteration (confignet_second_stage.py:277-288): D, synth-D, latent-D,

@@ -292,8 +292,9 @@ __global__ void gan_loss_bwd_kernel(const float* __restrict__ s, const float* __
 }
 
 __global__ void adam_kernel(float* __restrict__ th, const float* __restrict__ g, float* __restrict__ m,
-                            float* __restrict__ v, float* __restrict__ ema, size_t n, float lr_t, float b1, float b2,
-                            float eps, float alpha) {
+                            float* __restrict__ v, float* __restrict__ ema, size_t n, const float* __restrict__ lr_ptr,
+                            float b1, float b2, float eps, float alpha) {
+    const float lr_t = lr_ptr[0];
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const float gi = g[i];
         const float mi = b1 * m[i] + (1.f - b1) * gi;
@@ -470,9 +471,9 @@ extern "C" int cn_gan_loss_bwd(const float* s, const float* gout, float* gs, int
     CN_LAUNCH_CHECK();
     return CN_OK;
 }
-extern "C" int cn_adam_step(float* theta, const float* grad, float* m, float* v, float* ema, size_t numel, float lr_t,
-                            float beta1, float beta2, float eps, float ema_alpha, void* stream) {
-    CN_CHECK_ARG(theta && grad && m && v, "adam: NULL");
+extern "C" int cn_adam_step(float* theta, const float* grad, float* m, float* v, float* ema, size_t numel,
+                            const float* lr_t, float beta1, float beta2, float eps, float ema_alpha, void* stream) {
+    CN_CHECK_ARG(theta && grad && m && v && lr_t, "adam: NULL");
     if (!numel) return CN_OK;
     EW_LAUNCH(adam_kernel, numel, theta, grad, m, v, ema, numel, lr_t, beta1, beta2, eps, ema_alpha)
 }

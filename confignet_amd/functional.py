@@ -36,14 +36,16 @@ def _cg(t):
 
 
 def _tflip_cached(w):
-    """weight_tflip(w), cached on the tensor until it is modified in place."""
-    ver = w._version
+    """weight_tflip(w), cached on the tensor until the weights change (nn.WEIGHTS_EPOCH) or, for
+    non-parameter tensors, until torch's version counter moves."""
+    from .nn import WEIGHTS_EPOCH
+    key = (WEIGHTS_EPOCH[0], w._version, w.data_ptr())
     c = getattr(w, "_cn_tflip", None)
-    if c is not None and c[0] == ver and c[2] == w.data_ptr():
+    if c is not None and c[0] == key:
         return c[1]
     wt = ops.weight_tflip(w.detach())
     try:
-        w._cn_tflip = (ver, wt, w.data_ptr())
+        w._cn_tflip = (key, wt)
     except Exception:
         pass
     return wt

@@ -1,0 +1,55 @@
+"""HIP-graph capture of whole training steps.
+
+A reference training step issues ~10^3 small ops (the six R1 input-gradient passes alone are hundreds of
+launches); dispatched eagerly from Python the discriminator steps are host-bound (step_breakdown: GPU time ==
+enqueue time).  Each step function is therefore split into a host half (numpy batch sampling, upload into
+STATIC device buffers, optimizer.advance()) and a device half that only reads those buffers; the device half
+(forward, R1 tape, backward, Adam) is captured once into a HIP graph and replayed."""
+import torch
+
+from . import ops
+from .nn import WEIGHTS_EPOCH
+
+
+class StepGraph:
+    def __init__(self, fn, warmup=1):
+        self.fn, self.warmup = fn, warmup
+        self.calls, self.graph, self.out = 0, None, None
+
+    def __call__(self):
+        if self.graph is None:
+            if self.calls < self.warmup:
+                self.calls += 1
+                return self.fn()
+            torch.cuda.synchronize()
+            ops.prof_enable(False)                 # no event records inside a capture
+            WEIGHTS_EPOCH[0] += 1                  # derived caches must be rebuilt INSIDE this graph
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.out = self.fn()
+            WEIGHTS_EPOCH[0] += 1
+        self.graph.replay()
+        return self.out
+
+
+class StaticBuffers:
+    """Named device buffers with stable addresses; `stage` uploads new host data into them."""
+
+    def __init__(self, device):
+        self.device, self.bufs, self.generation = device, {}, 0
+
+    def stage(self, key, array, dtype=None):
+        t = torch.as_tensor(array)
+        if dtype is not None:
+            t = t.to(dtype)
+        t = t.contiguous()
+        b = self.bufs.get(key)
+        if b is None or b.shape != t.shape or b.dtype != t.dtype:
+            b = torch.empty(t.shape, dtype=t.dtype, device=self.device)
+            self.bufs[key] = b
+            self.generation += 1                   # addresses changed: captured graphs are stale
+        b.copy_(t)
+        return b
+
+    def __getitem__(self, key):
+        return self.bufs[key]

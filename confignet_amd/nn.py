@@ -35,7 +35,15 @@ def he_normal(rng, shape):
     return (rng.standard_normal(size=shape) * math.sqrt(2.0 / (rf * shape[-2]))).astype(np.float32)
 
 
+WEIGHTS_EPOCH = [0]     # bumped whenever any network's weights change in place (optimizer, set_weights, EMA)
+
+
 class Net:
+    def mark_updated(self):
+        """Raw-pointer kernels (Adam, EMA) do not bump torch's version counters: derived caches (the
+        tap-flipped filters of the data-gradient GEMM) are keyed on this epoch instead."""
+        WEIGHTS_EPOCH[0] += 1
+
     def __init__(self):
         self._entries = []          # (name, np array, trainable)
         self.weights = []           # torch tensors, Keras get_weights() order
@@ -92,6 +100,7 @@ class Net:
                 a = np.asarray(a, dtype=np.float32)
                 assert tuple(a.shape) == tuple(w.shape), "shape mismatch %s vs %s" % (a.shape, tuple(w.shape))
                 w.copy_(torch.from_numpy(np.ascontiguousarray(a)))
+        self.mark_updated()
 
     def copy_weights_from(self, other):
         with torch.no_grad():
@@ -99,6 +108,7 @@ class Net:
             for w, o in zip(self.weights, other.weights):
                 if not w.requires_grad:
                     w.copy_(o)
+        self.mark_updated()
 
     def zero_grad(self):
         self.grad_arena.zero_()

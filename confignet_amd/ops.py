@@ -294,7 +294,8 @@ def rotate3d_bwd(grid, rot, gout, need_rot):
 
 
 def adam_step(theta, grad, m, v, ema, lr_t, beta1, beta2, eps, ema_alpha=0.999):
-    check(lib.cn_adam_step(_ptr(theta), _ptr(grad), _ptr(m), _ptr(v), _ptr(ema), theta.numel(), lr_t, beta1, beta2,
+    """lr_t: a 1-element float32 CUDA tensor (read by the kernel at execution time)."""
+    check(lib.cn_adam_step(_ptr(theta), _ptr(grad), _ptr(m), _ptr(v), _ptr(ema), theta.numel(), _ptr(lr_t), beta1, beta2,
                            eps, ema_alpha, _stream()), "cn_adam_step")
 
 

@@ -16,22 +16,36 @@ class Adam:
         self.lr, self.beta_1, self.beta_2, self.epsilon = lr, beta_1, beta_2, epsilon
         self.iterations = 0
         self._state = {}
+        self._lr_dev = None
 
     def lr_t(self):
         t = self.iterations
         return self.lr * math.sqrt(1.0 - self.beta_2 ** t) / (1.0 - self.beta_1 ** t)
 
-    def apply_gradients(self, nets):
+    def advance(self):
+        """Host half of one Keras apply_gradients call: t += 1 and the new lr_t is written to a device scalar.
+        Kept apart from apply_gradients so that the device half can live inside a captured HIP graph."""
+        if self._lr_dev is None:
+            self._lr_dev = torch.zeros(1, device="cuda", dtype=torch.float32)
+        self.iterations += 1
+        self._lr_dev.fill_(self.lr_t())
+
+    def state_for(self, net):
+        st = self._state.get(id(net))
+        if st is None:
+            st = (torch.zeros_like(net.arena), torch.zeros_like(net.arena))
+            self._state[id(net)] = st
+        return st
+
+    def apply_gradients(self, nets, advance=True):
         """One Keras apply_gradients call over the flat arenas of `nets` (a Net or a list of Nets):
         data-parallel gradient all-reduce first, then one fused Adam launch per arena."""
         if not isinstance(nets, (list, tuple)):
             nets = [nets]
+        if advance:
+            self.advance()
         parallel.allreduce_gradients(nets)
-        self.iterations += 1
-        lr_t = self.lr_t()
         for net in nets:
-            st = self._state.get(id(net))
-            if st is None:
-                st = (torch.zeros_like(net.arena), torch.zeros_like(net.arena))
-                self._state[id(net)] = st
-            ops.adam_step(net.arena, net.grad_arena, st[0], st[1], None, lr_t, self.beta_1, self.beta_2, self.epsilon)
+            m, v = self.state_for(net)
+            ops.adam_step(net.arena, net.grad_arena, m, v, None, self._lr_dev, self.beta_1, self.beta_2, self.epsilon)
+            net.mark_updated()

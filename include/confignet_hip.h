@@ -139,10 +139,11 @@ int cn_rotate3d_bwd(const float* grid, const float* rot, const float* gout, floa
                     int n, int g, int c, void* stream);
 
 /* ---- optimizer: Keras Adam + EMA in one pass (confignet_first_stage.py:393-400,601-602) -----
- * theta -= lr_t * m/(sqrt(v)+eps) with lr_t supplied by the host (shared step counter rule);
- * if ema != NULL: ema = ema_alpha*ema + (1-ema_alpha)*theta_new. */
+ * theta -= lr_t * m/(sqrt(v)+eps); lr_t = lr*sqrt(1-b2^t)/(1-b1^t) is computed by the host (shared step
+ * counter rule) and read from DEVICE memory (one float) so a captured HIP graph of the step stays valid
+ * while t advances; if ema != NULL: ema = ema_alpha*ema + (1-ema_alpha)*theta_new. */
 int cn_adam_step(float* theta, const float* grad, float* m, float* v, float* ema, size_t numel,
-                 float lr_t, float beta1, float beta2, float eps, float ema_alpha, void* stream);
+                 const float* lr_t, float beta1, float beta2, float eps, float ema_alpha, void* stream);
 int cn_ema_step(float* ema, const float* theta, size_t numel, float alpha, void* stream);
 
 /* ---- data path: batch assembly on device (confignet_first_stage.py:438-450 ;

@@ -235,6 +235,6 @@ def test_adam_ema():
         opt.apply_gradients([(t64(gt), p)])
         ema_ref = 0.999 * ema_ref + 0.001 * p
         lr_t = 4e-4 * math.sqrt(1 - 0.9 ** t) / (1 - 0.0 ** t)
-        ops.adam_step(dth, dev(gt), m, v, ema, lr_t, 0.0, 0.9, 1e-7, 0.999)
+        ops.adam_step(dth, dev(gt), m, v, ema, dev([lr_t]), 0.0, 0.9, 1e-7, 0.999)
     close(dth, p, tol=1e-6)
     close(ema, ema_ref, tol=1e-6)
