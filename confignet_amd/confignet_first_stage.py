@@ -20,7 +20,7 @@ from .dnn_models.hologan_generator import HologanGenerator
 from .dnn_models.synthetic_encoder import SyntheticDataEncoder
 from .losses import (GAN_G_loss, compute_discriminator_loss, compute_latent_discriminator_loss,
                      compute_latent_regression_loss, eye_loss)
-from .nn import require_gpu
+from .nn import backward_into_arenas, require_gpu
 from .perceptual_loss import PerceptualLoss
 
 DEFAULT_CONFIG = {
@@ -331,9 +331,8 @@ class ConfigNetFirstStage:
         return g()
 
     def _discriminator_update(self, net, real_imgs, fake_imgs, optimizer):
-        net.zero_grad()
         losses = compute_discriminator_loss(net, real_imgs, fake_imgs)
-        torch.autograd.backward(losses["loss_sum"], inputs=net.trainable_weights)
+        backward_into_arenas(losses["loss_sum"], [net])
         optimizer.apply_gradients(net, advance=False)
         return losses
 
@@ -382,9 +381,8 @@ class ConfigNetFirstStage:
 
     def _latent_discriminator_update(self, real_latents, fake_latents, optimizer):
         net = self.latent_discriminator
-        net.zero_grad()
         losses = compute_latent_discriminator_loss(net, real_latents, fake_latents)
-        torch.autograd.backward(losses["loss_sum"], inputs=net.trainable_weights)
+        backward_into_arenas(losses["loss_sum"], [net])
         optimizer.apply_gradients(net, advance=False)
         return losses
 
@@ -425,8 +423,7 @@ class ConfigNetFirstStage:
         return losses
 
     def _generator_update(self, losses, nets, optimizer):
-        params = [p for n in nets for p in n.trainable_weights]
-        torch.autograd.backward(losses["loss_sum"], inputs=params)
+        backward_into_arenas(losses["loss_sum"], nets)
         optimizer.apply_gradients(nets, advance=False)
 
     def generator_training_step(self, real_training_set, synth_training_set, optimizer):
@@ -439,8 +436,6 @@ class ConfigNetFirstStage:
 
         def device():
             params, synth_rot, gt_imgs, eye_masks = self._synth_batch("g", synth_training_set)
-            for n in nets:
-                n.zero_grad()
             with frozen(self.discriminator, self.synth_discriminator, self.latent_discriminator):
                 losses = self._generator_loss(params, synth_rot, gt_imgs, eye_masks, self._bufs["g/z"], self._bufs["g/rot_real"])
                 self._generator_update(losses, nets, optimizer)

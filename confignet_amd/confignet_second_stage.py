@@ -11,7 +11,7 @@ from .confignet_first_stage import DEFAULT_CONFIG, ConfigNetFirstStage, frozen
 from .dnn_models.hologan_generator import HologanGenerator
 from .dnn_models.real_encoder import RealEncoder
 from .losses import GAN_D_loss, GAN_G_loss, compute_latent_discriminator_loss, eye_loss, mean_squared_error
-from .nn import Net
+from .nn import Net, backward_into_arenas
 from .perceptual_loss import PerceptualLoss
 
 
@@ -139,8 +139,6 @@ class ConfigNet(ConfigNetFirstStage):
         def device():
             params, synth_rot, synth_imgs, eye_masks = self._synth_batch("g", synth_training_set)
             real_imgs = self._real_imgs("g", real_training_set)
-            for n in nets:
-                n.zero_grad()
             with frozen(self.discriminator, self.synth_discriminator, self.latent_discriminator):
                 losses = self._generator_loss(params, synth_rot, synth_imgs, eye_masks, real_imgs)
                 self._generator_update(losses, nets, optimizer)
@@ -228,8 +226,6 @@ class ConfigNet(ConfigNetFirstStage):
         optimizer = optim.Adam(lr=0.0001)
         w = self.config
         for step_number in range(n_iters):
-            gen.zero_grad()
-            var.zero_grad()
             losses = {}
             with frozen(self.discriminator, self.latent_discriminator, self.latent_regressor):
                 pre_t, post_t = pre.repeat(n_imgs, 1), post.repeat(n_imgs, 1)
@@ -244,8 +240,7 @@ class ConfigNet(ConfigNetFirstStage):
                 labels = torch.cat((embeddings, w["latent_regressor_rot_weight"] * rotations), dim=-1)
                 losses["latent_regression_loss"] = self.compute_normalized_latent_regression_loss(out, labels)
                 losses["loss_sum"] = sum(losses.values())
-                params = gen.trainable_weights + [p for p in var.weights if p.requires_grad]
-                torch.autograd.backward(losses["loss_sum"], inputs=params)
+                backward_into_arenas(losses["loss_sum"], [gen, var])
             stale = torch.cat((pre_t, expr, post_t), dim=1).detach().clone()   # pre/post tiled BEFORE the step
             optimizer.apply_gradients([gen, var])
         # the reference returns pre/post tiled before the last optimizer step with the updated expr (l.402)

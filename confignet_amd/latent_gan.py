@@ -9,6 +9,7 @@ from . import ops, optim
 from .confignet_utils import merge_configs
 from .dnn_models.building_blocks import MLPSimple
 from .losses import GAN_D_loss, GAN_G_loss, gradient_regularization
+from .nn import backward_into_arenas
 
 DEFAULT_CONFIG = {
     "latent_dim": None,
@@ -91,21 +92,19 @@ class LatentGAN:
         idx = np.random.randint(0, gt_embeddings.shape[0], bs)
         real = self.discriminator.to_device(gt_embeddings[idx] if not torch.is_tensor(gt_embeddings)
                                             else gt_embeddings[torch.as_tensor(idx, device=gt_embeddings.device)])
-        self.discriminator.zero_grad()
         losses = self._discriminator_loss(real, fake)
-        torch.autograd.backward(losses["loss_sum"], inputs=self.discriminator.trainable_weights)
+        backward_into_arenas(losses["loss_sum"], [self.discriminator])
         optimizer.apply_gradients(self.discriminator)
         return losses
 
     def generator_training_step(self, optimizer):
         """latent_gan.py:151-165."""
         latents = self.sample_input_latent_vector(self.config["batch_size"])
-        self.generator.zero_grad()
         self.discriminator.requires_grad_(False)
         try:
             losses = {"gan_loss": GAN_G_loss(self.discriminator(self.generator(latents)))}
             losses["loss_sum"] = sum(losses.values())
-            torch.autograd.backward(losses["loss_sum"], inputs=self.generator.trainable_weights)
+            backward_into_arenas(losses["loss_sum"], [self.generator])
         finally:
             self.discriminator.requires_grad_(True)
         optimizer.apply_gradients(self.generator)

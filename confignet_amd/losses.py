@@ -44,17 +44,32 @@ def gradient_regularization(real_out, real_in):
 
 
 def compute_discriminator_loss(discriminator, real_imgs, fake_imgs):
-    """losses.py:20-47."""
-    real_imgs = real_imgs.detach().requires_grad_(True)
-    out_real = discriminator(real_imgs, twice_differentiable=True)
+    """losses.py:20-47.  The reference takes six separate input-gradients (one per head).  The input-gradient
+    is linear in the head cotangent, so here the real batch is replicated once per head (6N images), copy i
+    carries the cotangent of head i only, and ONE recorded input-gradient pass yields all six g_i; head i's
+    logits for the GAN term are read from copy i.  Same numbers, 6x fewer (6x larger) launches."""
+    n = real_imgs.shape[0]
+    heads = discriminator.num_resample + 1
+    real_rep = real_imgs.detach().repeat(heads, 1, 1, 1).requires_grad_(True)
+    out_rep = discriminator(real_rep, twice_differentiable=True)
     out_fake = discriminator(fake_imgs.detach())
+    keys = list(out_rep.keys())
+    out_real = {k: out_rep[k][i * n:(i + 1) * n] for i, k in enumerate(keys)}
     losses = {}
     for i, o in enumerate(out_real.values()):
         losses["GAN_loss_real_" + str(i)] = GAN_D_loss(1.0, o)
     for i, o in enumerate(out_fake.values()):
         losses["GAN_loss_fake_" + str(i)] = GAN_D_loss(0.0, o)
-    for i, o in enumerate(out_real.values()):
-        losses["gp_loss_" + str(i)] = gradient_regularization(o, real_imgs)
+    cot = []
+    for i in range(heads):
+        c = torch.zeros((heads * n, 1), device=real_rep.device, dtype=torch.float32)
+        c[i * n:(i + 1) * n] = 1.0
+        cot.append(c)
+    with F.input_grads_only():
+        (g,) = torch.autograd.grad([out_rep[k] for k in keys], real_rep, grad_outputs=cot, create_graph=True)
+    per_sample = F.row_sumsq(g)                                   # (6N,) = sum_hwc g_i^2 per (head, sample)
+    for i in range(heads):
+        losses["gp_loss_" + str(i)] = 10 * 0.5 * per_sample[i * n:(i + 1) * n].mean()
     losses["loss_sum"] = sum(losses.values())
     return losses
 

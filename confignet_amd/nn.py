@@ -126,3 +126,18 @@ class Net:
     def predict(self, x, batch_size=32):
         """keras Model.predict: batches of 32, numpy out (R11)."""
         raise NotImplementedError
+
+
+def backward_into_arenas(loss, nets):
+    """tape.gradient(loss, trainable_weights) written into the networks' gradient arenas.
+    Uses autograd.grad + one multi-tensor copy instead of .backward(): AccumulateGrad nodes are bound to the
+    stream they were created on, which breaks HIP-graph capture of a step on a capture stream."""
+    params = [p for n in nets for p in n.trainable_weights]
+    grads = torch.autograd.grad(loss, params, allow_unused=True)
+    dst = [p.grad for p, g in zip(params, grads) if g is not None]
+    src = [g.reshape(p.shape) for p, g in zip(params, grads) if g is not None]
+    if dst:
+        torch._foreach_copy_(dst, src)
+    for p, g in zip(params, grads):
+        if g is None:
+            p.grad.zero_()
