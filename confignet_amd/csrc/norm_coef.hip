@@ -118,3 +118,177 @@ extern "C" int cn_norm_coef_bwd(int mode, const float* t1, const float* t2, cons
     }
     return CN_OK;
 }
+
+// =============================================================================================
+// R1 penalty without a second-order tape.  d/dtheta |g|^2 with g = d out/d x equals
+// 2 * d/dtheta JVP_x(out)(v) at v = g held constant, so the penalty's gradient is an ordinary first-order
+// backward pass through a TANGENT forward pass of the discriminator.  These kernels are the O(N*C)
+// coefficient algebra of the tangent ("dual") DiscrBlock tail (style statistics + LeakyReLU + instance norm):
+//   a = lrelu(x), ta = lrelu'(x) tx, tmu = mean(ta), P = mean((a-mu) ta), tsigma = P/sigma, tq = -q^2 tsigma
+//   ty = gamma (q (ta - tmu) + tq (a - mu))            = C1*ta + C2*a + C0
+//   tstyle = [mean(tx) | mean((x-m) tx)/sd]
+// and of its backward (cotangents h of ty, u of tstyle):
+//   g_tx = lrelu'(x) (K1*h + K2*a + K0) + D2*x + D0
+//   g_x  = lrelu'(x) (kh*h + kt*ta + ka*a + kc) + et*tx + ex*x + e0       (the second-order terms)
+// =============================================================================================
+namespace {
+
+__global__ void dual_coef_fwd_kernel(const float* __restrict__ T1, const float* __restrict__ T2,
+                                     const float* __restrict__ U1, const float* __restrict__ U2,
+                                     const float* __restrict__ mean, const float* __restrict__ qv,
+                                     const float* __restrict__ sm, const float* __restrict__ ssd,
+                                     const float* __restrict__ gamma, float* __restrict__ C1, float* __restrict__ C2,
+                                     float* __restrict__ C0, float* __restrict__ tstyle, int N, int C, float invS, float eps) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * C) return;
+    const int n = i / C, c = i - n * C;
+    if (C1) {
+        const float mu = mean[i], q = qv[i], g = gamma[c];
+        const float sigma = fmaxf(1.f / q - eps, 1e-20f);
+        const float tmu = T1[i] * invS;
+        const float P = T2[i] * invS - mu * tmu;
+        const float tq = -q * q * P / sigma;
+        C1[i] = g * q;
+        C2[i] = g * tq;
+        C0[i] = -g * q * tmu - g * tq * mu;
+    }
+    if (tstyle) {
+        const float m = sm[i], sd = ssd[i];
+        const float tm = U1[i] * invS;
+        tstyle[n * 2 * C + c] = tm;
+        tstyle[n * 2 * C + C + c] = (U2[i] * invS - m * tm) / sd;
+    }
+}
+
+struct DualBwdOut {
+    float *K1, *K2, *K0, *D2, *D0, *kh, *kt, *ka, *kc, *et, *ex, *e0, *ggamma;
+};
+
+__global__ void dual_coef_bwd_kernel(const float* __restrict__ H1, const float* __restrict__ H2p,
+                                     const float* __restrict__ E, const float* __restrict__ u,
+                                     const float* __restrict__ T1, const float* __restrict__ T2,
+                                     const float* __restrict__ U1, const float* __restrict__ U2,
+                                     const float* __restrict__ mean, const float* __restrict__ qv,
+                                     const float* __restrict__ sm, const float* __restrict__ ssd,
+                                     const float* __restrict__ gamma, DualBwdOut o, int N, int C, float invS, float eps) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * C) return;
+    const int n = i / C, c = i - n * C;
+    if (H1) {
+        const float mu = mean[i], q = qv[i], g = gamma[c];
+        const float sigma = fmaxf(1.f / q - eps, 1e-20f);
+        const float tmu = T1[i] * invS;
+        const float P = T2[i] * invS - mu * tmu;
+        const float tq = -q * q * P / sigma;
+        const float h1 = H1[i], h2 = H2p[i] - mu * h1, e = E[i];
+        // adjoint of the tangent map (same form as the first-order instance-norm backward)
+        const float k2 = -g * q * q * h2 * invS / sigma;
+        o.K1[i] = g * q;
+        o.K2[i] = k2;
+        o.K0[i] = -g * q * h1 * invS - k2 * mu;
+        // second-order terms w.r.t. the primal activation a
+        const float ka = g * (-q * q * (e - tmu * h1) + h2 * (2.f * q * q * q * P / sigma + q * q * P / (sigma * sigma))) * invS / sigma;
+        const float k0 = (g * h2 * q * q * tmu / sigma - g * tq * h1) * invS;
+        o.kh[i] = g * tq;
+        o.kt[i] = -g * h2 * q * q * invS / sigma;
+        o.ka[i] = ka;
+        o.kc[i] = k0 - ka * mu;
+        unsafeAtomicAdd(&o.ggamma[c], q * e - q * tmu * h1 + tq * h2);
+    }
+    if (u) {
+        const float m = sm[i], sd = ssd[i];
+        const float um = u[n * 2 * C + c], usd = u[n * 2 * C + C + c];
+        const float tm = U1[i] * invS;
+        const float Q = U2[i] * invS - m * tm;
+        const float d2 = usd * invS / sd;
+        o.D2[i] = d2;
+        o.D0[i] = um * invS - d2 * m;
+        const float ex = -usd * Q * invS / (sd * sd * sd);
+        o.et[i] = usd * invS / sd;
+        o.ex[i] = ex;
+        o.e0[i] = -usd * tm * invS / sd - ex * m;
+    }
+}
+
+// g_x = lrelu'(x) (kh*h + kt*ta + ka*lrelu(x) + kc) + et*tx + ex*x + e0 ; any of the two groups may be absent
+__global__ void dual_gx_kernel(const float* __restrict__ h, const float* __restrict__ ta, const float* __restrict__ tx,
+                               const float* __restrict__ x, const float* __restrict__ kh, const float* __restrict__ kt,
+                               const float* __restrict__ ka, const float* __restrict__ kc, const float* __restrict__ et,
+                               const float* __restrict__ ex, const float* __restrict__ e0, float* __restrict__ out,
+                               long total4, int S, int C, float slope) {
+    const int C4 = C / 4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+        const int cg = (int)(i % C4);
+        const int n = (int)((i / C4) / S);
+        const long ci = (long)n * C + (long)cg * 4;
+        const float4 xv = reinterpret_cast<const float4*>(x)[i];
+        const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+        float r[4] = {0.f, 0.f, 0.f, 0.f};
+        if (kh) {
+            const float4 hv = reinterpret_cast<const float4*>(h)[i];
+            const float4 tv = reinterpret_cast<const float4*>(ta)[i];
+            const float hs[4] = {hv.x, hv.y, hv.z, hv.w}, ts[4] = {tv.x, tv.y, tv.z, tv.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float mk = xs[e] > 0.f ? 1.f : slope;
+                r[e] = mk * (kh[ci + e] * hs[e] + kt[ci + e] * ts[e] + ka[ci + e] * xs[e] * mk + kc[ci + e]);
+            }
+        }
+        if (et) {
+            const float4 tv = reinterpret_cast<const float4*>(tx)[i];
+            const float ts[4] = {tv.x, tv.y, tv.z, tv.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r[e] += et[ci + e] * ts[e] + ex[ci + e] * xs[e] + e0[ci + e];
+        }
+        reinterpret_cast<float4*>(out)[i] = make_float4(r[0], r[1], r[2], r[3]);
+    }
+}
+
+}  // namespace
+
+extern "C" int cn_dual_tail_coef_fwd(const float* T1, const float* T2, const float* U1, const float* U2, const float* mean,
+                                     const float* q, const float* sm, const float* ssd, const float* gamma, float* C1,
+                                     float* C2, float* C0, float* tstyle, int n, int c, int S, float eps, void* stream) {
+    CN_CHECK_ARG(n > 0 && c > 0 && S > 0 && (C1 || tstyle), "dual_tail_coef_fwd: bad args");
+    CN_CHECK_ARG(!C1 || (T1 && T2 && mean && q && gamma && C2 && C0), "dual_tail_coef_fwd: missing instance-norm tensors");
+    CN_CHECK_ARG(!tstyle || (U1 && U2 && sm && ssd), "dual_tail_coef_fwd: missing style tensors");
+    hipLaunchKernelGGL(dual_coef_fwd_kernel, dim3(cn_cdiv((long)n * c, 256)), dim3(256), 0, (hipStream_t)stream, T1, T2, U1, U2,
+                       mean, q, sm, ssd, gamma, C1, C2, C0, tstyle, n, c, 1.f / (float)S, eps);
+    CN_LAUNCH_CHECK();
+    return CN_OK;
+}
+
+extern "C" int cn_dual_tail_coef_bwd(const float* H1, const float* H2p, const float* E, const float* u, const float* T1,
+                                     const float* T2, const float* U1, const float* U2, const float* mean, const float* q,
+                                     const float* sm, const float* ssd, const float* gamma, float* const* out13, int n, int c,
+                                     int S, float eps, void* stream) {
+    CN_CHECK_ARG(n > 0 && c > 0 && S > 0 && out13 && (H1 || u), "dual_tail_coef_bwd: bad args");
+    DualBwdOut o;
+    o.K1 = out13[0]; o.K2 = out13[1]; o.K0 = out13[2]; o.D2 = out13[3]; o.D0 = out13[4];
+    o.kh = out13[5]; o.kt = out13[6]; o.ka = out13[7]; o.kc = out13[8];
+    o.et = out13[9]; o.ex = out13[10]; o.e0 = out13[11]; o.ggamma = out13[12];
+    CN_CHECK_ARG(!H1 || (H2p && E && T1 && T2 && mean && q && gamma && o.K1 && o.K2 && o.K0 && o.kh && o.kt && o.ka && o.kc && o.ggamma),
+                 "dual_tail_coef_bwd: missing instance-norm tensors");
+    CN_CHECK_ARG(!u || (U1 && U2 && sm && ssd && o.D2 && o.D0 && o.et && o.ex && o.e0), "dual_tail_coef_bwd: missing style tensors");
+    hipStream_t s = (hipStream_t)stream;
+    if (H1) CN_HIP(hipMemsetAsync(o.ggamma, 0, sizeof(float) * c, s));
+    hipLaunchKernelGGL(dual_coef_bwd_kernel, dim3(cn_cdiv((long)n * c, 256)), dim3(256), 0, s, H1, H2p, E, u, T1, T2, U1, U2, mean,
+                       q, sm, ssd, gamma, o, n, c, 1.f / (float)S, eps);
+    CN_LAUNCH_CHECK();
+    return CN_OK;
+}
+
+extern "C" int cn_dual_tail_gx(const float* h, const float* ta, const float* tx, const float* x, const float* kh,
+                               const float* kt, const float* ka, const float* kc, const float* et, const float* ex,
+                               const float* e0, float* out, int n, int s, int c, float slope, void* stream) {
+    CN_CHECK_ARG(x && out && n > 0 && s > 0 && c > 0 && c % 4 == 0 && (kh || et), "dual_tail_gx: bad args");
+    CN_CHECK_ARG(!kh || (h && ta && kt && ka && kc), "dual_tail_gx: missing instance-norm tensors");
+    CN_CHECK_ARG(!et || (tx && ex && e0), "dual_tail_gx: missing style tensors");
+    const long total4 = (long)n * s * (c / 4);
+    long blocks = (total4 + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(dual_gx_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, h, ta, tx, x, kh, kt, ka, kc, et, ex,
+                       e0, out, total4, s, c, slope);
+    CN_LAUNCH_CHECK();
+    return CN_OK;
+}

@@ -65,15 +65,18 @@ def conv_adain(x, z, w6, spec):
 DISCR_CONV = ConvSpec((3, 3), stride=2)
 
 
-def discr_block(x, w4, return_styles, twice_differentiable=False):
+def discr_block(x, w4, return_styles, twice_differentiable=False, intermediates=None):
     """DiscrBlock.call (building_blocks.py:97-111): conv k3 s2 same; styles from the pre-activation
     output; LeakyReLU(0.3) then instance norm.  The fused tail is first-order only; with
-    twice_differentiable=True (real images under the R1 penalty) every op is twice differentiable."""
+    twice_differentiable=True every op is twice differentiable (composite path, kept as the cross-check of
+    the tangent-pass R1).  `intermediates` (a list) receives the primal tensors the tangent pass reuses."""
     ck, cb, gamma, beta = w4
     x = F.conv(x, ck, cb, DISCR_CONV)
     if not twice_differentiable:
-        out = F.DiscrTailFn.apply(x, gamma, beta, return_styles, KERAS_LRELU)
-        return out if return_styles else (out, None)
+        y, style, mean, q, smean, ssd = F.DiscrTailFn.apply(x, gamma, beta, return_styles, KERAS_LRELU)
+        if intermediates is not None:
+            intermediates.append({"x": x, "mean": mean, "q": q, "smean": smean, "ssd": ssd})
+        return y, style
     styles = F.layer_style(x) if return_styles else None
     x = F.instance_norm(F.lrelu(x, KERAS_LRELU), gamma, beta)
     return x, styles

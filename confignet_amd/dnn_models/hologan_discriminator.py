@@ -46,7 +46,7 @@ class HologanDiscriminator(Net):
         self.add_weight("disc_map/bias", np.zeros(1, np.float32))
         self.finalize()
 
-    def __call__(self, input_img, twice_differentiable=False):
+    def __call__(self, input_img, twice_differentiable=False, intermediates=None):
         """Returns the insertion-ordered dict discr_style_0..n-1, discr_final (l.48-64)."""
         w = self.weights
         nr = self.num_resample
@@ -54,11 +54,31 @@ class HologanDiscriminator(Net):
         heads = 2 + 4 * nr
         out = OrderedDict()
         for i in range(nr):
-            x, st = discr_block(x, w[2 + 4 * i:6 + 4 * i], True, twice_differentiable)
+            x, st = discr_block(x, w[2 + 4 * i:6 + 4 * i], True, twice_differentiable, intermediates)
             out["discr_style_%d" % i] = F.linear(st, w[heads + 2 * i], w[heads + 2 * i + 1])
         x = x.reshape(x.shape[0], -1)
         out["discr_final"] = F.linear(x, w[-2], w[-1])
         return out
+
+    def tangent(self, v, intermediates, head):
+        """JVP of output `head` (0..n-1 style heads, n = final head) w.r.t. the input image in direction v,
+        evaluated at the primal pass that filled `intermediates`.  Linear layers act on the tangent without
+        bias; the DiscrBlock tail uses DualTailFn.  Returns (N, 1)."""
+        from .building_blocks import DISCR_CONV, KERAS_LRELU
+        w = self.weights
+        nr = self.num_resample
+        heads = 2 + 4 * nr
+        t = F.conv(v, w[0], None, C1)
+        for k in range(nr):
+            tx = F.conv(t, w[2 + 4 * k], None, DISCR_CONV)
+            it = intermediates[k]
+            style_head = head == k
+            ty, tstyle = F.DualTailFn.apply(tx, it["x"], w[4 + 4 * k], it["mean"], it["q"], it["smean"], it["ssd"],
+                                            not style_head, style_head, KERAS_LRELU)
+            if style_head:
+                return F.linear(tstyle, w[heads + 2 * k], None)
+            t = ty
+        return F.linear(t.reshape(t.shape[0], -1), w[-2], None)
 
     def predict(self, x, batch_size=32):
         with torch.no_grad():

@@ -400,10 +400,13 @@ def adain_composite(x, scale_bias):
 class DiscrTailFn(Function):
     """Tail of DiscrBlock.call (building_blocks.py:100-106) fused, first-order only: style statistics of the
     pre-activation tensor, LeakyReLU, instance normalisation.  x is read by two reduction passes and one
-    normalise pass; the backward pass is one reduction pass + one pass that also adds the style gradient."""
+    normalise pass; the backward pass is one reduction pass + one pass that also adds the style gradient.
+    Returns (y, style|None, mean, q, style_mean|None, style_std|None); the statistics are non-differentiable
+    side outputs reused by the tangent pass of the R1 penalty (DualTailFn)."""
 
     @staticmethod
     def forward(ctx, x, gamma, beta, want_style, slope):
+        ctx.set_materialize_grads(False)
         x, gamma, beta = _cg(x), _cg(gamma), _cg(beta)
         sp = _spatial(x)
         style = smean = ssd = None
@@ -415,24 +418,86 @@ class DiscrTailFn(Function):
         y = ops.nc_lin2(tuple(x.shape), x, a, b=b, flags=1, slope=slope)
         ctx.save_for_backward(x, gamma, mean, q, smean, ssd)
         ctx.slope, ctx.want_style = slope, want_style
-        if want_style:
-            return y, style
-        return y
+        nd = [t for t in (mean, q, smean, ssd) if t is not None]
+        ctx.mark_non_differentiable(*nd)
+        return y, style, mean, q, smean, ssd
 
     @staticmethod
-    def backward(ctx, gy, gstyle=None):
+    def backward(ctx, gy, gstyle, *_):
         if torch.is_grad_enabled():
             raise RuntimeError("DiscrTailFn is first-order only; use the composite discr_block path")
         x, gamma, mean, q, smean, ssd = ctx.saved_tensors
-        gy = _cg(gy)
         sp = _spatial(x)
-        t1, t2 = ops.nc_reduce(gy, x, flags=2, slope=ctx.slope)
-        c1, c2, c0, ggamma, gbeta = ops.norm_coef_bwd(ops.NORM_INSTANCE, t1, t2, mean, q, gamma, sp, 1e-3)
+        have_y = gy is not None
         d2 = d0 = None
         if ctx.want_style and gstyle is not None:
             _, d2, d0, _, _ = ops.norm_coef_bwd(ops.NORM_STYLE, _cg(gstyle), None, smean, ssd, None, sp, 1e-6)
-        gx = ops.nc_lin2(tuple(x.shape), gy, c1, x, c2, c0, flags=2 | 4, slope=ctx.slope, a3=d2, b3=d0)
-        return gx, ggamma, gbeta, None, None
+        if have_y:
+            gy = _cg(gy)
+            t1, t2 = ops.nc_reduce(gy, x, flags=2, slope=ctx.slope)
+            c1, c2, c0, ggamma, gbeta = ops.norm_coef_bwd(ops.NORM_INSTANCE, t1, t2, mean, q, gamma, sp, 1e-3)
+            gx = ops.nc_lin2(tuple(x.shape), gy, c1, x, c2, c0, flags=2 | 4, slope=ctx.slope, a3=d2, b3=d0)
+            return gx, ggamma, gbeta, None, None
+        # only the style statistics carry gradient (R1 input-gradient of a style head)
+        gx = ops.nc_lin2(tuple(x.shape), x, d2, b=d0) if d2 is not None else torch.zeros_like(x)
+        return gx, torch.zeros_like(gamma), torch.zeros_like(gamma), None, None
+
+
+class DualTailFn(Function):
+    """Tangent of the DiscrBlock tail in direction tx (include/confignet_hip.h: cn_dual_tail_*): returns
+    (ty | None, tstyle | None).  Its backward supplies the gradient w.r.t. the tangent input AND the
+    second-order terms w.r.t. the primal pre-activation x -- this is what makes the R1 penalty trainable with
+    ONE first-order backward pass."""
+
+    @staticmethod
+    def forward(ctx, tx, x, gamma, mean, q, smean, ssd, want_ty, want_style, slope):
+        ctx.set_materialize_grads(False)
+        tx, x = _cg(tx), _cg(x)
+        sp = _spatial(x)
+        shape = tuple(x.shape)
+        ta = T = U = None
+        if want_ty:
+            ta = ops.act_bwd(tx, x, ACT_LRELU, slope)               # lrelu'(x) * tx
+            T = ops.nc_reduce(ta, x, flags=2, slope=slope)          # sum ta, sum ta*lrelu(x)
+        if want_style:
+            U = ops.nc_reduce(tx, x)                                # sum tx, sum tx*x
+        C1, C2, C0, tstyle = ops.dual_tail_coef_fwd(T, U, mean if want_ty else None, q if want_ty else None,
+                                                    smean if want_style else None, ssd if want_style else None,
+                                                    gamma, sp)
+        ty = ops.nc_lin2(shape, ta, C1, x, C2, C0, flags=2, slope=slope) if want_ty else None
+        ctx.save_for_backward(tx, x, gamma, mean, q, smean, ssd, ta,
+                              T[0] if T else None, T[1] if T else None, U[0] if U else None, U[1] if U else None)
+        ctx.cfg = (want_ty, want_style, slope)
+        return ty, tstyle
+
+    @staticmethod
+    def backward(ctx, h, u):
+        if torch.is_grad_enabled():
+            raise RuntimeError("DualTailFn is first-order only")
+        tx, x, gamma, mean, q, smean, ssd, ta, T1, T2, U1, U2 = ctx.saved_tensors
+        want_ty, want_style, slope = ctx.cfg
+        sp = _spatial(x)
+        shape = tuple(x.shape)
+        use_h = want_ty and h is not None
+        use_u = want_style and u is not None
+        H = E = None
+        if use_h:
+            h = _cg(h)
+            H = ops.nc_reduce(h, x, flags=2, slope=slope)           # sum h, sum h*lrelu(x)
+            E = ops.nc_reduce(h, ta, want_sum=False)[1]             # sum h*ta
+        if not use_h and not use_u:
+            return torch.zeros_like(tx), torch.zeros_like(x), torch.zeros_like(gamma), None, None, None, None, None, None, None
+        co = ops.dual_tail_coef_bwd(H, E, _cg(u) if use_u else None, (T1, T2) if use_h else None,
+                                    (U1, U2) if use_u else None, mean if use_h else None, q if use_h else None,
+                                    smean if use_u else None, ssd if use_u else None, gamma, sp)
+        if use_h:
+            g_tx = ops.nc_lin2(shape, h, co["K1"], x, co["K2"], co["K0"], flags=2 | 4, slope=slope,
+                               a3=co["D2"], b3=co["D0"])
+        else:
+            g_tx = ops.nc_lin2(shape, x, co["D2"], b=co["D0"])
+        g_x = ops.dual_tail_gx(h if use_h else None, ta if use_h else None, tx, x, co, slope)
+        g_gamma = co["ggamma"] if use_h else torch.zeros_like(gamma)
+        return g_tx, g_x, g_gamma, None, None, None, None, None, None, None
 
 
 def instance_norm(x, gamma, beta, eps=1e-3):

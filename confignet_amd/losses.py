@@ -43,33 +43,48 @@ def gradient_regularization(real_out, real_in):
     return 10 * 0.5 * F.row_sumsq(g).mean()
 
 
-def compute_discriminator_loss(discriminator, real_imgs, fake_imgs):
-    """losses.py:20-47.  The reference takes six separate input-gradients (one per head).  The input-gradient
-    is linear in the head cotangent, so here the real batch is replicated once per head (6N images), copy i
-    carries the cotangent of head i only, and ONE recorded input-gradient pass yields all six g_i; head i's
-    logits for the GAN term are read from copy i.  Same numbers, 6x fewer (6x larger) launches."""
-    n = real_imgs.shape[0]
-    heads = discriminator.num_resample + 1
-    real_rep = real_imgs.detach().repeat(heads, 1, 1, 1).requires_grad_(True)
-    out_rep = discriminator(real_rep, twice_differentiable=True)
+def compute_discriminator_loss(discriminator, real_imgs, fake_imgs, second_order_tape=False):
+    """losses.py:20-47: GAN loss on real and fake for each of the 6 heads + R1 penalty per head.
+
+    Default: no second-order tape.  g_i = d sum(out_i)/d real is taken by an ordinary (fused, first-order)
+    backward pass; since d/dtheta |g_i|^2 = 2 d/dtheta JVP_x(out_i)(v)|_{v = g_i}, the penalty is expressed as
+    2*JVP - |v|^2 (equal in value to |g_i|^2) where the JVP is a tangent forward pass of the discriminator
+    (HologanDiscriminator.tangent).  One first-order backward then yields exactly the gradient
+    tf.GradientTape's nested tapes produce.  second_order_tape=True keeps the literal reverse-over-reverse
+    formulation on twice-differentiable composite ops (used as the cross-check in the tests)."""
+    if second_order_tape:
+        return _compute_discriminator_loss_tape(discriminator, real_imgs, fake_imgs)
+    real_imgs = real_imgs.detach().requires_grad_(True)
+    inter = []
+    out_real = discriminator(real_imgs, intermediates=inter)
     out_fake = discriminator(fake_imgs.detach())
-    keys = list(out_rep.keys())
-    out_real = {k: out_rep[k][i * n:(i + 1) * n] for i, k in enumerate(keys)}
     losses = {}
     for i, o in enumerate(out_real.values()):
         losses["GAN_loss_real_" + str(i)] = GAN_D_loss(1.0, o)
     for i, o in enumerate(out_fake.values()):
         losses["GAN_loss_fake_" + str(i)] = GAN_D_loss(0.0, o)
-    cot = []
-    for i in range(heads):
-        c = torch.zeros((heads * n, 1), device=real_rep.device, dtype=torch.float32)
-        c[i * n:(i + 1) * n] = 1.0
-        cot.append(c)
     with F.input_grads_only():
-        (g,) = torch.autograd.grad([out_rep[k] for k in keys], real_rep, grad_outputs=cot, create_graph=True)
-    per_sample = F.row_sumsq(g)                                   # (6N,) = sum_hwc g_i^2 per (head, sample)
-    for i in range(heads):
-        losses["gp_loss_" + str(i)] = 10 * 0.5 * per_sample[i * n:(i + 1) * n].mean()
+        gs = [torch.autograd.grad(o, real_imgs, grad_outputs=torch.ones_like(o), retain_graph=True)[0]
+              for o in out_real.values()]
+    for i, g in enumerate(gs):
+        g = g.detach()
+        jvp = discriminator.tangent(g, inter, i).reshape(-1)          # == |g_n|^2, carries d/dtheta
+        losses["gp_loss_" + str(i)] = 10 * 0.5 * (2.0 * jvp - F.row_sumsq(g)).mean()
+    losses["loss_sum"] = sum(losses.values())
+    return losses
+
+
+def _compute_discriminator_loss_tape(discriminator, real_imgs, fake_imgs):
+    real_imgs = real_imgs.detach().requires_grad_(True)
+    out_real = discriminator(real_imgs, twice_differentiable=True)
+    out_fake = discriminator(fake_imgs.detach())
+    losses = {}
+    for i, o in enumerate(out_real.values()):
+        losses["GAN_loss_real_" + str(i)] = GAN_D_loss(1.0, o)
+    for i, o in enumerate(out_fake.values()):
+        losses["GAN_loss_fake_" + str(i)] = GAN_D_loss(0.0, o)
+    for i, o in enumerate(out_real.values()):
+        losses["gp_loss_" + str(i)] = gradient_regularization(o, real_imgs)
     losses["loss_sum"] = sum(losses.values())
     return losses
 

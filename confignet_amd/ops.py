@@ -187,6 +187,57 @@ def norm_coef_bwd(mode, t1, t2, mean, r, p1, spatial, eps):
     return c1, c2, c0, gp1, gp2
 
 
+def dual_tail_coef_fwd(T, U, mean, q, sm, ssd, gamma, spatial, eps=1e-3):
+    """T = (T1, T2) or None (no ty wanted); U = (U1, U2) or None (no tstyle wanted)."""
+    ref = mean if mean is not None else sm
+    n, c = ref.shape
+    mk = lambda *sh: torch.empty(sh, device=ref.device, dtype=torch.float32)
+    C1 = C2 = C0 = ts = None
+    if T is not None:
+        C1, C2, C0 = mk(n, c), mk(n, c), mk(n, c)
+    if U is not None:
+        ts = mk(n, 2 * c)
+    T1, T2 = T if T is not None else (None, None)
+    U1, U2 = U if U is not None else (None, None)
+    check(lib.cn_dual_tail_coef_fwd(_ptr(T1), _ptr(T2), _ptr(U1), _ptr(U2), _ptr(mean), _ptr(q), _ptr(sm), _ptr(ssd),
+                                    _ptr(gamma), _ptr(C1), _ptr(C2), _ptr(C0), _ptr(ts), n, c, spatial, eps, _stream()),
+          "cn_dual_tail_coef_fwd")
+    return C1, C2, C0, ts
+
+
+def dual_tail_coef_bwd(H, E, u, T, U, mean, q, sm, ssd, gamma, spatial, eps=1e-3):
+    """Returns dict of coefficient tensors (see include/confignet_hip.h)."""
+    ref = mean if mean is not None else sm
+    n, c = ref.shape
+    names = ["K1", "K2", "K0", "D2", "D0", "kh", "kt", "ka", "kc", "et", "ex", "e0", "ggamma"]
+    out = {k: None for k in names}
+    mk = lambda *sh: torch.empty(sh, device=ref.device, dtype=torch.float32)
+    if H is not None:
+        for k in ("K1", "K2", "K0", "kh", "kt", "ka", "kc"):
+            out[k] = mk(n, c)
+        out["ggamma"] = mk(c)
+    if u is not None:
+        for k in ("D2", "D0", "et", "ex", "e0"):
+            out[k] = mk(n, c)
+    arr = (ctypes.c_void_p * 13)(*[(out[k].data_ptr() if out[k] is not None else None) for k in names])
+    H1, H2p = H if H is not None else (None, None)
+    T1, T2 = T if T is not None else (None, None)
+    U1, U2 = U if U is not None else (None, None)
+    check(lib.cn_dual_tail_coef_bwd(_ptr(H1), _ptr(H2p), _ptr(E), _ptr(u), _ptr(T1), _ptr(T2), _ptr(U1), _ptr(U2),
+                                    _ptr(mean), _ptr(q), _ptr(sm), _ptr(ssd), _ptr(gamma), arr, n, c, spatial, eps, _stream()),
+          "cn_dual_tail_coef_bwd")
+    return out
+
+
+def dual_tail_gx(h, ta, tx, x, co, slope):
+    n, s, c = _nsc(x)
+    out = torch.empty_like(x)
+    check(lib.cn_dual_tail_gx(_ptr(h), _ptr(ta), _ptr(tx), _ptr(x), _ptr(co["kh"]), _ptr(co["kt"]), _ptr(co["ka"]),
+                              _ptr(co["kc"]), _ptr(co["et"]), _ptr(co["ex"]), _ptr(co["e0"]), _ptr(out), n, s, c, slope,
+                              _stream()), "cn_dual_tail_gx")
+    return out
+
+
 def act_fwd(x, act, slope=0.0):
     y = torch.empty_like(x)
     check(lib.cn_act_fwd(_ptr(x), _ptr(y), x.numel(), act, slope, _stream()), "cn_act_fwd")

@@ -106,6 +106,24 @@ int cn_norm_coef_bwd(int mode, const float* t1, const float* t2, const float* sa
                      const float* p1, float* c1, float* c2, float* c0, float* gp1, float* gp2, int n, int c,
                      int S, float eps, void* stream);
 
+/* Tangent ("dual") DiscrBlock tail for the R1 penalty (losses.py:75-82) without a second-order tape: the
+ * penalty's weight gradient is 2 d/dtheta JVP_x(out)(v) at v = d out/d x held constant, i.e. a first-order
+ * backward through a tangent forward pass.  T1 = sum ta, T2 = sum ta*a (ta = lrelu'(x) tx, a = lrelu(x)),
+ * U1 = sum tx, U2 = sum tx*x; mean/q and sm/ssd are the primal instance-norm / style statistics.
+ * fwd: ty = C1*ta + C2*a + C0 and tstyle (N,2C).  bwd (H1 = sum h, H2p = sum h*a, E = sum h*ta, u = d tstyle):
+ *   out13 = {K1,K2,K0,D2,D0, kh,kt,ka,kc, et,ex,e0, dgamma}: g_tx = lrelu'(x)(K1 h + K2 a + K0) + D2 x + D0,
+ *   g_x = lrelu'(x)(kh h + kt ta + ka a + kc) + et tx + ex x + e0 (cn_dual_tail_gx).  Either half optional. */
+int cn_dual_tail_coef_fwd(const float* T1, const float* T2, const float* U1, const float* U2, const float* mean,
+                          const float* q, const float* sm, const float* ssd, const float* gamma, float* C1,
+                          float* C2, float* C0, float* tstyle, int n, int c, int S, float eps, void* stream);
+int cn_dual_tail_coef_bwd(const float* H1, const float* H2p, const float* E, const float* u, const float* T1,
+                          const float* T2, const float* U1, const float* U2, const float* mean, const float* q,
+                          const float* sm, const float* ssd, const float* gamma, float* const* out13, int n, int c,
+                          int S, float eps, void* stream);
+int cn_dual_tail_gx(const float* h, const float* ta, const float* tx, const float* x, const float* kh,
+                    const float* kt, const float* ka, const float* kc, const float* et, const float* ex,
+                    const float* e0, float* out, int n, int s, int c, float slope, void* stream);
+
 /* ---- elementwise / small ops ------------------------------------------------------------------*/
 int cn_act_fwd(const float* x, float* y, size_t numel, int act, float slope, void* stream);
 /* gx = gy * act'(.) evaluated from the activation OUTPUT (lrelu/relu: sign of y; tanh: 1-y^2). */

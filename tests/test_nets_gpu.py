@@ -123,6 +123,16 @@ def test_discriminator_loss_with_r1_double_backward():
     for k in losses:
         close(losses[k], ref_losses[k], what=k)
     close_grads(d, S.grads_of(ref_losses["loss_sum"], wr), "discriminator (R1)")
+    # the literal reverse-over-reverse formulation (second-order tape on composite ops) agrees as well
+    g_jvp = [p.grad.detach().clone() for p in d.weights]
+    d.zero_grad()
+    losses_t = compute_discriminator_loss(d, d.to_device(real), d.to_device(fake), second_order_tape=True)
+    torch.autograd.backward(losses_t["loss_sum"], inputs=d.trainable_weights)
+    for k in losses:
+        close(losses_t[k], ref_losses[k], what="tape " + k)
+    for a, p in zip(g_jvp, d.weights):
+        rel = float((a - p.grad).norm() / (p.grad.norm() + 1e-30))
+        assert rel < 2e-2, "JVP-R1 vs tape-R1 gradient: rel-L2 %.3e" % rel
 
 
 def test_latent_regressor_and_latent_discriminator():
