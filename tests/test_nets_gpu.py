@@ -418,7 +418,7 @@ def test_fused_norm_functions_match_composites_and_oracle():
     xt = torch.tensor(x, device="cuda", dtype=torch.float32, requires_grad=True)
     gt = torch.tensor(gamma, device="cuda", dtype=torch.float32, requires_grad=True)
     bt = torch.tensor(beta, device="cuda", dtype=torch.float32, requires_grad=True)
-    y, st = F.DiscrTailFn.apply(xt, gt, bt, True, 0.3)
+    y, st = F.DiscrTailFn.apply(xt, gt, bt, True, 0.3)[:2]
     loss = (y * torch.tensor(cy, device="cuda", dtype=torch.float32)).sum() + (st * torch.tensor(cs, device="cuda", dtype=torch.float32)).sum()
     g = torch.autograd.grad(loss, [xt, gt, bt])
     xr, gr, br = t64(x).requires_grad_(True), t64(gamma).requires_grad_(True), t64(beta).requires_grad_(True)
