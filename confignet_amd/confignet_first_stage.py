@@ -295,15 +295,15 @@ class ConfigNetFirstStage:
 
     def _stage_real(self, key, dataset, n):
         """Host half of a real-image batch: indices + flip flags (flip_random_subset_of_images)."""
-        self._stage(key + "/idx", np.random.randint(0, dataset.imgs.shape[0], n), torch.int64)
-        self._stage(key + "/flip", np.random.randint(0, 2, size=n), torch.uint8)
+        self._stage(key + "/real_idx", np.random.randint(0, dataset.imgs.shape[0], n), torch.int64)
+        self._stage(key + "/real_flip", np.random.randint(0, 2, size=n), torch.uint8)
 
     def _real_imgs(self, key, dataset):
-        return ops.gather_images_u8(self._pool(dataset)["imgs"], self._bufs[key + "/idx"], self._bufs[key + "/flip"])
+        return ops.gather_images_u8(self._pool(dataset)["imgs"], self._bufs[key + "/real_idx"], self._bufs[key + "/real_flip"])
 
     def _stage_synth(self, key, dataset, n):
         idx = np.random.randint(0, dataset.imgs.shape[0], n)
-        self._stage(key + "/idx", idx, torch.int64)
+        self._stage(key + "/synth_idx", idx, torch.int64)
         for name in self.config["facemodel_inputs"].keys():
             self._stage(key + "/p/" + name, dataset.metadata_inputs[name][idx])
         self._stage(key + "/rot", dataset.metadata_inputs["rotations"][idx])
@@ -313,13 +313,19 @@ class ConfigNetFirstStage:
         rot = self._bufs[key + "/rot"]
         if not imgs:
             return params, rot, None, None
-        idx = self._bufs[key + "/idx"]
+        idx = self._bufs[key + "/synth_idx"]
         pool = self._pool(dataset)
         return params, rot, ops.gather_images_u8(pool["imgs"], idx, None), pool["eye_masks"][idx].contiguous()
 
     def _run_step(self, name, datasets, optimizer, device_fn):
         """optimizer.advance() on the host, then the device half -- eagerly, or as a captured HIP graph."""
         optimizer.advance()
+        fn = device_fn
+
+        def device_fn():
+            # loss scalars are returned detached: keeping the tape alive would keep the leaves' AccumulateGrad
+            # nodes (and their stream binding) alive across steps
+            return {k: v.detach() for k, v in fn().items()}
         if not self.use_graphs:
             return device_fn()
         key = (name, tuple(id(d) for d in datasets), id(optimizer), self._bufs.generation)

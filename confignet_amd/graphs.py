@@ -12,20 +12,30 @@ from .nn import WEIGHTS_EPOCH
 
 
 class StepGraph:
+    """fn() -> dict of detached device scalars.  Call 1..warmup run eagerly ON THE CAPTURE STREAM (autograd's
+    per-leaf AccumulateGrad nodes are bound to the stream they are created on, so the leaves must first be
+    used under the stream the capture will use); the next call captures; later calls replay."""
+
     def __init__(self, fn, warmup=1):
         self.fn, self.warmup = fn, warmup
         self.calls, self.graph, self.out = 0, None, None
+        self.stream = torch.cuda.Stream()
 
     def __call__(self):
         if self.graph is None:
+            cur = torch.cuda.current_stream()
             if self.calls < self.warmup:
                 self.calls += 1
-                return self.fn()
+                self.stream.wait_stream(cur)
+                with torch.cuda.stream(self.stream):
+                    out = self.fn()
+                cur.wait_stream(self.stream)
+                return out
             torch.cuda.synchronize()
             ops.prof_enable(False)                 # no event records inside a capture
             WEIGHTS_EPOCH[0] += 1                  # derived caches must be rebuilt INSIDE this graph
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
+            with torch.cuda.graph(self.graph, stream=self.stream):
                 self.out = self.fn()
             WEIGHTS_EPOCH[0] += 1
         self.graph.replay()
