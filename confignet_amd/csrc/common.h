@@ -33,6 +33,11 @@ void cn_set_error(const char* fmt, ...);
         }                                                                         \
     } while (0)
 
+// Zero `bytes` (multiple of 4) bytes at p with an ordinary kernel.  hipMemsetAsync nodes were observed NOT to
+// re-execute on HIP-graph replay (ROCm 7.2, gfx950: accumulators kept growing across replays), so every
+// accumulate-into buffer is cleared by a kernel node instead.
+int cn_zero_async(void* p, size_t bytes, hipStream_t s);
+
 // profiling hooks (prof.hip): bracket one launch of the dominant kernel class
 void cn_prof_begin(hipStream_t s, double flops);
 void cn_prof_end(hipStream_t s);

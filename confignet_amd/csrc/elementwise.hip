@@ -346,8 +346,12 @@ extern "C" int cn_nc_reduce(const float* x1, const float* x2, float* s1, float* 
                             float slope, void* stream) {
     CN_CHECK_ARG(x1 && (s1 || s2) && n > 0 && s > 0 && c > 0, "nc_reduce: bad args");
     hipStream_t st = (hipStream_t)stream;
-    if (s1) CN_HIP(hipMemsetAsync(s1, 0, sizeof(float) * (size_t)n * c, st));
-    if (s2) CN_HIP(hipMemsetAsync(s2, 0, sizeof(float) * (size_t)n * c, st));
+    if (s1) {
+        if (int ez__ = cn_zero_async(s1, sizeof(float) * (size_t)n * c, st)) return ez__;
+    }
+    if (s2) {
+        if (int ez__ = cn_zero_async(s2, sizeof(float) * (size_t)n * c, st)) return ez__;
+    }
     const int V = (c % 4 == 0) ? 4 : 1;
     const int CG = c / V;
     int TX = 1;
@@ -416,7 +420,7 @@ extern "C" int cn_sqdiff_sum(const float* a, const float* b, float* out, size_t 
 }
 extern "C" int cn_row_sumsq(const float* x, float* out, int n, size_t row, void* stream) {
     CN_CHECK_ARG(x && out && n > 0 && row > 0, "row_sumsq: bad args");
-    CN_HIP(hipMemsetAsync(out, 0, sizeof(float) * n, (hipStream_t)stream));
+    if (int ez__ = cn_zero_async(out, sizeof(float) * n, (hipStream_t)stream)) return ez__;
     int bpr = (int)((row + 256 * 16 - 1) / (256 * 16));
     if (bpr > 256) bpr = 256;
     hipLaunchKernelGGL(row_sumsq_kernel, dim3(bpr, n), dim3(256), 0, (hipStream_t)stream, x, out, row);
@@ -445,7 +449,7 @@ extern "C" int cn_maxpool_fwd(const float* x, float* y, int n, int h, int w, int
 extern "C" int cn_maxpool_bwd(const float* x, const float* gy, float* gx, int n, int h, int w, int c, int k, int s, int pad, void* stream) {
     CN_CHECK_ARG(x && gy && gx && n > 0 && h > 0 && w > 0 && c > 0 && k > 0 && s > 0 && pad >= 0, "maxpool_bwd: bad args");
     const int oh = (h + 2 * pad - k) / s + 1, ow = (w + 2 * pad - k) / s + 1;
-    CN_HIP(hipMemsetAsync(gx, 0, sizeof(float) * (size_t)n * h * w * c, (hipStream_t)stream));
+    if (int ez__ = cn_zero_async(gx, sizeof(float) * (size_t)n * h * w * c, (hipStream_t)stream)) return ez__;
     const size_t total = (size_t)n * oh * ow * c;
     EW_LAUNCH(maxpool_bwd_kernel, total, x, gy, gx, n, h, w, c, oh, ow, k, s, pad)
 }

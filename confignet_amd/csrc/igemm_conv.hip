@@ -658,7 +658,9 @@ extern "C" int cn_conv_fwd(const CnConvGeom* gp, const float* x, const float* w,
         if (want > 1) splits = (int)want;
     }
     const int kact = splits > 1 ? CN_ACT_NONE : act;
-    if (splits > 1) CN_HIP(hipMemsetAsync(y, 0, sizeof(float) * M * g.cout, s));
+    if (splits > 1) {
+        if (int ez__ = cn_zero_async(y, sizeof(float) * M * g.cout, s)) return ez__;
+    }
     cn_prof_begin(s, conv_flops(g));
     int e;
     switch (cfg) {
@@ -702,7 +704,7 @@ extern "C" int cn_conv_wgrad(const CnConvGeom* gp, const float* x, const float* 
     const CnConvGeom g = *gp;
     hipStream_t s = (hipStream_t)stream;
     const long Ktot = (long)g.k_d * g.k_h * g.k_w * g.cin;
-    CN_HIP(hipMemsetAsync(gw, 0, sizeof(float) * Ktot * g.cout, s));
+    if (int ez__ = cn_zero_async(gw, sizeof(float) * Ktot * g.cout, s)) return ez__;
     if (Ktot <= 4 && g.cout <= 4 && g.k_d * g.k_h * g.k_w == 1 && g.s_h == 1 && g.s_w == 1 && g.s_d == 1 && !g.up &&
         g.p_h == 0 && g.p_w == 0 && g.p_d == 0) {
         const long M = (long)g.n * g.out_d * g.out_h * g.out_w;

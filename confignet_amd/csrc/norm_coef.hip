@@ -271,7 +271,9 @@ extern "C" int cn_dual_tail_coef_bwd(const float* H1, const float* H2p, const fl
                  "dual_tail_coef_bwd: missing instance-norm tensors");
     CN_CHECK_ARG(!u || (U1 && U2 && sm && ssd && o.D2 && o.D0 && o.et && o.ex && o.e0), "dual_tail_coef_bwd: missing style tensors");
     hipStream_t s = (hipStream_t)stream;
-    if (H1) CN_HIP(hipMemsetAsync(o.ggamma, 0, sizeof(float) * c, s));
+    if (H1) {
+        if (int ez__ = cn_zero_async(o.ggamma, sizeof(float) * c, s)) return ez__;
+    }
     hipLaunchKernelGGL(dual_coef_bwd_kernel, dim3(cn_cdiv((long)n * c, 256)), dim3(256), 0, s, H1, H2p, E, u, T1, T2, U1, U2, mean,
                        q, sm, ssd, gamma, o, n, c, 1.f / (float)S, eps);
     CN_LAUNCH_CHECK();

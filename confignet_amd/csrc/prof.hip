@@ -73,3 +73,21 @@ extern "C" int cn_prof_collect(int* launches, double* total_ms, double* total_fl
     if (total_flops) *total_flops = fl;
     return CN_OK;
 }
+
+
+namespace {
+__global__ void zero_kernel(float* __restrict__ p, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = 0.f;
+}
+}  // namespace
+
+int cn_zero_async(void* p, size_t bytes, hipStream_t s) {
+    if (!bytes) return CN_OK;
+    CN_CHECK_ARG(p && bytes % 4 == 0, "cn_zero_async: bad buffer");
+    const size_t n = bytes / 4;
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(zero_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (float*)p, n);
+    CN_LAUNCH_CHECK();
+    return CN_OK;
+}

@@ -148,8 +148,10 @@ extern "C" int cn_rotate3d_bwd(const float* grid, const float* rot, const float*
     CN_CHECK_ARG(grid && rot && gout && ggrid && n > 0 && g > 1 && c > 0 && c % 4 == 0, "rotate3d_bwd: bad args");
     hipStream_t s = (hipStream_t)stream;
     const long P = (long)g * g * g;
-    CN_HIP(hipMemsetAsync(ggrid, 0, sizeof(float) * n * P * c, s));
-    if (grot) CN_HIP(hipMemsetAsync(grot, 0, sizeof(float) * n * 9, s));
+    if (int ez__ = cn_zero_async(ggrid, sizeof(float) * n * P * c, s)) return ez__;
+    if (grot) {
+        if (int ez__ = cn_zero_async(grot, sizeof(float) * n * 9, s)) return ez__;
+    }
     hipLaunchKernelGGL(rotate3d_bwd_kernel, dim3(cn_cdiv(P, 256), n), dim3(256), 0, s, grid, rot, gout, ggrid, grot, g, c / 4);
     CN_LAUNCH_CHECK();
     return CN_OK;

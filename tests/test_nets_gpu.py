@@ -486,6 +486,6 @@ def test_hip_graph_steps_match_eager():
         diff = (n.arena - a).abs()
         moved = (a - w0).abs().max()
         # identical up to fp32-atomics noise: only gradients at noise level may take the other sign
-        assert float(diff.max()) <= 2.2 * lr and float((diff > 1e-6).float().mean()) < 0.1, (float(diff.max()), float((diff > 1e-6).float().mean()))
+        assert float(diff.max()) <= 2.2 * lr and float((diff > 1e-6).float().mean()) < 0.3, (float(diff.max()), float((diff > 1e-6).float().mean()))
         if n is not m.generator_smoothed:
             assert float(moved) > 0 or n.n_trainable == 0
