@@ -486,6 +486,7 @@ def test_hip_graph_steps_match_eager():
         diff = (n.arena - a).abs()
         moved = (a - w0).abs().max()
         # identical up to fp32-atomics noise: only gradients at noise level may take the other sign
-        assert float(diff.max()) <= 2.2 * lr and float((diff > 1e-6).float().mean()) < 0.3, (float(diff.max()), float((diff > 1e-6).float().mean()))
+        # |Adam step| <= lr_t/sqrt(1-beta_2) = 3.17 lr when beta_1 = 0; two opposite-sign steps differ by twice that
+        assert float(diff.max()) <= 6.5 * lr and float((diff > 1e-6).float().mean()) < 0.3, (float(diff.max()), float((diff > 1e-6).float().mean()))
         if n is not m.generator_smoothed:
             assert float(moved) > 0 or n.n_trainable == 0
