@@ -104,7 +104,7 @@ __device__ __forceinline__ void tap_decode(const CnConvGeom& g, int tap, int& kd
 // ---------------------------------------------------------------------------------------------
 // forward / data-gradient:  Y[m, co] = act( sum_{t,ci} X[src(m,t), ci] * W[t, ci, co] + bias[co] )
 // ---------------------------------------------------------------------------------------------
-template <int WM, int WN, int TM, int TN, bool VEC>
+template <int WM, int WN, int TM, int TN, bool VEC, bool BVEC = true>
 __global__ __launch_bounds__(256) void igemm_fwd_kernel(CnConvGeom g, const float* __restrict__ X,
                                                         const float* __restrict__ W, const float* __restrict__ bias,
                                                         float* __restrict__ Y, int act, float slope, int par) {
@@ -182,8 +182,15 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(CnConvGeom g, const floa
                 const int idx = tid + 256 * j;
                 const int brow = idx / (BN / 4), col = n0 + (idx % (BN / 4)) * 4;
                 const long kg = (long)tap * g.cin + c0 + brow;
-                rb[j] = (col < g.cout && idx < BK * BN / 4) ? *reinterpret_cast<const float4*>(W + kg * g.cout + col)
-                                                            : make_float4(0.f, 0.f, 0.f, 0.f);
+                if (BVEC) {
+                    rb[j] = (col < g.cout && idx < BK * BN / 4) ? *reinterpret_cast<const float4*>(W + kg * g.cout + col)
+                                                                : make_float4(0.f, 0.f, 0.f, 0.f);
+                } else {   // thin cout (3-channel image gradients): guarded scalar filter loads
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = (col + e < g.cout && idx < BK * BN / 4) ? W[kg * g.cout + col + e] : 0.f;
+                    rb[j] = make_float4(v[0], v[1], v[2], v[3]);
+                }
             }
         } else {
 #pragma unroll
@@ -450,6 +457,134 @@ __global__ __launch_bounds__(256) void thin_conv_kernel(CnConvGeom g, const floa
     for (int c = 0; c < CO; ++c) Y[(long)m * CO + c] = cn_apply_act(acc[c], act, slope);
 }
 
+// Cooperative thin-output convolution: G (= 8 or 16) lanes share one output pixel, lane c4 owning input
+// channels [4*c4, 4*c4+4), so every global load instruction is a run of fully used 16-byte pieces
+// (G*16 contiguous bytes per pixel), each thread carries PX pixels per filter read (4 broadcast-ish LDS
+// reads feed 4*CO*PX FMAs), and the partial sums are combined with G-lane shuffles.  In parity-ordered
+// mode (data-gradient of a stride-2 convolution into the 3-channel image) the per-class tap validity and
+// coordinate shifts come from a small LDS table instead of per-thread integer divisions.
+template <int CO, int G, int PX>
+__global__ __launch_bounds__(256) void thin_conv_coop_kernel(CnConvGeom g, const float* __restrict__ X,
+                                                             const float* __restrict__ W, const float* __restrict__ bias,
+                                                             float* __restrict__ Y, int act, float slope, int par) {
+    extern __shared__ __attribute__((aligned(16))) float wsh[];     // [taps*cin][4] filter
+    __shared__ int tab[8][32];                                      // par: class x tap -> packed shifts / -1
+    constexpr int PPB = 256 / G;                                    // pixel slots per block per step
+    const int M = g.n * g.out_d * g.out_h * g.out_w;
+    const int T = g.k_d * g.k_h * g.k_w;
+    const int Ktot = T * g.cin;
+    const int CL = g.cin / 4;
+    for (int i = threadIdx.x; i < Ktot; i += 256) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) wsh[i * 4 + c] = c < CO ? W[(long)i * CO + c] : 0.f;
+    }
+    if (par && threadIdx.x < 8 * 32) {
+        const int cls = threadIdx.x >> 5, tap = threadIdx.x & 31;
+        int e = -1;
+        if (cls < g.dl_d * g.dl_h * g.dl_w && tap < T) {
+            const int cw = cls % g.dl_w, ch = (cls / g.dl_w) % g.dl_h, cd = cls / (g.dl_w * g.dl_h);
+            int kd, kh, kw;
+            tap_decode(g, tap, kd, kh, kw);
+            const int vd = cd - g.p_d + kd, vh = ch - g.p_h + kh, vw = cw - g.p_w + kw;
+            if (vd % g.dl_d == 0 && vh % g.dl_h == 0 && vw % g.dl_w == 0)
+                e = ((vd / g.dl_d + 8) << 8) | ((vh / g.dl_h + 8) << 4) | (vw / g.dl_w + 8);   // shifts in [-8, 7]
+        }
+        tab[cls][tap] = e;
+    }
+    __syncthreads();
+    const int slot = threadIdx.x / G, c4 = threadIdx.x % G;
+    const bool lane_on = c4 < CL;
+    const int qd_ext = g.out_d / g.dl_d, qh_ext = g.out_h / g.dl_h, qw_ext = g.out_w / g.dl_w;
+    const int per = g.n * qd_ext * qh_ext * qw_ext;
+    int nb[PX], xd[PX], xh[PX], xw[PX], cls[PX], mrow[PX];
+#pragma unroll
+    for (int p = 0; p < PX; ++p) {
+        const int mp = (blockIdx.x * PX + p) * PPB + slot;
+        cls[p] = -1;
+        mrow[p] = -1;
+        nb[p] = xd[p] = xh[p] = xw[p] = 0;
+        if (mp >= M) continue;
+        if (par) {
+            const int c = mp / per;
+            int rem = mp - c * per;
+            const int cw = c % g.dl_w, chh = (c / g.dl_w) % g.dl_h, cd = c / (g.dl_w * g.dl_h);
+            xw[p] = rem % qw_ext; rem /= qw_ext;
+            xh[p] = rem % qh_ext; rem /= qh_ext;
+            xd[p] = rem % qd_ext;
+            const int n = rem / qd_ext;
+            nb[p] = n * g.in_d;
+            cls[p] = c;
+            mrow[p] = ((n * g.out_d + xd[p] * g.dl_d + cd) * g.out_h + xh[p] * g.dl_h + chh) * g.out_w + xw[p] * g.dl_w + cw;
+        } else {
+            int m = mp;
+            const int ow = m % g.out_w; m /= g.out_w;
+            const int oh = m % g.out_h; m /= g.out_h;
+            const int od = m % g.out_d;
+            nb[p] = (m / g.out_d) * g.in_d;
+            xd[p] = od * g.s_d - g.p_d; xh[p] = oh * g.s_h - g.p_h; xw[p] = ow * g.s_w - g.p_w;
+            cls[p] = 0;
+            mrow[p] = mp;
+        }
+    }
+    float acc[PX][CO];
+#pragma unroll
+    for (int p = 0; p < PX; ++p)
+#pragma unroll
+        for (int c = 0; c < CO; ++c) acc[p][c] = 0.f;
+    const int ed = g.in_d << g.up, eh = g.in_h << g.up, ew = g.in_w << g.up;
+    int tap = 0;
+    for (int kd = 0; kd < g.k_d; ++kd)
+        for (int kh = 0; kh < g.k_h; ++kh)
+            for (int kw = 0; kw < g.k_w; ++kw, ++tap) {
+                float4 xv[PX];
+                bool any = false;
+#pragma unroll
+                for (int p = 0; p < PX; ++p) {
+                    xv[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (cls[p] < 0 || !lane_on) continue;
+                    int qd, qh, qw;
+                    if (par) {
+                        const int e = tab[cls[p]][tap];
+                        if (e < 0) continue;
+                        qd = xd[p] + ((e >> 8) & 15) - 8; qh = xh[p] + ((e >> 4) & 15) - 8; qw = xw[p] + (e & 15) - 8;
+                        if (qd < 0 || qd >= g.in_d || qh < 0 || qh >= g.in_h || qw < 0 || qw >= g.in_w) continue;
+                    } else {
+                        qd = xd[p] + kd; qh = xh[p] + kh; qw = xw[p] + kw;
+                        if (qd < 0 || qd >= ed || qh < 0 || qh >= eh || qw < 0 || qw >= ew) continue;
+                        qd >>= g.up; qh >>= g.up; qw >>= g.up;
+                    }
+                    const long off = ((((long)nb[p] + qd) * g.in_h + qh) * g.in_w + qw) * g.cin + c4 * 4;
+                    xv[p] = *reinterpret_cast<const float4*>(X + off);
+                    any = true;
+                }
+                if (!any) continue;
+                const float4* wp = reinterpret_cast<const float4*>(wsh) + (tap * g.cin + c4 * 4);
+                const float4 w0 = wp[0], w1 = wp[1], w2 = wp[2], w3 = wp[3];
+                const float wv[4][4] = {{w0.x, w0.y, w0.z, w0.w}, {w1.x, w1.y, w1.z, w1.w},
+                                        {w2.x, w2.y, w2.z, w2.w}, {w3.x, w3.y, w3.z, w3.w}};
+#pragma unroll
+                for (int p = 0; p < PX; ++p)
+#pragma unroll
+                    for (int c = 0; c < CO; ++c)
+                        acc[p][c] += xv[p].x * wv[0][c] + xv[p].y * wv[1][c] + xv[p].z * wv[2][c] + xv[p].w * wv[3][c];
+            }
+#pragma unroll
+    for (int p = 0; p < PX; ++p) {
+#pragma unroll
+        for (int c = 0; c < CO; ++c) {
+            float v = acc[p][c];
+#pragma unroll
+            for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+            acc[p][c] = v;
+        }
+        if (c4 == 0 && mrow[p] >= 0) {
+#pragma unroll
+            for (int c = 0; c < CO; ++c)
+                Y[(long)mrow[p] * CO + c] = cn_apply_act(acc[p][c] + (bias ? bias[c] : 0.f), act, slope);
+        }
+    }
+}
+
 // filter gradient of a 1x1 convolution between thin tensors (cin, cout <= 4: the from-RGB conv,
 // hologan_discriminator.py:20): a plain HBM-bound reduction gw[ci][co] = sum_m x[m][ci] gy[m][co]
 __global__ __launch_bounds__(256) void tiny_wgrad_1x1_kernel(const float* __restrict__ X, const float* __restrict__ GY,
@@ -619,6 +754,30 @@ extern "C" int cn_conv_fwd(const CnConvGeom* gp, const float* x, const float* w,
         const int par = parity_ordered(g);
         const size_t lds = sizeof(float) * 4 * (size_t)g.k_d * g.k_h * g.k_w * g.cin;
         CN_CHECK_ARG(lds <= 64 * 1024, "thin conv: filter of %zu bytes does not fit the LDS stage", lds);
+        const int T = g.k_d * g.k_h * g.k_w, CL = g.cin / 4;
+        const bool dl1 = g.dl_d * g.dl_h * g.dl_w == 1;
+        if (par && g.cin % BK == 0 && act == CN_ACT_NONE) {
+            // zero-stuffed data-gradient into a thin image: per pixel only ~taps/4 * cin MACs, the per-pixel
+            // bookkeeping of a VALU kernel dominates; the 128x32 MFMA tile with dead-tap skipping is faster
+            dim3 grid(cn_cdiv(M, 128), 1, 1);
+            cn_prof_begin(s, conv_flops(g));
+            hipLaunchKernelGGL((igemm_fwd_kernel<4, 1, 1, 1, true, false>), grid, dim3(256), 0, s, g, x, w, bias, y, act, slope, 1);
+            cn_prof_end(s);
+            CN_LAUNCH_CHECK();
+            return CN_OK;
+        }
+        if (vec && g.cout == 3 && CL >= 5 && CL <= 16 && T <= 32 && (par || dl1) && g.dl_d * g.dl_h * g.dl_w <= 8) {
+            constexpr int PX = 4;
+            if (CL <= 8) {
+                dim3 grid(cn_cdiv(M, (256 / 8) * PX));
+                hipLaunchKernelGGL((thin_conv_coop_kernel<3, 8, PX>), grid, dim3(256), lds, s, g, x, w, bias, y, act, slope, par);
+            } else {
+                dim3 grid(cn_cdiv(M, (256 / 16) * PX));
+                hipLaunchKernelGGL((thin_conv_coop_kernel<3, 16, PX>), grid, dim3(256), lds, s, g, x, w, bias, y, act, slope, par);
+            }
+            CN_LAUNCH_CHECK();
+            return CN_OK;
+        }
         dim3 grid(cn_cdiv(M, 256));
 #define THIN(CO)                                                                                                      \
     if (vec)                                                                                                          \
