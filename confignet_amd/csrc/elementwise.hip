@@ -346,11 +346,15 @@ extern "C" int cn_nc_reduce(const float* x1, const float* x2, float* s1, float* 
                             float slope, void* stream) {
     CN_CHECK_ARG(x1 && (s1 || s2) && n > 0 && s > 0 && c > 0, "nc_reduce: bad args");
     hipStream_t st = (hipStream_t)stream;
-    if (s1) {
-        if (int ez__ = cn_zero_async(s1, sizeof(float) * (size_t)n * c, st)) return ez__;
-    }
-    if (s2) {
-        if (int ez__ = cn_zero_async(s2, sizeof(float) * (size_t)n * c, st)) return ez__;
+    if (s1 && s2 == s1 + (size_t)n * c) {
+        if (int ez__ = cn_zero_async(s1, sizeof(float) * 2 * (size_t)n * c, st)) return ez__;
+    } else {
+        if (s1) {
+            if (int ez__ = cn_zero_async(s1, sizeof(float) * (size_t)n * c, st)) return ez__;
+        }
+        if (s2) {
+            if (int ez__ = cn_zero_async(s2, sizeof(float) * (size_t)n * c, st)) return ez__;
+        }
     }
     const int V = (c % 4 == 0) ? 4 : 1;
     const int CG = c / V;

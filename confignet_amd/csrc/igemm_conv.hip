@@ -808,12 +808,12 @@ extern "C" int cn_conv_fwd(const CnConvGeom* gp, const float* x, const float* w,
     else { cfg = 2; tiles = (long)cn_cdiv(M, 64) * cn_cdiv(g.cout, 64); }
     // split-K for small outputs with a long reduction (ResNet stage 4/5, Conv3D at 4^3->8^3)
     int splits = 1;
-    if (vec && tiles < 256) {
+    if (vec && tiles < 512) {
         long nks = (long)g.k_d * g.k_h * g.k_w * (g.cin / BK);
         if (par) nks /= (long)g.dl_d * g.dl_h * g.dl_w;
-        long want = (512 + tiles - 1) / tiles;
+        long want = (1024 + tiles - 1) / tiles;      // aim at ~4 workgroups per CU
         if (want > 16) want = 16;
-        if (want > nks / 8) want = nks / 8;
+        if (want > nks / 16) want = nks / 16;        // at least 16 K steps per workgroup
         if (want > 1) splits = (int)want;
     }
     const int kact = splits > 1 ? CN_ACT_NONE : act;

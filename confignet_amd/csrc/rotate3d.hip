@@ -133,6 +133,91 @@ __global__ __launch_bounds__(256) void rotate3d_bwd_kernel(const float* __restri
         }
 }
 
+// Backward through LDS: one workgroup owns (sample n, CC channels) and keeps the whole G^3 x CC gradient
+// slab (<= 128 KiB of the CU's 160 KiB LDS) on chip; the 8-tap scatter of every output voxel is an LDS
+// atomic add, the slab is written to HBM once with plain stores (no global atomics, no clearing pass).
+constexpr int SLAB_FLOATS = 32768;
+__global__ __launch_bounds__(256) void rotate3d_bwd_lds_kernel(const float* __restrict__ grid, const float* __restrict__ rot,
+                                                               const float* __restrict__ gout, float* __restrict__ ggrid,
+                                                               float* __restrict__ grot, int G, int C, int CC) {
+    __shared__ float slab[SLAB_FLOATS];
+    __shared__ float red[4];
+    const int n = blockIdx.y, c0 = blockIdx.x * CC;
+    const int P = G * G * G;
+    const int cc = min(CC, C - c0);
+    for (int i = threadIdx.x; i < P * CC; i += 256) slab[i] = 0.f;
+    __syncthreads();
+    const float* R = rot + n * 9;
+    const float ctr = 0.5f * (float)(G - 1);
+    float g9[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) g9[i] = 0.f;
+    const float* gsrc = grid + (long)n * P * C;
+    for (int p = threadIdx.x; p < P; p += 256) {
+        const Taps t = make_taps(R, p, G);
+        const float wx0 = 1.f - t.dx, wy0 = 1.f - t.dy, wz0 = 1.f - t.dz;
+        const int o000 = (t.x0 * G + t.y0) * G + t.z0, o100 = (t.x1 * G + t.y0) * G + t.z0;
+        const int o001 = (t.x0 * G + t.y0) * G + t.z1, o101 = (t.x1 * G + t.y0) * G + t.z1;
+        const int o010 = (t.x0 * G + t.y1) * G + t.z0, o110 = (t.x1 * G + t.y1) * G + t.z0;
+        const int o011 = (t.x0 * G + t.y1) * G + t.z1, o111 = (t.x1 * G + t.y1) * G + t.z1;
+        const float* go = gout + ((long)n * P + p) * C + c0;
+        float gq0 = 0.f, gq1 = 0.f, gq2 = 0.f;
+        for (int c = 0; c < cc; ++c) {
+            const float gv = go[c];
+            atomicAdd(&slab[o000 * CC + c], gv * wx0 * wy0 * wz0);
+            atomicAdd(&slab[o100 * CC + c], gv * t.dx * wy0 * wz0);
+            atomicAdd(&slab[o001 * CC + c], gv * wx0 * wy0 * t.dz);
+            atomicAdd(&slab[o101 * CC + c], gv * t.dx * wy0 * t.dz);
+            atomicAdd(&slab[o010 * CC + c], gv * wx0 * t.dy * wz0);
+            atomicAdd(&slab[o110 * CC + c], gv * t.dx * t.dy * wz0);
+            atomicAdd(&slab[o011 * CC + c], gv * wx0 * t.dy * t.dz);
+            atomicAdd(&slab[o111 * CC + c], gv * t.dx * t.dy * t.dz);
+            if (grot) {
+                const float c000 = gsrc[(long)o000 * C + c0 + c], c100 = gsrc[(long)o100 * C + c0 + c];
+                const float c001 = gsrc[(long)o001 * C + c0 + c], c101 = gsrc[(long)o101 * C + c0 + c];
+                const float c010 = gsrc[(long)o010 * C + c0 + c], c110 = gsrc[(long)o110 * C + c0 + c];
+                const float c011 = gsrc[(long)o011 * C + c0 + c], c111 = gsrc[(long)o111 * C + c0 + c];
+                const float c00 = c000 * wx0 + c100 * t.dx, c01 = c001 * wx0 + c101 * t.dx;
+                const float c10 = c010 * wx0 + c110 * t.dx, c11 = c011 * wx0 + c111 * t.dx;
+                const float cc0 = c00 * wy0 + c10 * t.dy, cc1 = c01 * wy0 + c11 * t.dy;
+                gq2 += gv * (cc1 - cc0);
+                gq1 += gv * ((c10 - c00) * wz0 + (c11 - c01) * t.dz);
+                const float ex0 = (c100 - c000) * wy0 + (c110 - c010) * t.dy;
+                const float ex1 = (c101 - c001) * wy0 + (c111 - c011) * t.dy;
+                gq0 += gv * (ex0 * wz0 + ex1 * t.dz);
+            }
+        }
+        if (grot) {
+            if (!t.px) gq0 = 0.f;
+            if (!t.py) gq1 = 0.f;
+            if (!t.pz) gq2 = 0.f;
+            const float pc0 = (float)(p / (G * G)) - ctr, pc1 = (float)((p / G) % G) - ctr, pc2 = (float)(p % G) - ctr;
+            g9[0] += gq0 * pc0; g9[1] += gq0 * pc1; g9[2] += gq0 * pc2;
+            g9[3] += gq1 * pc0; g9[4] += gq1 * pc1; g9[5] += gq1 * pc2;
+            g9[6] += gq2 * pc0; g9[7] += gq2 * pc1; g9[8] += gq2 * pc2;
+        }
+    }
+    __syncthreads();
+    float* dst = ggrid + (long)n * P * C + c0;
+    for (int i = threadIdx.x; i < P * cc; i += 256) {
+        const int p = i / cc, c = i - p * cc;
+        dst[(long)p * C + c] = slab[p * CC + c];
+    }
+    if (grot) {
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            float v = g9[i];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+            __syncthreads();
+            if (lane == 0) red[w] = v;
+            __syncthreads();
+            if (threadIdx.x == 0) unsafeAtomicAdd(&grot[n * 9 + i], red[0] + red[1] + red[2] + red[3]);
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int cn_rotate3d_fwd(const float* grid, const float* rot, float* out, int n, int g, int c, void* stream) {
@@ -148,11 +233,18 @@ extern "C" int cn_rotate3d_bwd(const float* grid, const float* rot, const float*
     CN_CHECK_ARG(grid && rot && gout && ggrid && n > 0 && g > 1 && c > 0 && c % 4 == 0, "rotate3d_bwd: bad args");
     hipStream_t s = (hipStream_t)stream;
     const long P = (long)g * g * g;
-    if (int ez__ = cn_zero_async(ggrid, sizeof(float) * n * P * c, s)) return ez__;
     if (grot) {
         if (int ez__ = cn_zero_async(grot, sizeof(float) * n * 9, s)) return ez__;
     }
-    hipLaunchKernelGGL(rotate3d_bwd_kernel, dim3(cn_cdiv(P, 256), n), dim3(256), 0, s, grid, rot, gout, ggrid, grot, g, c / 4);
+    if (P * 4 <= SLAB_FLOATS) {
+        int CC = (int)(SLAB_FLOATS / P);
+        if (CC > c) CC = c;
+        CC = CC / 4 * 4;
+        hipLaunchKernelGGL(rotate3d_bwd_lds_kernel, dim3(cn_cdiv(c, CC), n), dim3(256), 0, s, grid, rot, gout, ggrid, grot, g, c, CC);
+    } else {
+        if (int ez__ = cn_zero_async(ggrid, sizeof(float) * n * P * c, s)) return ez__;
+        hipLaunchKernelGGL(rotate3d_bwd_kernel, dim3(cn_cdiv(P, 256), n), dim3(256), 0, s, grid, rot, gout, ggrid, grot, g, c / 4);
+    }
     CN_LAUNCH_CHECK();
     return CN_OK;
 }

@@ -58,9 +58,12 @@ class RealEncoder(Net):
     def _conv_bn(self, ci, x, res=None, relu=True):
         first, spec = self._convs[ci]
         k, b, gamma, beta, mean, var = self.weights[first:first + 6]
-        z = F.conv(x, k, b, spec)
-        a = gamma * torch.rsqrt(var + BN_EPS)                    # (C,) host-side plumbing
-        return F.channel_affine_act(z, a, beta - mean * a, res, relu)
+        # conv bias and BN (inference) fold into ONE per-channel affine after the bias-free conv:
+        # bn(conv + b) = a*conv + (beta + a*(b - mean)); the (C,) coefficient algebra is host-side plumbing and
+        # carries the gradients of gamma, beta and the conv bias (no activation-sized bias-gradient pass).
+        z = F.conv(x, k, None, spec)
+        a = gamma * torch.rsqrt(var + BN_EPS)
+        return F.channel_affine_act(z, a, beta + a * (b - mean), res, relu)
 
     def features(self, img):
         x = F.caffe_preprocess(img)                              # real_encoder.py:24-25
