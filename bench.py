@@ -39,7 +39,7 @@ def main():
     ap.add_argument("--pool", type=int, default=512, help="images in each synthetic uint8 pool")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graphs", action="store_true", help="dispatch every kernel eagerly (no HIP graph replay)")
-    ap.add_argument("--cpu-batch", type=int, default=4)
+    ap.add_argument("--cpu-batch", type=int, default=16)
     args = ap.parse_args()
 
     import torch
