@@ -104,15 +104,18 @@ __device__ __forceinline__ void tap_decode(const CnConvGeom& g, int tap, int& kd
 // ---------------------------------------------------------------------------------------------
 // forward / data-gradient:  Y[m, co] = act( sum_{t,ci} X[src(m,t), ci] * W[t, ci, co] + bias[co] )
 // ---------------------------------------------------------------------------------------------
-template <int WM, int WN, int TM, int TN, bool VEC, bool BVEC = true>
+template <int WM, int WN, int TM, int TN, bool VEC, bool BVEC = true, int KB = BK>
 __global__ __launch_bounds__(256) void igemm_fwd_kernel(CnConvGeom g, const float* __restrict__ X,
                                                         const float* __restrict__ W, const float* __restrict__ bias,
                                                         float* __restrict__ Y, int act, float slope, int par) {
     static_assert(WM * WN == 4, "4 waves per workgroup");
     constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN, LDA = BM + 4, LDB = BN + 4;
-    constexpr int AP = BM / 64, BP = (BN + 63) / 64;   // float4 loads per thread per K step
-    __shared__ float As[2][BK][LDA];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BK][LDB];
+    constexpr int KQ = KB / 4;                          // float4 pieces per A row per K step
+    constexpr int RPP = 256 / KQ;                       // A rows loaded per pass of the workgroup
+    constexpr int AP = BM / RPP, BP = (KB * BN / 4 + 255) / 256;   // float4 loads per thread per K step
+    static_assert(!VEC ? KB == BK : true, "scalar gather path uses the 16-deep stage");
+    __shared__ float As[2][KB][LDA];
+    __shared__ __attribute__((aligned(16))) float Bs[2][KB][LDB];
     __shared__ int rowmap[BM];                          // tile row -> output row (or -1)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN, half = lane >> 5, l31 = lane & 31;
@@ -121,18 +124,18 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(CnConvGeom g, const floa
     const int Ktot = T * g.cin;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
 
-    const int kq = tid & 3, arow = tid >> 2;
+    const int kq = tid % KQ, arow = tid / KQ;
     RowInfo ri[AP];
     unsigned long long tapmask = T >= 64 ? ~0ull : ((1ull << T) - 1ull);
 #pragma unroll
     for (int i = 0; i < AP; ++i) {
-        int mrow = m0 + arow + 64 * i;
+        int mrow = m0 + arow + RPP * i;
         if (par) {
             int cls;
             mrow = par_row(g, mrow, M, cls);
         }
         ri[i] = decode_row(g, mrow, M);
-        if (kq == 0) rowmap[arow + 64 * i] = ri[i].ok ? mrow : -1;
+        if (kq == 0) rowmap[arow + RPP * i] = ri[i].ok ? mrow : -1;
     }
     if (par) {
         int c0, c1;
@@ -151,7 +154,7 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(CnConvGeom g, const floa
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     float4 ra[AP], rb[BP];
-    const int cpb = VEC ? g.cin / BK : 1;
+    const int cpb = VEC ? g.cin / KB : 1;
     const int nks_all = VEC ? __popcll(tapmask) * cpb : (Ktot + BK - 1) / BK;
     // split-K over gridDim.z (small-M problems): this workgroup walks K steps [ks_beg, ks_end)
     const int per_z = (nks_all + gridDim.z - 1) / gridDim.z;
@@ -161,7 +164,7 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(CnConvGeom g, const floa
     auto load_tiles = [&](int ks) {
         if (VEC) {
             const int ord = ks / cpb;
-            const int c0 = (ks - ord * cpb) * BK;
+            const int c0 = (ks - ord * cpb) * KB;
             if (ord != cur_ord) {
                 while (cur_ord < ord) {
                     cur_tap += __ffsll((long long)(tapmask >> (cur_tap + 1)));
@@ -183,12 +186,12 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(CnConvGeom g, const floa
                 const int brow = idx / (BN / 4), col = n0 + (idx % (BN / 4)) * 4;
                 const long kg = (long)tap * g.cin + c0 + brow;
                 if (BVEC) {
-                    rb[j] = (col < g.cout && idx < BK * BN / 4) ? *reinterpret_cast<const float4*>(W + kg * g.cout + col)
+                    rb[j] = (col < g.cout && idx < KB * BN / 4) ? *reinterpret_cast<const float4*>(W + kg * g.cout + col)
                                                                 : make_float4(0.f, 0.f, 0.f, 0.f);
                 } else {   // thin cout (3-channel image gradients): guarded scalar filter loads
                     float v[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = (col + e < g.cout && idx < BK * BN / 4) ? W[kg * g.cout + col + e] : 0.f;
+                    for (int e = 0; e < 4; ++e) v[e] = (col + e < g.cout && idx < KB * BN / 4) ? W[kg * g.cout + col + e] : 0.f;
                     rb[j] = make_float4(v[0], v[1], v[2], v[3]);
                 }
             }
@@ -215,7 +218,7 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(CnConvGeom g, const floa
                 const int idx = tid + 256 * j;
                 const int brow = idx / (BN / 4), col = n0 + (idx % (BN / 4)) * 4;
                 const long kg = (long)ks * BK + brow;
-                rb[j] = (col < g.cout && kg < Ktot && idx < BK * BN / 4)
+                rb[j] = (col < g.cout && kg < Ktot && idx < KB * BN / 4)
                             ? *reinterpret_cast<const float4*>(W + kg * g.cout + col)
                             : make_float4(0.f, 0.f, 0.f, 0.f);
             }
@@ -224,7 +227,7 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(CnConvGeom g, const floa
     auto store_tiles = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < AP; ++i) {
-            const int r = arow + 64 * i;
+            const int r = arow + RPP * i;
             As[buf][kq * 4 + 0][r] = ra[i].x;
             As[buf][kq * 4 + 1][r] = ra[i].y;
             As[buf][kq * 4 + 2][r] = ra[i].z;
@@ -234,7 +237,7 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(CnConvGeom g, const floa
         for (int j = 0; j < BP; ++j) {
             const int idx = tid + 256 * j;
             const int brow = idx / (BN / 4), bcol = (idx % (BN / 4)) * 4;
-            if (idx < BK * BN / 4) *reinterpret_cast<float4*>(&Bs[buf][brow][bcol]) = rb[j];
+            if (idx < KB * BN / 4) *reinterpret_cast<float4*>(&Bs[buf][brow][bcol]) = rb[j];
         }
     };
 
@@ -247,7 +250,7 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(CnConvGeom g, const floa
     for (int ks = ks_beg; ks < ks_end; ++ks) {
         const int buf = (ks - ks_beg) & 1;
         if (ks + 1 < ks_end) load_tiles(ks + 1);
-        mma_step<TM, TN, LDA, LDB>(As[buf], Bs[buf], acc, a_col, b_col, half);
+        mma_step<TM, TN, LDA, LDB, KB>(As[buf], Bs[buf], acc, a_col, b_col, half);
         if (ks + 1 < ks_end) store_tiles(buf ^ 1);
         __syncthreads();
     }
@@ -704,12 +707,20 @@ int check_geom(const CnConvGeom* g) {
     return CN_OK;
 }
 
+static int g_force_kb16 = -1;
+
 template <int WM, int WN, int TM, int TN>
 int launch_fwd(const CnConvGeom& g, bool vec, int par, int splits, const float* x, const float* w, const float* bias,
                float* y, int act, float slope, hipStream_t s) {
     const long M = (long)g.n * g.out_d * g.out_h * g.out_w;
     dim3 grid(cn_cdiv(M, 32 * WM * TM), cn_cdiv(g.cout, 32 * WN * TN), splits);
-    if (vec)
+    if (g_force_kb16 < 0) g_force_kb16 = getenv("CN_KB32") ? 0 : 1;   // 32-deep stages only on request (A/B: no net win)
+    // 32-deep LDS stages: twice the MFMA work per barrier / per global-load round trip, which is what the
+    // smaller tiles need to cover the L2/HBM latency of the gathered operand
+    const bool kb32 = vec && g.cin % 32 == 0 && !g_force_kb16;
+    if (kb32)
+        hipLaunchKernelGGL((igemm_fwd_kernel<WM, WN, TM, TN, true, true, 32>), grid, dim3(256), 0, s, g, x, w, bias, y, act, slope, par);
+    else if (vec)
         hipLaunchKernelGGL((igemm_fwd_kernel<WM, WN, TM, TN, true>), grid, dim3(256), 0, s, g, x, w, bias, y, act, slope, par);
     else
         hipLaunchKernelGGL((igemm_fwd_kernel<WM, WN, TM, TN, false>), grid, dim3(256), 0, s, g, x, w, bias, y, act, slope, par);
@@ -816,6 +827,8 @@ extern "C" int cn_conv_fwd(const CnConvGeom* gp, const float* x, const float* w,
         if (want > nks / 16) want = nks / 16;        // at least 16 K steps per workgroup
         if (want > 1) splits = (int)want;
     }
+    if (const char* e = getenv("CN_CFG")) cfg = atoi(e);          // tuning overrides (scripts/conv_tune.py)
+    if (const char* e = getenv("CN_SPLITS")) splits = atoi(e);
     const int kact = splits > 1 ? CN_ACT_NONE : act;
     if (splits > 1) {
         if (int ez__ = cn_zero_async(y, sizeof(float) * M * g.cout, s)) return ez__;
