@@ -92,6 +92,8 @@ class ConfigNetFirstStage:
         from .graphs import StaticBuffers
         self._bufs = StaticBuffers(self.device)
         self._graphs = {}
+        self._deferred = None
+        self._side_streams = []
         self.use_graphs = False       # capture each step's device half into a HIP graph (single-GPU runs)
 
         self.generator = None
@@ -319,7 +321,7 @@ class ConfigNetFirstStage:
 
     def _run_step(self, name, datasets, optimizer, device_fn):
         """optimizer.advance() on the host, then the device half -- eagerly, or as a captured HIP graph."""
-        optimizer.advance()
+        optimizer.advance(name)
         fn = device_fn
 
         def device_fn():
@@ -334,12 +336,40 @@ class ConfigNetFirstStage:
             from .graphs import StepGraph
             self._graphs = {k: v for k, v in self._graphs.items() if k[3] == self._bufs.generation}
             g = self._graphs[key] = StepGraph(device_fn)
+        if self._deferred is not None and g.graph is not None:
+            self._deferred.append(g)           # replayed together with its independent sibling steps
+            return g.out
         return g()
 
-    def _discriminator_update(self, net, real_imgs, fake_imgs, optimizer):
+    def run_concurrently(self, step_calls):
+        """Runs step functions that do not depend on each other (the three discriminator-type steps of one
+        iteration: each updates only its own network and reads generator/encoder weights that stay fixed until
+        the generator step) as HIP graphs replayed on separate streams, so their many small launches overlap on
+        the 256 CUs.  Host halves (sampling, staging, step counters) still run in the reference's order."""
+        if not self.use_graphs:
+            return [c() for c in step_calls]
+        self._deferred = []
+        try:
+            outs = [c() for c in step_calls]
+            pending, self._deferred = self._deferred, None
+        finally:
+            self._deferred = None
+        if pending:
+            cur = torch.cuda.current_stream()
+            while len(self._side_streams) < len(pending):
+                self._side_streams.append(torch.cuda.Stream())
+            for g, st in zip(pending, self._side_streams):
+                st.wait_stream(cur)
+                with torch.cuda.stream(st):
+                    g.graph.replay()
+            for _, st in zip(pending, self._side_streams):
+                cur.wait_stream(st)
+        return outs
+
+    def _discriminator_update(self, net, real_imgs, fake_imgs, optimizer, slot="default"):
         losses = compute_discriminator_loss(net, real_imgs, fake_imgs)
         backward_into_arenas(losses["loss_sum"], [net])
-        optimizer.apply_gradients(net, advance=False)
+        optimizer.apply_gradients(net, advance=False, slot=slot)
         return losses
 
     def get_discriminator_batch(self, training_set):
@@ -362,7 +392,7 @@ class ConfigNetFirstStage:
     def discriminator_training_step(self, training_set, optimizer):
         self._stage_d_batch(training_set)
         return self._run_step("d", (training_set,), optimizer, lambda: self._discriminator_update(
-            self.discriminator, *self._d_batch(training_set), optimizer))
+            self.discriminator, *self._d_batch(training_set), optimizer, "d"))
 
     def get_synth_discriminator_batch(self, training_set):
         self._stage_sd_batch(training_set)
@@ -383,13 +413,13 @@ class ConfigNetFirstStage:
     def synth_discriminator_training_step(self, synth_training_set, optimizer):
         self._stage_sd_batch(synth_training_set)
         return self._run_step("sd", (synth_training_set,), optimizer, lambda: self._discriminator_update(
-            self.synth_discriminator, *self._sd_batch(synth_training_set), optimizer))
+            self.synth_discriminator, *self._sd_batch(synth_training_set), optimizer, "sd"))
 
     def _latent_discriminator_update(self, real_latents, fake_latents, optimizer):
         net = self.latent_discriminator
         losses = compute_latent_discriminator_loss(net, real_latents, fake_latents)
         backward_into_arenas(losses["loss_sum"], [net])
-        optimizer.apply_gradients(net, advance=False)
+        optimizer.apply_gradients(net, advance=False, slot="ld")
         return losses
 
     def latent_discriminator_training_step(self, synth_training_set, optimizer):
@@ -430,7 +460,7 @@ class ConfigNetFirstStage:
 
     def _generator_update(self, losses, nets, optimizer):
         backward_into_arenas(losses["loss_sum"], nets)
-        optimizer.apply_gradients(nets, advance=False)
+        optimizer.apply_gradients(nets, advance=False, slot="g")
 
     def generator_training_step(self, real_training_set, synth_training_set, optimizer):
         n_synth = self.get_batch_size() // 2

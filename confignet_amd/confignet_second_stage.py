@@ -149,10 +149,11 @@ class ConfigNet(ConfigNetFirstStage):
         """One reference training iteration (confignet_second_stage.py:277-288): D, synth-D, latent-D,
         G, EMA.  Returns the four loss dicts (device scalars; no host sync here)."""
         for _ in range(self.config["n_discriminator_updates"]):
-            d_loss = self.discriminator_training_step(real_training_set, discriminator_optimizer)
-            synth_d_loss = self.synth_discriminator_training_step(synth_training_set, discriminator_optimizer)
-            latent_d_loss = self.latent_discriminator_training_step(real_training_set, synth_training_set,
-                                                                    discriminator_optimizer)
+            d_loss, synth_d_loss, latent_d_loss = self.run_concurrently([
+                lambda: self.discriminator_training_step(real_training_set, discriminator_optimizer),
+                lambda: self.synth_discriminator_training_step(synth_training_set, discriminator_optimizer),
+                lambda: self.latent_discriminator_training_step(real_training_set, synth_training_set,
+                                                                discriminator_optimizer)])
         for _ in range(self.config["n_generator_updates"]):
             g_loss = self.generator_training_step(real_training_set, synth_training_set, generator_optimizer)
         self.update_smoothed_weights()

@@ -16,19 +16,21 @@ class Adam:
         self.lr, self.beta_1, self.beta_2, self.epsilon = lr, beta_1, beta_2, epsilon
         self.iterations = 0
         self._state = {}
-        self._lr_dev = None
+        self._lr_dev = {}
 
     def lr_t(self):
         t = self.iterations
         return self.lr * math.sqrt(1.0 - self.beta_2 ** t) / (1.0 - self.beta_1 ** t)
 
-    def advance(self):
+    def advance(self, slot="default"):
         """Host half of one Keras apply_gradients call: t += 1 and the new lr_t is written to a device scalar.
-        Kept apart from apply_gradients so that the device half can live inside a captured HIP graph."""
-        if self._lr_dev is None:
-            self._lr_dev = torch.zeros(1, device="cuda", dtype=torch.float32)
+        Kept apart from apply_gradients so that the device half can live inside a captured HIP graph.  Each
+        step function owns a `slot` (its own scalar), so several captured steps that share this optimizer can
+        be in flight at once, each with the lr_t of ITS position in the shared step count."""
+        if slot not in self._lr_dev:
+            self._lr_dev[slot] = torch.zeros(1, device="cuda", dtype=torch.float32)
         self.iterations += 1
-        self._lr_dev.fill_(self.lr_t())
+        self._lr_dev[slot].fill_(self.lr_t())
 
     def state_for(self, net):
         st = self._state.get(id(net))
@@ -37,15 +39,15 @@ class Adam:
             self._state[id(net)] = st
         return st
 
-    def apply_gradients(self, nets, advance=True):
+    def apply_gradients(self, nets, advance=True, slot="default"):
         """One Keras apply_gradients call over the flat arenas of `nets` (a Net or a list of Nets):
         data-parallel gradient all-reduce first, then one fused Adam launch per arena."""
         if not isinstance(nets, (list, tuple)):
             nets = [nets]
         if advance:
-            self.advance()
+            self.advance(slot)
         parallel.allreduce_gradients(nets)
         for net in nets:
             m, v = self.state_for(net)
-            ops.adam_step(net.arena, net.grad_arena, m, v, None, self._lr_dev, self.beta_1, self.beta_2, self.epsilon)
+            ops.adam_step(net.arena, net.grad_arena, m, v, None, self._lr_dev[slot], self.beta_1, self.beta_2, self.epsilon)
             net.mark_updated()
