@@ -117,7 +117,7 @@ def main():
                        "parallelism": "dp%d" % world, "losses_finite": bool(finite),
                        "dispatch": "hip-graph replay per step function" if (world == 1 and not args.no_graphs) else "eager"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                         "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": pmc_traffic(),
                          "kernel": "igemm_fwd/igemm_wgrad (implicit-GEMM conv, v_mfma_f32_32x32x2_f32)",
                          "launches_per_step": launches / max(args.steps, 1),
                          "kernel_ms_per_step": round(kernel_ms / max(args.steps, 1), 3),
@@ -129,6 +129,17 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def pmc_traffic():
+    """HBM bytes per launch of the dominant kernel class from the committed rocprofv3 PMC passes of this same
+    command (profiles/round1_pmc_traffic.json: FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE);
+    hardware counters cannot be read from inside the benchmark process, hence a recorded measurement."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "round1_pmc_traffic.json")) as fp:
+            return round(json.load(fp)["hbm_bytes_per_launch"])
+    except Exception:
+        return None
 
 
 def cpu_baseline(args):

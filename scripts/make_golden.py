@@ -1,0 +1,115 @@
+"""Generates tests/golden/first_stage_128.npz from the CPU oracle (float64): seeded Keras-ordered weights and
+inputs -> generator image crop + checksum, the 6 discriminator logits, every loss scalar of the first-stage
+steps (BASELINE.json configs[0] run at 128x128), and a Keras-Adam trace.
+
+The reference itself cannot be executed here (tensorflow-gpu==2.1.0 is not installable, no weights), so these
+vectors pin the ORACLE (regression) and give the GPU tests a fixture that needs no oracle run; they are not
+TensorFlow outputs."""
+import os
+import sys
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import ref_nets as R, ref_ops as O, ref_steps as S   # noqa: E402
+
+FM = OrderedDict([("beard_style_embedding", (9, 7)), ("blendshape_values", (62, 30)), ("eye_color", (8, 3)),
+                  ("head_hair_color", (3, 3))])
+RES, L = 128, 43
+
+
+def seeded_weights(shapes, seed, he=False):
+    rng = np.random.default_rng(seed)
+    out = []
+    for s in shapes:
+        if len(s) == 1:
+            out.append((rng.standard_normal(s) * 0.05).astype(np.float32))
+        elif he:
+            rf = int(np.prod(s[:-2])) if len(s) > 2 else 1
+            out.append((rng.standard_normal(s) * np.sqrt(2.0 / (rf * s[-2]))).astype(np.float32))
+        else:
+            out.append(O.glorot_uniform(rng, s))
+    return out
+
+
+def build():
+    W = {
+        "generator": seeded_weights(R.generator_weight_shapes(L, RES), 1),
+        "discriminator": seeded_weights(R.discriminator_weight_shapes(RES), 2),
+        "synth_discriminator": seeded_weights(R.discriminator_weight_shapes(RES), 3),
+        "latent_discriminator": seeded_weights(R.mlp_weight_shapes(4, L, L, 1), 4),
+        "latent_regressor": seeded_weights(R.latent_regressor_weight_shapes(L, RES), 5),
+        "synthetic_encoder": seeded_weights(R.synthetic_encoder_weight_shapes(list(FM.values())), 6),
+    }
+    W["generator"][0][:] = 0.0
+    W["generator"][1][:] = 1.0 + W["generator"][1] * 0.0
+    for k in ("discriminator", "synth_discriminator", "latent_regressor"):
+        for i in range(5):
+            W[k][2 + 4 * i + 2] = (1.0 + W[k][2 + 4 * i + 2]).astype(np.float32)     # instance-norm gamma ~ 1
+    vgg = seeded_weights(R.vgg_weight_shapes(R.VGG19_CFG), 7, he=True)
+    rng = np.random.default_rng(8)
+    n = 2
+    inp = {
+        "z": rng.standard_normal((n, L)), "rot": np.stack([rng.uniform(-0.5, 0.5, n), rng.uniform(-0.17, 0.17, n), np.zeros(n)], 1),
+        "real": rng.uniform(-1, 1, (n, RES, RES, 3)), "fake": rng.uniform(-1, 1, (n, RES, RES, 3)),
+        "params": [rng.standard_normal((1, d[0])) for d in FM.values()],
+        "synth_rot": np.array([[0.2, -0.1, 0.0]]), "gt": rng.uniform(-1, 1, (1, RES, RES, 3)),
+        "z_real": rng.standard_normal((1, L)), "rot_real": np.array([[-0.3, 0.05, 0.0]]),
+    }
+    masks = np.zeros((1, RES, RES), np.uint8)
+    masks[:, 40:52, 50:70] = 1
+    inp["masks"] = masks
+    return W, vgg, inp
+
+
+def t64(a, grad=False):
+    return torch.tensor(np.asarray(a), dtype=torch.float64, requires_grad=grad)
+
+
+def compute(W, vgg, inp):
+    cfg = {"output_shape": (RES, RES, 3), "image_loss_weight": 5e-5, "eye_loss_weight": 5, "domain_adverserial_loss_weight": 5.0,
+           "latent_regression_weight": 10.0, "latent_regressor_rot_weight": 5.0}
+    Wt = {k: [t64(w, True) for w in v] for k, v in W.items()}
+    vt = [t64(w) for w in vgg]
+    out = {}
+    img = R.generator_forward(Wt["generator"], t64(inp["z"]), t64(inp["rot"]), RES)
+    out["gen_crop"] = img[:, 48:80, 48:80, :].detach().numpy()
+    out["gen_checksum"] = np.array([float(img.sum()), float((img ** 2).sum())])
+    logits = R.discriminator_forward(Wt["discriminator"], t64(inp["real"]))
+    out["d_logits"] = np.concatenate([v.detach().numpy() for v in logits.values()], axis=1)
+    dl = S.discriminator_loss(Wt["discriminator"], t64(inp["real"]), t64(inp["fake"]))
+    out["d_loss_names"] = np.array(list(dl.keys()))
+    out["d_loss_values"] = np.array([float(v) for v in dl.values()])
+    ld = S.latent_discriminator_loss(Wt["latent_discriminator"], t64(inp["z"]), t64(inp["z"][::-1].copy() * 0.5))
+    out["ld_loss_names"] = np.array(list(ld.keys()))
+    out["ld_loss_values"] = np.array([float(v) for v in ld.values()])
+    gl, _ = S.first_stage_generator_loss(Wt, cfg, [t64(p) for p in inp["params"]], t64(inp["synth_rot"]), t64(inp["gt"]),
+                                         torch.as_tensor(inp["masks"]), t64(inp["z_real"]), t64(inp["rot_real"]), vt)
+    out["g_loss_names"] = np.array(list(gl.keys()))
+    out["g_loss_values"] = np.array([float(v) for v in gl.values()])
+    grads = S.grads_of(gl["loss_sum"], Wt["generator"])
+    out["g_grad_norms"] = np.array([float(g.norm()) for g in grads])
+    # Keras Adam with the shared counter: 4 applications on a 1000-element tensor
+    rng = np.random.default_rng(9)
+    th, g = rng.standard_normal(1000), rng.standard_normal(1000)
+    p = t64(th).clone()
+    opt = O.KerasAdam(lr=4e-4, beta_1=0.0, beta_2=0.9)
+    trace = []
+    for t in range(1, 5):
+        opt.apply_gradients([(t64(g * t), p)])
+        trace.append(p.numpy().copy())
+    out["adam_theta0"], out["adam_grad"], out["adam_trace"] = th, g, np.stack(trace)
+    return out
+
+
+if __name__ == "__main__":
+    W, vgg, inp = build()
+    out = compute(W, vgg, inp)
+    path = os.path.join(ROOT, "tests", "golden", "first_stage_128.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes")
+    for k in ("d_loss_values", "g_loss_values", "gen_checksum"):
+        print(k, out[k])

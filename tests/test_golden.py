@@ -1,0 +1,93 @@
+"""Golden fixtures (tests/golden/first_stage_128.npz, made by scripts/make_golden.py from the float64 oracle).
+CPU: the oracle still reproduces them (regression pin).  GPU: the HIP path matches them at the north_star
+tolerance (1e-3 max-abs on outputs / loss scalars) WITHOUT running the oracle."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "scripts"))
+import make_golden as MG   # noqa: E402
+
+GOLD = np.load(os.path.join(ROOT, "tests", "golden", "first_stage_128.npz"))
+
+
+def test_oracle_reproduces_golden_generator_and_discriminator():
+    W, vgg, inp = MG.build()
+    Wt = {k: [MG.t64(w) for w in v] for k, v in W.items()}
+    from oracle import ref_nets as R
+    img = R.generator_forward(Wt["generator"], MG.t64(inp["z"]), MG.t64(inp["rot"]), MG.RES)
+    np.testing.assert_allclose(img[:, 48:80, 48:80, :].numpy(), GOLD["gen_crop"], atol=1e-12)
+    np.testing.assert_allclose([float(img.sum()), float((img ** 2).sum())], GOLD["gen_checksum"], rtol=1e-12)
+    logits = R.discriminator_forward(Wt["discriminator"], MG.t64(inp["real"]))
+    np.testing.assert_allclose(np.concatenate([v.numpy() for v in logits.values()], axis=1), GOLD["d_logits"], atol=1e-12)
+    assert list(GOLD["d_loss_names"]) == ["GAN_loss_real_%d" % i for i in range(6)] + ["GAN_loss_fake_%d" % i for i in range(6)] + \
+        ["gp_loss_%d" % i for i in range(6)] + ["loss_sum"]
+
+
+def test_oracle_adam_trace_matches_golden():
+    from oracle import ref_ops as O
+    p = MG.t64(GOLD["adam_theta0"]).clone()
+    opt = O.KerasAdam(lr=4e-4, beta_1=0.0, beta_2=0.9)
+    for t in range(1, 5):
+        opt.apply_gradients([(MG.t64(GOLD["adam_grad"] * t), p)])
+        np.testing.assert_allclose(p.numpy(), GOLD["adam_trace"][t - 1], atol=1e-15)
+
+
+def _model():
+    from confignet_amd import ConfigNetFirstStage
+    W, vgg, inp = MG.build()
+    cfg = {"output_shape": (MG.RES, MG.RES, 3), "batch_size": 2, "facemodel_inputs": dict(MG.FM)}
+    m = ConfigNetFirstStage(cfg, seed=0)
+    assert m.config["latent_dim"] == MG.L
+    m.generator.set_weights(W["generator"]); m.generator_smoothed.set_weights(W["generator"])
+    m.discriminator.set_weights(W["discriminator"]); m.synth_discriminator.set_weights(W["synth_discriminator"])
+    m.latent_discriminator.set_weights(W["latent_discriminator"]); m.latent_regressor.set_weights(W["latent_regressor"])
+    m.synthetic_encoder.set_weights(W["synthetic_encoder"])
+    m.perceptual_loss._pretrained_dnn_activations.set_weights(vgg)
+    return m, inp
+
+
+@pytest.mark.gpu
+def test_hip_path_matches_golden_first_stage():
+    from confignet_amd.confignet_first_stage import frozen
+    from confignet_amd.losses import compute_discriminator_loss, compute_latent_discriminator_loss
+    m, inp = _model()
+    dev = m._dev
+    img = m.generator((inp["z"], inp["rot"].astype(np.float32)))
+    got = img.detach().cpu().double().numpy()
+    assert np.abs(got[:, 48:80, 48:80, :] - GOLD["gen_crop"]).max() < 1e-3
+    np.testing.assert_allclose([got.sum(), (got ** 2).sum()], GOLD["gen_checksum"], rtol=1e-4)
+    logits = m.discriminator(inp["real"])
+    assert np.abs(np.concatenate([v.detach().cpu().numpy() for v in logits.values()], axis=1) - GOLD["d_logits"]).max() < 1e-3
+    dl = compute_discriminator_loss(m.discriminator, dev(inp["real"]), dev(inp["fake"]))
+    assert list(dl.keys()) == list(GOLD["d_loss_names"])
+    for k, v in zip(dl.keys(), GOLD["d_loss_values"]):
+        assert abs(float(dl[k]) - v) <= 1e-3 * max(1.0, abs(v)), (k, float(dl[k]), v)
+    ld = compute_latent_discriminator_loss(m.latent_discriminator, dev(inp["z"]), dev(inp["z"][::-1].copy() * 0.5))
+    for k, v in zip(ld.keys(), GOLD["ld_loss_values"]):
+        assert abs(float(ld[k]) - v) <= 1e-3 * max(1.0, abs(v)), (k, float(ld[k]), v)
+    with frozen(m.discriminator, m.synth_discriminator, m.latent_discriminator):
+        gl = m._generator_loss([dev(p) for p in inp["params"]], dev(inp["synth_rot"]), dev(inp["gt"]),
+                               torch.as_tensor(inp["masks"]).cuda(), dev(inp["z_real"]), dev(inp["rot_real"]))
+        grads = torch.autograd.grad(gl["loss_sum"], m.generator.trainable_weights)
+    assert list(gl.keys()) == list(GOLD["g_loss_names"])
+    for k, v in zip(gl.keys(), GOLD["g_loss_values"]):
+        assert abs(float(gl[k]) - v) <= 1e-3 * max(1.0, abs(v)), (k, float(gl[k]), v)
+    norms = np.array([float(g.norm()) for g in grads])
+    np.testing.assert_allclose(norms, GOLD["g_grad_norms"], rtol=2e-2, atol=1e-6)     # fp32 ReLU-branch noise, see test_nets_gpu
+
+
+@pytest.mark.gpu
+def test_hip_adam_matches_golden_trace():
+    from confignet_amd import ops
+    import math
+    th = torch.tensor(GOLD["adam_theta0"], dtype=torch.float32).cuda()
+    m_, v_ = torch.zeros_like(th), torch.zeros_like(th)
+    for t in range(1, 5):
+        lr_t = torch.tensor([4e-4 * math.sqrt(1 - 0.9 ** t)], dtype=torch.float32).cuda()
+        ops.adam_step(th, torch.tensor(GOLD["adam_grad"] * t, dtype=torch.float32).cuda(), m_, v_, None, lr_t, 0.0, 0.9, 1e-7)
+        assert np.abs(th.cpu().double().numpy() - GOLD["adam_trace"][t - 1]).max() < 2e-6
