@@ -21,6 +21,9 @@ DEFAULT_CONFIG = {
     "n_samples_for_metrics": 1000,
     "verbose_log_period": 500,
     "logging_img_square_size": 6,
+    # Not in the reference: draw the input latents on the GPU (torch Philox stream) instead of np.random.  The
+    # reference's np.random.normal costs ~29 ms per (4096,145) batch on the host -- 20x the device time of a step.
+    "device_latent_sampling": False,
 }
 
 
@@ -70,6 +73,11 @@ class LatentGAN:
         self.discriminator = MLPSimple(n, L, hidden, 1, rng=self._rng)
 
     def sample_input_latent_vector(self, n_samples):
+        if self.config.get("device_latent_sampling"):
+            shape = (n_samples, self.config["latent_dim"])
+            if self.config["latent_distribution_type"] == "uniform":
+                return torch.rand(shape, device=self.generator.device) * 2.0 - 1.0
+            return torch.randn(shape, device=self.generator.device)
         if self.config["latent_distribution_type"] == "uniform":
             return np.random.uniform(-1, 1, (n_samples, self.config["latent_dim"]))
         return np.random.normal(0, 1, (n_samples, self.config["latent_dim"]))
@@ -131,4 +139,5 @@ class LatentGAN:
             print("[step: %d] [D loss: %f] [G loss: %f]" % (step_number, d_loss["loss_sum"], g_loss["loss_sum"]))
 
     def generate_latents(self, n_samples, truncation=1.0):
-        return self.generator_smoothed.predict(self.sample_input_latent_vector(n_samples) * truncation)
+        z = self.sample_input_latent_vector(n_samples) * truncation
+        return self.generator_smoothed.predict(z.cpu().numpy() if torch.is_tensor(z) else z)
