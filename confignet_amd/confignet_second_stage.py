@@ -226,7 +226,9 @@ class ConfigNet(ConfigNetFirstStage):
         imgs_dev = gen.to_device(input_images)
         optimizer = optim.Adam(lr=0.0001)
         w = self.config
-        for step_number in range(n_iters):
+        state = {}
+
+        def device_step():
             losses = {}
             with frozen(self.discriminator, self.latent_discriminator, self.latent_regressor):
                 pre_t, post_t = pre.repeat(n_imgs, 1), post.repeat(n_imgs, 1)
@@ -242,8 +244,21 @@ class ConfigNet(ConfigNetFirstStage):
                 losses["latent_regression_loss"] = self.compute_normalized_latent_regression_loss(out, labels)
                 losses["loss_sum"] = sum(losses.values())
                 backward_into_arenas(losses["loss_sum"], [gen, var])
-            stale = torch.cat((pre_t, expr, post_t), dim=1).detach().clone()   # pre/post tiled BEFORE the step
-            optimizer.apply_gradients([gen, var])
+            # pre/post tiled BEFORE this step's update (what the reference returns after the last step, l.363-364,402)
+            state["stale"] = torch.cat((pre_t, expr, post_t), dim=1).detach().clone()
+            optimizer.apply_gradients([gen, var], advance=False, slot="ft")
+            return {k: v.detach() for k, v in losses.items()}
+
+        # N = 1 makes this loop latency-bound: the step is captured once into a HIP graph and replayed
+        if self.use_graphs:
+            from .graphs import StepGraph
+            runner = StepGraph(device_step)
+        else:
+            runner = device_step
+        for step_number in range(n_iters):
+            optimizer.advance("ft")
+            self.last_fine_tune_losses = runner()
+        stale = state["stale"]
         # the reference returns pre/post tiled before the last optimizer step with the updated expr (l.402)
         result = stale.cpu().numpy()
         result[:, list(expr_idxs)] = expr.detach().cpu().numpy()

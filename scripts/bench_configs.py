@@ -14,6 +14,7 @@ ds = SyntheticFaceDataset(8, 256, seed=1)
 cfg = merge_configs(DEFAULT_CONFIG, {"batch_size": 2, "output_shape": (256, 256, 3)})
 ds.process_metadata(cfg, True)
 m = ConfigNet(cfg, seed=0)
+m.use_graphs = True
 m.fine_tune_on_img(ds.imgs[0], n_iters=3)
 torch.cuda.synchronize(); t0 = time.perf_counter()
 emb, rot = m.fine_tune_on_img(ds.imgs[0], n_iters=200)
