@@ -328,11 +328,40 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(CnConvGeom g, const fl
     float4 ra[AP], rb[BP];
     const int nks = (mend - mbeg + BK - 1) / BK;
 
+    // output coordinates of this thread's gathered row, advanced by BK rows per K step with carries instead of
+    // re-dividing the row index every step (load_tiles is called with ks = 0, 1, 2, ... in order)
+    int p_m[AP], p_n[AP], p_d[AP], p_h[AP], p_w[AP];
+#pragma unroll
+    for (int ii = 0; ii < AP; ++ii) {
+        int m = mbeg + a_krow[ii];
+        p_m[ii] = m;
+        p_w[ii] = m % g.out_w; m /= g.out_w;
+        p_h[ii] = m % g.out_h; m /= g.out_h;
+        p_d[ii] = m % g.out_d;
+        p_n[ii] = m / g.out_d;
+    }
+
     auto load_tiles = [&](int ks) {
 #pragma unroll
         for (int ii = 0; ii < AP; ++ii) {
-            const int m = mbeg + ks * BK + a_krow[ii];
-            const RowInfo r = decode_row(g, m, mend);
+            RowInfo r;
+            r.ok = p_m[ii] < mend;
+            r.nbase = p_n[ii] * g.in_d;
+            r.vd = p_d[ii] * g.s_d - g.p_d;
+            r.vh = p_h[ii] * g.s_h - g.p_h;
+            r.vw = p_w[ii] * g.s_w - g.p_w;
+            p_m[ii] += BK;
+            p_w[ii] += BK;
+            while (p_w[ii] >= g.out_w) {
+                p_w[ii] -= g.out_w;
+                if (++p_h[ii] == g.out_h) {
+                    p_h[ii] = 0;
+                    if (++p_d[ii] == g.out_d) {
+                        p_d[ii] = 0;
+                        ++p_n[ii];
+                    }
+                }
+            }
             if (VEC) {
                 const int off = a_ok[ii][0] ? src_off(g, r, a_kd[ii][0], a_kh[ii][0], a_kw[ii][0]) : -1;
                 ra[ii] = off >= 0 ? *reinterpret_cast<const float4*>(X + off + a_ci[ii][0])
