@@ -327,7 +327,11 @@ class ConfigNetFirstStage:
         def device_fn():
             # loss scalars are returned detached: keeping the tape alive would keep the leaves' AccumulateGrad
             # nodes (and their stream binding) alive across steps
-            return {k: v.detach() for k, v in fn().items()}
+            ops.zero_pool_begin(name, self.device)
+            try:
+                return {k: v.detach() for k, v in fn().items()}
+            finally:
+                ops.zero_pool_end()
         if not self.use_graphs:
             return device_fn()
         key = (name, tuple(id(d) for d in datasets), id(optimizer), self._bufs.generation)

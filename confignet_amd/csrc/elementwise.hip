@@ -346,7 +346,9 @@ extern "C" int cn_nc_reduce(const float* x1, const float* x2, float* s1, float* 
                             float slope, void* stream) {
     CN_CHECK_ARG(x1 && (s1 || s2) && n > 0 && s > 0 && c > 0, "nc_reduce: bad args");
     hipStream_t st = (hipStream_t)stream;
-    if (s1 && s2 == s1 + (size_t)n * c) {
+    if (flags & 16) {
+        // outputs were cleared by the caller (per-step zero pool: one clearing launch per step, not per call)
+    } else if (s1 && s2 == s1 + (size_t)n * c) {
         if (int ez__ = cn_zero_async(s1, sizeof(float) * 2 * (size_t)n * c, st)) return ez__;
     } else {
         if (s1) {

@@ -899,13 +899,15 @@ extern "C" int cn_conv_dgrad(const CnConvGeom* gp, const float* gy, const float*
     return cn_conv_fwd(&d, gy, w_tflip, nullptr, gu, CN_ACT_NONE, 0.f, stream);
 }
 
-extern "C" int cn_conv_wgrad(const CnConvGeom* gp, const float* x, const float* gy, float* gw, void* stream) {
+extern "C" int cn_conv_wgrad(const CnConvGeom* gp, const float* x, const float* gy, float* gw, int accumulate, void* stream) {
     if (int e = check_geom(gp)) return e;
     CN_CHECK_ARG(x && gy && gw, "NULL tensor");
     const CnConvGeom g = *gp;
     hipStream_t s = (hipStream_t)stream;
     const long Ktot = (long)g.k_d * g.k_h * g.k_w * g.cin;
-    if (int ez__ = cn_zero_async(gw, sizeof(float) * Ktot * g.cout, s)) return ez__;
+    if (!accumulate) {
+        if (int ez__ = cn_zero_async(gw, sizeof(float) * Ktot * g.cout, s)) return ez__;
+    }
     if (Ktot <= 4 && g.cout <= 4 && g.k_d * g.k_h * g.k_w == 1 && g.s_h == 1 && g.s_w == 1 && g.s_d == 1 && !g.up &&
         g.p_h == 0 && g.p_w == 0 && g.p_d == 0) {
         const long M = (long)g.n * g.out_d * g.out_h * g.out_w;

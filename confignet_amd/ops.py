@@ -101,9 +101,60 @@ def conv_dgrad(gy, wt, g):
 
 
 def conv_wgrad(x, gy, g, w_shape):
-    gw = torch.empty(w_shape, device=x.device, dtype=torch.float32)
-    check(lib.cn_conv_wgrad(ctypes.byref(g), _ptr(x), _ptr(gy), _ptr(gw), _stream()), "cn_conv_wgrad")
+    gw = zero_pool_alloc(w_shape, x.device)
+    pre = gw is not None
+    if not pre:
+        gw = torch.empty(w_shape, device=x.device, dtype=torch.float32)
+    check(lib.cn_conv_wgrad(ctypes.byref(g), _ptr(x), _ptr(gy), _ptr(gw), int(pre), _stream()), "cn_conv_wgrad")
     return gw
+
+
+# ---------------------------------------------------------------------------------------------
+# per-step zero pool: accumulate-into outputs (statistics sums, filter gradients) are carved from a buffer that
+# is cleared by ONE launch at the start of a training step instead of one clearing launch per call
+# ---------------------------------------------------------------------------------------------
+class _ZeroPool:
+    def __init__(self, device, numel):
+        self.buf = torch.zeros(numel, device=device, dtype=torch.float32)
+        self.cur = 0
+        self.dirty = 0          # high-water mark of the previous use
+
+
+_pools = {}
+_active_pool = None
+ZERO_POOL_FLOATS = 96 * 1024 * 1024
+
+
+def zero_pool_begin(name, device):
+    """Activate pool `name` (created on first use) and clear what its previous use dirtied."""
+    global _active_pool
+    p = _pools.get((name, device))
+    if p is None:
+        p = _pools[(name, device)] = _ZeroPool(device, ZERO_POOL_FLOATS)
+    if p.dirty:
+        p.buf[:p.dirty].zero_()
+    p.cur = 0
+    _active_pool = p
+
+
+def zero_pool_end():
+    global _active_pool
+    if _active_pool is not None:
+        _active_pool.dirty = max(_active_pool.dirty, _active_pool.cur)
+    _active_pool = None
+
+
+def zero_pool_alloc(shape, device):
+    p = _active_pool
+    if p is None or p.buf.device != device:
+        return None
+    n = int(math.prod(shape))
+    n4 = (n + 3) // 4 * 4
+    if p.cur + n4 > p.buf.numel():
+        return None
+    out = p.buf[p.cur:p.cur + n].view(shape)
+    p.cur += n4
+    return out
 
 
 def sumpool2(gu):
@@ -139,8 +190,12 @@ def nc_reduce(x1, x2=None, want_sum=True, want_dot=True, flags=0, slope=0.0, per
     n, s, c = _nsc(x1)
     if per_channel:
         n, s = 1, n * s
-    if want_sum and want_dot:           # adjacent outputs: the library clears both with one launch
-        s12 = torch.empty((2, n, c), device=x1.device, dtype=torch.float32)
+    if want_sum and want_dot:           # adjacent outputs: cleared by one launch (or by the step's zero pool)
+        s12 = zero_pool_alloc((2, n, c), x1.device)
+        if s12 is not None:
+            flags |= 16
+        else:
+            s12 = torch.empty((2, n, c), device=x1.device, dtype=torch.float32)
         s1, s2 = s12[0], s12[1]
     else:
         s1 = torch.empty((n, c), device=x1.device, dtype=torch.float32) if want_sum else None

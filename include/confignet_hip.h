@@ -61,9 +61,9 @@ int cn_conv_weight_tflip(const float* w, float* w_tflip, int taps, int cin, int 
  * (in << up).  Replaces the Conv*DBackpropInput ops tf.GradientTape issues
  * (confignet_first_stage.py:473,485,557 ; losses.py:76). */
 int cn_conv_dgrad(const CnConvGeom* g, const float* gy, const float* w_tflip, float* gu, void* stream);
-/* Filter gradient (Conv*DBackpropFilter): gw[(t,ci),co] = sum_m x[src(m,t),ci]*gy[m,co]; gw is
- * overwritten. */
-int cn_conv_wgrad(const CnConvGeom* g, const float* x, const float* gy, float* gw, void* stream);
+/* Filter gradient (Conv*DBackpropFilter): gw[(t,ci),co] (+)= sum_m x[src(m,t),ci]*gy[m,co]; gw is overwritten,
+ * or accumulated into when `accumulate` != 0 (the caller guarantees its previous content, e.g. zeros). */
+int cn_conv_wgrad(const CnConvGeom* g, const float* x, const float* gy, float* gw, int accumulate, void* stream);
 /* Backward of the folded nearest x2 upsample: out[n,p,c] = sum of the 2^nd children of p. */
 int cn_sumpool2(const float* gu, float* gx, int nd, int n, int d, int h, int w, int c, void* stream);
 
@@ -78,7 +78,8 @@ int cn_gemm(int trans_a, int trans_b, int m, int n, int k, const float* a, int l
  * (instance_normalization.py:108-131), get_layer_style (confignet_utils.py:147-159), BN inference
  * (keras ResNet50), global average pooling and every bias gradient.
  *   a = f1(x1), b = x2 ? f2(x2) : a ;  sum1[n,c] = sum_s a ; sum2[n,c] = sum_s a*b
- *   flags: bit0 leaky-relu(slope) on x1, bit1 leaky-relu(slope) on x2.  Outputs are overwritten. */
+ *   flags: bit0 leaky-relu(slope) on x1, bit1 leaky-relu(slope) on x2, bit4: the outputs are already zero
+ *   (skip the clearing launch).  Outputs are overwritten. */
 int cn_nc_reduce(const float* x1, const float* x2, float* sum1, float* sum2, int n, int s, int c,
                  int flags, float slope, void* stream);
 /* y = A1*f1(x1) + A2*f2(x2) + B, coefficient tensors indexed [n*cstride + c] (cstride = c, or 0 for
