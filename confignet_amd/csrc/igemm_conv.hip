@@ -107,7 +107,8 @@ __device__ __forceinline__ void tap_decode(const CnConvGeom& g, int tap, int& kd
 template <int WM, int WN, int TM, int TN, bool VEC, bool BVEC = true, int KB = BK>
 __global__ __launch_bounds__(256) void igemm_fwd_kernel(CnConvGeom g, const float* __restrict__ X,
                                                         const float* __restrict__ W, const float* __restrict__ bias,
-                                                        float* __restrict__ Y, int act, float slope, int par) {
+                                                        float* __restrict__ Y, int act, float slope, int par,
+                                                        int xcd_swizzle) {
     static_assert(WM * WN == 4, "4 waves per workgroup");
     constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN, LDA = BM + 4, LDB = BN + 4;
     constexpr int KQ = KB / 4;                          // float4 pieces per A row per K step
@@ -122,7 +123,15 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(CnConvGeom g, const floa
     const int M = g.n * g.out_d * g.out_h * g.out_w;
     const int T = g.k_d * g.k_h * g.k_w;
     const int Ktot = T * g.cin;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    // XCD-aware tile order: workgroup b runs on XCD b % 8 (observed dispatch order); give each XCD a contiguous
+    // run of M tiles so that neighbouring tiles (shared input halo rows) hit the same 4 MiB L2.  Bijective for
+    // any grid size; placement only affects speed, never results.
+    int bx = blockIdx.x;
+    if (xcd_swizzle && !par) {   // parity-ordered rows: classes have 1/2/2/4 live taps, keep them interleaved over XCDs
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bx & 7, idx = bx >> 3;
+        bx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int m0 = bx * BM, n0 = blockIdx.y * BN;
 
     const int kq = tid % KQ, arow = tid / KQ;
     RowInfo ri[AP];
@@ -737,6 +746,7 @@ int check_geom(const CnConvGeom* g) {
 }
 
 static int g_force_kb16 = -1;
+static int g_xcd = getenv("CN_NO_XCD") ? 0 : 1;
 
 template <int WM, int WN, int TM, int TN>
 int launch_fwd(const CnConvGeom& g, bool vec, int par, int splits, const float* x, const float* w, const float* bias,
@@ -748,11 +758,11 @@ int launch_fwd(const CnConvGeom& g, bool vec, int par, int splits, const float* 
     // smaller tiles need to cover the L2/HBM latency of the gathered operand
     const bool kb32 = vec && g.cin % 32 == 0 && !g_force_kb16;
     if (kb32)
-        hipLaunchKernelGGL((igemm_fwd_kernel<WM, WN, TM, TN, true, true, 32>), grid, dim3(256), 0, s, g, x, w, bias, y, act, slope, par);
+        hipLaunchKernelGGL((igemm_fwd_kernel<WM, WN, TM, TN, true, true, 32>), grid, dim3(256), 0, s, g, x, w, bias, y, act, slope, par, g_xcd);
     else if (vec)
-        hipLaunchKernelGGL((igemm_fwd_kernel<WM, WN, TM, TN, true>), grid, dim3(256), 0, s, g, x, w, bias, y, act, slope, par);
+        hipLaunchKernelGGL((igemm_fwd_kernel<WM, WN, TM, TN, true>), grid, dim3(256), 0, s, g, x, w, bias, y, act, slope, par, g_xcd);
     else
-        hipLaunchKernelGGL((igemm_fwd_kernel<WM, WN, TM, TN, false>), grid, dim3(256), 0, s, g, x, w, bias, y, act, slope, par);
+        hipLaunchKernelGGL((igemm_fwd_kernel<WM, WN, TM, TN, false>), grid, dim3(256), 0, s, g, x, w, bias, y, act, slope, par, g_xcd);
     CN_LAUNCH_CHECK();
     return CN_OK;
 }
@@ -801,7 +811,7 @@ extern "C" int cn_conv_fwd(const CnConvGeom* gp, const float* x, const float* w,
             // bookkeeping of a VALU kernel dominates; the 128x32 MFMA tile with dead-tap skipping is faster
             dim3 grid(cn_cdiv(M, 128), 1, 1);
             cn_prof_begin(s, conv_flops(g));
-            hipLaunchKernelGGL((igemm_fwd_kernel<4, 1, 1, 1, true, false>), grid, dim3(256), 0, s, g, x, w, bias, y, act, slope, 1);
+            hipLaunchKernelGGL((igemm_fwd_kernel<4, 1, 1, 1, true, false>), grid, dim3(256), 0, s, g, x, w, bias, y, act, slope, 1, g_xcd);
             cn_prof_end(s);
             CN_LAUNCH_CHECK();
             return CN_OK;
