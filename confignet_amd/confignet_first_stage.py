@@ -366,6 +366,7 @@ class ConfigNetFirstStage:
                 st.wait_stream(cur)
                 with torch.cuda.stream(st):
                     g.graph.replay()
+                    g.finish()
             for _, st in zip(pending, self._side_streams):
                 cur.wait_stream(st)
         return outs
@@ -495,9 +496,10 @@ class ConfigNetFirstStage:
         for _ in range(start_step, n_steps):
             t0 = time.perf_counter()
             for _ in range(self.config["n_discriminator_updates"]):
-                d_loss = self.discriminator_training_step(real_training_set, discriminator_optimizer)
-                synth_d_loss = self.synth_discriminator_training_step(synth_training_set, discriminator_optimizer)
-                latent_d_loss = self.latent_discriminator_training_step(synth_training_set, discriminator_optimizer)
+                d_loss, synth_d_loss, latent_d_loss = self.run_concurrently([
+                    lambda: self.discriminator_training_step(real_training_set, discriminator_optimizer),
+                    lambda: self.synth_discriminator_training_step(synth_training_set, discriminator_optimizer),
+                    lambda: self.latent_discriminator_training_step(synth_training_set, discriminator_optimizer)])
             for _ in range(self.config["n_generator_updates"]):
                 g_loss = self.generator_training_step(real_training_set, synth_training_set, generator_optimizer)
             self.update_smoothed_weights()

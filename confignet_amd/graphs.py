@@ -8,18 +8,39 @@ STATIC device buffers, optimizer.advance()) and a device half that only reads th
 import torch
 
 from . import ops
+from . import optim
+from . import parallel
 from .nn import WEIGHTS_EPOCH
 
 
 class StepGraph:
     """fn() -> dict of detached device scalars.  Call 1..warmup run eagerly ON THE CAPTURE STREAM (autograd's
     per-leaf AccumulateGrad nodes are bound to the stream they are created on, so the leaves must first be
-    used under the stream the capture will use); the next call captures; later calls replay."""
+    used under the stream the capture will use); the next call captures; later calls replay.
+
+    Data-parallel runs (parallel.active()): the graph holds forward + backward only; the optimizer calls made by
+    fn are recorded (optim.deferred_updates) and issued eagerly after every replay by `finish()` -- gradient
+    all-reduce over RCCL, then Adam -- on whatever stream the replay was issued on."""
 
     def __init__(self, fn, warmup=1):
         self.fn, self.warmup = fn, warmup
         self.calls, self.graph, self.out = 0, None, None
         self.stream = torch.cuda.Stream()
+        self.split = parallel.active()
+        self.tail = []
+
+    def _run_fn(self):
+        if not self.split:
+            return self.fn()
+        with optim.deferred_updates() as items:
+            out = self.fn()
+        self.tail = list(items)
+        return out
+
+    def finish(self):
+        """Eager tail of one execution (no-op for single-rank graphs, whose Adam launches are graph nodes)."""
+        if self.tail:
+            optim.run_deferred(self.tail)
 
     def __call__(self):
         if self.graph is None:
@@ -28,17 +49,21 @@ class StepGraph:
                 self.calls += 1
                 self.stream.wait_stream(cur)
                 with torch.cuda.stream(self.stream):
-                    out = self.fn()
+                    out = self._run_fn()
                 cur.wait_stream(self.stream)
+                self.finish()
                 return out
             torch.cuda.synchronize()
             ops.prof_enable(False)                 # no event records inside a capture
             WEIGHTS_EPOCH[0] += 1                  # derived caches must be rebuilt INSIDE this graph
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph, stream=self.stream):
-                self.out = self.fn()
+            # RCCL's watchdog thread polls events while a process group exists: keep its calls out of the capture
+            mode = "thread_local" if self.split else "global"
+            with torch.cuda.graph(self.graph, stream=self.stream, capture_error_mode=mode):
+                self.out = self._run_fn()
             WEIGHTS_EPOCH[0] += 1
         self.graph.replay()
+        self.finish()
         return self.out
 
 

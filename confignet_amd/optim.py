@@ -10,6 +10,31 @@ from . import ops
 from . import parallel
 
 
+_deferred = None     # list of (optimizer, nets, slot) while a step is recorded with deferred updates
+
+
+class deferred_updates:
+    """Inside this context apply_gradients() only RECORDS its (optimizer, nets, slot): used when a step's device
+    half is captured into a HIP graph for a multi-rank run, where the gradient all-reduce (RCCL, not capturable
+    together with the compute here) and the Adam launches that depend on it are issued eagerly after each replay
+    (`run_deferred`)."""
+
+    def __enter__(self):
+        global _deferred
+        self.prev, _deferred = _deferred, []
+        self.items = _deferred
+        return self.items
+
+    def __exit__(self, *exc):
+        global _deferred
+        _deferred = self.prev
+
+
+def run_deferred(items):
+    for opt, nets, slot in items:
+        opt.apply_gradients(nets, advance=False, slot=slot)
+
+
 class Adam:
     def __init__(self, lr=0.001, beta_1=0.9, beta_2=0.999, epsilon=1e-7, amsgrad=False, **_):
         assert not amsgrad, "amsgrad is False everywhere in the reference"
@@ -44,6 +69,10 @@ class Adam:
         data-parallel gradient all-reduce first, then one fused Adam launch per arena."""
         if not isinstance(nets, (list, tuple)):
             nets = [nets]
+        if _deferred is not None:
+            assert not advance
+            _deferred.append((self, list(nets), slot))
+            return
         if advance:
             self.advance(slot)
         parallel.allreduce_gradients(nets)

@@ -437,9 +437,14 @@ def test_hip_graph_steps_match_eager():
     device-side lr_t scalar) replays to the same losses / weight updates as eager dispatch FROM THE SAME STATE:
     two graph iterations (eager warm-up + capture, then a pure replay), snapshot, one more replayed iteration,
     restore the snapshot and run the same iteration eagerly."""
-    from confignet_amd import ConfigNet, SyntheticFaceDataset, optim
+    import os
+    from confignet_amd import ConfigNet, SyntheticFaceDataset, optim, parallel
     from confignet_amd.confignet_first_stage import DEFAULT_CONFIG
     from confignet_amd.confignet_utils import merge_configs
+    forced_dp = os.environ.get("CN_FORCE_DP", "0") == "1"      # set by test_data_parallel_graph_path_single_rank
+    if forced_dp:
+        parallel.init_from_env()
+        assert parallel.active()
     ds = SyntheticFaceDataset(16, 128, seed=3)
     cfg = merge_configs(DEFAULT_CONFIG, {"batch_size": 4, "output_shape": (128, 128, 3)})
     ds.process_metadata(cfg, True)
@@ -451,6 +456,7 @@ def test_hip_graph_steps_match_eager():
     for _ in range(3):
         m.training_iteration(ds, ds, dopt, gopt)
     assert len(m._graphs) == 4 and all(g.graph is not None for g in m._graphs.values())
+    assert all(bool(g.tail) == forced_dp for g in m._graphs.values())     # DP: all-reduce + Adam outside the graph
     assert dopt.iterations == 9 and gopt.iterations == 3
     nets = m.all_networks()
 
@@ -490,3 +496,17 @@ def test_hip_graph_steps_match_eager():
         assert float(diff.max()) <= 6.5 * lr and float((diff > 1e-6).float().mean()) < 0.5, (float(diff.max()), float((diff > 1e-6).float().mean()))
         if n is not m.generator_smoothed:
             assert float(moved) > 0 or n.n_trainable == 0
+
+
+def test_data_parallel_graph_path_single_rank():
+    """The multi-rank dispatch (graphs hold forward+backward; RCCL all-reduce of the gradient arenas and Adam are
+    issued eagerly after each replay, also from the side streams of the concurrent discriminator phase) exercised on
+    one GPU: CN_FORCE_DP=1 creates a 1-rank RCCL process group and routes through exactly that code."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, CN_FORCE_DP="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", RANK="0", WORLD_SIZE="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_nets_gpu.py"), "-x", "-q", "-m", "gpu",
+                        "-k", "test_hip_graph_steps_match_eager"], env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
