@@ -68,22 +68,35 @@ class StepGraph:
 
 
 class StaticBuffers:
-    """Named device buffers with stable addresses; `stage` uploads new host data into them."""
+    """Named device buffers with stable addresses; `stage` uploads new host data into them through a pinned host
+    mirror with an asynchronous copy on the current stream.  (A pageable-memory copy blocks the host until everything
+    queued before it on that stream has run, i.e. until the previous step has finished, which serialised host
+    sampling with the device.)  The event per key bounds how far the host may run ahead: a mirror is not
+    overwritten before the copy that read it has executed."""
 
     def __init__(self, device):
         self.device, self.bufs, self.generation = device, {}, 0
+        self._pinned, self._events = {}, {}
 
     def stage(self, key, array, dtype=None):
         t = torch.as_tensor(array)
         if dtype is not None:
             t = t.to(dtype)
-        t = t.contiguous()
         b = self.bufs.get(key)
         if b is None or b.shape != t.shape or b.dtype != t.dtype:
             b = torch.empty(t.shape, dtype=t.dtype, device=self.device)
             self.bufs[key] = b
+            self._pinned[key] = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+            self._events[key] = None
             self.generation += 1                   # addresses changed: captured graphs are stale
-        b.copy_(t)
+        ev = self._events[key]
+        if ev is not None:
+            ev.synchronize()
+        else:
+            ev = self._events[key] = torch.cuda.Event()
+        self._pinned[key].copy_(t)
+        b.copy_(self._pinned[key], non_blocking=True)
+        ev.record()
         return b
 
     def __getitem__(self, key):
