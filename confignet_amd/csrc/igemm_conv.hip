@@ -745,6 +745,99 @@ int check_geom(const CnConvGeom* g) {
     return CN_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Data gradient of a 3x3 stride-2 convolution INTO a 3-channel image (first DiscrBlock of the discriminators and
+// of the latent regressor: 29 launches per second-stage iteration).  As a gather -- one output pixel = <= 4 live
+// taps x C channels x 3 outputs -- the 32-column MFMA tile spends 10x the useful work on padding.  Transposed,
+// every INPUT pixel owns one small dense product
+//     P[pixel][tap*3 + co] = sum_c gy[pixel][c] * wt[tap][c][co]        (C x 27, one 32-column MFMA block)
+// and each output pixel is the sum of the <= 4 entries of P that land on it (col2im).  One workgroup: (TH+1) x (TW+1)
+// input pixels (one halo row/column, on the side the padding fixes) -> P in LDS -> its 2TH x 2TW output pixels.
+// No atomics, gy is read once (+ halo), K order is permuted so that a lane's A operand is one float4 load.
+template <int NG>   // C = 8 * NG
+__global__ __launch_bounds__(256) void s2_image_dgrad_kernel(CnConvGeom g, const float* __restrict__ GY,
+                                                             const float* __restrict__ WT, float* __restrict__ Y) {
+    constexpr int TH = 8, TW = 32, RW = TW + 1, R = (TH + 1) * RW, MT = (R + 31) / 32, PS = 28, C = 8 * NG;
+    __shared__ float P[MT * 32][PS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, half = lane >> 5;
+    const int tiles_w = (g.in_w + TW - 1) / TW, tiles_h = (g.in_h + TH - 1) / TH;
+    int b = blockIdx.x;
+    const int tj = b % tiles_w; b /= tiles_w;
+    const int ti = b % tiles_h;
+    const int n = b / tiles_h;
+    const int i0 = ti * TH, j0 = tj * TW;
+    // output row y = 2i + p - kh (kh = 0..2): rows [2 i0, 2 i0 + 2 TH) are fed by input rows [i0 + off, i0 + off + TH]
+    const int offh = g.p_h == 2 ? -1 : 0, offw = g.p_w == 2 ? -1 : 0;
+
+    // B operand (K x 32 slice of wt, K permuted as below), resident in registers for the whole workgroup
+    float breg[NG][4];
+#pragma unroll
+    for (int jg = 0; jg < NG; ++jg)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int k = 8 * jg + 4 * half + q;
+            breg[jg][q] = l31 < 27 ? WT[((l31 / 3) * C + k) * 3 + l31 % 3] : 0.f;
+        }
+
+    for (int mt = wave; mt < MT; mt += 4) {
+        const int r = mt * 32 + l31;
+        const int ri = r / RW, rj = r - ri * RW;
+        const int ii = i0 + offh + ri, jj = j0 + offw + rj;
+        const bool inb = r < R && ii >= 0 && ii < g.in_h && jj >= 0 && jj < g.in_w;
+        // lane (row, half) holds channels 8 jg + 4 half + {0..3}: MFMA step (jg, q) contracts channel pair
+        // {8 jg + q, 8 jg + 4 + q} -- any K order is fine as long as A and B agree
+        const float* src = GY + (((long)n * g.in_h + ii) * g.in_w + jj) * C + 4 * half;
+        float4 a[NG];
+#pragma unroll
+        for (int jg = 0; jg < NG; ++jg)
+            a[jg] = inb ? *reinterpret_cast<const float4*>(src + 8 * jg) : make_float4(0.f, 0.f, 0.f, 0.f);
+        f32x16 acc;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+#pragma unroll
+        for (int jg = 0; jg < NG; ++jg) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[jg].x, breg[jg][0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[jg].y, breg[jg][1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[jg].z, breg[jg][2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[jg].w, breg[jg][3], acc, 0, 0, 0);
+        }
+        if (l31 < PS) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) P[mt * 32 + 4 * half + (q & 3) + 8 * (q >> 2)][l31] = acc[q];
+        }
+    }
+    __syncthreads();
+
+    // col2im: 2TH x 2TW output pixels, 4 per thread
+#pragma unroll
+    for (int q = 0; q < (2 * TH * 2 * TW) / 256; ++q) {
+        const int px = threadIdx.x + 256 * q;
+        const int ly = px / (2 * TW), lx = px - ly * (2 * TW);
+        const int y = 2 * i0 + ly, x = 2 * j0 + lx;
+        if (y >= g.out_h || x >= g.out_w) continue;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int vy = y - g.p_h + kh;
+            if (vy < 0 || (vy & 1) || (vy >> 1) >= g.in_h) continue;
+            const int ri = (vy >> 1) - (i0 + offh);
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int vx = x - g.p_w + kw;
+                if (vx < 0 || (vx & 1) || (vx >> 1) >= g.in_w) continue;
+                const float* pr = &P[ri * RW + (vx >> 1) - (j0 + offw)][(kh * 3 + kw) * 3];
+                s0 += pr[0];
+                s1 += pr[1];
+                s2 += pr[2];
+            }
+        }
+        float* dst = Y + (((long)n * g.out_h + y) * g.out_w + x) * 3;
+        dst[0] = s0;
+        dst[1] = s1;
+        dst[2] = s2;
+    }
+}
+
 static int g_force_kb16 = -1;
 static int g_xcd = getenv("CN_NO_XCD") ? 0 : 1;
 
@@ -806,6 +899,16 @@ extern "C" int cn_conv_fwd(const CnConvGeom* gp, const float* x, const float* w,
         CN_CHECK_ARG(lds <= 64 * 1024, "thin conv: filter of %zu bytes does not fit the LDS stage", lds);
         const int T = g.k_d * g.k_h * g.k_w, CL = g.cin / 4;
         const bool dl1 = g.dl_d * g.dl_h * g.dl_w == 1;
+        if (g.nd == 2 && g.k_h == 3 && g.k_w == 3 && g.dl_h == 2 && g.dl_w == 2 && g.s_h == 1 && g.s_w == 1 && !g.up &&
+            g.cout == 3 && g.cin == 48 && !bias && act == CN_ACT_NONE && g.p_h >= 0 && g.p_h <= 2 && g.p_w >= 0 &&
+            g.p_w <= 2 && g.out_h <= 2 * g.in_h && g.out_w <= 2 * g.in_w && !getenv("CN_NO_S2IMG")) {
+            dim3 grid((unsigned)(g.n * cn_cdiv(g.in_h, 8) * cn_cdiv(g.in_w, 32)));
+            cn_prof_begin(s, conv_flops(g));
+            hipLaunchKernelGGL((s2_image_dgrad_kernel<6>), grid, dim3(256), 0, s, g, x, w, y);
+            cn_prof_end(s);
+            CN_LAUNCH_CHECK();
+            return CN_OK;
+        }
         if (par && g.cin % BK == 0 && act == CN_ACT_NONE) {
             // zero-stuffed data-gradient into a thin image: per pixel only ~taps/4 * cin MACs, the per-pixel
             // bookkeeping of a VALU kernel dominates; the 128x32 MFMA tile with dead-tap skipping is faster

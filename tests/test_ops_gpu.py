@@ -35,6 +35,8 @@ CONV_CASES = [
     ((1, 8, 8, 8, 64), (3, 3, 3), 64, 1, 0, None, 1, 0.3),    # map_3d_post
     ((3, 16, 16, 1024), (1, 1), 512, 1, 0, None, 1, 0.2),     # projection conv
     ((2, 64, 64, 3), (3, 3), 48, 2, 0, None, 0, 0.0),         # D block 0 (scalar gather, stride 2)
+    ((2, 37, 45, 3), (3, 3), 48, 2, 0, None, 0, 0.0),         # D block 0, odd extents (other SAME padding split)
+    ((1, 100, 70, 3), (3, 3), 48, 2, 0, None, 0, 0.0),        # D block 0, extents that do not fill the 8x32 tiles
     ((2, 32, 32, 48), (3, 3), 96, 2, 0, None, 0, 0.0),        # D block 1
     ((2, 17, 13, 48), (3, 3), 96, 2, 0, None, 0, 0.0),        # ragged odd extents
     ((2, 32, 32, 3), (3, 3), 64, 1, 0, None, 2, 0.0),         # VGG conv1_1 + relu
