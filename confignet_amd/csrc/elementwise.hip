@@ -125,6 +125,63 @@ __global__ __launch_bounds__(256) void nc_lin2_kernel(const float* __restrict__ 
     }
 }
 
+// nc_lin2 for tensors big enough to care: grid (gx, n) with gx*256 a multiple of the channel-group count, so a
+// thread keeps ONE channel group for its whole grid-stride walk through a sample: no per-element div/mod (the
+// 64-bit ones of the generic kernel cost more than the 48 bytes they index) and the (n, c) coefficients live in
+// registers.  G = float4 groups per sample.
+template <int V>
+__global__ __launch_bounds__(256) void nc_lin2_rows_kernel(const float* __restrict__ x1, const float* __restrict__ a1,
+                                                           const float* __restrict__ x2, const float* __restrict__ a2,
+                                                           const float* __restrict__ bb, const float* __restrict__ a3,
+                                                           const float* __restrict__ b3, float* __restrict__ y, int G,
+                                                           int CG, int cstride, int flags, float slope) {
+    const int t0 = blockIdx.x * 256 + threadIdx.x;
+    const int adv = gridDim.x * 256;
+    const int cg = t0 % CG;
+    const long ci = (long)blockIdx.y * cstride + (long)cg * V;
+    float k1[V], k2[V], kb[V], k3[V], kb3[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+        k1[e] = a1 ? a1[ci + e] : 1.f;
+        k2[e] = a2 ? a2[ci + e] : 1.f;
+        kb[e] = bb ? bb[ci + e] : 0.f;
+        k3[e] = a3 ? a3[ci + e] : 0.f;
+        kb3[e] = (a3 && b3) ? b3[ci + e] : 0.f;
+    }
+    const long base = (long)blockIdx.y * G;
+    const bool f1 = flags & 1, f2 = flags & 2, fm = flags & 4, fr = flags & 8;
+    for (int j = t0; j < G; j += adv) {
+        const long i = (base + j) * V;
+        float v1[V], v2[V], r[V];
+        if (V == 4) {
+            if (x1) {
+                const float4 t = *reinterpret_cast<const float4*>(x1 + i);
+                v1[0] = t.x; v1[1 % V] = t.y; v1[2 % V] = t.z; v1[3 % V] = t.w;
+            }
+            if (x2) {
+                const float4 t = *reinterpret_cast<const float4*>(x2 + i);
+                v2[0] = t.x; v2[1 % V] = t.y; v2[2 % V] = t.z; v2[3 % V] = t.w;
+            }
+        } else {
+            if (x1) v1[0] = x1[i];
+            if (x2) v2[0] = x2[i];
+        }
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            r[e] = kb[e];
+            if (x1) r[e] += k1[e] * (f1 ? lrelu(v1[e], slope) : v1[e]);
+            if (x2) {
+                r[e] += k2[e] * (f2 ? lrelu(v2[e], slope) : v2[e]);
+                if (fm) r[e] *= v2[e] > 0.f ? 1.f : slope;
+                if (a3) r[e] += k3[e] * v2[e] + kb3[e];
+            }
+            if (fr) r[e] = fmaxf(r[e], 0.f);
+        }
+        if (V == 4) *reinterpret_cast<float4*>(y + i) = make_float4(r[0], r[1 % V], r[2 % V], r[3 % V]);
+        else y[i] = r[0];
+    }
+}
+
 __global__ void act_fwd_kernel(const float* x, float* y, size_t n, int act, float slope) {   // may run in place
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
         y[i] = cn_apply_act(x[i], act, slope);
@@ -367,6 +424,7 @@ extern "C" int cn_nc_reduce(const float* x1, const float* x2, float* s1, float* 
     // ~2048 workgroups in total, at least 4*TY rows each
     long want = 2048 / ((long)cblk * n);
     if (want < 1) want = 1;
+    if (want > 256) want = 256;     // same-address atomics serialise (~100 ns each): 2048 per address cost 200 us
     long rpb = (s + want - 1) / want;
     if (rpb < 4 * TY) rpb = 4 * TY;
     const int sblk = cn_cdiv(s, rpb);
@@ -385,6 +443,25 @@ extern "C" int cn_nc_lin2(const float* x1, const float* a1, const float* x2, con
     const int V = (c % 4 == 0) ? 4 : 1;
     const long total = (long)n * s * (c / V);
     hipStream_t st = (hipStream_t)stream;
+    {
+        // big tensors: per-sample grid with a fixed channel group per thread (nc_lin2_rows_kernel)
+        const int CG = c / V;
+        const int ny = cstride ? n : 1;
+        const long G = total / ny;                 // groups per grid row (per_channel: the whole tensor)
+        int gcd = CG, r256 = 256;
+        while (r256) { const int t = gcd % r256; gcd = r256; r256 = t; }
+        const int q = CG / gcd;                    // gx must be a multiple of q
+        if (G >= 16384 && G < 2147483647L - 256 * 8192L && q <= 32) {
+            long gx = (G + 256 * 4 - 1) / (256 * 4);           // ~4 groups per thread
+            if (gx * ny > 8192) gx = 8192 / ny;
+            if (gx < 1) gx = 1;
+            gx = (gx + q - 1) / q * q;
+            if (V == 4) hipLaunchKernelGGL(nc_lin2_rows_kernel<4>, dim3((unsigned)gx, ny), dim3(256), 0, st, x1, a1, x2, a2, bb, a3, b3, y, (int)G, CG, cstride, flags, slope);
+            else hipLaunchKernelGGL(nc_lin2_rows_kernel<1>, dim3((unsigned)gx, ny), dim3(256), 0, st, x1, a1, x2, a2, bb, a3, b3, y, (int)G, CG, cstride, flags, slope);
+            CN_LAUNCH_CHECK();
+            return CN_OK;
+        }
+    }
     if (V == 4) hipLaunchKernelGGL(nc_lin2_kernel<4>, dim3(ew_blocks(total)), dim3(256), 0, st, x1, a1, x2, a2, bb, a3, b3, y, total, s, c, cstride, flags, slope);
     else hipLaunchKernelGGL(nc_lin2_kernel<1>, dim3(ew_blocks(total)), dim3(256), 0, st, x1, a1, x2, a2, bb, a3, b3, y, total, s, c, cstride, flags, slope);
     CN_LAUNCH_CHECK();

@@ -188,8 +188,14 @@ def _nsc(x):
 def nc_reduce(x1, x2=None, want_sum=True, want_dot=True, flags=0, slope=0.0, per_channel=False):
     """(sum_s f1(x1), sum_s f1(x1)*f2(x2 or x1)) per (n, c); per_channel folds n into s."""
     n, s, c = _nsc(x1)
+    rep = 1
     if per_channel:
-        n, s = 1, n * s
+        # every workgroup ends in one atomic per channel: spread a long reduction over `rep` partial rows (as if
+        # they were samples) so that no address takes more than ~128 of them, then add the partials
+        rows = n * s
+        if rows >= 8192:
+            rep = next(r for r in (16, 8, 4, 2, 1) if rows % r == 0)
+        n, s = rep, rows // rep
     if want_sum and want_dot:           # adjacent outputs: cleared by one launch (or by the step's zero pool)
         s12 = zero_pool_alloc((2, n, c), x1.device)
         if s12 is not None:
@@ -201,6 +207,12 @@ def nc_reduce(x1, x2=None, want_sum=True, want_dot=True, flags=0, slope=0.0, per
         s1 = torch.empty((n, c), device=x1.device, dtype=torch.float32) if want_sum else None
         s2 = torch.empty((n, c), device=x1.device, dtype=torch.float32) if want_dot else None
     check(lib.cn_nc_reduce(_ptr(x1), _ptr(x2), _ptr(s1), _ptr(s2), n, s, c, flags, slope, _stream()), "cn_nc_reduce")
+    if rep > 1:
+        if want_sum and want_dot:
+            s12 = s12.sum(1, keepdim=True)
+            return s12[0], s12[1]
+        s1 = s1.sum(0, keepdim=True) if s1 is not None else None
+        s2 = s2.sum(0, keepdim=True) if s2 is not None else None
     return s1, s2
 
 
