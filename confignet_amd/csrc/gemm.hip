@@ -96,6 +96,38 @@ __global__ __launch_bounds__(256) void gemm_kernel(int ta, int tb, int M, int N,
     }
 }
 
+// Dense layers with <= 4 outputs and few rows (discriminator / rotation heads: M = batch, N = 1 or 3, K up to 32768): a
+// 64x64 MFMA tile would walk the whole K in ONE workgroup (120 us for K = 2048).  One workgroup per (row, K slice)
+// instead: 256 lanes stride K, wave shuffles + LDS combine.  bias/act need the full sum, so slices > 1 only without act.
+__global__ __launch_bounds__(256) void thin_gemm_kernel(int M, int N, int K, const float* __restrict__ A, int lda,
+                                                        const float* __restrict__ B, int ldb, float* __restrict__ C, int ldc,
+                                                        const float* __restrict__ bias, int act, float slope, int kps) {
+    const int m = blockIdx.x;
+    const int kbeg = blockIdx.y * kps, kend = min(K, kbeg + kps);
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    const float* ar = A + (long)m * lda;
+    for (int k = kbeg + threadIdx.x; k < kend; k += 256) {
+        const float av = ar[k];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (j < N) acc[j] += av * B[(long)k * ldb + j];
+    }
+    __shared__ float red[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float v = acc[j];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][j] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < N) {
+        const int j = threadIdx.x;
+        const float v = red[0][j] + red[1][j] + red[2][j] + red[3][j];
+        if (gridDim.y > 1) unsafeAtomicAdd(&C[(long)m * ldc + j], v + ((bias && blockIdx.y == 0) ? bias[j] : 0.f));
+        else C[(long)m * ldc + j] = cn_apply_act(v + (bias ? bias[j] : 0.f), act, slope);
+    }
+}
+
 __global__ void zero_rows_kernel(float* C, int M, int N, int ldc) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < (long)M * N) C[(i / N) * ldc + i % N] = 0.f;
@@ -108,6 +140,19 @@ extern "C" int cn_gemm(int ta, int tb, int m, int n, int k, const float* a, int 
     CN_CHECK_ARG(m > 0 && n > 0 && k > 0 && a && b && c, "gemm: bad args m=%d n=%d k=%d", m, n, k);
     CN_CHECK_ARG(lda >= (ta ? m : k) && ldb >= (tb ? k : n) && ldc >= n, "gemm: leading dimension too small");
     hipStream_t s = (hipStream_t)stream;
+    if (!ta && !tb && n <= 4 && m <= 256 && k >= 128) {
+        int slices = 1;
+        if (act == CN_ACT_NONE && k >= 8192) slices = k / 4096;
+        const int kps = (k + slices - 1) / slices;
+        slices = (k + kps - 1) / kps;
+        if (slices > 1) {
+            hipLaunchKernelGGL(zero_rows_kernel, dim3(cn_cdiv((long)m * n, 256)), dim3(256), 0, s, c, m, n, ldc);
+            CN_LAUNCH_CHECK();
+        }
+        hipLaunchKernelGGL(thin_gemm_kernel, dim3(m, slices), dim3(256), 0, s, m, n, k, a, lda, b, ldb, c, ldc, bias, act, slope, kps);
+        CN_LAUNCH_CHECK();
+        return CN_OK;
+    }
     const long tiles = (long)cn_cdiv(m, 64) * cn_cdiv(n, 64);
     int splitk = 1;
     if (act == CN_ACT_NONE && tiles < 128 && k >= 1024) {

@@ -96,7 +96,8 @@ def test_conv_fwd_dgrad_wgrad(case):
 
 
 @pytest.mark.parametrize("m,n,k,ta,tb", [(16, 148, 32768, 0, 0), (16, 1, 32768, 0, 0), (8, 145, 145, 0, 0), (4096, 217, 145, 0, 0),
-                                         (16, 32768, 148, 0, 1), (32768, 148, 16, 1, 0), (7, 5, 3, 1, 1), (130, 70, 33, 0, 1)])
+                                         (16, 32768, 148, 0, 1), (32768, 148, 16, 1, 0), (7, 5, 3, 1, 1), (130, 70, 33, 0, 1),
+                                         (16, 3, 2048, 0, 0), (16, 1, 768, 0, 0), (5, 4, 129, 0, 0)])
 def test_gemm(m, n, k, ta, tb):
     from confignet_amd import ops
     rng = np.random.default_rng(m * 7 + n)
@@ -105,7 +106,7 @@ def test_gemm(m, n, k, ta, tb):
     bias = rng.normal(size=n)
     ref = (t64(a).T if ta else t64(a)) @ (t64(b).T if tb else t64(b)) + t64(bias)
     close(ops.gemm(dev(a), dev(b), bool(ta), bool(tb), dev(bias)), ref, what="gemm")
-    if k < 1000:
+    if k < 1000 or n <= 4:
         close(ops.gemm(dev(a), dev(b), bool(ta), bool(tb), dev(bias), act=1, slope=0.3), O.leaky_relu(ref, 0.3), what="gemm+lrelu")
 
 
