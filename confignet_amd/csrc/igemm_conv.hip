@@ -959,14 +959,26 @@ extern "C" int cn_conv_fwd(const CnConvGeom* gp, const float* x, const float* w,
     else if (g.cout > 64 && t128 >= 512) { cfg = 0; tiles = t128; }
     else if (t128x64 >= 512) { cfg = 1; tiles = t128x64; }
     else { cfg = 2; tiles = (long)cn_cdiv(M, 64) * cn_cdiv(g.cout, 64); }
+    // cout = 96 / 192 (discriminator blocks 1-2 and the data gradients of blocks 2-3): a 128 x 96 tile wastes nothing
+    // where 128- or 64-wide tiles pad a quarter of their columns
+    static const int no_n96 = getenv("CN_NO_N96") ? 1 : 0;
+    if (!no_n96 && g.cout % 96 == 0 && g.cout % 128 != 0 &&
+        (long)cn_cdiv(M, 128) * (g.cout / 96) >= (g.cout == 96 ? 256 : 512)) {
+        cfg = 4;
+        tiles = (long)cn_cdiv(M, 128) * (g.cout / 96);
+    }
     // split-K for small outputs with a long reduction (ResNet stage 4/5, Conv3D at 4^3->8^3)
     int splits = 1;
-    if (vec && tiles < 512) {
+    // (parity-ordered data gradients: tiles of the 4-tap class carry 4x the K of the 1-tap class, so more, smaller
+    // K slices also even out the load -- conv_tune.py dgrad: 123 -> 95 us at M=16384 N=192, 124 -> 104 us at M=4096 N=384)
+    const bool par_small = par && cfg == 2;          // 64 x 64 tiles of a parity-ordered data gradient
+    if (vec && tiles < (par_small ? 1024 : 512)) {
         long nks = (long)g.k_d * g.k_h * g.k_w * (g.cin / BK);
         if (par) nks /= (long)g.dl_d * g.dl_h * g.dl_w;
-        long want = (1024 + tiles - 1) / tiles;      // aim at ~4 workgroups per CU
+        long want = ((par_small ? 3072 : 1024) + tiles - 1) / tiles;      // aim at ~4 (12) workgroups per CU
         if (want > 16) want = 16;
-        if (want > nks / 16) want = nks / 16;        // at least 16 K steps per workgroup
+        const long min_steps = par_small ? 8 : 16;   // average K steps per workgroup
+        if (want > nks / min_steps) want = nks / min_steps;
         if (want > 1) splits = (int)want;
     }
     if (const char* e = getenv("CN_CFG")) cfg = atoi(e);          // tuning overrides (scripts/conv_tune.py)
@@ -979,6 +991,7 @@ extern "C" int cn_conv_fwd(const CnConvGeom* gp, const float* x, const float* w,
     int e;
     switch (cfg) {
         case 3: e = launch_fwd<4, 1, 1, 1>(g, vec, par, splits, x, w, bias, y, kact, slope, s); break;   // 128 x 32
+        case 4: e = launch_fwd<4, 1, 1, 3>(g, vec, par, splits, x, w, bias, y, kact, slope, s); break;   // 128 x 96
         case 0: e = launch_fwd<2, 2, 2, 2>(g, vec, par, splits, x, w, bias, y, kact, slope, s); break;   // 128 x 128
         case 1: e = launch_fwd<2, 2, 2, 1>(g, vec, par, splits, x, w, bias, y, kact, slope, s); break;   // 128 x 64
         default: e = launch_fwd<2, 2, 1, 1>(g, vec, par, splits, x, w, bias, y, kact, slope, s); break;  // 64 x 64
