@@ -1044,8 +1044,11 @@ extern "C" int cn_conv_wgrad(const CnConvGeom* gp, const float* x, const float* 
     }
     cn_prof_begin(s, conv_flops(g));
     int e;
+    static const int no_n96 = getenv("CN_NO_N96") ? 1 : 0;
     if (g.cout <= 32)
         e = launch_wgrad<4, 1, 1, 1>(g, x, gy, gw, s);       // 128 (tap,ci) x 32 co
+    else if (!no_n96 && Ktot >= 128 && g.cout % 96 == 0 && g.cout % 128 != 0)
+        e = launch_wgrad<4, 1, 1, 3>(g, x, gy, gw, s);       // 128 x 96: cout 96 / 192 without column padding
     else if (Ktot >= 128 && g.cout >= 128)
         e = launch_wgrad<2, 2, 2, 2>(g, x, gy, gw, s);       // 128 x 128
     else
