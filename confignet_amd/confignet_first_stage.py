@@ -94,6 +94,8 @@ class ConfigNetFirstStage:
         self._graphs = {}
         self._deferred = None
         self._side_streams = []
+        self.fork_generator_step = os.environ.get("CN_NO_FORK") is None   # second stage: real / synthetic branches of the generator step on two streams
+        self._branch_stream_obj = None
         self.use_graphs = False       # capture each step's device half into a HIP graph (single-GPU runs)
 
         self.generator = None
@@ -289,6 +291,12 @@ class ConfigNetFirstStage:
             dataset._cn_device_pool = cache
         return cache
 
+    @property
+    def _branch_stream(self):
+        if self._branch_stream_obj is None:
+            self._branch_stream_obj = torch.cuda.Stream()
+        return self._branch_stream_obj
+
     def _dev(self, a):
         return torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32)).to(self.device)
 
@@ -359,16 +367,17 @@ class ConfigNetFirstStage:
         finally:
             self._deferred = None
         if pending:
+            # every graph is replayed on the stream it was captured on (streams that exist before any graph is
+            # instantiated: creating replay streams later changed how they share hardware queues with the internal
+            # streams of multi-branch graphs and serialised this phase)
             cur = torch.cuda.current_stream()
-            while len(self._side_streams) < len(pending):
-                self._side_streams.append(torch.cuda.Stream())
-            for g, st in zip(pending, self._side_streams):
-                st.wait_stream(cur)
-                with torch.cuda.stream(st):
+            for g in pending:
+                g.stream.wait_stream(cur)
+                with torch.cuda.stream(g.stream):
                     g.graph.replay()
                     g.finish()
-            for _, st in zip(pending, self._side_streams):
-                cur.wait_stream(st)
+            for g in pending:
+                cur.wait_stream(g.stream)
         return outs
 
     def _discriminator_update(self, net, real_imgs, fake_imgs, optimizer, slot="default"):

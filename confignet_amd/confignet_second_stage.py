@@ -100,23 +100,38 @@ class ConfigNet(ConfigNetFirstStage):
         return self._run_step("ld", (real_training_set, synth_training_set), optimizer, device)
 
     def _generator_loss(self, facemodel_params, synth_rotations, synth_imgs, eye_masks, real_imgs):
-        """The taped part of ConfigNet.generator_training_step (l.167-211)."""
+        """The taped part of ConfigNet.generator_training_step (l.167-211).
+
+        The real-image branch (encoder -> generator -> perceptual / adversarial terms) and the synthetic branch
+        (synthetic encoder -> generator -> perceptual / eye / adversarial terms) only meet in the latent regressor
+        and in the loss sum, so the real branch is issued on a second stream: forward here, and backward too, since
+        autograd replays every node on the stream its forward ran on.  Captured into the step's HIP graph the two
+        branches become parallel paths, and the many small launches of one overlap the big ones of the other."""
         cfg = self.config
         n_synth, n_real = synth_imgs.shape[0], real_imgs.shape[0]
         losses = {}
+        main = torch.cuda.current_stream()
+        side = self._branch_stream if self.fork_generator_step else main
+        if side is not main:
+            side.wait_stream(main)
+        with torch.cuda.stream(side):
+            real_latents, real_rotations = self.encoder(real_imgs)
+            generator_output_real = self.generator((real_latents, real_rotations))
+            image_loss_real = cfg["image_loss_weight"] * self.perceptual_loss.loss(real_imgs, generator_output_real)
+            gan_real = [GAN_G_loss(o) for o in self.discriminator(generator_output_real).values()]
+            out_real = self.latent_discriminator(real_latents)
         synth_latents = self.synthetic_encoder(facemodel_params)
         generator_output_synth = self.generator((synth_latents, synth_rotations))
-        real_latents, real_rotations = self.encoder(real_imgs)
-        generator_output_real = self.generator((real_latents, real_rotations))
         losses["image_loss_synth"] = cfg["image_loss_weight"] * self.perceptual_loss.loss(synth_imgs, generator_output_synth)
-        losses["image_loss_real"] = cfg["image_loss_weight"] * self.perceptual_loss.loss(real_imgs, generator_output_real)
+        if side is not main:
+            main.wait_stream(side)
+        losses["image_loss_real"] = image_loss_real
         losses["eye_loss"] = cfg["eye_loss_weight"] * eye_loss(synth_imgs, generator_output_synth, eye_masks)
         for i, o in enumerate(self.synth_discriminator(generator_output_synth).values()):
             losses["GAN_loss_synth_" + str(i)] = GAN_G_loss(o)
-        for i, o in enumerate(self.discriminator(generator_output_real).values()):
-            losses["GAN_loss_real_" + str(i)] = GAN_G_loss(o)
+        for i, l in enumerate(gan_real):
+            losses["GAN_loss_real_" + str(i)] = l
         out_synth = self.latent_discriminator(synth_latents)
-        out_real = self.latent_discriminator(real_latents)
         # labels: real -> 0, synth -> 1 (l.160-163,195-197); mean over the concatenation
         latent_gan_loss = (n_real * GAN_D_loss(0.0, out_real) + n_synth * GAN_D_loss(1.0, out_synth)) / (n_real + n_synth)
         losses["latent_GAN_loss"] = cfg["domain_adverserial_loss_weight"] * latent_gan_loss

@@ -1,4 +1,5 @@
 """Config / bookkeeping helpers (reference: confignet/confignet_utils.py:14-61,198-212)."""
+import copy
 import json
 import sys
 
@@ -18,7 +19,7 @@ def merge_configs(default_config, input_config):
             else:
                 result[name] = rhs
         else:
-            result[name] = lhs
+            result[name] = copy.deepcopy(lhs)      # never alias the defaults' nested dicts: callers mutate their config
     for name in input_config:
         rhs = input_config[name]
         if isinstance(rhs, dict) and name in default_config.keys():

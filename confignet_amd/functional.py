@@ -39,7 +39,8 @@ def _tflip_cached(w):
     """weight_tflip(w), cached on the tensor until the weights change (nn.WEIGHTS_EPOCH) or, for
     non-parameter tensors, until torch's version counter moves."""
     from .nn import WEIGHTS_EPOCH
-    key = (WEIGHTS_EPOCH[0], w._version, w.data_ptr())
+    # (per stream: a forked step computes it once on each branch instead of sharing a tensor across streams)
+    key = (WEIGHTS_EPOCH[0], w._version, w.data_ptr(), torch.cuda.current_stream().cuda_stream if w.is_cuda else 0)
     c = getattr(w, "_cn_tflip", None)
     if c is not None and c[0] == key:
         return c[1]
