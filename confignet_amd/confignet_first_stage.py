@@ -452,15 +452,25 @@ class ConfigNetFirstStage:
         """The taped part of generator_training_step (l.518-554)."""
         cfg = self.config
         losses = {}
+        # the sampled-latent branch (generator -> discriminator) runs on a second stream next to the synthetic branch
+        # (see ConfigNet._generator_loss); both meet again in the latent regressor
+        main = torch.cuda.current_stream()
+        side = self._branch_stream if self.fork_generator_step else main
+        if side is not main:
+            side.wait_stream(main)
+        with torch.cuda.stream(side):
+            generator_output_real = self.generator((real_latents, real_rotations))
+            gan_real = [GAN_G_loss(o) for o in self.discriminator(generator_output_real).values()]
         synth_latents = self.synthetic_encoder(facemodel_params)
         generator_output_synth = self.generator((synth_latents, synth_rotations))
-        generator_output_real = self.generator((real_latents, real_rotations))
         losses["image_loss"] = cfg["image_loss_weight"] * self.perceptual_loss.loss(gt_imgs, generator_output_synth)
         losses["eye_loss"] = cfg["eye_loss_weight"] * eye_loss(gt_imgs, generator_output_synth, eye_masks)
         for i, o in enumerate(self.synth_discriminator(generator_output_synth).values()):
             losses["GAN_loss_synth_" + str(i)] = GAN_G_loss(o)
-        for i, o in enumerate(self.discriminator(generator_output_real).values()):
-            losses["GAN_loss_real_" + str(i)] = GAN_G_loss(o)
+        if side is not main:
+            main.wait_stream(side)
+        for i, l in enumerate(gan_real):
+            losses["GAN_loss_real_" + str(i)] = l
         latent_discriminator_output = self.latent_discriminator(synth_latents)
         losses["latent_GAN_loss"] = cfg["domain_adverserial_loss_weight"] * GAN_G_loss(latent_discriminator_output)
         stacked_latents = torch.cat((synth_latents, real_latents), dim=0)
