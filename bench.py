@@ -39,6 +39,8 @@ def main():
     ap.add_argument("--pool", type=int, default=512, help="images in each synthetic uint8 pool")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graphs", action="store_true", help="dispatch every kernel eagerly (no HIP graph replay)")
+    ap.add_argument("--serial", action="store_true",
+                    help="one stream, eager dispatch: no kernel overlaps another (the form to trace for per-kernel durations)")
     ap.add_argument("--cpu-batch", type=int, default=16)
     args = ap.parse_args()
 
@@ -75,6 +77,9 @@ def main():
     # Every step's device half is one captured HIP graph (confignet_amd/graphs.py); with N > 1 the graph ends
     # after the backward pass and the RCCL all-reduce + Adam follow eagerly on the same stream.  Warm-up covers
     # the eager call + the capture of each graph.
+    if args.serial:
+        args.no_graphs = True
+        model.fork_generator_step = False
     model.use_graphs = not args.no_graphs
     try:
         for _ in range(max(args.warmup, 2 if model.use_graphs else 0)):
@@ -97,9 +102,11 @@ def main():
     finite = all(np.isfinite(float(l["loss_sum"].detach())) for l in losses)
 
     # Roofline of the dominant kernel class, measured live with HIP events recorded on the launch stream
-    # around every implicit-GEMM convolution launch of the SAME K iterations dispatched eagerly right after the
-    # timed region (event records cannot sit inside a replayed graph; the kernels and shapes are identical).
+    # around every implicit-GEMM convolution launch of the SAME K iterations dispatched eagerly AND ON ONE STREAM
+    # right after the timed region (event records cannot sit inside a replayed graph, and a per-kernel duration only
+    # means something when the kernel has the GPU to itself; the kernels and shapes are identical).
     model.use_graphs = False
+    model.fork_generator_step = False      # kernels of the two branches would overlap and stretch each other's events
     ops.prof_reset()
     ops.prof_enable(True)
     for _ in range(0 if os.environ.get("CN_BENCH_SKIP_ROOFLINE_PASS") == "1" else args.steps):   # (trace-only runs)
@@ -126,13 +133,15 @@ def main():
                                    "batch %d per GPU, fp32, Keras-Adam" % (args.res, args.res, args.batch),
                        "global_batch": args.batch * world, "resolution": args.res, "latent_dim": cfg_latent(model),
                        "parallelism": "dp%d" % world, "losses_finite": bool(finite),
-                       "dispatch": ("eager" if args.no_graphs else "hip-graph replay per step function" +
+                       "dispatch": ("eager, one stream" if args.serial else "eager" if args.no_graphs else
+                                    "hip-graph replay per step function, D-type steps concurrent, G step forked over 2 streams" +
                                     ("" if not parallel.active() else " (fwd+bwd), eager RCCL all-reduce + Adam"))},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": pmc_traffic(),
                          "kernel": "igemm_fwd/igemm_wgrad (implicit-GEMM conv, v_mfma_f32_32x32x2_f32)",
                          "launches_per_step": launches / max(args.steps, 1),
                          "kernel_ms_per_step": round(kernel_ms / max(args.steps, 1), 3),
+                         "measured": "HIP events around every launch of the class, same K iterations run serially (eager, one stream)",
                          "algorithmic_gflop_per_step": round(kernel_flops / max(args.steps, 1) / 1e9, 2)},
         }
         if world == 1 and not args.no_cpu_baseline:
