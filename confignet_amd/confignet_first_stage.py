@@ -23,6 +23,10 @@ from .losses import (GAN_G_loss, compute_discriminator_loss, compute_latent_disc
 from .nn import backward_into_arenas, require_gpu
 from .perceptual_loss import PerceptualLoss
 
+# the generator step deliberately runs one branch of the tape on a second stream (see _generator_loss)
+if hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
+    torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
+
 DEFAULT_CONFIG = {
     "model_type": None,
     "latent_dim": 128,

@@ -12,17 +12,27 @@ constexpr int BK = 16;   // K depth of one LDS stage
 template <int TM, int TN, int LDA, int LDB, int KB = BK>
 __device__ __forceinline__ void mma_step(const float (*As)[LDA], const float (*Bs)[LDB], f32x16 (&acc)[TM][TN],
                                          int a_col, int b_col, int half) {
+    // operands of k-pair kk+2 are fetched from LDS BEFORE the MFMAs of k-pair kk are issued (two register sets), so
+    // the wave never sits in s_waitcnt lgkmcnt(0) between two MFMA groups
+    float a[2][TM], b[2][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) a[0][i] = As[half][a_col + 32 * i];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) b[0][j] = Bs[half][b_col + 32 * j];
 #pragma unroll
     for (int kk = 0; kk < KB; kk += 2) {
-        float a[TM], b[TN];
+        const int cur = (kk >> 1) & 1, nxt = cur ^ 1;
+        if (kk + 2 < KB) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i) a[i] = As[kk + half][a_col + 32 * i];
+            for (int i = 0; i < TM; ++i) a[nxt][i] = As[kk + 2 + half][a_col + 32 * i];
 #pragma unroll
-        for (int j = 0; j < TN; ++j) b[j] = Bs[kk + half][b_col + 32 * j];
+            for (int j = 0; j < TN; ++j) b[nxt][j] = Bs[kk + 2 + half][b_col + 32 * j];
+        }
+        __builtin_amdgcn_sched_barrier(0);   // keep the fetch of the next operands ahead of this group's MFMAs
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
     }
 }
-
