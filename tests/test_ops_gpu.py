@@ -110,7 +110,8 @@ def test_gemm(m, n, k, ta, tb):
         close(ops.gemm(dev(a), dev(b), bool(ta), bool(tb), dev(bias), act=1, slope=0.3), O.leaky_relu(ref, 0.3), what="gemm+lrelu")
 
 
-@pytest.mark.parametrize("shape", [(2, 16, 16, 48), (3, 8, 8, 8, 128), (2, 128, 128, 32), (2, 5, 7, 3), (4, 1, 1, 2048)])
+@pytest.mark.parametrize("shape", [(2, 16, 16, 48), (3, 8, 8, 8, 128), (2, 128, 128, 32), (2, 5, 7, 3), (4, 1, 1, 2048),
+                                   (2, 64, 64, 48), (3, 40, 24, 20), (5, 64, 64, 3)])
 def test_nc_reduce_and_lin2(shape):
     from confignet_amd import ops
     rng = np.random.default_rng(sum(shape))
@@ -137,6 +138,15 @@ def test_nc_reduce_and_lin2(shape):
     close(y, torch.relu(t64(A1[0]) * t64(x1) + t64(B[0])), what="lin2 per-channel relu")
     y = ops.nc_lin2(shape, None, None, None, None, dev(B))
     close(y, bc(B).expand(shape), what="lin2 broadcast")
+    # per-channel sum + dot (long reductions are spread over partial rows and re-added)
+    s1, s2 = ops.nc_reduce(dev(x1), dev(x2), per_channel=True)
+    close(s1, t64(x1).sum(dim=(0,) + axes).reshape(1, c), tol=2e-4, what="colsum (pair)")
+    close(s2, (t64(x1) * t64(x2)).sum(dim=(0,) + axes).reshape(1, c), tol=2e-4, what="coldot")
+    # third coefficient pair (tangent pass of the DiscrBlock tail): masked sum + a3*x2 + b3
+    A3, B3 = rng.normal(size=(n, c)), rng.normal(size=(n, c))
+    y = ops.nc_lin2(shape, dev(x1), dev(A1), dev(x2), dev(A2), dev(B), flags=4, slope=0.3, a3=dev(A3), b3=dev(B3))
+    ref = (bc(A1) * t64(x1) + bc(A2) * t64(x2) + bc(B)) * torch.where(t64(x2) > 0, 1.0, 0.3) + bc(A3) * t64(x2) + bc(B3)
+    close(y, ref, what="lin2 a3/b3")
 
 
 def test_elementwise_and_losses():
