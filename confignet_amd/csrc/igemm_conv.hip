@@ -866,7 +866,8 @@ int launch_wgrad(const CnConvGeom& g, const float* x, const float* gy, float* gw
     const long M = (long)g.n * g.out_d * g.out_h * g.out_w;
     const long Ktot = (long)g.k_d * g.k_h * g.k_w * g.cin;
     const long tiles = (long)cn_cdiv(Ktot, BMt) * cn_cdiv(g.cout, BNt);
-    long splits = (1024 + tiles - 1) / tiles;
+    static const long wg_blocks = getenv("CN_WG_BLOCKS") ? atol(getenv("CN_WG_BLOCKS")) : 2048;   // sweep 256..4096: flat from 1536 up
+    long splits = (wg_blocks + tiles - 1) / tiles;
     long rows = (M + splits - 1) / splits;
     if (rows < 256) rows = 256;
     rows = (rows + BK - 1) / BK * BK;
