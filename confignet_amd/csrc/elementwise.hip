@@ -3,6 +3,7 @@
 // average pool), activations, pooling, loss reductions, image pre/post-processing, Adam+EMA.
 // All are single-pass, float4-vectorised over the channel (fastest) axis where C % 4 == 0.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -182,32 +183,79 @@ __global__ __launch_bounds__(256) void nc_lin2_rows_kernel(const float* __restri
     }
 }
 
-__global__ void act_fwd_kernel(const float* x, float* y, size_t n, int act, float slope) {   // may run in place
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-        y[i] = cn_apply_act(x[i], act, slope);
+// ---- streaming maps: one float4 per lane per trip when the pointers are 16-byte aligned (they are for every tensor
+// the host side allocates), scalar tail / fallback otherwise.  VEC is decided by the launcher. ----
+__device__ __forceinline__ float act_deriv(float o, int act, float slope) {
+    if (act == CN_ACT_LRELU) return o > 0.f ? 1.f : slope;
+    if (act == CN_ACT_RELU) return o > 0.f ? 1.f : 0.f;
+    if (act == CN_ACT_TANH) return 1.f - o * o;
+    return 1.f;
 }
 
-__global__ void act_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ y, float* __restrict__ gx,
-                               size_t n, int act, float slope) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const float o = y[i], g = gy[i];
-        float d = 1.f;
-        if (act == CN_ACT_LRELU) d = o > 0.f ? 1.f : slope;
-        else if (act == CN_ACT_RELU) d = o > 0.f ? 1.f : 0.f;
-        else if (act == CN_ACT_TANH) d = 1.f - o * o;
-        gx[i] = g * d;
+template <bool VEC>
+__global__ void act_fwd_kernel(const float* x, float* y, size_t n, int act, float slope) {   // may run in place
+    const size_t stride = (size_t)gridDim.x * blockDim.x, t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (VEC) {
+        for (size_t i = t; i < n / 4; i += stride) {
+            float4 v = reinterpret_cast<const float4*>(x)[i];
+            v.x = cn_apply_act(v.x, act, slope); v.y = cn_apply_act(v.y, act, slope);
+            v.z = cn_apply_act(v.z, act, slope); v.w = cn_apply_act(v.w, act, slope);
+            reinterpret_cast<float4*>(y)[i] = v;
+        }
+        for (size_t i = (n / 4) * 4 + t; i < n; i += stride) y[i] = cn_apply_act(x[i], act, slope);
+    } else {
+        for (size_t i = t; i < n; i += stride) y[i] = cn_apply_act(x[i], act, slope);
     }
 }
 
-__global__ void axpby_kernel(const float* __restrict__ x, const float* __restrict__ y, float* __restrict__ o, size_t n,
-                             float a, float b) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-        o[i] = a * x[i] + (y ? b * y[i] : 0.f);
+template <bool VEC>
+__global__ void act_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ y, float* __restrict__ gx,
+                               size_t n, int act, float slope) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x, t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (VEC) {
+        for (size_t i = t; i < n / 4; i += stride) {
+            const float4 o = reinterpret_cast<const float4*>(y)[i], g = reinterpret_cast<const float4*>(gy)[i];
+            reinterpret_cast<float4*>(gx)[i] = make_float4(g.x * act_deriv(o.x, act, slope), g.y * act_deriv(o.y, act, slope),
+                                                           g.z * act_deriv(o.z, act, slope), g.w * act_deriv(o.w, act, slope));
+        }
+        for (size_t i = (n / 4) * 4 + t; i < n; i += stride) gx[i] = gy[i] * act_deriv(y[i], act, slope);
+    } else {
+        for (size_t i = t; i < n; i += stride) gx[i] = gy[i] * act_deriv(y[i], act, slope);
+    }
 }
 
+template <bool VEC>
+__global__ void axpby_kernel(const float* __restrict__ x, const float* __restrict__ y, float* __restrict__ o, size_t n,
+                             float a, float b) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x, t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (VEC) {
+        for (size_t i = t; i < n / 4; i += stride) {
+            const float4 u = reinterpret_cast<const float4*>(x)[i];
+            float4 r = make_float4(a * u.x, a * u.y, a * u.z, a * u.w);
+            if (y) {
+                const float4 w = reinterpret_cast<const float4*>(y)[i];
+                r.x += b * w.x; r.y += b * w.y; r.z += b * w.z; r.w += b * w.w;
+            }
+            reinterpret_cast<float4*>(o)[i] = r;
+        }
+        for (size_t i = (n / 4) * 4 + t; i < n; i += stride) o[i] = a * x[i] + (y ? b * y[i] : 0.f);
+    } else {
+        for (size_t i = t; i < n; i += stride) o[i] = a * x[i] + (y ? b * y[i] : 0.f);
+    }
+}
+
+template <bool VEC>
 __global__ void mul_kernel(const float* __restrict__ x, const float* __restrict__ y, float* __restrict__ o, size_t n) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-        o[i] = x[i] * y[i];
+    const size_t stride = (size_t)gridDim.x * blockDim.x, t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (VEC) {
+        for (size_t i = t; i < n / 4; i += stride) {
+            const float4 u = reinterpret_cast<const float4*>(x)[i], w = reinterpret_cast<const float4*>(y)[i];
+            reinterpret_cast<float4*>(o)[i] = make_float4(u.x * w.x, u.y * w.y, u.z * w.z, u.w * w.w);
+        }
+        for (size_t i = (n / 4) * 4 + t; i < n; i += stride) o[i] = x[i] * y[i];
+    } else {
+        for (size_t i = t; i < n; i += stride) o[i] = x[i] * y[i];
+    }
 }
 
 __device__ __forceinline__ float block_sum(float v) {
@@ -222,32 +270,60 @@ __device__ __forceinline__ float block_sum(float v) {
 }
 
 __global__ __launch_bounds__(256) void sqdiff_sum_kernel(const float* __restrict__ a, const float* __restrict__ b,
-                                                         float* __restrict__ out, size_t n, float scale) {
+                                                         float* __restrict__ out, size_t n, float scale, int vec) {
     float acc = 0.f;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const float d = a[i] - b[i];
-        acc += d * d;
+    const size_t stride = (size_t)gridDim.x * blockDim.x, t0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (vec) {
+        for (size_t i = t0; i < n / 4; i += stride) {
+            const float4 u = reinterpret_cast<const float4*>(a)[i], w = reinterpret_cast<const float4*>(b)[i];
+            const float d0 = u.x - w.x, d1 = u.y - w.y, d2 = u.z - w.z, d3 = u.w - w.w;
+            acc += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+        }
+        for (size_t i = (n / 4) * 4 + t0; i < n; i += stride) {
+            const float d = a[i] - b[i];
+            acc += d * d;
+        }
+    } else {
+        for (size_t i = t0; i < n; i += stride) {
+            const float d = a[i] - b[i];
+            acc += d * d;
+        }
     }
     const float t = block_sum(acc);
     if (threadIdx.x == 0) unsafeAtomicAdd(out, t * scale);
 }
 
 // grid (blocks_per_row, n)
-__global__ __launch_bounds__(256) void row_sumsq_kernel(const float* __restrict__ x, float* __restrict__ out, size_t row) {
+__global__ __launch_bounds__(256) void row_sumsq_kernel(const float* __restrict__ x, float* __restrict__ out, size_t row,
+                                                        int vec) {
     const float* p = x + (size_t)blockIdx.y * row;
     float acc = 0.f;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < row; i += (size_t)gridDim.x * blockDim.x)
-        acc += p[i] * p[i];
+    const size_t stride = (size_t)gridDim.x * blockDim.x, t0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (vec) {           // row % 4 == 0 and x 16-byte aligned
+        for (size_t i = t0; i < row / 4; i += stride) {
+            const float4 u = reinterpret_cast<const float4*>(p)[i];
+            acc += u.x * u.x + u.y * u.y + u.z * u.z + u.w * u.w;
+        }
+    } else {
+        for (size_t i = t0; i < row; i += stride) acc += p[i] * p[i];
+    }
     const float t = block_sum(acc);
     if (threadIdx.x == 0) unsafeAtomicAdd(&out[blockIdx.y], t);
 }
 
 __global__ void row_scale_kernel(const float* __restrict__ x, const float* __restrict__ s, float* __restrict__ o,
-                                 size_t row, float k) {
+                                 size_t row, float k, int vec) {
     const float f = s[blockIdx.y] * k;
     const size_t base = (size_t)blockIdx.y * row;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < row; i += (size_t)gridDim.x * blockDim.x)
-        o[base + i] = x[base + i] * f;
+    const size_t stride = (size_t)gridDim.x * blockDim.x, t0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (vec) {
+        for (size_t i = t0; i < row / 4; i += stride) {
+            const float4 u = reinterpret_cast<const float4*>(x + base)[i];
+            reinterpret_cast<float4*>(o + base)[i] = make_float4(u.x * f, u.y * f, u.z * f, u.w * f);
+        }
+    } else {
+        for (size_t i = t0; i < row; i += stride) o[base + i] = x[base + i] * f;
+    }
 }
 
 __global__ void masked_diff_kernel(const float* __restrict__ a, const float* __restrict__ b, const uint8_t* __restrict__ m,
@@ -421,8 +497,9 @@ extern "C" int cn_nc_reduce(const float* x1, const float* x2, float* s1, float* 
     while (TX < CG && TX < 64) TX <<= 1;
     const int TY = 256 / TX;
     const int cblk = cn_cdiv(CG, TX);
-    // ~2048 workgroups in total, at least 4*TY rows each
-    long want = 2048 / ((long)cblk * n);
+    // ~512 workgroups in total, at least 4*TY rows each
+    static const long red_blocks = getenv("CN_RED_BLOCKS") ? atol(getenv("CN_RED_BLOCKS")) : 512;   // sweep: fewer, longer workgroups = shorter same-address atomic tails
+    long want = red_blocks / ((long)cblk * n);
     if (want < 1) want = 1;
     if (want > 256) want = 256;     // same-address atomics serialise (~100 ns each): 2048 per address cost 200 us
     long rpb = (s + want - 1) / want;
@@ -473,48 +550,59 @@ extern "C" int cn_nc_lin2(const float* x1, const float* a1, const float* x2, con
     CN_LAUNCH_CHECK();                                                                                         \
     return CN_OK;
 
+static inline bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+// float4 form of a streaming map when every pointer is 16-byte aligned (quarter the grid: one float4 per lane per trip)
+#define EW_LAUNCH_V(kernel, n, vec, ...)                                                                                   \
+    if (vec) hipLaunchKernelGGL(kernel<true>, dim3(ew_blocks(((n) + 3) / 4)), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); \
+    else hipLaunchKernelGGL(kernel<false>, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__);             \
+    CN_LAUNCH_CHECK();                                                                                                     \
+    return CN_OK;
+
 extern "C" int cn_act_fwd(const float* x, float* y, size_t numel, int act, float slope, void* stream) {
     CN_CHECK_ARG(x && y, "act_fwd: NULL");
     if (!numel) return CN_OK;
-    EW_LAUNCH(act_fwd_kernel, numel, x, y, numel, act, slope)
+    EW_LAUNCH_V(act_fwd_kernel, numel, al16(x) && al16(y), x, y, numel, act, slope)
 }
 extern "C" int cn_act_bwd(const float* gy, const float* y, float* gx, size_t numel, int act, float slope, void* stream) {
     CN_CHECK_ARG(gy && y && gx, "act_bwd: NULL");
     if (!numel) return CN_OK;
-    EW_LAUNCH(act_bwd_kernel, numel, gy, y, gx, numel, act, slope)
+    EW_LAUNCH_V(act_bwd_kernel, numel, al16(gy) && al16(y) && al16(gx), gy, y, gx, numel, act, slope)
 }
 extern "C" int cn_axpby(const float* x, const float* y, float* out, size_t numel, float a, float b, void* stream) {
     CN_CHECK_ARG(x && out, "axpby: NULL");
     if (!numel) return CN_OK;
-    EW_LAUNCH(axpby_kernel, numel, x, y, out, numel, a, b)
+    EW_LAUNCH_V(axpby_kernel, numel, al16(x) && al16(y) && al16(out), x, y, out, numel, a, b)
 }
 extern "C" int cn_mul(const float* x, const float* y, float* out, size_t numel, void* stream) {
     CN_CHECK_ARG(x && y && out, "mul: NULL");
     if (!numel) return CN_OK;
-    EW_LAUNCH(mul_kernel, numel, x, y, out, numel)
+    EW_LAUNCH_V(mul_kernel, numel, al16(x) && al16(y) && al16(out), x, y, out, numel)
 }
 extern "C" int cn_sqdiff_sum(const float* a, const float* b, float* out, size_t numel, float scale, void* stream) {
     CN_CHECK_ARG(a && b && out, "sqdiff_sum: NULL");
     if (!numel) return CN_OK;
-    const int blocks = ew_blocks(numel) > 2048 ? 2048 : ew_blocks(numel);
-    hipLaunchKernelGGL(sqdiff_sum_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, b, out, numel, scale);
+    const int vec = al16(a) && al16(b);
+    const int blocks = ew_blocks(numel / (vec ? 4 : 1) + 1) > 512 ? 512 : ew_blocks(numel / (vec ? 4 : 1) + 1);   // one atomic each
+    hipLaunchKernelGGL(sqdiff_sum_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, b, out, numel, scale, vec);
     CN_LAUNCH_CHECK();
     return CN_OK;
 }
 extern "C" int cn_row_sumsq(const float* x, float* out, int n, size_t row, void* stream) {
     CN_CHECK_ARG(x && out && n > 0 && row > 0, "row_sumsq: bad args");
     if (int ez__ = cn_zero_async(out, sizeof(float) * n, (hipStream_t)stream)) return ez__;
-    int bpr = (int)((row + 256 * 16 - 1) / (256 * 16));
-    if (bpr > 256) bpr = 256;
-    hipLaunchKernelGGL(row_sumsq_kernel, dim3(bpr, n), dim3(256), 0, (hipStream_t)stream, x, out, row);
+    const int vec = al16(x) && row % 4 == 0;
+    int bpr = (int)((row + 256 * 32 - 1) / (256 * 32));
+    if (bpr > 64) bpr = 64;
+    hipLaunchKernelGGL(row_sumsq_kernel, dim3(bpr, n), dim3(256), 0, (hipStream_t)stream, x, out, row, vec);
     CN_LAUNCH_CHECK();
     return CN_OK;
 }
 extern "C" int cn_row_scale(const float* x, const float* s, float* out, int n, size_t row, float k, void* stream) {
     CN_CHECK_ARG(x && s && out && n > 0 && row > 0, "row_scale: bad args");
-    int bpr = (int)((row + 256 * 8 - 1) / (256 * 8));
+    const int vec = al16(x) && al16(out) && row % 4 == 0;
+    int bpr = (int)((row + 256 * 16 - 1) / (256 * 16));
     if (bpr > 512) bpr = 512;
-    hipLaunchKernelGGL(row_scale_kernel, dim3(bpr, n), dim3(256), 0, (hipStream_t)stream, x, s, out, row, k);
+    hipLaunchKernelGGL(row_scale_kernel, dim3(bpr, n), dim3(256), 0, (hipStream_t)stream, x, s, out, row, k, vec);
     CN_LAUNCH_CHECK();
     return CN_OK;
 }

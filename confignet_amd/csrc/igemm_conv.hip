@@ -838,6 +838,78 @@ __global__ __launch_bounds__(256) void s2_image_dgrad_kernel(CnConvGeom g, const
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// First layers: 3x3 convolution of a 3-channel image (DiscrBlock 0 of both discriminators and the latent regressor,
+// VGG conv1_1): K = 27.  The generic kernel gathers those 27 values with per-element integer division (cin = 3 is not
+// a float4).  Here a workgroup stages the input patch of an 8 x 32 output tile in LDS once (coalesced rows), the K
+// axis is padded to 28 = 14 MFMA steps, rows = output pixels and the whole filter sits in registers.
+// (A matching filter-gradient kernel -- rows = the 27 filter rows, K' = pixels -- was tried and dropped: with a
+// 27 x cout output every workgroup ends in the same 1296 atomics, and ~75 ns per same-address atomic put it at
+// 70-90 us against the generic kernel's 65.)
+template <int S, int NB>
+__global__ __launch_bounds__(256) void c3_fwd_kernel(CnConvGeom g, const float* __restrict__ X, const float* __restrict__ W,
+                                                     const float* __restrict__ bias, float* __restrict__ Y, int act, float slope) {
+    constexpr int TH = 8, TW = 32, PR = (TH - 1) * S + 3, PC = ((TW - 1) * S + 3) * 3, PCP = PC + 1;
+    __shared__ float patch[PR * PCP];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, half = lane >> 5;
+    const int tiles_w = (g.out_w + TW - 1) / TW, tiles_h = (g.out_h + TH - 1) / TH;
+    int b = blockIdx.x;
+    const int tj = b % tiles_w; b /= tiles_w;
+    const int ti = b % tiles_h;
+    const int n = b / tiles_h;
+    const int oy0 = ti * TH, ox0 = tj * TW, iy0 = oy0 * S - g.p_h, ix0 = ox0 * S - g.p_w;
+    for (int idx = threadIdx.x; idx < PR * PC; idx += 256) {
+        const int r = idx / PC, c = idx - r * PC;
+        const int iy = iy0 + r, ix = ix0 + c / 3;
+        float v = 0.f;
+        if (iy >= 0 && iy < g.in_h && ix >= 0 && ix < g.in_w) v = X[(((long)n * g.in_h + iy) * g.in_w + ix0) * 3 + c];
+        patch[r * PCP + c] = v;
+    }
+    float breg[14][NB];
+    int aoff[14];
+#pragma unroll
+    for (int q = 0; q < 14; ++q) {
+        const int k = 2 * q + half;
+        const int kh = k / 9, kw = (k - kh * 9) / 3, ci = k - kh * 9 - kw * 3;
+        aoff[q] = k < 27 ? kh * PCP + kw * 3 + ci : 0;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const int col = nb * 32 + l31;
+            breg[q][nb] = (k < 27 && col < g.cout) ? W[k * g.cout + col] : 0.f;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+        const int r = wave * 2 + rr;
+        const int base = r * S * PCP + l31 * S * 3;
+        f32x16 acc[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[nb][q] = 0.f;
+#pragma unroll
+        for (int q = 0; q < 14; ++q) {
+            const float a = patch[base + aoff[q]];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, breg[q][nb], acc[nb], 0, 0, 0);
+        }
+        const int oy = oy0 + r;
+        if (oy >= g.out_h) continue;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const int col = nb * 32 + l31;
+            if (col >= g.cout) continue;
+            const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int ox = ox0 + 4 * half + (q & 3) + 8 * (q >> 2);
+                if (ox < g.out_w) Y[(((long)n * g.out_h + oy) * g.out_w + ox) * g.cout + col] = cn_apply_act(acc[nb][q] + bv, act, slope);
+            }
+        }
+    }
+}
+
 static int g_force_kb16 = -1;
 static int g_xcd = getenv("CN_NO_XCD") ? 0 : 1;
 
@@ -945,6 +1017,19 @@ extern "C" int cn_conv_fwd(const CnConvGeom* gp, const float* x, const float* w,
             default: THIN(4); break;
         }
 #undef THIN
+        CN_LAUNCH_CHECK();
+        return CN_OK;
+    }
+    static const int no_c3 = getenv("CN_NO_C3") ? 1 : 0;
+    if (!no_c3 && g.nd == 2 && g.cin == 3 && g.k_h == 3 && g.k_w == 3 && g.s_h == g.s_w && (g.s_h == 1 || g.s_h == 2) &&
+        g.dl_h == 1 && g.dl_w == 1 && !g.up && g.cout > 4 && g.cout <= 64) {
+        dim3 grid((unsigned)(g.n * cn_cdiv(g.out_h, 8) * cn_cdiv(g.out_w, 32)));
+        cn_prof_begin(s, conv_flops(g));
+#define C3F(S_, NB_) hipLaunchKernelGGL((c3_fwd_kernel<S_, NB_>), grid, dim3(256), 0, s, g, x, w, bias, y, act, slope)
+        if (g.s_h == 1) { if (g.cout <= 32) C3F(1, 1); else C3F(1, 2); }
+        else { if (g.cout <= 32) C3F(2, 1); else C3F(2, 2); }
+#undef C3F
+        cn_prof_end(s);
         CN_LAUNCH_CHECK();
         return CN_OK;
     }
