@@ -204,8 +204,12 @@ def nc_reduce(x1, x2=None, want_sum=True, want_dot=True, flags=0, slope=0.0, per
             s12 = torch.empty((2, n, c), device=x1.device, dtype=torch.float32)
         s1, s2 = s12[0], s12[1]
     else:
-        s1 = torch.empty((n, c), device=x1.device, dtype=torch.float32) if want_sum else None
-        s2 = torch.empty((n, c), device=x1.device, dtype=torch.float32) if want_dot else None
+        one = zero_pool_alloc((n, c), x1.device)
+        if one is not None:
+            flags |= 16
+        else:
+            one = torch.empty((n, c), device=x1.device, dtype=torch.float32)
+        s1, s2 = (one, None) if want_sum else (None, one)
     check(lib.cn_nc_reduce(_ptr(x1), _ptr(x2), _ptr(s1), _ptr(s2), n, s, c, flags, slope, _stream()), "cn_nc_reduce")
     if rep > 1:
         if want_sum and want_dot:
