@@ -123,15 +123,16 @@ class ConfigNet(ConfigNetFirstStage):
         synth_latents = self.synthetic_encoder(facemodel_params)
         generator_output_synth = self.generator((synth_latents, synth_rotations))
         losses["image_loss_synth"] = cfg["image_loss_weight"] * self.perceptual_loss.loss(synth_imgs, generator_output_synth)
-        if side is not main:
-            main.wait_stream(side)
-        losses["image_loss_real"] = image_loss_real
+        losses["image_loss_real"] = None                      # (keeps the reference's key order; filled after the join)
         losses["eye_loss"] = cfg["eye_loss_weight"] * eye_loss(synth_imgs, generator_output_synth, eye_masks)
         for i, o in enumerate(self.synth_discriminator(generator_output_synth).values()):
             losses["GAN_loss_synth_" + str(i)] = GAN_G_loss(o)
+        out_synth = self.latent_discriminator(synth_latents)
+        if side is not main:
+            main.wait_stream(side)                            # join: everything below needs both branches
+        losses["image_loss_real"] = image_loss_real
         for i, l in enumerate(gan_real):
             losses["GAN_loss_real_" + str(i)] = l
-        out_synth = self.latent_discriminator(synth_latents)
         # labels: real -> 0, synth -> 1 (l.160-163,195-197); mean over the concatenation
         latent_gan_loss = (n_real * GAN_D_loss(0.0, out_real) + n_synth * GAN_D_loss(1.0, out_synth)) / (n_real + n_synth)
         losses["latent_GAN_loss"] = cfg["domain_adverserial_loss_weight"] * latent_gan_loss
