@@ -68,6 +68,7 @@ SIGNATURES = {
     "cn_ema_step": [_p, _p, _z, _f, _p],
     "cn_gather_images_u8": [_p, _p, _p, _p, _i, _i, _i, _i, _p],
     "cn_to_uint8": [_p, _p, _z, _p],
+    "cn_spin": [ctypes.c_ulonglong, _p],
     "cn_prof_enable": [_i],
     "cn_prof_reset": [],
     "cn_prof_collect": [ctypes.POINTER(_i), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)],

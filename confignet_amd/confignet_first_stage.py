@@ -99,7 +99,7 @@ class ConfigNetFirstStage:
         self._deferred = None
         self._side_streams = []
         self.fork_generator_step = os.environ.get("CN_NO_FORK") is None   # second stage: real / synthetic branches of the generator step on two streams
-        self._branch_stream_obj = None
+        self._work_streams = []
         self.use_graphs = False       # capture each step's device half into a HIP graph (single-GPU runs)
 
         self.generator = None
@@ -295,11 +295,39 @@ class ConfigNetFirstStage:
             dataset._cn_device_pool = cache
         return cache
 
+    # Four streams for the whole model, chosen on first use: one carries the main line of an iteration (host staging
+    # copies, the generator-step replay, EMA), the discriminator-type steps capture and replay on one each, and the
+    # generator step reuses "d"'s for its capture and "sd"'s for its real-image branch (the two phases never overlap).
+    # Streams share the few hardware queues (GPU_MAX_HW_QUEUES = 4) and two replay streams on one queue serialise the
+    # concurrent phase (scripts/stream_probe.py: 31 -> 40 ms, depending on how many unrelated streams the process had
+    # created before), so the four are picked by measurement (graphs.independent_streams).
+    _WORK_SLOTS = {"main": 0, "d": 1, "sd": 2, "ld": 3, "g": 1}
+
+    def _work_stream(self, name):
+        if not self._work_streams:
+            from .graphs import independent_streams
+            self._work_streams = independent_streams(4)
+        return self._work_streams[self._WORK_SLOTS.get(name, 1)]
+
+    @contextlib.contextmanager
+    def _main_line(self):
+        """Runs the enclosed iteration on the model's own main-line stream (graph mode), ordered after the caller's
+        stream on entry and before it on exit."""
+        if not self.use_graphs:
+            yield
+            return
+        caller, own = torch.cuda.current_stream(), self._work_stream("main")
+        if caller == own:
+            yield
+            return
+        own.wait_stream(caller)
+        with torch.cuda.stream(own):
+            yield
+        caller.wait_stream(own)
+
     @property
     def _branch_stream(self):
-        if self._branch_stream_obj is None:
-            self._branch_stream_obj = torch.cuda.Stream()
-        return self._branch_stream_obj
+        return self._work_stream("sd")
 
     def _dev(self, a):
         return torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32)).to(self.device)
@@ -351,7 +379,7 @@ class ConfigNetFirstStage:
         if g is None:
             from .graphs import StepGraph
             self._graphs = {k: v for k, v in self._graphs.items() if k[3] == self._bufs.generation}
-            g = self._graphs[key] = StepGraph(device_fn)
+            g = self._graphs[key] = StepGraph(device_fn, stream=self._work_stream(name))
         if self._deferred is not None and g.graph is not None:
             self._deferred.append(g)           # replayed together with its independent sibling steps
             return g.out
@@ -518,14 +546,15 @@ class ConfigNetFirstStage:
         generator_optimizer = optim.Adam(**self.config["optimizer"])
         for _ in range(start_step, n_steps):
             t0 = time.perf_counter()
-            for _ in range(self.config["n_discriminator_updates"]):
-                d_loss, synth_d_loss, latent_d_loss = self.run_concurrently([
-                    lambda: self.discriminator_training_step(real_training_set, discriminator_optimizer),
-                    lambda: self.synth_discriminator_training_step(synth_training_set, discriminator_optimizer),
-                    lambda: self.latent_discriminator_training_step(synth_training_set, discriminator_optimizer)])
-            for _ in range(self.config["n_generator_updates"]):
-                g_loss = self.generator_training_step(real_training_set, synth_training_set, generator_optimizer)
-            self.update_smoothed_weights()
+            with self._main_line():
+                for _ in range(self.config["n_discriminator_updates"]):
+                    d_loss, synth_d_loss, latent_d_loss = self.run_concurrently([
+                        lambda: self.discriminator_training_step(real_training_set, discriminator_optimizer),
+                        lambda: self.synth_discriminator_training_step(synth_training_set, discriminator_optimizer),
+                        lambda: self.latent_discriminator_training_step(synth_training_set, discriminator_optimizer)])
+                for _ in range(self.config["n_generator_updates"]):
+                    g_loss = self.generator_training_step(real_training_set, synth_training_set, generator_optimizer)
+                self.update_smoothed_weights()
             torch.cuda.synchronize()
             self.last_iteration_time = time.perf_counter() - t0
             print("[D loss: %f] [synth_D loss: %f] [latent_D_loss: %f] [G loss: %f]" %

@@ -164,15 +164,16 @@ class ConfigNet(ConfigNetFirstStage):
     def training_iteration(self, real_training_set, synth_training_set, discriminator_optimizer, generator_optimizer):
         """One reference training iteration (confignet_second_stage.py:277-288): D, synth-D, latent-D,
         G, EMA.  Returns the four loss dicts (device scalars; no host sync here)."""
-        for _ in range(self.config["n_discriminator_updates"]):
-            d_loss, synth_d_loss, latent_d_loss = self.run_concurrently([
-                lambda: self.discriminator_training_step(real_training_set, discriminator_optimizer),
-                lambda: self.synth_discriminator_training_step(synth_training_set, discriminator_optimizer),
-                lambda: self.latent_discriminator_training_step(real_training_set, synth_training_set,
-                                                                discriminator_optimizer)])
-        for _ in range(self.config["n_generator_updates"]):
-            g_loss = self.generator_training_step(real_training_set, synth_training_set, generator_optimizer)
-        self.update_smoothed_weights()
+        with self._main_line():
+            for _ in range(self.config["n_discriminator_updates"]):
+                d_loss, synth_d_loss, latent_d_loss = self.run_concurrently([
+                    lambda: self.discriminator_training_step(real_training_set, discriminator_optimizer),
+                    lambda: self.synth_discriminator_training_step(synth_training_set, discriminator_optimizer),
+                    lambda: self.latent_discriminator_training_step(real_training_set, synth_training_set,
+                                                                    discriminator_optimizer)])
+            for _ in range(self.config["n_generator_updates"]):
+                g_loss = self.generator_training_step(real_training_set, synth_training_set, generator_optimizer)
+            self.update_smoothed_weights()
         return d_loss, synth_d_loss, latent_d_loss, g_loss
 
     def setup_training(self, log_dir, synth_training_set, n_samples_for_metrics, attribute_classifier=None,

@@ -16,6 +16,17 @@ void cn_set_error(const char* fmt, ...) {
 extern "C" const char* cn_last_error_string(void) { return g_err; }
 extern "C" int cn_version(void) { return 1; }
 
+__global__ void spin_kernel(unsigned long long ticks) {
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+
+extern "C" int cn_spin(unsigned long long ticks, void* stream) {
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ticks);
+    CN_LAUNCH_CHECK();
+    return CN_OK;
+}
+
 namespace {
 struct Rec { hipEvent_t a, b; double flops; };
 std::mutex g_mu;

@@ -22,10 +22,10 @@ class StepGraph:
     fn are recorded (optim.deferred_updates) and issued eagerly after every replay by `finish()` -- gradient
     all-reduce over RCCL, then Adam -- on whatever stream the replay was issued on."""
 
-    def __init__(self, fn, warmup=1):
+    def __init__(self, fn, warmup=1, stream=None):
         self.fn, self.warmup = fn, warmup
         self.calls, self.graph, self.out = 0, None, None
-        self.stream = torch.cuda.Stream()
+        self.stream = stream if stream is not None else torch.cuda.Stream()
         self.split = parallel.active()
         self.tail = []
 
@@ -65,6 +65,43 @@ class StepGraph:
         self.graph.replay()
         self.finish()
         return self.out
+
+
+def independent_streams(n, candidates=12, spin_us=300.0):
+    """`n` streams that provably run side by side.  HIP streams share a handful of hardware queues
+    (GPU_MAX_HW_QUEUES, 4 by default) and two streams on one queue execute back to back; which streams collide depends
+    on everything the process created before, so it is measured: a one-wave kernel that busy-waits `spin_us` is
+    launched on a pair of candidate streams and the pair is kept apart if the two launches took about twice as long
+    as one.  Greedy selection over `candidates` fresh streams; falls back to colliding streams when fewer than `n`
+    independent ones exist."""
+    import time
+    from ._lib import lib
+    ticks = int(spin_us * 100)                      # wall_clock64 runs at 100 MHz
+    cands = [torch.cuda.Stream() for _ in range(candidates)]
+
+    def pair_ms(a, b):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ops.check(lib.cn_spin(ticks, a.cuda_stream), "cn_spin")
+        ops.check(lib.cn_spin(ticks, b.cuda_stream), "cn_spin")
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) * 1e3
+
+    for st in cands[:2]:                            # warm the launch path
+        pair_ms(st, st)
+    serial = min(pair_ms(cands[0], cands[0]) for _ in range(3))          # two spins on ONE stream
+    chosen = [cands[0]]
+    for c in cands[1:]:
+        if len(chosen) == n:
+            break
+        if all(min(pair_ms(c, k), pair_ms(c, k)) < 0.75 * serial for k in chosen):
+            chosen.append(c)
+    for c in cands:                                 # not enough independent queues: fill up
+        if len(chosen) == n:
+            break
+        if c not in chosen:
+            chosen.append(c)
+    return chosen
 
 
 class StaticBuffers:

@@ -179,6 +179,11 @@ int cn_prof_reset(void);
 /* synchronises the recorded events; returns launches, summed kernel ms and algorithmic flops */
 int cn_prof_collect(int* launches, double* total_ms, double* total_flops);
 
+/* ---- stream calibration: one wave busy-waits `ticks` of the 100 MHz wall clock on `stream`.  Two such launches on
+ * streams that share a hardware queue run back to back, on independent queues side by side: graphs.py uses that to
+ * pick replay streams that really run concurrently (no reference counterpart; runtime plumbing) ---------------*/
+int cn_spin(unsigned long long ticks, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

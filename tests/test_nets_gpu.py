@@ -510,3 +510,28 @@ def test_data_parallel_graph_path_single_rank():
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_nets_gpu.py"), "-x", "-q", "-m", "gpu",
                         "-k", "test_hip_graph_steps_match_eager"], env=env, cwd=root, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+def test_independent_streams_run_side_by_side():
+    """graphs.independent_streams picks replay streams by measurement: two busy-wait launches on any two of them must
+    overlap (they do not when two streams share a hardware queue)."""
+    import time
+    from confignet_amd import graphs
+    from confignet_amd._lib import lib
+    sts = graphs.independent_streams(3)
+    assert len(sts) == 3 and len({s.cuda_stream for s in sts}) == 3
+
+    def spins(a, b):
+        best = 1e9
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            assert lib.cn_spin(50000, a.cuda_stream) == 0 and lib.cn_spin(50000, b.cuda_stream) == 0   # 0.5 ms each
+            torch.cuda.synchronize()
+            best = min(best, time.perf_counter() - t0)
+        return best
+    serial = spins(sts[0], sts[0])
+    assert 0.9e-3 < serial < 3e-3, serial
+    for i in range(3):
+        for j in range(i + 1, 3):
+            assert spins(sts[i], sts[j]) < 0.75 * serial, (i, j, spins(sts[i], sts[j]), serial)
