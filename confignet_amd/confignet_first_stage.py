@@ -97,7 +97,6 @@ class ConfigNetFirstStage:
         self._bufs = StaticBuffers(self.device)
         self._graphs = {}
         self._deferred = None
-        self._side_streams = []
         self.fork_generator_step = os.environ.get("CN_NO_FORK") is None   # second stage: real / synthetic branches of the generator step on two streams
         self._work_streams = []
         self.use_graphs = False       # capture each step's device half into a HIP graph (single-GPU runs)
@@ -399,9 +398,8 @@ class ConfigNetFirstStage:
         finally:
             self._deferred = None
         if pending:
-            # every graph is replayed on the stream it was captured on (streams that exist before any graph is
-            # instantiated: creating replay streams later changed how they share hardware queues with the internal
-            # streams of multi-branch graphs and serialised this phase)
+            # every graph is replayed on the stream it was captured on: one of the model's measured-independent
+            # work streams (see _work_stream)
             cur = torch.cuda.current_stream()
             for g in pending:
                 g.stream.wait_stream(cur)
