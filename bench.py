@@ -82,7 +82,10 @@ def main():
         model.fork_generator_step = False
     model.use_graphs = not args.no_graphs
     try:
-        for _ in range(max(args.warmup, 2 if model.use_graphs else 0)):
+        # graph mode needs three untimed iterations whatever W says: eager call, capture, first replay (which still
+        # pays the graph's one-off upload); the JSON reports the number actually run
+        args.warmup = max(args.warmup, 3 if model.use_graphs else 0)
+        for _ in range(args.warmup):
             model.training_iteration(real_set, synth_set, d_opt, g_opt)
         sync()
     except RuntimeError as e:                          # deterministic on every rank: all fall back together
