@@ -32,8 +32,8 @@ FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=20)      # >= 20 timed iterations after >= 5 warm-up
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=16, help="images per GPU per step function")
     ap.add_argument("--res", type=int, default=256)
     ap.add_argument("--pool", type=int, default=512, help="images in each synthetic uint8 pool")
@@ -104,6 +104,28 @@ def main():
     elapsed = time.perf_counter() - t0
     finite = all(np.isfinite(float(l["loss_sum"].detach())) for l in losses)
 
+    # Per-step-function times: each function of the iteration on its own, in the dispatch mode
+    # of the timed region, 5 calls each; "d_phase" is the three discriminator-type steps as the iteration runs them.
+    def timed_ms(fn, reps=5):
+        sync()
+        t = time.perf_counter()
+        for _ in range(reps):
+            with model._main_line():
+                fn()
+        sync()
+        return round(1e3 * (time.perf_counter() - t) / reps, 3)
+
+    step_ms = {
+        "discriminator": timed_ms(lambda: model.discriminator_training_step(real_set, d_opt)),
+        "synth_discriminator": timed_ms(lambda: model.synth_discriminator_training_step(synth_set, d_opt)),
+        "latent_discriminator": timed_ms(lambda: model.latent_discriminator_training_step(real_set, synth_set, d_opt)),
+        "d_phase": timed_ms(lambda: model.run_concurrently([
+            lambda: model.discriminator_training_step(real_set, d_opt),
+            lambda: model.synth_discriminator_training_step(synth_set, d_opt),
+            lambda: model.latent_discriminator_training_step(real_set, synth_set, d_opt)])),
+        "generator": timed_ms(lambda: model.generator_training_step(real_set, synth_set, g_opt)),
+    }
+
     # Roofline of the dominant kernel class, measured live with HIP events recorded on the launch stream
     # around every implicit-GEMM convolution launch of the SAME K iterations dispatched eagerly AND ON ONE STREAM
     # right after the timed region (event records cannot sit inside a replayed graph, and a per-kernel duration only
@@ -139,6 +161,7 @@ def main():
                        "dispatch": ("eager, one stream" if args.serial else "eager" if args.no_graphs else
                                     "hip-graph replay per step function, D-type steps concurrent, G step forked over 2 streams" +
                                     ("" if not parallel.active() else " (fwd+bwd), eager RCCL all-reduce + Adam"))},
+            "step_functions_ms": step_ms,
             "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": pmc_traffic(),
                          "kernel": "igemm_fwd/igemm_wgrad (implicit-GEMM conv, v_mfma_f32_32x32x2_f32)",
