@@ -164,6 +164,7 @@ def main():
             "step_functions_ms": step_ms,
             "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": pmc_traffic(),
+                         "mfma_busy_pmc": pmc_mfma_busy(),
                          "kernel": "igemm_fwd/igemm_wgrad (implicit-GEMM conv, v_mfma_f32_32x32x2_f32)",
                          "launches_per_step": launches / max(args.steps, 1),
                          "kernel_ms_per_step": round(kernel_ms / max(args.steps, 1), 3),
@@ -185,6 +186,16 @@ def pmc_traffic():
     try:
         with open(os.path.join(ROOT, "profiles", "round1_pmc_traffic.json")) as fp:
             return round(json.load(fp)["hbm_bytes_per_launch"])
+    except Exception:
+        return None
+
+
+def pmc_mfma_busy():
+    """MFMA-pipe busy fraction of the class from the committed PMC pass (profiles/round1_pmc_mfma.json:
+    SQ_VALU_MFMA_BUSY_CYCLES against GRBM_GUI_ACTIVE; scripts/pmc_mfma.py states the normalisation)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "round1_pmc_mfma.json")) as fp:
+            return round(json.load(fp)["mfma_busy_fraction"], 4)
     except Exception:
         return None
 
