@@ -54,8 +54,8 @@ class ConfigNet(ConfigNetFirstStage):
         return super().all_networks() + [self.encoder]
 
     # ---- training code ----------------------------------------------------------------------------
-    def face_reco_loss(self, gt_imgs, gen_imgs):
-        return self.perceptual_loss_face_reco.loss(gen_imgs, gt_imgs)
+    def face_reco_loss(self, gt_imgs, gen_imgs, cached=None):
+        return self.perceptual_loss_face_reco.loss(gen_imgs, gt_imgs, cached=cached)
 
     def compute_normalized_latent_regression_loss(self, generator_outputs, labels):
         """confignet_second_stage.py:93-107.  The (N, L+3) batch statistics are latent-vector algebra
@@ -244,6 +244,12 @@ class ConfigNet(ConfigNetFirstStage):
         optimizer = optim.Adam(lr=0.0001)
         w = self.config
         state = {}
+        # The target image's VGG19 / VGGFace activations do not change over the loop.  The reference recomputes them
+        # every step (l.369-370); here they are computed once -- identical values, 2 of the 6 VGG passes per step saved
+        # (set cache_target_features = False for the literal recomputation).
+        cache = getattr(self, "cache_target_features", True)
+        tgt_vgg = self.perceptual_loss.features(imgs_dev) if cache else None
+        tgt_face = self.perceptual_loss_face_reco.features(imgs_dev) if cache else None
 
         def device_step():
             losses = {}
@@ -251,8 +257,8 @@ class ConfigNet(ConfigNetFirstStage):
                 pre_t, post_t = pre.repeat(n_imgs, 1), post.repeat(n_imgs, 1)
                 embeddings = torch.cat((pre_t, expr, post_t), dim=1)
                 out = gen((embeddings, rotations))
-                losses["image_loss_real"] = 0.5 * w["image_loss_weight"] * self.perceptual_loss.loss(imgs_dev, out)
-                losses["face_reco_loss"] = 0.5 * w["image_loss_weight"] * self.face_reco_loss(imgs_dev, out)
+                losses["image_loss_real"] = 0.5 * w["image_loss_weight"] * self.perceptual_loss.loss(imgs_dev, out, cached=tgt_vgg)
+                losses["face_reco_loss"] = 0.5 * w["image_loss_weight"] * self.face_reco_loss(imgs_dev, out, cached=tgt_face)
                 for i, o in enumerate(self.discriminator(out).values()):
                     losses["GAN_loss_real_" + str(i)] = GAN_G_loss(o)
                 latent_gan_loss = GAN_D_loss(1.0, self.latent_discriminator(embeddings))

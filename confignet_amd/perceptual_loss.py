@@ -28,9 +28,15 @@ class PerceptualLoss:
         with torch.no_grad():
             return net(self._preprocess_input(img))
 
-    def loss(self, predicted, data):
+    def features(self, img):
+        """phi(img) at the tapped layers, without a tape: for a side of the loss that does not change between calls
+        (the target image of the fine-tune loop), computed once and passed back as `cached`."""
+        return [f.detach() for f in self._activations(img, False)]
+
+    def loss(self, predicted, data, cached=None):
         """sum over the 4 tapped layers of mean((phi(predicted)-phi(data))^2) (perceptual_loss.py:43-82).
-        Symmetric; the side that carries gradient (the generated image) keeps its activations."""
+        Symmetric; the side that carries gradient (the generated image) keeps its activations.  `cached`: the
+        activations of the constant side from `features()` (same values as recomputing them, as the reference does)."""
         p_grad = torch.is_tensor(predicted) and predicted.requires_grad
         d_grad = torch.is_tensor(data) and data.requires_grad
         if p_grad and not d_grad:
@@ -38,7 +44,7 @@ class PerceptualLoss:
         else:
             live, const = data, predicted
         fl = self._activations(live, torch.is_tensor(live) and live.requires_grad)
-        fc = self._activations(const, torch.is_tensor(const) and const.requires_grad)
+        fc = cached if cached is not None else self._activations(const, torch.is_tensor(const) and const.requires_grad)
         total = 0
         for a, b in zip(fl, fc):
             total = total + F.mse_sum(a, b)

@@ -359,6 +359,14 @@ def test_full_iteration_runs_and_api(tmp_path):
     assert e3.shape == (1, 145) and np.isfinite(e3).all()
     # only the expression slice differs from a stale pre/post return after the steps
     assert m.generator_fine_tuned is not None
+    # cached target activations (default) == recomputing them every step as the reference does
+    first = {}
+    for cache in (False, True):
+        m.cache_target_features = cache
+        m.fine_tune_on_img(ds.imgs[:1], n_iters=1)
+        first[cache] = {k: float(v) for k, v in m.last_fine_tune_losses.items()}
+    for k, v in first[False].items():          # (fp32 atomics in the statistics kernels: runs agree to ~1e-4, not bitwise)
+        assert abs(first[True][k] - v) <= 1e-3 * max(1.0, abs(v)), (k, first[True][k], v)
 
 
 def test_latent_gan_step():
