@@ -542,6 +542,10 @@ class ConfigNetFirstStage:
         start_step = self.get_training_step_number()
         discriminator_optimizer = optim.Adam(**self.config["optimizer"])
         generator_optimizer = optim.Adam(**self.config["optimizer"])
+        # the training loop dispatches through HIP graphs unless config["use_hip_graphs"] says otherwise (direct calls of
+        # the step functions stay eager by default: in graph mode the returned loss scalars are the graph's static
+        # outputs, overwritten by the next replay)
+        self.use_graphs = bool(self.config.get("use_hip_graphs", True))
         for _ in range(start_step, n_steps):
             t0 = time.perf_counter()
             with self._main_line():

@@ -543,3 +543,26 @@ def test_independent_streams_run_side_by_side():
     for i in range(3):
         for j in range(i + 1, 3):
             assert spins(sts[i], sts[j]) < 0.75 * serial, (i, j, spins(sts[i], sts[j]), serial)
+
+
+def test_train_loops_run_with_graph_dispatch(tmp_path, capsys):
+    """ConfigNetFirstStage.train / ConfigNet.train as train_confignet.py drives them (l.57-71): HIP-graph dispatch by
+    default, loss logs grow by one entry per iteration, periodic checkpoints land in output_dir/checkpoints."""
+    import os
+    from confignet_amd import ConfigNet, ConfigNetFirstStage, SyntheticFaceDataset
+    from confignet_amd.confignet_first_stage import DEFAULT_CONFIG
+    from confignet_amd.confignet_utils import merge_configs
+    np.random.seed(11)
+    ds = SyntheticFaceDataset(12, 128, seed=4)
+    cfg = merge_configs(DEFAULT_CONFIG, {"batch_size": 4, "output_shape": (128, 128, 3), "metrics_checkpoint_period": 3})
+    ds.process_metadata(cfg, True)
+    first = ConfigNetFirstStage(cfg, seed=0)
+    first.train(ds, ds, str(tmp_path / "first"), None, n_steps=5)
+    assert first.use_graphs and first.get_training_step_number() == 4      # (the reference counts len(log) - 1)
+    assert all(np.isfinite(v).all() for v in first.g_losses.values()) and len(first.g_losses["loss_sum"]) == 5
+    assert os.path.exists(tmp_path / "first" / "checkpoints" / "000003.json")
+    second = ConfigNet(cfg, seed=0)
+    ConfigNetFirstStage.set_weights(second, first.get_weights())
+    second.train(ds, ds, None, None, str(tmp_path / "second"), None, n_steps=4)
+    assert second.get_training_step_number() == 3 and np.isfinite(second.g_losses["loss_sum"]).all()
+    assert "[D loss:" in capsys.readouterr().out
