@@ -95,6 +95,52 @@ def test_conv_fwd_dgrad_wgrad(case):
     close(gw, wr.grad, tol=5e-4, what="wgrad")
 
 
+# The layer shapes of the 256x256, batch-16 iteration (BASELINE.json configs[1]) are too big for the float64 oracle; at
+# full size the three convolution kernels of a layer are checked against each other through the adjoint identities
+#   <conv(x, w), gy> == <x_up, dgrad(gy, w)> == <w, wgrad(x, gy)>      (exact in exact arithmetic, size-independent)
+# and through linearity in x, with the inner products accumulated in float64 on the device.
+FULL_SIZE_LAYERS = [
+    # (x shape, kernel, cout, stride, up)
+    ((16, 256, 256, 3), (3, 3), 48, 2, 0),        # DiscrBlock 0: c3_fwd, s2_image_dgrad, K = 27 wgrad
+    ((16, 128, 128, 48), (3, 3), 96, 2, 0),       # DiscrBlock 1: 128 x 96 tiles, parity-ordered dgrad
+    ((16, 64, 64, 96), (3, 3), 192, 2, 0),        # DiscrBlock 2
+    ((16, 16, 16, 384), (3, 3), 768, 2, 0),       # DiscrBlock 4: split-K forward and dgrad
+    ((8, 8, 8, 8, 512), (3, 3, 3), 256, 1, 1),    # generator Conv3D 8^3 -> 16^3 with folded upsample
+    ((8, 64, 64, 64), (4, 4), 32, 1, 1),          # generator k4 + upsample to 128^2
+    ((8, 128, 128, 32), (4, 4), 3, 1, 1),         # map_final: thin cout
+    ((16, 256, 256, 64), (3, 3), 64, 1, 0),       # VGG block1_conv2
+    ((16, 64, 64, 256), (3, 3), 256, 1, 0),       # VGG block3
+    ((8, 16, 16, 1024), (1, 1), 512, 1, 0),       # generator projection conv / ResNet 1x1
+]
+
+
+@pytest.mark.parametrize("case", FULL_SIZE_LAYERS, ids=[str(i) for i in range(len(FULL_SIZE_LAYERS))])
+def test_conv_adjoint_identities_full_size(case):
+    from confignet_amd import ops
+    xs, k, cout, stride, up = case
+    gen = torch.Generator(device="cuda").manual_seed(sum(xs) + cout)
+    rnd = lambda *shape: torch.randn(*shape, device="cuda", generator=gen)
+    cin = xs[-1]
+    x, x2 = rnd(*xs), rnd(*xs)
+    w = rnd(*k, cin, cout) / math.sqrt(np.prod(k) * cin)
+    spec = ops.ConvSpec(k, stride=stride, up=up)
+    g = spec.geom(xs, cout)
+    y = ops.conv_fwd(x, w, None, g, 0, 0.0)
+    gy = rnd(*y.shape)
+    dot = lambda a, b: float((a.double() * b.double()).sum())
+    lhs = dot(y, gy)
+    gu = ops.conv_dgrad(gy, ops.weight_tflip(w), g)                    # gradient at the (upsampled) input extent
+    gx = ops.sumpool2(gu) if up else gu
+    gw = ops.conv_wgrad(x, gy, g, tuple(w.shape))
+    scale = math.sqrt(dot(y, y) * dot(gy, gy))                         # Cauchy-Schwarz bound of the inner product
+    assert abs(lhs - dot(x, gx)) <= 2e-5 * scale, ("dgrad adjoint", lhs, dot(x, gx), scale)
+    assert abs(lhs - dot(w, gw)) <= 2e-5 * scale, ("wgrad adjoint", lhs, dot(w, gw), scale)
+    y12 = ops.conv_fwd(x + 0.5 * x2, w, None, g, 0, 0.0)
+    y2 = ops.conv_fwd(x2, w, None, g, 0, 0.0)
+    err = float((y12 - (y + 0.5 * y2)).abs().max())
+    assert err <= 2e-4 * max(1.0, float(y.abs().max())), ("linearity", err)
+
+
 @pytest.mark.parametrize("m,n,k,ta,tb", [(16, 148, 32768, 0, 0), (16, 1, 32768, 0, 0), (8, 145, 145, 0, 0), (4096, 217, 145, 0, 0),
                                          (16, 32768, 148, 0, 1), (32768, 148, 16, 1, 0), (7, 5, 3, 1, 1), (130, 70, 33, 0, 1),
                                          (16, 3, 2048, 0, 0), (16, 1, 768, 0, 0), (5, 4, 129, 0, 0)])
@@ -147,6 +193,67 @@ def test_nc_reduce_and_lin2(shape):
     y = ops.nc_lin2(shape, dev(x1), dev(A1), dev(x2), dev(A2), dev(B), flags=4, slope=0.3, a3=dev(A3), b3=dev(B3))
     ref = (bc(A1) * t64(x1) + bc(A2) * t64(x2) + bc(B)) * torch.where(t64(x2) > 0, 1.0, 0.3) + bc(A3) * t64(x2) + bc(B3)
     close(y, ref, what="lin2 a3/b3")
+
+
+@pytest.mark.parametrize("shape", [(16, 128, 128, 48), (16, 256, 256, 64), (8, 16, 16, 16, 128), (16, 256, 256, 3)])
+def test_elementwise_full_size_against_torch_float64(shape):
+    """The statistics / affine / streaming kernels at the activation sizes of the 256x256 batch-16 iteration, against
+    torch float64 arithmetic on the device (an independent implementation; the float64 CPU oracle covers small sizes)."""
+    from confignet_amd import ops
+    gen = torch.Generator(device="cuda").manual_seed(len(shape) + shape[-1])
+    x1, x2 = torch.randn(*shape, device="cuda", generator=gen), torch.randn(*shape, device="cuda", generator=gen)
+    n, c = shape[0], shape[-1]
+    axes = tuple(range(1, len(shape) - 1))
+    spatial = int(np.prod(shape[1:-1]))
+    d1, d2 = x1.double(), x2.double()
+    rel = lambda got, ref: float((got.double() - ref).abs().max() / ref.abs().max().clamp_min(1.0))
+    s1, s2 = ops.nc_reduce(x1, x2, flags=2, slope=0.3)
+    l2 = torch.where(d2 > 0, d2, 0.3 * d2)
+    assert rel(s1, d1.sum(dim=axes)) < 1e-5 * math.sqrt(spatial) and rel(s2, (d1 * l2).sum(dim=axes)) < 1e-5 * math.sqrt(spatial)
+    sc, sd = ops.nc_reduce(x1, x2, per_channel=True)
+    assert rel(sc, d1.sum(dim=(0,) + axes).reshape(1, c)) < 1e-5 * math.sqrt(n * spatial)
+    assert rel(sd, (d1 * d2).sum(dim=(0,) + axes).reshape(1, c)) < 1e-5 * math.sqrt(n * spatial)
+    A1, A2, B = (torch.randn(n, c, device="cuda", generator=gen) for _ in range(3))
+    bc = lambda v: v.double().reshape(n, *([1] * len(axes)), c)
+    y = ops.nc_lin2(shape, x1, A1, x2, A2, B, flags=2 | 4, slope=0.3)
+    ref = (bc(A1) * d1 + bc(A2) * l2 + bc(B)) * torch.where(d2 > 0, 1.0, 0.3)
+    assert rel(y, ref) < 1e-5
+    y = ops.nc_lin2(shape, x1, A1[0], x2, A2[0], B[0], flags=8, per_channel=True)
+    assert rel(y, torch.relu(A1[0].double() * d1 + A2[0].double() * d2 + B[0].double())) < 1e-5
+    out = ops.act_fwd(x1, 1, 0.3)
+    assert rel(ops.act_bwd(x2, out, 1, 0.3), d2 * torch.where(d1 > 0, 1.0, 0.3)) < 1e-6
+    assert rel(ops.axpby(x1, x2, 2.0, -0.5), 2 * d1 - 0.5 * d2) < 1e-6
+    assert rel(ops.sqdiff_sum(x1, x2, 0.25), (0.25 * ((d1 - d2) ** 2).sum()).reshape(1)) < 1e-5
+    assert rel(ops.row_sumsq(x1), (d1 ** 2).reshape(n, -1).sum(1)) < 1e-5
+    s = torch.randn(n, device="cuda", generator=gen)
+    assert rel(ops.row_scale(x1, s, 2.0), d1 * 2.0 * s.double().reshape(n, *([1] * (len(shape) - 1)))) < 1e-6
+
+
+def test_adam_ema_full_arena():
+    """Adam + EMA over an encoder-sized arena (23.6 M parameters): first step is lr_t * g / (|g| + eps) (a sign step),
+    then the fp32 recurrences against float64 on the device for 3 more steps with the shared-counter lr_t."""
+    from confignet_amd import ops
+    n = 23_600_000
+    gen = torch.Generator(device="cuda").manual_seed(7)
+    theta = torch.randn(n, device="cuda", generator=gen)
+    m, v, ema = torch.zeros_like(theta), torch.zeros_like(theta), theta.clone()
+    t64_, m64, v64, e64 = theta.double(), m.double(), v.double(), ema.double()
+    lr, b1, b2, eps = 4e-4, 0.0, 0.9, 1e-7
+    for t in range(1, 5):
+        g = torch.randn(n, device="cuda", generator=gen)
+        lr_t = lr * math.sqrt(1 - b2 ** t) / (1 - b1 ** t)
+        ops.adam_step(theta, g, m, v, None, torch.full((1,), lr_t, device="cuda"), b1, b2, eps)
+        ops.ema_step(ema, theta, 0.999)
+        g64 = g.double()
+        m64 = b1 * m64 + (1 - b1) * g64
+        v64 = b2 * v64 + (1 - b2) * g64 * g64
+        step = lr_t * m64 / (v64.sqrt() + eps)
+        if t == 1:                                  # first step: |delta| = lr wherever |g| >> eps (R10)
+            assert float(((step.abs() - lr).abs() * (g64.abs() > 1e-2)).max()) < 1e-4 * lr
+        t64_ = t64_ - step
+        e64 = 0.999 * e64 + 0.001 * t64_
+    assert float((theta.double() - t64_).abs().max()) < 4e-6        # 4 steps x one fp32 ulp at |theta| ~ 5
+    assert float((ema.double() - e64).abs().max()) < 4e-6
 
 
 def test_elementwise_and_losses():
