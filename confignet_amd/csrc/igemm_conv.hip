@@ -910,6 +910,101 @@ __global__ __launch_bounds__(256) void c3_fwd_kernel(CnConvGeom g, const float* 
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// map_final of the generator: x2 nearest upsample folded into a 4x4 convolution from C (= 32) channels to the 3-channel
+// image, + bias + tanh.  Same transposition as s2_image_dgrad_kernel: every INPUT pixel owns
+//     P[pixel][tap*3 + co] = sum_c x[pixel][c] * w[tap][c][co]                 (C x 48: two 32-column MFMA blocks)
+// and an output pixel (y, x) adds the 16 entries P[((y+kh-p)>>1, (x+kw-p)>>1)][kh*4+kw] that land on it.  One workgroup:
+// (TH+2) x (TW+2) input pixels -> P in LDS -> its 2TH x 2TW output pixels.  The VALU kernel it replaces spent 240 us
+// on 16 images at 256^2 (3.2 GFLOP of lane-serial FMAs); here the contraction is 1 GFLOP of MFMA and the pass is
+// bounded by reading the input once.
+template <int NG>   // C = 8 * NG
+__global__ __launch_bounds__(256) void up2k4_rgb_fwd_kernel(CnConvGeom g, const float* __restrict__ X, const float* __restrict__ W,
+                                                            const float* __restrict__ bias, float* __restrict__ Y, int act,
+                                                            float slope) {
+    constexpr int TH = 8, TW = 16, RW = TW + 2, R = (TH + 2) * RW, MT = (R + 31) / 32, PS = 49, C = 8 * NG;
+    __shared__ float P[MT * 32 * PS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, half = lane >> 5;
+    const int tiles_w = (g.in_w + TW - 1) / TW, tiles_h = (g.in_h + TH - 1) / TH;
+    int b = blockIdx.x;
+    const int tj = b % tiles_w; b /= tiles_w;
+    const int ti = b % tiles_h;
+    const int n = b / tiles_h;
+    const int i0 = ti * TH - 1, j0 = tj * TW - 1;          // first input row / column of the patch (may be -1)
+    float breg[NG * 4][2];
+#pragma unroll
+    for (int q = 0; q < NG * 4; ++q) {
+        const int k = 8 * (q >> 2) + 4 * half + (q & 3);
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            const int col = nb * 32 + l31;                 // = tap * 3 + co
+            breg[q][nb] = col < 48 ? W[((col / 3) * C + k) * 3 + col % 3] : 0.f;
+        }
+    }
+    for (int mt = wave; mt < MT; mt += 4) {
+        const int r = mt * 32 + l31;
+        const int ri = r / RW, rj = r - ri * RW;
+        const int ii = i0 + ri, jj = j0 + rj;
+        const bool inb = r < R && ii >= 0 && ii < g.in_h && jj >= 0 && jj < g.in_w;
+        const float* src = X + (((long)n * g.in_h + ii) * g.in_w + jj) * C + 4 * half;
+        float4 a[NG];
+#pragma unroll
+        for (int jg = 0; jg < NG; ++jg)
+            a[jg] = inb ? *reinterpret_cast<const float4*>(src + 8 * jg) : make_float4(0.f, 0.f, 0.f, 0.f);
+        f32x16 acc[2];
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[nb][q] = 0.f;
+#pragma unroll
+        for (int jg = 0; jg < NG; ++jg) {
+            const float av[4] = {a[jg].x, a[jg].y, a[jg].z, a[jg].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], breg[jg * 4 + e][nb], acc[nb], 0, 0, 0);
+        }
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            const int col = nb * 32 + l31;
+            if (col < 48) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) P[(mt * 32 + 4 * half + (q & 3) + 8 * (q >> 2)) * PS + col] = acc[nb][q];
+            }
+        }
+    }
+    __syncthreads();
+    const float b0 = bias ? bias[0] : 0.f, b1 = bias ? bias[1] : 0.f, b2 = bias ? bias[2] : 0.f;
+#pragma unroll
+    for (int q = 0; q < (2 * TH * 2 * TW) / 256; ++q) {
+        const int px = threadIdx.x + 256 * q;
+        const int ly = px / (2 * TW), lx = px - ly * (2 * TW);
+        const int y = 2 * (i0 + 1) + ly, x = 2 * (j0 + 1) + lx;
+        if (y >= g.out_h || x >= g.out_w) continue;
+        float s0 = b0, s1 = b1, s2 = b2;
+#pragma unroll
+        for (int kh = 0; kh < 4; ++kh) {
+            const int uy = y + kh - g.p_h;                 // row of the upsampled image
+            if (uy < 0 || uy >= 2 * g.in_h) continue;
+            const int ri = (uy >> 1) - i0;
+#pragma unroll
+            for (int kw = 0; kw < 4; ++kw) {
+                const int ux = x + kw - g.p_w;
+                if (ux < 0 || ux >= 2 * g.in_w) continue;
+                const float* pr = &P[(ri * RW + (ux >> 1) - j0) * PS + (kh * 4 + kw) * 3];
+                s0 += pr[0];
+                s1 += pr[1];
+                s2 += pr[2];
+            }
+        }
+        float* dst = Y + (((long)n * g.out_h + y) * g.out_w + x) * 3;
+        dst[0] = cn_apply_act(s0, act, slope);
+        dst[1] = cn_apply_act(s1, act, slope);
+        dst[2] = cn_apply_act(s2, act, slope);
+    }
+}
+
 static int g_force_kb16 = -1;
 static int g_xcd = getenv("CN_NO_XCD") ? 0 : 1;
 
@@ -972,6 +1067,16 @@ extern "C" int cn_conv_fwd(const CnConvGeom* gp, const float* x, const float* w,
         CN_CHECK_ARG(lds <= 64 * 1024, "thin conv: filter of %zu bytes does not fit the LDS stage", lds);
         const int T = g.k_d * g.k_h * g.k_w, CL = g.cin / 4;
         const bool dl1 = g.dl_d * g.dl_h * g.dl_w == 1;
+        if (g.nd == 2 && g.up == 1 && g.k_h == 4 && g.k_w == 4 && g.s_h == 1 && g.s_w == 1 && g.dl_h == 1 && g.dl_w == 1 &&
+            g.cout == 3 && g.cin == 32 && g.p_h == 1 && g.p_w == 1 && g.out_h <= 2 * g.in_h && g.out_w <= 2 * g.in_w &&
+            !getenv("CN_NO_RGB")) {
+            dim3 grid((unsigned)(g.n * cn_cdiv(g.in_h, 8) * cn_cdiv(g.in_w, 16)));
+            cn_prof_begin(s, conv_flops(g));
+            hipLaunchKernelGGL((up2k4_rgb_fwd_kernel<4>), grid, dim3(256), 0, s, g, x, w, bias, y, act, slope);
+            cn_prof_end(s);
+            CN_LAUNCH_CHECK();
+            return CN_OK;
+        }
         if (g.nd == 2 && g.k_h == 3 && g.k_w == 3 && g.dl_h == 2 && g.dl_w == 2 && g.s_h == 1 && g.s_w == 1 && !g.up &&
             g.cout == 3 && g.cin == 48 && !bias && act == CN_ACT_NONE && g.p_h >= 0 && g.p_h <= 2 && g.p_w >= 0 &&
             g.p_w <= 2 && g.out_h <= 2 * g.in_h && g.out_w <= 2 * g.in_w && !getenv("CN_NO_S2IMG")) {
