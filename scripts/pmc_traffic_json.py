@@ -2,7 +2,7 @@
 HBM bytes per launch of the implicit-GEMM kernel class.  usage: pmc_traffic_json.py <fetch_dir> <write_dir> <out.json> <cmd>"""
 import glob, json, sqlite3, sys
 
-CLASS = ("igemm_fwd_kernel", "igemm_wgrad_kernel", "s2_image_dgrad_kernel", "c3_fwd_kernel")
+CLASS = ("igemm_fwd_kernel", "igemm_wgrad_kernel", "s2_image_dgrad_kernel", "c3_fwd_kernel", "up2k4_rgb_fwd_kernel")
 
 
 def load(d, counter):
