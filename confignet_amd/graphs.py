@@ -94,7 +94,7 @@ def independent_streams(n, candidates=12, spin_us=300.0):
     for c in cands[1:]:
         if len(chosen) == n:
             break
-        if all(min(pair_ms(c, k), pair_ms(c, k)) < 0.75 * serial for k in chosen):
+        if all(min(pair_ms(c, k) for _ in range(3)) < 0.75 * serial for k in chosen):
             chosen.append(c)
     for c in cands:                                 # not enough independent queues: fill up
         if len(chosen) == n:

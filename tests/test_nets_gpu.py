@@ -531,7 +531,7 @@ def test_independent_streams_run_side_by_side():
 
     def spins(a, b):
         best = 1e9
-        for _ in range(3):
+        for _ in range(6):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             assert lib.cn_spin(50000, a.cuda_stream) == 0 and lib.cn_spin(50000, b.cuda_stream) == 0   # 0.5 ms each
@@ -539,10 +539,10 @@ def test_independent_streams_run_side_by_side():
             best = min(best, time.perf_counter() - t0)
         return best
     serial = spins(sts[0], sts[0])
-    assert 0.9e-3 < serial < 3e-3, serial
+    assert 0.9e-3 < serial < 5e-3, serial
     for i in range(3):
         for j in range(i + 1, 3):
-            assert spins(sts[i], sts[j]) < 0.75 * serial, (i, j, spins(sts[i], sts[j]), serial)
+            assert spins(sts[i], sts[j]) < 0.8 * serial, (i, j, spins(sts[i], sts[j]), serial)
 
 
 def test_train_loops_run_with_graph_dispatch(tmp_path, capsys):
