@@ -52,6 +52,8 @@ def main():
 
     world = parallel.init_from_env()
     rank = parallel.rank()
+    if world > 1:                                     # N processes share the host: keep each rank's CPU thread pool small
+        torch.set_num_threads(max(1, min(8, (os.cpu_count() or 8) // world)))
     assert world == args.gpus or world == 1 and args.gpus == 1, "WORLD_SIZE=%d but --gpus %d" % (world, args.gpus)
     if world == 1:
         torch.cuda.set_device(0)
