@@ -105,11 +105,61 @@ def compute(W, vgg, inp):
     return out
 
 
+def build_second_stage():
+    """Second-stage extras (confignet_second_stage.py:149-218): seeded real-encoder (ResNet-50 v1 + two heads) weights,
+    a real image for the encoder branch; the rest is shared with the first-stage fixture."""
+    W, vgg, inp = build()
+    enc = seeded_weights(R.real_encoder_weight_shapes(L), 10, he=True)
+    shapes = R.real_encoder_weight_shapes(L)
+    rng = np.random.default_rng(11)
+    # every ResNet conv block is [kernel, bias, gamma, beta, moving mean, moving variance]: identity-like BatchNorm
+    # statistics so that 50 layers neither vanish nor explode (SURVEY.md 8d)
+    i = 0
+    while i < len(shapes):
+        if len(shapes[i]) == 4 and i + 5 < len(shapes) and all(len(shapes[i + k]) == 1 for k in range(1, 6)):
+            c = shapes[i + 1][0]
+            enc[i + 1] = (0.05 * rng.standard_normal(c)).astype(np.float32)                      # conv bias
+            enc[i + 2] = (0.5 + 0.05 * rng.standard_normal(c)).astype(np.float32)                # gamma (< 1: keeps 16 residual blocks O(1))
+            enc[i + 3] = (0.05 * rng.standard_normal(c)).astype(np.float32)                      # beta
+            enc[i + 4] = (0.05 * rng.standard_normal(c)).astype(np.float32)                      # moving mean
+            enc[i + 5] = (1.0 + 0.05 * np.abs(rng.standard_normal(c))).astype(np.float32)        # moving variance
+            i += 6
+        else:
+            i += 1
+    enc[-4] = (enc[-4] * 0.05).astype(np.float32)      # heads: keep tanh unsaturated and the latents O(1)
+    enc[-2] = (enc[-2] * 0.05).astype(np.float32)
+    W["real_encoder"] = enc
+    inp["real_for_encoder"] = rng.uniform(-1, 1, (1, RES, RES, 3))
+    return W, vgg, inp
+
+
+def compute_second_stage(W, vgg, inp):
+    cfg = {"output_shape": (RES, RES, 3), "image_loss_weight": 5e-4, "eye_loss_weight": 5, "domain_adverserial_loss_weight": 5.0,
+           "latent_regression_weight": 10.0, "latent_regressor_rot_weight": 5.0, "rotation_ranges": ((-30, 30), (-10, 10), (0, 0))}
+    Wt = {k: [t64(w, True) for w in v] for k, v in W.items()}
+    vt = [t64(w) for w in vgg]
+    lat, rot = R.real_encoder_forward(Wt["real_encoder"], t64(inp["real_for_encoder"]), cfg["rotation_ranges"])
+    gl, _ = S.second_stage_generator_loss(Wt, cfg, [t64(p) for p in inp["params"]], t64(inp["synth_rot"]), t64(inp["gt"]),
+                                          torch.as_tensor(inp["masks"]), t64(inp["real_for_encoder"]), vt)
+    grads = S.grads_of(gl["loss_sum"], Wt["real_encoder"])
+    return {"enc_latents": lat.detach().numpy(), "enc_rotations": rot.detach().numpy(),
+            "g_loss_names": np.array(list(gl.keys())), "g_loss_values": np.array([float(v) for v in gl.values()]),
+            "enc_grad_norm_total": np.array([float(torch.sqrt(sum((g ** 2).sum() for g in grads if g is not None)))])}
+
+
 if __name__ == "__main__":
     W, vgg, inp = build()
     out = compute(W, vgg, inp)
     path = os.path.join(ROOT, "tests", "golden", "first_stage_128.npz")
-    np.savez_compressed(path, **out)
-    print("wrote", path, os.path.getsize(path), "bytes")
+    if "--second-only" not in sys.argv:
+        np.savez_compressed(path, **out)
+        print("wrote", path, os.path.getsize(path), "bytes")
     for k in ("d_loss_values", "g_loss_values", "gen_checksum"):
         print(k, out[k])
+    W2, vgg2, inp2 = build_second_stage()
+    out2 = compute_second_stage(W2, vgg2, inp2)
+    path2 = os.path.join(ROOT, "tests", "golden", "second_stage_128.npz")
+    np.savez_compressed(path2, **out2)
+    print("wrote", path2, os.path.getsize(path2), "bytes")
+    for k in ("g_loss_names", "g_loss_values", "enc_rotations", "enc_grad_norm_total"):
+        print(k, out2[k])

@@ -91,3 +91,45 @@ def test_hip_adam_matches_golden_trace():
         lr_t = torch.tensor([4e-4 * math.sqrt(1 - 0.9 ** t)], dtype=torch.float32).cuda()
         ops.adam_step(th, torch.tensor(GOLD["adam_grad"] * t, dtype=torch.float32).cuda(), m_, v_, None, lr_t, 0.0, 0.9, 1e-7)
         assert np.abs(th.cpu().double().numpy() - GOLD["adam_trace"][t - 1]).max() < 2e-6
+
+
+GOLD2 = np.load(os.path.join(os.path.dirname(__file__), "golden", "second_stage_128.npz"))
+
+
+def test_second_stage_golden_is_reproduced_by_the_oracle_encoder():
+    """(CPU) the committed encoder outputs come from scripts/make_golden.py's seeded ResNet-50 restatement."""
+    from oracle import ref_nets as R
+    W, vgg, inp = MG.build_second_stage()
+    lat, rot = R.real_encoder_forward([torch.tensor(w, dtype=torch.float64) for w in W["real_encoder"]],
+                                      torch.tensor(inp["real_for_encoder"]))
+    assert np.abs(lat.numpy() - GOLD2["enc_latents"]).max() < 1e-9 and np.abs(rot.numpy() - GOLD2["enc_rotations"]).max() < 1e-12
+
+
+@pytest.mark.gpu
+def test_hip_path_matches_golden_second_stage():
+    """ConfigNet (second stage) generator step on the HIP path against the committed oracle vector: real encoder
+    (ResNet-50, BatchNorm in inference mode) outputs and all 18 loss scalars incl. the batch-normalised latent regression."""
+    from confignet_amd import ConfigNet
+    from confignet_amd.confignet_first_stage import frozen
+    W, vgg, inp = MG.build_second_stage()
+    cfg = {"output_shape": (MG.RES, MG.RES, 3), "batch_size": 2, "facemodel_inputs": dict(MG.FM)}
+    m = ConfigNet(cfg, seed=0)
+    m.config["image_loss_weight"] *= 10                                    # train_confignet.py:67
+    m.generator.set_weights(W["generator"]); m.discriminator.set_weights(W["discriminator"])
+    m.synth_discriminator.set_weights(W["synth_discriminator"]); m.latent_discriminator.set_weights(W["latent_discriminator"])
+    m.latent_regressor.set_weights(W["latent_regressor"]); m.synthetic_encoder.set_weights(W["synthetic_encoder"])
+    m.encoder.set_weights(W["real_encoder"])
+    m.perceptual_loss._pretrained_dnn_activations.set_weights(vgg)
+    dev = m._dev
+    lat, rot = m.encoder(dev(inp["real_for_encoder"]))
+    assert np.abs(lat.detach().cpu().double().numpy() - GOLD2["enc_latents"]).max() < 1e-3
+    assert np.abs(rot.detach().cpu().double().numpy() - GOLD2["enc_rotations"]).max() < 1e-4
+    with frozen(m.discriminator, m.synth_discriminator, m.latent_discriminator):
+        gl = m._generator_loss([dev(p) for p in inp["params"]], dev(inp["synth_rot"]), dev(inp["gt"]),
+                               torch.as_tensor(inp["masks"]).cuda(), dev(inp["real_for_encoder"]))
+        grads = torch.autograd.grad(gl["loss_sum"], m.encoder.trainable_weights)
+    assert list(gl.keys()) == list(GOLD2["g_loss_names"])
+    for k, v in zip(gl.keys(), GOLD2["g_loss_values"]):
+        assert abs(float(gl[k]) - v) <= 1e-3 * max(1.0, abs(v)), (k, float(gl[k]), v)
+    total = float(torch.sqrt(sum((g.double() ** 2).sum() for g in grads)))
+    assert abs(total - float(GOLD2["enc_grad_norm_total"][0])) <= 3e-2 * float(GOLD2["enc_grad_norm_total"][0])
