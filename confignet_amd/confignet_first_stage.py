@@ -519,6 +519,8 @@ class ConfigNetFirstStage:
     def generator_training_step(self, real_training_set, synth_training_set, optimizer):
         n_synth = self.get_batch_size() // 2
         n_real = self.get_batch_size() - n_synth
+        assert n_synth > 0, "the generator step splits the batch into a synthetic and a real half: batch_size >= 2 " \
+                            "(the reference's losses are means over an empty synthetic batch, i.e. NaN, at batch_size 1)"
         self._stage_synth("g", synth_training_set, n_synth)
         self._stage("g/z", self.sample_latent_vector(n_real))
         self._stage("g/rot_real", self.sample_rotations(n_real))

@@ -566,3 +566,29 @@ def test_train_loops_run_with_graph_dispatch(tmp_path, capsys):
     second.train(ds, ds, None, None, str(tmp_path / "second"), None, n_steps=4)
     assert second.get_training_step_number() == 3 and np.isfinite(second.g_losses["loss_sum"]).all()
     assert "[D loss:" in capsys.readouterr().out
+
+
+@pytest.mark.parametrize("res,batch,graphs", [(512, 2, False), (128, 3, True), (256, 5, True)])
+def test_other_resolutions_and_odd_batches(res, batch, graphs):
+    """BASELINE's other shapes: 512x512 (one more upsampling / resampling level everywhere), batches that do not split
+    evenly into the synthetic and real halves (confignet_second_stage.py:150-151: n_synth = B // 2)."""
+    from confignet_amd import ConfigNet, SyntheticFaceDataset, optim
+    from confignet_amd.confignet_first_stage import DEFAULT_CONFIG
+    from confignet_amd.confignet_utils import merge_configs
+    np.random.seed(0)
+    ds = SyntheticFaceDataset(6, res, seed=1)
+    cfg = merge_configs(DEFAULT_CONFIG, {"batch_size": batch, "output_shape": (res, res, 3)})
+    ds.process_metadata(cfg, True)
+    m = ConfigNet(cfg, seed=0)
+    m.setup_training(None, ds, 0, real_training_set=ds)
+    d, g = optim.Adam(**cfg["optimizer"]), optim.Adam(**cfg["optimizer"])
+    m.use_graphs = graphs
+    for _ in range(4 if graphs else 2):
+        out = m.training_iteration(ds, ds, d, g)
+    assert all(np.isfinite(float(o["loss_sum"])) for o in out)
+    imgs = m.generate_images(m.sample_latent_vector(2), m.sample_rotations(2))
+    assert imgs.shape == (2, res, res, 3) and imgs.dtype == np.uint8
+    m1 = ConfigNet(merge_configs(cfg, {"batch_size": 1}), seed=0)
+    m1.setup_training(None, ds, 0, real_training_set=ds)
+    with pytest.raises(AssertionError, match="batch_size >= 2"):
+        m1.generator_training_step(ds, ds, g)
