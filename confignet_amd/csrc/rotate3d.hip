@@ -240,6 +240,8 @@ extern "C" int cn_rotate3d_bwd(const float* grid, const float* rot, const float*
         int CC = (int)(SLAB_FLOATS / P);
         if (CC > c) CC = c;
         CC = CC / 4 * 4;
+        // fewer channels per workgroup while that still adds workgroups on idle CUs (n = 8, C = 128: 128 -> 256 workgroups)
+        while (CC > 4 && (long)cn_cdiv(c, CC) * n < 256) CC -= 4;
         hipLaunchKernelGGL(rotate3d_bwd_lds_kernel, dim3(cn_cdiv(c, CC), n), dim3(256), 0, s, grid, rot, gout, ggrid, grot, g, c, CC);
     } else {
         if (int ez__ = cn_zero_async(ggrid, sizeof(float) * n * P * c, s)) return ez__;
