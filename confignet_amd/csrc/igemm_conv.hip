@@ -626,6 +626,43 @@ __global__ __launch_bounds__(256) void thin_conv_coop_kernel(CnConvGeom g, const
     }
 }
 
+// from-RGB conv (3 -> 3): four pixels = three float4 per tensor per trip
+__global__ __launch_bounds__(256) void tiny_wgrad_3x3_kernel(const float* __restrict__ X, const float* __restrict__ GY,
+                                                             float* __restrict__ GW, long M) {
+    float acc[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) acc[i] = 0.f;
+    const long quads = M / 4;
+    for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < quads; q += (long)gridDim.x * 256) {
+        const float4* xp = reinterpret_cast<const float4*>(X + q * 12);
+        const float4* gp = reinterpret_cast<const float4*>(GY + q * 12);
+        const float4 x0 = xp[0], x1 = xp[1], x2 = xp[2], g0 = gp[0], g1 = gp[1], g2 = gp[2];
+        const float xv[12] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w, x2.x, x2.y, x2.z, x2.w};
+        const float gv[12] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w, g2.x, g2.y, g2.z, g2.w};
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) acc[i * 3 + j] += xv[p * 3 + i] * gv[p * 3 + j];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (long m = quads * 4; m < M; ++m)
+            for (int i = 0; i < 3; ++i)
+                for (int j = 0; j < 3; ++j) acc[i * 3 + j] += X[m * 3 + i] * GY[m * 3 + j];
+    __shared__ float sh[4][9];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        float v = acc[i];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+        if (lane == 0) sh[w][i] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 9) unsafeAtomicAdd(&GW[threadIdx.x], sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+}
+
 // filter gradient of a 1x1 convolution between thin tensors (cin, cout <= 4: the from-RGB conv,
 // hologan_discriminator.py:20): a plain HBM-bound reduction gw[ci][co] = sum_m x[m][ci] gy[m][co]
 __global__ __launch_bounds__(256) void tiny_wgrad_1x1_kernel(const float* __restrict__ X, const float* __restrict__ GY,
@@ -1229,7 +1266,10 @@ extern "C" int cn_conv_wgrad(const CnConvGeom* gp, const float* x, const float* 
         g.p_h == 0 && g.p_w == 0 && g.p_d == 0) {
         const long M = (long)g.n * g.out_d * g.out_h * g.out_w;
         const int blocks = (int)(cn_cdiv(M, 256) > 1024 ? 1024 : cn_cdiv(M, 256));
-        hipLaunchKernelGGL(tiny_wgrad_1x1_kernel, dim3(blocks), dim3(256), 0, s, x, gy, gw, M, g.cin, g.cout);
+        if (g.cin == 3 && g.cout == 3 && (((uintptr_t)x | (uintptr_t)gy) & 15) == 0)
+            hipLaunchKernelGGL(tiny_wgrad_3x3_kernel, dim3(blocks > 512 ? 512 : blocks), dim3(256), 0, s, x, gy, gw, M);
+        else
+            hipLaunchKernelGGL(tiny_wgrad_1x1_kernel, dim3(blocks), dim3(256), 0, s, x, gy, gw, M, g.cin, g.cout);
         CN_LAUNCH_CHECK();
         return CN_OK;
     }
