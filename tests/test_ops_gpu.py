@@ -44,6 +44,7 @@ CONV_CASES = [
     ((2, 32, 32, 32), (4, 4), 3, 1, 1, None, 3, 0.0),         # map_final: thin cout + tanh + upsample
     ((1, 20, 13, 32), (4, 4), 3, 1, 1, None, 3, 0.0),         # map_final, extents that do not fill the 8x16 tiles
     ((2, 32, 32, 3), (1, 1), 3, 1, 0, None, 0, 0.0),          # from-RGB 1x1
+    ((1, 5, 7, 3), (1, 1), 3, 1, 0, None, 1, 0.3),            # from-RGB 1x1, pixel count not a multiple of 4
     ((4, 8, 8, 256), (3, 3), 512, 1, 0, None, 2, 0.0),        # VGG block4 shape, 64x64 tiles
     ((1, 8, 8, 128), (1, 1), 512, 2, 0, None, 0, 0.0),        # ResNet strided 1x1
 ]
