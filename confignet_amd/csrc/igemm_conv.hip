@@ -1042,6 +1042,149 @@ __global__ __launch_bounds__(256) void up2k4_rgb_fwd_kernel(CnConvGeom g, const 
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// EXPERIMENTAL (CN_BF16X3=1, off by default; not the product path of round 1): the same implicit GEMM with every fp32
+// operand split into two bf16 terms, x = hi + lo (+ 2^-17 |x|), and  a*b ~= a_hi*b_hi + a_hi*b_lo + a_lo*b_hi  evaluated by
+// three v_mfma_f32_32x32x16_bf16 with fp32 accumulation (relative error ~2^-16 per product against 2^-24 for the fp32
+// MFMA; the bf16 pipe is 16x wider).  128 x 128 tile, 32-deep stages, operands stored k-contiguous in LDS so that a lane
+// fetches its 8 bf16 of one MFMA with one ds_read_b128.  Forward geometry only (no parity order, no split-K).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void split_bf16(float x, unsigned short& hi, unsigned short& lo) {
+    const unsigned u = __float_as_uint(x);
+    const unsigned h = (u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u;       // round to nearest even
+    const unsigned v = __float_as_uint(x - __uint_as_float(h));
+    hi = (unsigned short)(h >> 16);
+    lo = (unsigned short)((v + 0x7FFFu + ((v >> 16) & 1u)) >> 16);
+}
+
+__global__ __launch_bounds__(256) void igemm_fwd_bf16x3_kernel(CnConvGeom g, const float* __restrict__ X,
+                                                               const float* __restrict__ W, const float* __restrict__ bias,
+                                                               float* __restrict__ Y, int act, float slope) {
+    constexpr int BM = 128, BN = 128, KB = 32, LD = KB + 8;             // LD in bf16 elements (80-byte rows, 16-byte aligned)
+    constexpr int AP = 4, BP = 4;
+    __shared__ __attribute__((aligned(16))) unsigned short Ahi[2][BM][LD], Alo[2][BM][LD], Bhi[2][BN][LD], Blo[2][BN][LD];
+    __shared__ int rowmap[BM];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, half = lane >> 5, l31 = lane & 31;
+    const int M = g.n * g.out_d * g.out_h * g.out_w;
+    const int T = g.k_d * g.k_h * g.k_w;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int kq = tid & 7, arow = tid >> 3;                            // A: 8 float4 per row per stage, 32 rows per pass
+    RowInfo ri[AP];
+#pragma unroll
+    for (int i = 0; i < AP; ++i) {
+        const int mrow = m0 + arow + 32 * i;
+        ri[i] = decode_row(g, mrow, M);
+        if (kq == 0) rowmap[arow + 32 * i] = ri[i].ok ? mrow : -1;
+    }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int cpb = g.cin / KB, nks = T * cpb;
+    float4 ra[AP], rb[BP];
+    int aoff[AP];
+    int cur_tap = -1;
+    auto load_tiles = [&](int ks) {
+        const int tap = ks / cpb, c0 = (ks - tap * cpb) * KB;
+        if (tap != cur_tap) {
+            cur_tap = tap;
+            int kd, kh, kw;
+            tap_decode(g, tap, kd, kh, kw);
+#pragma unroll
+            for (int i = 0; i < AP; ++i) aoff[i] = src_off(g, ri[i], kd, kh, kw);
+        }
+#pragma unroll
+        for (int i = 0; i < AP; ++i)
+            ra[i] = aoff[i] >= 0 ? *reinterpret_cast<const float4*>(X + aoff[i] + c0 + kq * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int j = 0; j < BP; ++j) {
+            const int idx = tid + 256 * j;
+            const int brow = idx >> 5, col = n0 + (idx & 31) * 4;
+            const long kg = (long)tap * g.cin + c0 + brow;
+            rb[j] = col < g.cout ? *reinterpret_cast<const float4*>(W + kg * g.cout + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto store_tiles = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < AP; ++i) {
+            const float v[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
+            unsigned short h[4], l[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) split_bf16(v[e], h[e], l[e]);
+            const int r = arow + 32 * i;
+            *reinterpret_cast<uint2*>(&Ahi[buf][r][kq * 4]) = make_uint2(h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16));
+            *reinterpret_cast<uint2*>(&Alo[buf][r][kq * 4]) = make_uint2(l[0] | ((unsigned)l[1] << 16), l[2] | ((unsigned)l[3] << 16));
+        }
+#pragma unroll
+        for (int j = 0; j < BP; ++j) {
+            const int idx = tid + 256 * j;
+            const int brow = idx >> 5, bcol = (idx & 31) * 4;
+            const float v[4] = {rb[j].x, rb[j].y, rb[j].z, rb[j].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                unsigned short h, l;
+                split_bf16(v[e], h, l);
+                Bhi[buf][bcol + e][brow] = h;                       // transposed: k contiguous per output column
+                Blo[buf][bcol + e][brow] = l;
+            }
+        }
+    };
+    load_tiles(0);
+    store_tiles(0);
+    __syncthreads();
+    for (int ks = 0; ks < nks; ++ks) {
+        const int buf = ks & 1;
+        if (ks + 1 < nks) load_tiles(ks + 1);
+#pragma unroll
+        for (int k16 = 0; k16 < KB; k16 += 16) {
+            union U { uint4 u; bf16x8 v; };
+            U ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int r = wm * 64 + 32 * i + l31;
+                ah[i].u = *reinterpret_cast<const uint4*>(&Ahi[buf][r][k16 + 8 * half]);
+                al[i].u = *reinterpret_cast<const uint4*>(&Alo[buf][r][k16 + 8 * half]);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int c = wn * 64 + 32 * j + l31;
+                bh[j].u = *reinterpret_cast<const uint4*>(&Bhi[buf][c][k16 + 8 * half]);
+                bl[j].u = *reinterpret_cast<const uint4*>(&Blo[buf][c][k16 + 8 * half]);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i].v, bh[j].v, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i].v, bl[j].v, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i].v, bh[j].v, acc[i][j], 0, 0, 0);
+                }
+        }
+        if (ks + 1 < nks) store_tiles(buf ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = n0 + wn * 64 + 32 * j + l31;
+        if (col >= g.cout) continue;
+        const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int rbase = wm * 64 + 32 * i + 4 * half;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = rowmap[rbase + (r & 3) + 8 * (r >> 2)];
+                if (row >= 0) Y[(long)row * g.cout + col] = cn_apply_act(acc[i][j][r] + bv, act, slope);
+            }
+        }
+    }
+}
+
 static int g_force_kb16 = -1;
 static int g_xcd = getenv("CN_NO_XCD") ? 0 : 1;
 
@@ -1208,6 +1351,15 @@ extern "C" int cn_conv_fwd(const CnConvGeom* gp, const float* x, const float* w,
         const long min_steps = par_small ? 8 : 16;   // average K steps per workgroup
         if (want > nks / min_steps) want = nks / min_steps;
         if (want > 1) splits = (int)want;
+    }
+    static const int bf16x3 = getenv("CN_BF16X3") ? atoi(getenv("CN_BF16X3")) : 0;
+    if (bf16x3 && vec && !par && g.cin % 32 == 0 && g.cout % 4 == 0 && (long)cn_cdiv(M, 128) * cn_cdiv(g.cout, 128) >= 256) {
+        dim3 grid(cn_cdiv(M, 128), cn_cdiv(g.cout, 128));
+        cn_prof_begin(s, conv_flops(g));
+        hipLaunchKernelGGL(igemm_fwd_bf16x3_kernel, grid, dim3(256), 0, s, g, x, w, bias, y, act, slope);
+        cn_prof_end(s);
+        CN_LAUNCH_CHECK();
+        return CN_OK;
     }
     if (const char* e = getenv("CN_CFG")) cfg = atoi(e);          // tuning overrides (scripts/conv_tune.py)
     if (const char* e = getenv("CN_SPLITS")) splits = atoi(e);
