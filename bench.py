@@ -42,6 +42,8 @@ def main():
     ap.add_argument("--serial", action="store_true",
                     help="one stream, eager dispatch: no kernel overlaps another (the form to trace for per-kernel durations)")
     ap.add_argument("--cpu-batch", type=int, default=16)
+    ap.add_argument("--bf16x3", action="store_true",
+                    help="EXPERIMENTAL, not the headline: error-compensated bf16 MFMA convolutions (DESIGN.md section 9 item 8)")
     args = ap.parse_args()
 
     import torch
@@ -50,6 +52,8 @@ def main():
     from confignet_amd.confignet_first_stage import DEFAULT_CONFIG
     from confignet_amd.confignet_utils import merge_configs
 
+    if args.bf16x3:
+        ops.BF16X3 = True
     world = parallel.init_from_env()
     rank = parallel.rank()
     if world > 1:                                     # N processes share the host: keep each rank's CPU thread pool small
@@ -155,7 +159,8 @@ def main():
             "metric": "train-step images/sec at 256x256 (G+D fwd+bwd)",
             "value": round(value, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32" if not args.bf16x3 else "f32 emulated: bf16x3-split MFMA, fp32 accumulate (EXPERIMENTAL, not the headline)",
+            "data": "synthetic",
             "config": {"workload": "ConfigNet second-stage iteration (D + synth-D + latent-D + G + EMA), %dx%d, "
                                    "batch %d per GPU, fp32, Keras-Adam" % (args.res, args.res, args.batch),
                        "global_batch": args.batch * world, "resolution": args.res, "latent_dim": cfg_latent(model),

@@ -1046,7 +1046,7 @@ __global__ __launch_bounds__(256) void up2k4_rgb_fwd_kernel(CnConvGeom g, const 
 // EXPERIMENTAL (CN_BF16X3=1, off by default; not the product path of round 1): the same implicit GEMM with every fp32
 // operand split into two bf16 terms, x = hi + lo (+ 2^-17 |x|), and  a*b ~= a_hi*b_hi + a_hi*b_lo + a_lo*b_hi  evaluated by
 // three v_mfma_f32_32x32x16_bf16 with fp32 accumulation (relative error ~2^-16 per product against 2^-24 for the fp32
-// MFMA; the bf16 pipe is 16x wider).  128 x 128 tile, 32-deep stages, operands stored k-contiguous in LDS so that a lane
+// MFMA; the bf16 pipe is 16x wider).  128 x 128 tile, 16-deep stages (48 KB of LDS: 3 workgroups per CU), operands stored k-contiguous in LDS so that a lane
 // fetches its 8 bf16 of one MFMA with one ds_read_b128.  Forward geometry only (no parity order, no split-K).
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
@@ -1058,11 +1058,26 @@ __device__ __forceinline__ void split_bf16(float x, unsigned short& hi, unsigned
     lo = (unsigned short)((v + 0x7FFFu + ((v >> 16) & 1u)) >> 16);
 }
 
+// filter pre-split for the experimental path: W[tap][ci][co] (fp32) -> Whi / Wlo [tap][co][ci] (bf16, k contiguous)
+__global__ void wsplit_bf16_kernel(const float* __restrict__ W, unsigned short* __restrict__ Whi, unsigned short* __restrict__ Wlo,
+                                   int T, int cin, int cout) {
+    const long total = (long)T * cin * cout;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int ci = (int)(i % cin);
+        const long r = i / cin;
+        const int co = (int)(r % cout), tap = (int)(r / cout);
+        unsigned short h, l;
+        split_bf16(W[((long)tap * cin + ci) * cout + co], h, l);
+        Whi[i] = h;
+        Wlo[i] = l;
+    }
+}
+
 __global__ __launch_bounds__(256) void igemm_fwd_bf16x3_kernel(CnConvGeom g, const float* __restrict__ X,
-                                                               const float* __restrict__ W, const float* __restrict__ bias,
-                                                               float* __restrict__ Y, int act, float slope) {
-    constexpr int BM = 128, BN = 128, KB = 32, LD = KB + 8;             // LD in bf16 elements (80-byte rows, 16-byte aligned)
-    constexpr int AP = 4, BP = 4;
+                                                               const unsigned short* __restrict__ Whi, const unsigned short* __restrict__ Wlo,
+                                                               const float* __restrict__ bias, float* __restrict__ Y, int act, float slope) {
+    constexpr int BM = 128, BN = 128, KB = 16, LD = KB + 8;             // LD in bf16 elements (48-byte rows, 16-byte aligned)
+    constexpr int KQ = KB / 4, RPP = 256 / KQ, AP = BM / RPP;
     __shared__ __attribute__((aligned(16))) unsigned short Ahi[2][BM][LD], Alo[2][BM][LD], Bhi[2][BN][LD], Blo[2][BN][LD];
     __shared__ int rowmap[BM];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1070,13 +1085,13 @@ __global__ __launch_bounds__(256) void igemm_fwd_bf16x3_kernel(CnConvGeom g, con
     const int M = g.n * g.out_d * g.out_h * g.out_w;
     const int T = g.k_d * g.k_h * g.k_w;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-    const int kq = tid & 7, arow = tid >> 3;                            // A: 8 float4 per row per stage, 32 rows per pass
+    const int kq = tid % KQ, arow = tid / KQ;
     RowInfo ri[AP];
 #pragma unroll
     for (int i = 0; i < AP; ++i) {
-        const int mrow = m0 + arow + 32 * i;
+        const int mrow = m0 + arow + RPP * i;
         ri[i] = decode_row(g, mrow, M);
-        if (kq == 0) rowmap[arow + 32 * i] = ri[i].ok ? mrow : -1;
+        if (kq == 0) rowmap[arow + RPP * i] = ri[i].ok ? mrow : -1;
     }
     f32x16 acc[2][2];
 #pragma unroll
@@ -1086,7 +1101,8 @@ __global__ __launch_bounds__(256) void igemm_fwd_bf16x3_kernel(CnConvGeom g, con
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     const int cpb = g.cin / KB, nks = T * cpb;
-    float4 ra[AP], rb[BP];
+    float4 ra[AP];
+    uint4 rbh, rbl;                                                   // one (column, 8 k) piece of each split filter per thread
     int aoff[AP];
     int cur_tap = -1;
     auto load_tiles = [&](int ks) {
@@ -1101,12 +1117,12 @@ __global__ __launch_bounds__(256) void igemm_fwd_bf16x3_kernel(CnConvGeom g, con
 #pragma unroll
         for (int i = 0; i < AP; ++i)
             ra[i] = aoff[i] >= 0 ? *reinterpret_cast<const float4*>(X + aoff[i] + c0 + kq * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int j = 0; j < BP; ++j) {
-            const int idx = tid + 256 * j;
-            const int brow = idx >> 5, col = n0 + (idx & 31) * 4;
-            const long kg = (long)tap * g.cin + c0 + brow;
-            rb[j] = col < g.cout ? *reinterpret_cast<const float4*>(W + kg * g.cout + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+        {
+            const int bn = tid >> 1, k8 = tid & 1;                       // KB = 16: two 8-element pieces per column
+            const int col = n0 + bn;
+            const long off = ((long)tap * g.cout + col) * g.cin + c0 + 8 * k8;
+            rbh = col < g.cout ? *reinterpret_cast<const uint4*>(Whi + off) : make_uint4(0, 0, 0, 0);
+            rbl = col < g.cout ? *reinterpret_cast<const uint4*>(Wlo + off) : make_uint4(0, 0, 0, 0);
         }
     };
     auto store_tiles = [&](int buf) {
@@ -1116,23 +1132,12 @@ __global__ __launch_bounds__(256) void igemm_fwd_bf16x3_kernel(CnConvGeom g, con
             unsigned short h[4], l[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) split_bf16(v[e], h[e], l[e]);
-            const int r = arow + 32 * i;
+            const int r = arow + RPP * i;
             *reinterpret_cast<uint2*>(&Ahi[buf][r][kq * 4]) = make_uint2(h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16));
             *reinterpret_cast<uint2*>(&Alo[buf][r][kq * 4]) = make_uint2(l[0] | ((unsigned)l[1] << 16), l[2] | ((unsigned)l[3] << 16));
         }
-#pragma unroll
-        for (int j = 0; j < BP; ++j) {
-            const int idx = tid + 256 * j;
-            const int brow = idx >> 5, bcol = (idx & 31) * 4;
-            const float v[4] = {rb[j].x, rb[j].y, rb[j].z, rb[j].w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                unsigned short h, l;
-                split_bf16(v[e], h, l);
-                Bhi[buf][bcol + e][brow] = h;                       // transposed: k contiguous per output column
-                Blo[buf][bcol + e][brow] = l;
-            }
-        }
+        *reinterpret_cast<uint4*>(&Bhi[buf][tid >> 1][8 * (tid & 1)]) = rbh;
+        *reinterpret_cast<uint4*>(&Blo[buf][tid >> 1][8 * (tid & 1)]) = rbl;
     };
     load_tiles(0);
     store_tiles(0);
@@ -1352,15 +1357,6 @@ extern "C" int cn_conv_fwd(const CnConvGeom* gp, const float* x, const float* w,
         if (want > nks / min_steps) want = nks / min_steps;
         if (want > 1) splits = (int)want;
     }
-    static const int bf16x3 = getenv("CN_BF16X3") ? atoi(getenv("CN_BF16X3")) : 0;
-    if (bf16x3 && vec && !par && g.cin % 32 == 0 && g.cout % 4 == 0 && (long)cn_cdiv(M, 128) * cn_cdiv(g.cout, 128) >= 256) {
-        dim3 grid(cn_cdiv(M, 128), cn_cdiv(g.cout, 128));
-        cn_prof_begin(s, conv_flops(g));
-        hipLaunchKernelGGL(igemm_fwd_bf16x3_kernel, grid, dim3(256), 0, s, g, x, w, bias, y, act, slope);
-        cn_prof_end(s);
-        CN_LAUNCH_CHECK();
-        return CN_OK;
-    }
     if (const char* e = getenv("CN_CFG")) cfg = atoi(e);          // tuning overrides (scripts/conv_tune.py)
     if (const char* e = getenv("CN_SPLITS")) splits = atoi(e);
     const int kact = splits > 1 ? CN_ACT_NONE : act;
@@ -1450,4 +1446,43 @@ extern "C" int cn_sumpool2(const float* gu, float* gx, int nd, int n, int d, int
         hipLaunchKernelGGL(sumpool2_kernel<2>, dim3(cn_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, gu, gx, n, d, h, w, c / 4);
     CN_LAUNCH_CHECK();
     return CN_OK;
+}
+
+// ---- EXPERIMENTAL error-compensated bf16 convolution (never called unless CN_BF16X3=1) ----
+extern "C" int cn_conv_weight_split_bf16(const float* w, uint16_t* whi, uint16_t* wlo, int taps, int cin, int cout, void* stream) {
+    CN_CHECK_ARG(w && whi && wlo && taps > 0 && cin > 0 && cout > 0, "bad weight_split args");
+    hipLaunchKernelGGL(wsplit_bf16_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, w, whi, wlo, taps, cin, cout);
+    CN_LAUNCH_CHECK();
+    return CN_OK;
+}
+
+extern "C" int cn_conv_fwd_bf16x3(const CnConvGeom* gp, const float* x, const uint16_t* whi, const uint16_t* wlo,
+                                  const float* bias, float* y, int act, float slope, void* stream) {
+    if (int e = check_geom(gp)) return e;
+    CN_CHECK_ARG(x && whi && wlo && y, "NULL tensor");
+    const CnConvGeom g = *gp;
+    const long M = (long)g.n * g.out_d * g.out_h * g.out_w;
+    if (g.dl_d * g.dl_h * g.dl_w != 1 || g.cin % 16 || g.cout % 4 || (long)cn_cdiv(M, 128) * cn_cdiv(g.cout, 128) < 256)
+        return CN_EUNSUPPORTED;                     // outside the prototype's envelope: nothing was launched
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid(cn_cdiv(M, 128), cn_cdiv(g.cout, 128));
+    cn_prof_begin(s, conv_flops(g));
+    hipLaunchKernelGGL(igemm_fwd_bf16x3_kernel, grid, dim3(256), 0, s, g, x, whi, wlo, bias, y, act, slope);
+    cn_prof_end(s);
+    CN_LAUNCH_CHECK();
+    return CN_OK;
+}
+
+extern "C" int cn_conv_dgrad_bf16x3(const CnConvGeom* gp, const float* gy, const uint16_t* wthi, const uint16_t* wtlo, float* gu,
+                                    void* stream) {
+    if (int e = check_geom(gp)) return e;
+    if (gp->s_d != 1 || gp->s_h != 1 || gp->s_w != 1) return CN_EUNSUPPORTED;      // strided: parity-ordered fp32 path
+    CnConvGeom d = *gp;
+    d.in_d = gp->out_d; d.in_h = gp->out_h; d.in_w = gp->out_w; d.cin = gp->cout;
+    d.out_d = gp->in_d << gp->up; d.out_h = gp->in_h << gp->up; d.out_w = gp->in_w << gp->up;
+    if (gp->nd == 2) d.out_d = 1;
+    d.cout = gp->cin;
+    d.p_d = gp->k_d - 1 - gp->p_d; d.p_h = gp->k_h - 1 - gp->p_h; d.p_w = gp->k_w - 1 - gp->p_w;
+    d.up = 0;
+    return cn_conv_fwd_bf16x3(&d, gy, wthi, wtlo, nullptr, gu, CN_ACT_NONE, 0.f, stream);
 }

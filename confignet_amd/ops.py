@@ -2,6 +2,7 @@
 stream, torch tensors out.  torch only allocates memory and provides the stream here."""
 import ctypes
 import math
+import os
 
 import torch
 
@@ -17,7 +18,7 @@ def _stream():
 def _ptr(t):
     if t is None:
         return None
-    assert t.is_cuda and t.dtype in (torch.float32, torch.uint8, torch.int64) and t.is_contiguous(), \
+    assert t.is_cuda and t.dtype in (torch.float32, torch.uint8, torch.int64, torch.int16) and t.is_contiguous(), \
         "confignet_amd ops need contiguous CUDA tensors (got %s %s contiguous=%s)" % (t.device, t.dtype, t.is_contiguous())
     return ctypes.c_void_p(t.data_ptr())
 
@@ -80,8 +81,40 @@ def geom_in_shape(g, upsampled=False):
     return (g.n, g.in_h << u, g.in_w << u, g.cin)
 
 
+# EXPERIMENTAL: error-compensated bf16 convolution, only with CN_BF16X3=1
+BF16X3 = os.environ.get("CN_BF16X3") == "1"
+CN_EUNSUPPORTED = -3
+
+
+def _bf16x3_rows_cout(rows, cout, cin, dilated):
+    return (not dilated) and cin % 16 == 0 and cout % 4 == 0 and ((rows + 127) // 128) * ((cout + 127) // 128) >= 256
+
+
+def weight_split_bf16(w):
+    """(whi, wlo): [taps][cout][cin] bf16 halves of w [..taps.., cin, cout], cached on the tensor per weights epoch / stream."""
+    from .nn import WEIGHTS_EPOCH
+    key = (WEIGHTS_EPOCH[0], w._version, w.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    c = getattr(w, "_cn_wsplit", None)
+    if c is not None and c[0] == key:
+        return c[1]
+    taps, cin, cout = int(math.prod(w.shape[:-2])), w.shape[-2], w.shape[-1]
+    halves = torch.empty((2, taps, cout, cin), device=w.device, dtype=torch.int16)
+    check(lib.cn_conv_weight_split_bf16(_ptr(w), _ptr(halves[0]), _ptr(halves[1]), taps, cin, cout, _stream()), "cn_conv_weight_split_bf16")
+    try:
+        w._cn_wsplit = (key, halves)
+    except Exception:
+        pass
+    return halves
+
+
 def conv_fwd(x, w, bias, g, act=ACT_NONE, slope=0.0):
     y = torch.empty(geom_out_shape(g), device=x.device, dtype=torch.float32)
+    if BF16X3 and _bf16x3_rows_cout(y.numel() // g.cout, g.cout, g.cin, g.dl_d * g.dl_h * g.dl_w != 1):
+        halves = weight_split_bf16(w)
+        rc = lib.cn_conv_fwd_bf16x3(ctypes.byref(g), _ptr(x), _ptr(halves[0]), _ptr(halves[1]), _ptr(bias), _ptr(y), act, slope, _stream())
+        if rc != CN_EUNSUPPORTED:
+            check(rc, "cn_conv_fwd_bf16x3")
+            return y
     check(lib.cn_conv_fwd(ctypes.byref(g), _ptr(x), _ptr(w), _ptr(bias), _ptr(y), act, slope, _stream()), "cn_conv_fwd")
     return y
 
@@ -96,6 +129,12 @@ def weight_tflip(w):
 def conv_dgrad(gy, wt, g):
     """Gradient w.r.t. the (virtually upsampled) input of the conv described by g."""
     gu = torch.empty(geom_in_shape(g, upsampled=True), device=gy.device, dtype=torch.float32)
+    if BF16X3 and g.s_d * g.s_h * g.s_w == 1 and _bf16x3_rows_cout(gu.numel() // g.cin, g.cin, g.cout, False):
+        halves = weight_split_bf16(wt)
+        rc = lib.cn_conv_dgrad_bf16x3(ctypes.byref(g), _ptr(gy), _ptr(halves[0]), _ptr(halves[1]), _ptr(gu), _stream())
+        if rc != CN_EUNSUPPORTED:
+            check(rc, "cn_conv_dgrad_bf16x3")
+            return gu
     check(lib.cn_conv_dgrad(ctypes.byref(g), _ptr(gy), _ptr(wt), _ptr(gu), _stream()), "cn_conv_dgrad")
     return gu
 

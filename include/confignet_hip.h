@@ -22,6 +22,7 @@ extern "C" {
 #define CN_OK 0
 #define CN_EINVAL (-1)   /* bad argument / unsupported geometry */
 #define CN_EHIP (-2)     /* HIP runtime error */
+#define CN_EUNSUPPORTED (-3) /* experimental entry points only: geometry outside the envelope, nothing launched */
 
 /* activation codes for fused epilogues */
 #define CN_ACT_NONE 0
@@ -178,6 +179,16 @@ int cn_prof_enable(int on);
 int cn_prof_reset(void);
 /* synchronises the recorded events; returns launches, summed kernel ms and algorithmic flops */
 int cn_prof_collect(int* launches, double* total_ms, double* total_flops);
+
+/* ---- EXPERIMENTAL, not part of the round-1 product path (reached only with CN_BF16X3=1):
+ * convolution with every fp32 operand split into two bf16 terms and a*b ~= a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on the
+ * bf16 MFMA pipe with fp32 accumulation.  w [taps][cin][cout] -> whi/wlo [taps][cout][cin]; fwd/dgrad return
+ * CN_EUNSUPPORTED without launching when the geometry is outside the prototype's envelope ------------------------*/
+int cn_conv_weight_split_bf16(const float* w, uint16_t* whi, uint16_t* wlo, int taps, int cin, int cout, void* stream);
+int cn_conv_fwd_bf16x3(const CnConvGeom* g, const float* x, const uint16_t* whi, const uint16_t* wlo, const float* bias,
+                       float* y, int act, float slope, void* stream);
+int cn_conv_dgrad_bf16x3(const CnConvGeom* g, const float* gy, const uint16_t* wthi, const uint16_t* wtlo, float* gu,
+                         void* stream);
 
 /* ---- stream calibration: one wave busy-waits `ticks` of the 100 MHz wall clock on `stream`.  Two such launches on
  * streams that share a hardware queue run back to back, on independent queues side by side: graphs.py uses that to
