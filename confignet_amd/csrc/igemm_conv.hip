@@ -1073,10 +1073,11 @@ __global__ void wsplit_bf16_kernel(const float* __restrict__ W, unsigned short* 
     }
 }
 
+template <int TN>   // output columns per workgroup = 64 * TN
 __global__ __launch_bounds__(256) void igemm_fwd_bf16x3_kernel(CnConvGeom g, const float* __restrict__ X,
                                                                const unsigned short* __restrict__ Whi, const unsigned short* __restrict__ Wlo,
                                                                const float* __restrict__ bias, float* __restrict__ Y, int act, float slope) {
-    constexpr int BM = 128, BN = 128, KB = 16, LD = KB + 8;             // LD in bf16 elements (48-byte rows, 16-byte aligned)
+    constexpr int BM = 128, BN = 64 * TN, KB = 16, LD = KB + 8;             // LD in bf16 elements (48-byte rows, 16-byte aligned)
     constexpr int KQ = KB / 4, RPP = 256 / KQ, AP = BM / RPP;
     __shared__ __attribute__((aligned(16))) unsigned short Ahi[2][BM][LD], Alo[2][BM][LD], Bhi[2][BN][LD], Blo[2][BN][LD];
     __shared__ int rowmap[BM];
@@ -1093,11 +1094,11 @@ __global__ __launch_bounds__(256) void igemm_fwd_bf16x3_kernel(CnConvGeom g, con
         ri[i] = decode_row(g, mrow, M);
         if (kq == 0) rowmap[arow + RPP * i] = ri[i].ok ? mrow : -1;
     }
-    f32x16 acc[2][2];
+    f32x16 acc[2][TN];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     const int cpb = g.cin / KB, nks = T * cpb;
@@ -1121,8 +1122,9 @@ __global__ __launch_bounds__(256) void igemm_fwd_bf16x3_kernel(CnConvGeom g, con
             const int bn = tid >> 1, k8 = tid & 1;                       // KB = 16: two 8-element pieces per column
             const int col = n0 + bn;
             const long off = ((long)tap * g.cout + col) * g.cin + c0 + 8 * k8;
-            rbh = col < g.cout ? *reinterpret_cast<const uint4*>(Whi + off) : make_uint4(0, 0, 0, 0);
-            rbl = col < g.cout ? *reinterpret_cast<const uint4*>(Wlo + off) : make_uint4(0, 0, 0, 0);
+            const bool on = bn < BN && col < g.cout;
+            rbh = on ? *reinterpret_cast<const uint4*>(Whi + off) : make_uint4(0, 0, 0, 0);
+            rbl = on ? *reinterpret_cast<const uint4*>(Wlo + off) : make_uint4(0, 0, 0, 0);
         }
     };
     auto store_tiles = [&](int buf) {
@@ -1136,8 +1138,10 @@ __global__ __launch_bounds__(256) void igemm_fwd_bf16x3_kernel(CnConvGeom g, con
             *reinterpret_cast<uint2*>(&Ahi[buf][r][kq * 4]) = make_uint2(h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16));
             *reinterpret_cast<uint2*>(&Alo[buf][r][kq * 4]) = make_uint2(l[0] | ((unsigned)l[1] << 16), l[2] | ((unsigned)l[3] << 16));
         }
-        *reinterpret_cast<uint4*>(&Bhi[buf][tid >> 1][8 * (tid & 1)]) = rbh;
-        *reinterpret_cast<uint4*>(&Blo[buf][tid >> 1][8 * (tid & 1)]) = rbl;
+        if ((tid >> 1) < BN) {
+            *reinterpret_cast<uint4*>(&Bhi[buf][tid >> 1][8 * (tid & 1)]) = rbh;
+            *reinterpret_cast<uint4*>(&Blo[buf][tid >> 1][8 * (tid & 1)]) = rbl;
+        }
     };
     load_tiles(0);
     store_tiles(0);
@@ -1148,7 +1152,7 @@ __global__ __launch_bounds__(256) void igemm_fwd_bf16x3_kernel(CnConvGeom g, con
 #pragma unroll
         for (int k16 = 0; k16 < KB; k16 += 16) {
             union U { uint4 u; bf16x8 v; };
-            U ah[2], al[2], bh[2], bl[2];
+            U ah[2], al[2], bh[TN], bl[TN];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int r = wm * 64 + 32 * i + l31;
@@ -1156,15 +1160,15 @@ __global__ __launch_bounds__(256) void igemm_fwd_bf16x3_kernel(CnConvGeom g, con
                 al[i].u = *reinterpret_cast<const uint4*>(&Alo[buf][r][k16 + 8 * half]);
             }
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int c = wn * 64 + 32 * j + l31;
+            for (int j = 0; j < TN; ++j) {
+                const int c = wn * 32 * TN + 32 * j + l31;
                 bh[j].u = *reinterpret_cast<const uint4*>(&Bhi[buf][c][k16 + 8 * half]);
                 bl[j].u = *reinterpret_cast<const uint4*>(&Blo[buf][c][k16 + 8 * half]);
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
+                for (int j = 0; j < TN; ++j) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i].v, bh[j].v, acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i].v, bl[j].v, acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i].v, bh[j].v, acc[i][j], 0, 0, 0);
@@ -1174,8 +1178,8 @@ __global__ __launch_bounds__(256) void igemm_fwd_bf16x3_kernel(CnConvGeom g, con
         __syncthreads();
     }
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int col = n0 + wn * 64 + 32 * j + l31;
+    for (int j = 0; j < TN; ++j) {
+        const int col = n0 + wn * 32 * TN + 32 * j + l31;
         if (col >= g.cout) continue;
         const float bv = bias ? bias[col] : 0.f;
 #pragma unroll
@@ -1462,12 +1466,15 @@ extern "C" int cn_conv_fwd_bf16x3(const CnConvGeom* gp, const float* x, const ui
     CN_CHECK_ARG(x && whi && wlo && y, "NULL tensor");
     const CnConvGeom g = *gp;
     const long M = (long)g.n * g.out_d * g.out_h * g.out_w;
-    if (g.dl_d * g.dl_h * g.dl_w != 1 || g.cin % 16 || g.cout % 4 || (long)cn_cdiv(M, 128) * cn_cdiv(g.cout, 128) < 256)
+    const bool narrow = g.cout <= 64 || (long)cn_cdiv(M, 128) * cn_cdiv(g.cout, 128) < 512;      // 128 x 64 tiles
+    const long tiles = (long)cn_cdiv(M, 128) * cn_cdiv(g.cout, narrow ? 64 : 128);
+    if (g.dl_d * g.dl_h * g.dl_w != 1 || g.cin % 16 || g.cout % 4 || tiles < 256)
         return CN_EUNSUPPORTED;                     // outside the prototype's envelope: nothing was launched
     hipStream_t s = (hipStream_t)stream;
-    dim3 grid(cn_cdiv(M, 128), cn_cdiv(g.cout, 128));
+    dim3 grid(cn_cdiv(M, 128), cn_cdiv(g.cout, narrow ? 64 : 128));
     cn_prof_begin(s, conv_flops(g));
-    hipLaunchKernelGGL(igemm_fwd_bf16x3_kernel, grid, dim3(256), 0, s, g, x, whi, wlo, bias, y, act, slope);
+    if (narrow) hipLaunchKernelGGL(igemm_fwd_bf16x3_kernel<1>, grid, dim3(256), 0, s, g, x, whi, wlo, bias, y, act, slope);
+    else hipLaunchKernelGGL(igemm_fwd_bf16x3_kernel<2>, grid, dim3(256), 0, s, g, x, whi, wlo, bias, y, act, slope);
     cn_prof_end(s);
     CN_LAUNCH_CHECK();
     return CN_OK;

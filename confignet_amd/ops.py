@@ -87,7 +87,7 @@ CN_EUNSUPPORTED = -3
 
 
 def _bf16x3_rows_cout(rows, cout, cin, dilated):
-    return (not dilated) and cin % 16 == 0 and cout % 4 == 0 and ((rows + 127) // 128) * ((cout + 127) // 128) >= 256
+    return (not dilated) and cin % 16 == 0 and cout % 4 == 0 and ((rows + 127) // 128) * ((cout + 63) // 64) >= 256
 
 
 def weight_split_bf16(w):
