@@ -69,9 +69,9 @@ SIGNATURES = {
     "cn_gather_images_u8": [_p, _p, _p, _p, _i, _i, _i, _i, _p],
     "cn_to_uint8": [_p, _p, _z, _p],
     "cn_spin": [ctypes.c_ulonglong, _p],
-    "cn_conv_weight_split_bf16": [_p, _p, _p, _i, _i, _i, _p],
-    "cn_conv_fwd_bf16x3": [_G, _p, _p, _p, _p, _p, _i, _f, _p],
-    "cn_conv_dgrad_bf16x3": [_G, _p, _p, _p, _p, _p],
+    "cn_conv_weight_split_bf16": [_p, _p, _i, _i, _i, _i, _p],
+    "cn_conv_fwd_bf16x3": [_G, _p, _p, _i, _p, _p, _i, _f, _p],
+    "cn_conv_dgrad_bf16x3": [_G, _p, _p, _i, _p, _p],
     "cn_prof_enable": [_i],
     "cn_prof_reset": [],
     "cn_prof_collect": [ctypes.POINTER(_i), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)],

@@ -1050,36 +1050,44 @@ __global__ __launch_bounds__(256) void up2k4_rgb_fwd_kernel(CnConvGeom g, const 
 // fetches its 8 bf16 of one MFMA with one ds_read_b128.  Forward geometry only (no parity order, no split-K).
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-__device__ __forceinline__ void split_bf16(float x, unsigned short& hi, unsigned short& lo) {
-    const unsigned u = __float_as_uint(x);
-    const unsigned h = (u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u;       // round to nearest even
-    const unsigned v = __float_as_uint(x - __uint_as_float(h));
-    hi = (unsigned short)(h >> 16);
-    lo = (unsigned short)((v + 0x7FFFu + ((v >> 16) & 1u)) >> 16);
+
+// n-way bf16 split of an fp32 value: x = t[0] + t[1] (+ t[2]) + O(2^-(8 n + 1) |x|); every difference below is exact in fp32
+template <int NS>
+__device__ __forceinline__ void split_bf16_n(float x, unsigned short (&t)[NS]) {
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        const unsigned u = __float_as_uint(x);
+        const unsigned h = (u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u;       // round to nearest even
+        t[i] = (unsigned short)(h >> 16);
+        x -= __uint_as_float(h);
+    }
 }
 
-// filter pre-split for the experimental path: W[tap][ci][co] (fp32) -> Whi / Wlo [tap][co][ci] (bf16, k contiguous)
-__global__ void wsplit_bf16_kernel(const float* __restrict__ W, unsigned short* __restrict__ Whi, unsigned short* __restrict__ Wlo,
-                                   int T, int cin, int cout) {
+// filter pre-split for the experimental path: W[tap][ci][co] (fp32) -> NS arrays [tap][co][ci] (bf16, k contiguous)
+template <int NS>
+__global__ void wsplit_bf16_kernel(const float* __restrict__ W, unsigned short* __restrict__ Ws, int T, int cin, int cout) {
     const long total = (long)T * cin * cout;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int ci = (int)(i % cin);
         const long r = i / cin;
         const int co = (int)(r % cout), tap = (int)(r / cout);
-        unsigned short h, l;
-        split_bf16(W[((long)tap * cin + ci) * cout + co], h, l);
-        Whi[i] = h;
-        Wlo[i] = l;
+        unsigned short t[NS];
+        split_bf16_n<NS>(W[((long)tap * cin + ci) * cout + co], t);
+#pragma unroll
+        for (int q = 0; q < NS; ++q) Ws[q * total + i] = t[q];
     }
 }
 
-template <int TN>   // output columns per workgroup = 64 * TN
+// NS = 2: a*b ~= a0 b0 + a0 b1 + a1 b0 (3 MFMAs, 16 operand bits); NS = 3: + a0 b2 + a2 b0 + a1 b1 (6 MFMAs: every dropped term
+// is <= 2^-24 of the product, the size of one fp32 rounding).  TN: output columns per workgroup = 64 * TN.
+template <int TN, int NS>
 __global__ __launch_bounds__(256) void igemm_fwd_bf16x3_kernel(CnConvGeom g, const float* __restrict__ X,
-                                                               const unsigned short* __restrict__ Whi, const unsigned short* __restrict__ Wlo,
-                                                               const float* __restrict__ bias, float* __restrict__ Y, int act, float slope) {
+                                                               const unsigned short* __restrict__ Ws, long wstride,
+                                                               const float* __restrict__ bias, float* __restrict__ Y, int act,
+                                                               float slope) {
     constexpr int BM = 128, BN = 64 * TN, KB = 16, LD = KB + 8;             // LD in bf16 elements (48-byte rows, 16-byte aligned)
     constexpr int KQ = KB / 4, RPP = 256 / KQ, AP = BM / RPP;
-    __shared__ __attribute__((aligned(16))) unsigned short Ahi[2][BM][LD], Alo[2][BM][LD], Bhi[2][BN][LD], Blo[2][BN][LD];
+    __shared__ __attribute__((aligned(16))) unsigned short As[NS][2][BM][LD], Bs[NS][2][BN][LD];
     __shared__ int rowmap[BM];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, half = lane >> 5, l31 = lane & 31;
@@ -1103,7 +1111,7 @@ __global__ __launch_bounds__(256) void igemm_fwd_bf16x3_kernel(CnConvGeom g, con
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     const int cpb = g.cin / KB, nks = T * cpb;
     float4 ra[AP];
-    uint4 rbh, rbl;                                                   // one (column, 8 k) piece of each split filter per thread
+    uint4 rbs[NS];                                                    // one (column, 8 k) piece of each filter term per thread
     int aoff[AP];
     int cur_tap = -1;
     auto load_tiles = [&](int ks) {
@@ -1123,24 +1131,27 @@ __global__ __launch_bounds__(256) void igemm_fwd_bf16x3_kernel(CnConvGeom g, con
             const int col = n0 + bn;
             const long off = ((long)tap * g.cout + col) * g.cin + c0 + 8 * k8;
             const bool on = bn < BN && col < g.cout;
-            rbh = on ? *reinterpret_cast<const uint4*>(Whi + off) : make_uint4(0, 0, 0, 0);
-            rbl = on ? *reinterpret_cast<const uint4*>(Wlo + off) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < NS; ++q)
+                rbs[q] = on ? *reinterpret_cast<const uint4*>(Ws + q * wstride + off) : make_uint4(0, 0, 0, 0);
         }
     };
     auto store_tiles = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < AP; ++i) {
             const float v[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
-            unsigned short h[4], l[4];
+            unsigned short t[4][NS];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) split_bf16(v[e], h[e], l[e]);
+            for (int e = 0; e < 4; ++e) split_bf16_n<NS>(v[e], t[e]);
             const int r = arow + RPP * i;
-            *reinterpret_cast<uint2*>(&Ahi[buf][r][kq * 4]) = make_uint2(h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16));
-            *reinterpret_cast<uint2*>(&Alo[buf][r][kq * 4]) = make_uint2(l[0] | ((unsigned)l[1] << 16), l[2] | ((unsigned)l[3] << 16));
+#pragma unroll
+            for (int q = 0; q < NS; ++q)
+                *reinterpret_cast<uint2*>(&As[q][buf][r][kq * 4]) =
+                    make_uint2(t[0][q] | ((unsigned)t[1][q] << 16), t[2][q] | ((unsigned)t[3][q] << 16));
         }
         if ((tid >> 1) < BN) {
-            *reinterpret_cast<uint4*>(&Bhi[buf][tid >> 1][8 * (tid & 1)]) = rbh;
-            *reinterpret_cast<uint4*>(&Blo[buf][tid >> 1][8 * (tid & 1)]) = rbl;
+#pragma unroll
+            for (int q = 0; q < NS; ++q) *reinterpret_cast<uint4*>(&Bs[q][buf][tid >> 1][8 * (tid & 1)]) = rbs[q];
         }
     };
     load_tiles(0);
@@ -1149,30 +1160,25 @@ __global__ __launch_bounds__(256) void igemm_fwd_bf16x3_kernel(CnConvGeom g, con
     for (int ks = 0; ks < nks; ++ks) {
         const int buf = ks & 1;
         if (ks + 1 < nks) load_tiles(ks + 1);
-#pragma unroll
-        for (int k16 = 0; k16 < KB; k16 += 16) {
+        {
             union U { uint4 u; bf16x8 v; };
-            U ah[2], al[2], bh[TN], bl[TN];
+            U a[NS][2], b[NS][TN];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int r = wm * 64 + 32 * i + l31;
-                ah[i].u = *reinterpret_cast<const uint4*>(&Ahi[buf][r][k16 + 8 * half]);
-                al[i].u = *reinterpret_cast<const uint4*>(&Alo[buf][r][k16 + 8 * half]);
+            for (int q = 0; q < NS; ++q) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) a[q][i].u = *reinterpret_cast<const uint4*>(&As[q][buf][wm * 64 + 32 * i + l31][8 * half]);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[q][j].u = *reinterpret_cast<const uint4*>(&Bs[q][buf][wn * 32 * TN + 32 * j + l31][8 * half]);
             }
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int c = wn * 32 * TN + 32 * j + l31;
-                bh[j].u = *reinterpret_cast<const uint4*>(&Bhi[buf][c][k16 + 8 * half]);
-                bl[j].u = *reinterpret_cast<const uint4*>(&Blo[buf][c][k16 + 8 * half]);
+            // smallest terms first; every (qa, qb) with qa + qb < NS, spelled out so that all indices are compile-time
+#define CN_BFX_TERM(QA, QB)                                                                                              \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j)                         \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[QA][i].v, b[QB][j].v, acc[i][j], 0, 0, 0);
+            if constexpr (NS == 3) {
+                CN_BFX_TERM(0, 2) CN_BFX_TERM(2, 0) CN_BFX_TERM(1, 1)
             }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i].v, bh[j].v, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i].v, bl[j].v, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i].v, bh[j].v, acc[i][j], 0, 0, 0);
-                }
+            CN_BFX_TERM(0, 1) CN_BFX_TERM(1, 0) CN_BFX_TERM(0, 0)
+#undef CN_BFX_TERM
         }
         if (ks + 1 < nks) store_tiles(buf ^ 1);
         __syncthreads();
@@ -1453,17 +1459,18 @@ extern "C" int cn_sumpool2(const float* gu, float* gx, int nd, int n, int d, int
 }
 
 // ---- EXPERIMENTAL error-compensated bf16 convolution (never called unless CN_BF16X3=1) ----
-extern "C" int cn_conv_weight_split_bf16(const float* w, uint16_t* whi, uint16_t* wlo, int taps, int cin, int cout, void* stream) {
-    CN_CHECK_ARG(w && whi && wlo && taps > 0 && cin > 0 && cout > 0, "bad weight_split args");
-    hipLaunchKernelGGL(wsplit_bf16_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, w, whi, wlo, taps, cin, cout);
+extern "C" int cn_conv_weight_split_bf16(const float* w, uint16_t* ws, int terms, int taps, int cin, int cout, void* stream) {
+    CN_CHECK_ARG(w && ws && (terms == 2 || terms == 3) && taps > 0 && cin > 0 && cout > 0, "bad weight_split args");
+    if (terms == 2) hipLaunchKernelGGL(wsplit_bf16_kernel<2>, dim3(1024), dim3(256), 0, (hipStream_t)stream, w, ws, taps, cin, cout);
+    else hipLaunchKernelGGL(wsplit_bf16_kernel<3>, dim3(1024), dim3(256), 0, (hipStream_t)stream, w, ws, taps, cin, cout);
     CN_LAUNCH_CHECK();
     return CN_OK;
 }
 
-extern "C" int cn_conv_fwd_bf16x3(const CnConvGeom* gp, const float* x, const uint16_t* whi, const uint16_t* wlo,
-                                  const float* bias, float* y, int act, float slope, void* stream) {
+extern "C" int cn_conv_fwd_bf16x3(const CnConvGeom* gp, const float* x, const uint16_t* ws, int terms, const float* bias,
+                                  float* y, int act, float slope, void* stream) {
     if (int e = check_geom(gp)) return e;
-    CN_CHECK_ARG(x && whi && wlo && y, "NULL tensor");
+    CN_CHECK_ARG(x && ws && y && (terms == 2 || terms == 3), "bad bf16-split convolution args");
     const CnConvGeom g = *gp;
     const long M = (long)g.n * g.out_d * g.out_h * g.out_w;
     const bool narrow = g.cout <= 64 || (long)cn_cdiv(M, 128) * cn_cdiv(g.cout, 128) < 512;      // 128 x 64 tiles
@@ -1472,16 +1479,18 @@ extern "C" int cn_conv_fwd_bf16x3(const CnConvGeom* gp, const float* x, const ui
         return CN_EUNSUPPORTED;                     // outside the prototype's envelope: nothing was launched
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(cn_cdiv(M, 128), cn_cdiv(g.cout, narrow ? 64 : 128));
+    const long wstride = (long)g.k_d * g.k_h * g.k_w * g.cin * g.cout;
     cn_prof_begin(s, conv_flops(g));
-    if (narrow) hipLaunchKernelGGL(igemm_fwd_bf16x3_kernel<1>, grid, dim3(256), 0, s, g, x, whi, wlo, bias, y, act, slope);
-    else hipLaunchKernelGGL(igemm_fwd_bf16x3_kernel<2>, grid, dim3(256), 0, s, g, x, whi, wlo, bias, y, act, slope);
+#define BFX(TN_, NS_) hipLaunchKernelGGL((igemm_fwd_bf16x3_kernel<TN_, NS_>), grid, dim3(256), 0, s, g, x, ws, wstride, bias, y, act, slope)
+    if (terms == 2) { if (narrow) BFX(1, 2); else BFX(2, 2); }
+    else { if (narrow) BFX(1, 3); else BFX(2, 3); }
+#undef BFX
     cn_prof_end(s);
     CN_LAUNCH_CHECK();
     return CN_OK;
 }
 
-extern "C" int cn_conv_dgrad_bf16x3(const CnConvGeom* gp, const float* gy, const uint16_t* wthi, const uint16_t* wtlo, float* gu,
-                                    void* stream) {
+extern "C" int cn_conv_dgrad_bf16x3(const CnConvGeom* gp, const float* gy, const uint16_t* wts, int terms, float* gu, void* stream) {
     if (int e = check_geom(gp)) return e;
     if (gp->s_d != 1 || gp->s_h != 1 || gp->s_w != 1) return CN_EUNSUPPORTED;      // strided: parity-ordered fp32 path
     CnConvGeom d = *gp;
@@ -1491,5 +1500,5 @@ extern "C" int cn_conv_dgrad_bf16x3(const CnConvGeom* gp, const float* gy, const
     d.cout = gp->cin;
     d.p_d = gp->k_d - 1 - gp->p_d; d.p_h = gp->k_h - 1 - gp->p_h; d.p_w = gp->k_w - 1 - gp->p_w;
     d.up = 0;
-    return cn_conv_fwd_bf16x3(&d, gy, wthi, wtlo, nullptr, gu, CN_ACT_NONE, 0.f, stream);
+    return cn_conv_fwd_bf16x3(&d, gy, wts, terms, nullptr, gu, CN_ACT_NONE, 0.f, stream);
 }

@@ -82,7 +82,8 @@ def geom_in_shape(g, upsampled=False):
 
 
 # EXPERIMENTAL: error-compensated bf16 convolution, only with CN_BF16X3=1
-BF16X3 = os.environ.get("CN_BF16X3") == "1"
+BF16X3 = os.environ.get("CN_BF16X3") in ("1", "2", "3")
+BF16_TERMS = 3 if os.environ.get("CN_BF16X3") == "3" else 2      # 2: 16 operand bits, 3 MFMAs; 3: all 24 bits, 6 MFMAs
 CN_EUNSUPPORTED = -3
 
 
@@ -91,15 +92,15 @@ def _bf16x3_rows_cout(rows, cout, cin, dilated):
 
 
 def weight_split_bf16(w):
-    """(whi, wlo): [taps][cout][cin] bf16 halves of w [..taps.., cin, cout], cached on the tensor per weights epoch / stream."""
+    """[terms][taps][cout][cin] bf16 terms of w [..taps.., cin, cout], cached on the tensor per weights epoch / stream."""
     from .nn import WEIGHTS_EPOCH
-    key = (WEIGHTS_EPOCH[0], w._version, w.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    key = (WEIGHTS_EPOCH[0], w._version, w.data_ptr(), torch.cuda.current_stream().cuda_stream, BF16_TERMS)
     c = getattr(w, "_cn_wsplit", None)
     if c is not None and c[0] == key:
         return c[1]
     taps, cin, cout = int(math.prod(w.shape[:-2])), w.shape[-2], w.shape[-1]
-    halves = torch.empty((2, taps, cout, cin), device=w.device, dtype=torch.int16)
-    check(lib.cn_conv_weight_split_bf16(_ptr(w), _ptr(halves[0]), _ptr(halves[1]), taps, cin, cout, _stream()), "cn_conv_weight_split_bf16")
+    halves = torch.empty((BF16_TERMS, taps, cout, cin), device=w.device, dtype=torch.int16)
+    check(lib.cn_conv_weight_split_bf16(_ptr(w), _ptr(halves), BF16_TERMS, taps, cin, cout, _stream()), "cn_conv_weight_split_bf16")
     try:
         w._cn_wsplit = (key, halves)
     except Exception:
@@ -111,7 +112,7 @@ def conv_fwd(x, w, bias, g, act=ACT_NONE, slope=0.0):
     y = torch.empty(geom_out_shape(g), device=x.device, dtype=torch.float32)
     if BF16X3 and _bf16x3_rows_cout(y.numel() // g.cout, g.cout, g.cin, g.dl_d * g.dl_h * g.dl_w != 1):
         halves = weight_split_bf16(w)
-        rc = lib.cn_conv_fwd_bf16x3(ctypes.byref(g), _ptr(x), _ptr(halves[0]), _ptr(halves[1]), _ptr(bias), _ptr(y), act, slope, _stream())
+        rc = lib.cn_conv_fwd_bf16x3(ctypes.byref(g), _ptr(x), _ptr(halves), BF16_TERMS, _ptr(bias), _ptr(y), act, slope, _stream())
         if rc != CN_EUNSUPPORTED:
             check(rc, "cn_conv_fwd_bf16x3")
             return y
@@ -131,7 +132,7 @@ def conv_dgrad(gy, wt, g):
     gu = torch.empty(geom_in_shape(g, upsampled=True), device=gy.device, dtype=torch.float32)
     if BF16X3 and g.s_d * g.s_h * g.s_w == 1 and _bf16x3_rows_cout(gu.numel() // g.cin, g.cin, g.cout, False):
         halves = weight_split_bf16(wt)
-        rc = lib.cn_conv_dgrad_bf16x3(ctypes.byref(g), _ptr(gy), _ptr(halves[0]), _ptr(halves[1]), _ptr(gu), _stream())
+        rc = lib.cn_conv_dgrad_bf16x3(ctypes.byref(g), _ptr(gy), _ptr(halves), BF16_TERMS, _ptr(gu), _stream())
         if rc != CN_EUNSUPPORTED:
             check(rc, "cn_conv_dgrad_bf16x3")
             return gu

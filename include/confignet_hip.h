@@ -181,14 +181,15 @@ int cn_prof_reset(void);
 int cn_prof_collect(int* launches, double* total_ms, double* total_flops);
 
 /* ---- EXPERIMENTAL, not part of the round-1 product path (reached only with CN_BF16X3=1):
- * convolution with every fp32 operand split into two bf16 terms and a*b ~= a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on the
- * bf16 MFMA pipe with fp32 accumulation.  w [taps][cin][cout] -> whi/wlo [taps][cout][cin]; fwd/dgrad return
+ * convolution with every fp32 operand split into 2 (or 3) bf16 terms, x = t0 + t1 (+ t2), and the product expanded into 3
+ * (or 6) bf16 MFMAs with fp32 accumulation: terms = 2 keeps 16 operand bits, terms = 3 all 24 (every dropped cross term is
+ * <= 2^-24 of the product).  w [taps][cin][cout] -> ws [terms][taps][cout][cin]; fwd/dgrad return
  * CN_EUNSUPPORTED without launching when the geometry is outside the prototype's envelope ------------------------*/
-int cn_conv_weight_split_bf16(const float* w, uint16_t* whi, uint16_t* wlo, int taps, int cin, int cout, void* stream);
-int cn_conv_fwd_bf16x3(const CnConvGeom* g, const float* x, const uint16_t* whi, const uint16_t* wlo, const float* bias,
+int cn_conv_weight_split_bf16(const float* w, uint16_t* ws /* [terms][taps][cout][cin] */, int terms /* 2 or 3 */,
+                              int taps, int cin, int cout, void* stream);
+int cn_conv_fwd_bf16x3(const CnConvGeom* g, const float* x, const uint16_t* ws, int terms, const float* bias,
                        float* y, int act, float slope, void* stream);
-int cn_conv_dgrad_bf16x3(const CnConvGeom* g, const float* gy, const uint16_t* wthi, const uint16_t* wtlo, float* gu,
-                         void* stream);
+int cn_conv_dgrad_bf16x3(const CnConvGeom* g, const float* gy, const uint16_t* wts, int terms, float* gu, void* stream);
 
 /* ---- stream calibration: one wave busy-waits `ticks` of the 100 MHz wall clock on `stream`.  Two such launches on
  * streams that share a hardware queue run back to back, on independent queues side by side: graphs.py uses that to

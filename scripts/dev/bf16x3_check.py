@@ -28,7 +28,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
         os.environ.get("CN_BF16X3", "0"), us, 2.0 * n * h * w * k * k * cin * cout / us / 1e6, err, float(ref.abs().max())))
     sys.exit(0)
 for shape in ("16 64 64 256 256 3", "16 128 128 128 128 3", "16 32 32 512 512 3", "16 256 256 64 64 3"):
-    for mode in ("0", "1"):
+    for mode in ("0", "1", "3"):     # fp32 MFMA / 2-term split (3 MFMAs) / 3-term split (6 MFMAs)
         env = dict(os.environ, CN_BF16X3=mode)
         out = subprocess.run([sys.executable, __file__, "child"] + shape.split(), env=env, capture_output=True, text=True)
         print(shape, "| bf16x3 =", (out.stdout.strip().splitlines() or [out.stderr[-300:]])[-1])
