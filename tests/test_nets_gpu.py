@@ -501,7 +501,9 @@ def test_hip_graph_steps_match_eager():
         moved = (a - w0).abs().max()
         # identical up to fp32-atomics noise: only gradients at noise level may take the other sign
         # |Adam step| <= lr_t/sqrt(1-beta_2) = 3.17 lr when beta_1 = 0; two opposite-sign steps differ by twice that
-        assert float(diff.max()) <= 6.5 * lr and float((diff > 1e-6).float().mean()) < 0.5, (float(diff.max()), float((diff > 1e-6).float().mean()))
+        # ... and on average the two runs' updates differ by a small fraction of the update itself
+        upd = float((a - w0).abs().mean())
+        assert float(diff.max()) <= 6.5 * lr and float(diff.mean()) <= 0.05 * upd + 1e-7, (float(diff.max()), float(diff.mean()), upd)
         if n is not m.generator_smoothed:
             assert float(moved) > 0 or n.n_trainable == 0
 
