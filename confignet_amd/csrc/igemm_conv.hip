@@ -108,7 +108,7 @@ template <int WM, int WN, int TM, int TN, bool VEC, bool BVEC = true, int KB = B
 __global__ __launch_bounds__(256) void igemm_fwd_kernel(CnConvGeom g, const float* __restrict__ X,
                                                         const float* __restrict__ W, const float* __restrict__ bias,
                                                         float* __restrict__ Y, int act, float slope, int par,
-                                                        int xcd_swizzle) {
+                                                        int xcd_swizzle, int ntiles_m, int ntiles_n) {
     static_assert(WM * WN == 4, "4 waves per workgroup");
     constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN, LDA = BM + 4, LDB = BN + 4;
     constexpr int KQ = KB / 4;                          // float4 pieces per A row per K step
@@ -126,12 +126,24 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(CnConvGeom g, const floa
     // XCD-aware tile order: workgroup b runs on XCD b % 8 (observed dispatch order); give each XCD a contiguous
     // run of M tiles so that neighbouring tiles (shared input halo rows) hit the same 4 MiB L2.  Bijective for
     // any grid size; placement only affects speed, never results.
-    int bx = blockIdx.x;
-    if (xcd_swizzle && !par) {   // parity-ordered rows: classes have 1/2/2/4 live taps, keep them interleaved over XCDs
+    int bx = blockIdx.x, by = blockIdx.y;
+    if ((xcd_swizzle & 3) == 2) {
+        // 1-D launch over all (M tile, cout tile) pairs: XCD = id % 8 gets a contiguous run of M tiles and, within it, the
+        // cout tiles of one M tile in consecutive slots -- they read the same input rows, which then come from that XCD's
+        // L2 instead of being fetched once per cout tile
+        const int nt = ntiles_n, nmt = ntiles_m;
+        const int id = blockIdx.x, xcd = id & 7, j = id >> 3;
+        const int q = nmt >> 3, r = nmt & 7;                              // M tiles per XCD: q (+1 for the first r XCDs)
+        const int mine = q + (xcd < r ? 1 : 0);
+        const int ml = j / nt;
+        if (ml >= mine) return;                                           // padding slot of the rounded-up launch
+        by = j - ml * nt;
+        bx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + ml;
+    } else if (xcd_swizzle && !par) {   // parity-ordered rows: classes have 1/2/2/4 live taps, keep them interleaved over XCDs
         const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bx & 7, idx = bx >> 3;
         bx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int m0 = bx * BM, n0 = blockIdx.y * BN;
+    const int m0 = bx * BM, n0 = by * BN;
 
     const int kq = tid % KQ, arow = tid / KQ;
     RowInfo ri[AP];
@@ -169,20 +181,43 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(CnConvGeom g, const floa
     const int per_z = (nks_all + gridDim.z - 1) / gridDim.z;
     const int ks_beg = blockIdx.z * per_z, ks_end = min(nks_all, ks_beg + per_z);
     int cur_ord = -1, cur_tap = -1;                     // ordinal among live taps / tap index
+    const bool tap_minor = VEC && xcd_swizzle >= 2 && !par && gridDim.z == 1 && T > 1 && T <= 9 && (xcd_swizzle & 4);
+    extern __shared__ int offtab[];                     // tap-minor order: gather offset of every (tap, row of this thread)
+    if (tap_minor) {
+        for (int t = 0; t < T; ++t) {
+            int kd, kh, kw;
+            tap_decode(g, t, kd, kh, kw);
+#pragma unroll
+            for (int i = 0; i < AP; ++i) offtab[(t * AP + i) * 256 + tid] = src_off(g, ri[i], kd, kh, kw);
+        }
+    }
 
+    // K order.  Tap-major (all channel chunks of a tap, then the next tap) recomputes the gather offsets once per tap.
+    // Tap-minor (tap_minor != 0: all taps of a channel chunk, then the next chunk) recomputes them every step but keeps
+    // the XCD's working set at (tiles in flight) x (rows) x KB channels, so the taps' shifted re-reads of a chunk hit
+    // the 4 MiB L2 instead of going back to the fabric (stride-1 layers with many channels).
     auto load_tiles = [&](int ks) {
         if (VEC) {
-            const int ord = ks / cpb;
-            const int c0 = (ks - ord * cpb) * KB;
-            if (ord != cur_ord) {
-                while (cur_ord < ord) {
-                    cur_tap += __ffsll((long long)(tapmask >> (cur_tap + 1)));
-                    ++cur_ord;
-                }
-                int kd, kh, kw;
-                tap_decode(g, cur_tap, kd, kh, kw);
+            int c0;
+            if (tap_minor) {
+                const int chunk = ks / T;
+                cur_tap = ks - chunk * T;
+                c0 = chunk * KB;
 #pragma unroll
-                for (int i = 0; i < AP; ++i) aoff[i] = src_off(g, ri[i], kd, kh, kw);
+                for (int i = 0; i < AP; ++i) aoff[i] = offtab[(cur_tap * AP + i) * 256 + tid];
+            } else {
+                const int ord = ks / cpb;
+                c0 = (ks - ord * cpb) * KB;
+                if (ord != cur_ord) {
+                    while (cur_ord < ord) {
+                        cur_tap += __ffsll((long long)(tapmask >> (cur_tap + 1)));
+                        ++cur_ord;
+                    }
+                    int kd, kh, kw;
+                    tap_decode(g, cur_tap, kd, kh, kw);
+#pragma unroll
+                    for (int i = 0; i < AP; ++i) aoff[i] = src_off(g, ri[i], kd, kh, kw);
+                }
             }
             const int tap = cur_tap;
 #pragma unroll
@@ -1208,16 +1243,30 @@ int launch_fwd(const CnConvGeom& g, bool vec, int par, int splits, const float* 
                float* y, int act, float slope, hipStream_t s) {
     const long M = (long)g.n * g.out_d * g.out_h * g.out_w;
     dim3 grid(cn_cdiv(M, 32 * WM * TM), cn_cdiv(g.cout, 32 * WN * TN), splits);
+    int xcd = g_xcd;
+    const int ntm = (int)grid.x, ntn = (int)grid.y;
+    static const int tap_minor_on = getenv("CN_TAP_MINOR") ? atoi(getenv("CN_TAP_MINOR")) : 1;
+    // cout tiles of one M tile grouped per XCD (several cout tiles), taps inside channel chunks (wide layers on the big tiles:
+    // that is where the tap re-reads miss L2; the offset table costs LDS the small tiles' occupancy cannot spare)
+    const bool wide = TM * TN >= 2 && g.cin >= 128;
+    if (g_xcd && !par && splits == 1 && ntm >= 64 && (ntn > 1 || wide)) {
+        xcd = 2 | ((tap_minor_on && wide) ? 4 : 0);
+        const int per_xcd = (ntm + 7) / 8;
+        grid = dim3((unsigned)(per_xcd * ntn * 8), 1, 1);
+    }
     if (g_force_kb16 < 0) g_force_kb16 = getenv("CN_KB32") ? 0 : 1;   // 32-deep stages only on request (A/B: no net win)
     // 32-deep LDS stages: twice the MFMA work per barrier / per global-load round trip, which is what the
     // smaller tiles need to cover the L2/HBM latency of the gathered operand
     const bool kb32 = vec && g.cin % 32 == 0 && !g_force_kb16;
+    const int taps = g.k_d * g.k_h * g.k_w;
+    if ((xcd & 4) && (taps < 2 || taps > 9 || !vec)) xcd &= ~4;         // (offset table: taps x AP x 1 KiB of LDS)
+    const size_t dyn = (xcd & 4) ? sizeof(int) * taps * (32 * WM * TM / (256 / ((kb32 ? 32 : BK) / 4))) * 256 : 0;   // taps x AP x 256 threads
     if (kb32)
-        hipLaunchKernelGGL((igemm_fwd_kernel<WM, WN, TM, TN, true, true, 32>), grid, dim3(256), 0, s, g, x, w, bias, y, act, slope, par, g_xcd);
+        hipLaunchKernelGGL((igemm_fwd_kernel<WM, WN, TM, TN, true, true, 32>), grid, dim3(256), dyn, s, g, x, w, bias, y, act, slope, par, xcd, ntm, ntn);
     else if (vec)
-        hipLaunchKernelGGL((igemm_fwd_kernel<WM, WN, TM, TN, true>), grid, dim3(256), 0, s, g, x, w, bias, y, act, slope, par, g_xcd);
+        hipLaunchKernelGGL((igemm_fwd_kernel<WM, WN, TM, TN, true>), grid, dim3(256), dyn, s, g, x, w, bias, y, act, slope, par, xcd, ntm, ntn);
     else
-        hipLaunchKernelGGL((igemm_fwd_kernel<WM, WN, TM, TN, false>), grid, dim3(256), 0, s, g, x, w, bias, y, act, slope, par, g_xcd);
+        hipLaunchKernelGGL((igemm_fwd_kernel<WM, WN, TM, TN, false>), grid, dim3(256), 0, s, g, x, w, bias, y, act, slope, par, xcd, ntm, ntn);
     CN_LAUNCH_CHECK();
     return CN_OK;
 }
@@ -1287,7 +1336,7 @@ extern "C" int cn_conv_fwd(const CnConvGeom* gp, const float* x, const float* w,
             // bookkeeping of a VALU kernel dominates; the 128x32 MFMA tile with dead-tap skipping is faster
             dim3 grid(cn_cdiv(M, 128), 1, 1);
             cn_prof_begin(s, conv_flops(g));
-            hipLaunchKernelGGL((igemm_fwd_kernel<4, 1, 1, 1, true, false>), grid, dim3(256), 0, s, g, x, w, bias, y, act, slope, 1, g_xcd);
+            hipLaunchKernelGGL((igemm_fwd_kernel<4, 1, 1, 1, true, false>), grid, dim3(256), 0, s, g, x, w, bias, y, act, slope, 1, g_xcd, 0, 0);
             cn_prof_end(s);
             CN_LAUNCH_CHECK();
             return CN_OK;
