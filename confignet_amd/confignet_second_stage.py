@@ -284,9 +284,12 @@ class ConfigNet(ConfigNetFirstStage):
             runner = StepGraph(device_step)
         else:
             runner = device_step
+        log = getattr(self, "fine_tune_loss_log", None)       # a list: receives every step's losses as floats (one sync per step)
         for step_number in range(n_iters):
             optimizer.advance("ft")
             self.last_fine_tune_losses = runner()
+            if log is not None:
+                log.append({k: float(v) for k, v in self.last_fine_tune_losses.items()})
         stale = state["stale"]
         # the reference returns pre/post tiled before the last optimizer step with the updated expr (l.402)
         result = stale.cpu().numpy()

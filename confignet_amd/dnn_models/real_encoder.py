@@ -18,34 +18,67 @@ C1 = {1: ConvSpec((1, 1)), 2: ConvSpec((1, 1), stride=2)}
 C3 = ConvSpec((3, 3))
 
 
+def resnet50_layers():
+    """Weight-carrying layers of keras.applications ResNet50 (include_top=False) in `model.layers` order, which is
+    the order of `get_weights()` and therefore of the `real_encoder_weights` list in a checkpoint
+    (confignet_second_stage.py:35-43).  [TF-2.1] A functional model sorts layers by depth from the output; inside one
+    depth by a depth-first walk from the output that visits the Add's shortcut input first, so a conv-shortcut block
+    lists  _1_conv, _1_bn, _2_conv, _2_bn, _0_conv, _3_conv, _0_bn, _3_bn  (as `ResNet50().summary()` prints it).
+    Yields (name, kind, cin, cout, k)."""
+    yield "conv1_conv", "conv", 3, 64, 7
+    yield "conv1_bn", "bn", 0, 64, 0
+    cin = 64
+    for si, (f, blocks, _) in enumerate(RESNET50_STACKS):
+        for bi in range(blocks):
+            n = "conv%d_block%d" % (si + 2, bi + 1)
+            yield n + "_1_conv", "conv", cin, f, 1
+            yield n + "_1_bn", "bn", 0, f, 0
+            yield n + "_2_conv", "conv", f, f, 3
+            yield n + "_2_bn", "bn", 0, f, 0
+            if bi == 0:
+                yield n + "_0_conv", "conv", cin, 4 * f, 1
+                yield n + "_3_conv", "conv", f, 4 * f, 1
+                yield n + "_0_bn", "bn", 0, 4 * f, 0
+                yield n + "_3_bn", "bn", 0, 4 * f, 0
+            else:
+                yield n + "_3_conv", "conv", f, 4 * f, 1
+                yield n + "_3_bn", "bn", 0, 4 * f, 0
+            cin = 4 * f
+
+
 class RealEncoder(Net):
     def __init__(self, latent_dim, input_shape, rotation_ranges, rng=None):
         super().__init__()
         rng = rng or np.random.default_rng()
-        self._convs = []           # (first weight index, spec)
+        # weights are registered in the Keras get_weights() order; the forward pass addresses them by layer name
+        where = {}
+        for name, kind, cin, cout, k in resnet50_layers():
+            where[name] = len(self._entries)
+            if kind == "conv":
+                self.add_weight(name + "/kernel", he_normal(rng, (k, k, cin, cout)))
+                self.add_weight(name + "/bias", np.zeros(cout, np.float32))
+            else:
+                # a residual branch's last BN starts small so 16 stacked blocks keep O(1) activations
+                self.add_weight(name + "/gamma", np.full(cout, 0.25 if name.endswith("_3_bn") else 1.0, np.float32))
+                self.add_weight(name + "/beta", np.zeros(cout, np.float32))
+                self.add_weight(name + "/moving_mean", np.zeros(cout, np.float32), trainable=False)
+                self.add_weight(name + "/moving_variance", np.ones(cout, np.float32), trainable=False)
+        # execution order: (kernel index, bn index, spec) per conv+BN pair -- shortcut (0), then 1, 2, 3 of every block
+        self._convs = []
 
-        def conv_bn(k, cin, cout, spec, last_in_block=False):
-            first = len(self._entries)
-            self.add_weight("conv%d/kernel" % first, he_normal(rng, (k, k, cin, cout)))
-            self.add_weight("conv%d/bias" % first, np.zeros(cout, np.float32))
-            # a residual branch's last BN starts small so 16 stacked blocks keep O(1) activations
-            self.add_weight("bn%d/gamma" % first, np.full(cout, 0.25 if last_in_block else 1.0, np.float32))
-            self.add_weight("bn%d/beta" % first, np.zeros(cout, np.float32))
-            self.add_weight("bn%d/moving_mean" % first, np.zeros(cout, np.float32), trainable=False)
-            self.add_weight("bn%d/moving_variance" % first, np.ones(cout, np.float32), trainable=False)
-            self._convs.append((first, spec))
+        def conv_bn(prefix, spec):
+            self._convs.append((where[prefix + "_conv"], where[prefix + "_bn"], spec))
 
-        conv_bn(7, 3, 64, C7)
-        cin = 64
-        for filters, blocks, stride1 in RESNET50_STACKS:
+        conv_bn("conv1", C7)
+        for si, (filters, blocks, stride1) in enumerate(RESNET50_STACKS):
             for bi in range(blocks):
+                n = "conv%d_block%d" % (si + 2, bi + 1)
                 s = stride1 if bi == 0 else 1
                 if bi == 0:
-                    conv_bn(1, cin, 4 * filters, C1[s])          # 0_conv shortcut
-                conv_bn(1, cin, filters, C1[s])                  # 1_conv (stride on the first 1x1)
-                conv_bn(3, filters, filters, C3)                 # 2_conv
-                conv_bn(1, filters, 4 * filters, C1[1], True)    # 3_conv
-                cin = 4 * filters
+                    conv_bn(n + "_0", C1[s])                     # 0_conv shortcut
+                conv_bn(n + "_1", C1[s])                         # 1_conv (stride on the first 1x1)
+                conv_bn(n + "_2", C3)                            # 2_conv
+                conv_bn(n + "_3", C1[1])                         # 3_conv
         self.resnet_feature_dim = 2048
         self.add_weight("rotation_regressor/kernel", glorot_uniform(rng, (2048, 3)))
         self.add_weight("rotation_regressor/bias", np.zeros(3, np.float32))
@@ -61,25 +94,28 @@ class RealEncoder(Net):
         bn(conv + b) = a*conv + shift,  a = gamma*rsqrt(var+eps),  shift = beta + a*(b - mean).
         The (C,) coefficient algebra is host-side plumbing and carries the gradients of gamma, beta and b."""
         ws = self.weights
-        firsts = [f for f, _ in self._convs]
-        sizes = [ws[f + 1].shape[0] for f in firsts]
-        bias = torch.cat([ws[f + 1] for f in firsts])
-        gamma = torch.cat([ws[f + 2] for f in firsts])
-        beta = torch.cat([ws[f + 3] for f in firsts])
+        ks = [k for k, _, _ in self._convs]
+        bs = [b for _, b, _ in self._convs]
+        sizes = [ws[k + 1].shape[0] for k in ks]
+        bias = torch.cat([ws[k + 1] for k in ks])
+        gamma = torch.cat([ws[b] for b in bs])
+        beta = torch.cat([ws[b + 1] for b in bs])
         if getattr(self, "_stat_cache", None) is None:
-            self._stat_cache = (torch.cat([ws[f + 4] for f in firsts]), torch.cat([ws[f + 5] for f in firsts]))
+            self._stat_cache = (torch.cat([ws[b + 2] for b in bs]), torch.cat([ws[b + 3] for b in bs]))
         mean, var = self._stat_cache
         a = gamma * torch.rsqrt(var + BN_EPS)
         shift = beta + a * (bias - mean)
         return torch.split(a, sizes), torch.split(shift, sizes)
 
-    def set_weights(self, weights):
-        super().set_weights(weights)
+    def non_trainable_changed(self):
+        """set_weights / copy_weights_from / a data-parallel broadcast rewrote the moving mean / variance in place: drop
+        their concatenated copy.  (Not tied to mark_updated(): the optimizer calls that every step, and a copy re-made
+        inside one captured step graph must not be shared with another.)"""
         self._stat_cache = None
 
     def _conv_bn(self, ci, x, coef, res=None, relu=True):
-        first, spec = self._convs[ci]
-        z = F.conv(x, self.weights[first], None, spec)           # bias folded into the affine shift
+        kidx, _, spec = self._convs[ci]
+        z = F.conv(x, self.weights[kidx], None, spec)           # bias folded into the affine shift
         return F.channel_affine_act(z, coef[0][ci], coef[1][ci], res, relu)
 
     def features(self, img):

@@ -44,6 +44,9 @@ class Net:
         tap-flipped filters of the data-gradient GEMM) are keyed on this epoch instead."""
         WEIGHTS_EPOCH[0] += 1
 
+    def non_trainable_changed(self):
+        """Hook: the non-trainable tensors (BatchNorm moving statistics) were rewritten in place."""
+
     def __init__(self):
         self._entries = []          # (name, np array, trainable)
         self.weights = []           # torch tensors, Keras get_weights() order
@@ -101,6 +104,7 @@ class Net:
                 assert tuple(a.shape) == tuple(w.shape), "shape mismatch %s vs %s" % (a.shape, tuple(w.shape))
                 w.copy_(torch.from_numpy(np.ascontiguousarray(a)))
         self.mark_updated()
+        self.non_trainable_changed()
 
     def copy_weights_from(self, other):
         with torch.no_grad():
@@ -109,6 +113,7 @@ class Net:
                 if not w.requires_grad:
                     w.copy_(o)
         self.mark_updated()
+        self.non_trainable_changed()
 
     def zero_grad(self):
         self.grad_arena.zero_()
@@ -131,8 +136,12 @@ class Net:
 def backward_into_arenas(loss, nets):
     """tape.gradient(loss, trainable_weights) written into the networks' gradient arenas.
     Uses autograd.grad + one multi-tensor copy instead of .backward(): AccumulateGrad nodes are bound to the
-    stream they were created on, which breaks HIP-graph capture of a step on a capture stream."""
-    params = [p for n in nets for p in n.trainable_weights]
+    stream they were created on, which breaks HIP-graph capture of a step on a capture stream.
+    Weights switched off with requires_grad_(False) (a variable the caller leaves out of the reference's
+    trainable list, e.g. the expression slice of fine_tune_on_img(force_neutral_expression=True)) get a zero
+    gradient: Keras-Adam on a zero gradient with zero moments leaves them unchanged."""
+    every = [p for n in nets for p in n.trainable_weights]
+    params = [p for p in every if p.requires_grad]
     grads = torch.autograd.grad(loss, params, allow_unused=True)
     dst = [p.grad for p, g in zip(params, grads) if g is not None]
     src = [g.reshape(p.shape) for p, g in zip(params, grads) if g is not None]
@@ -140,4 +149,7 @@ def backward_into_arenas(loss, nets):
         torch._foreach_copy_(dst, src)
     for p, g in zip(params, grads):
         if g is None:
+            p.grad.zero_()
+    for p in every:
+        if not p.requires_grad:
             p.grad.zero_()

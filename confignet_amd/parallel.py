@@ -77,3 +77,5 @@ def broadcast_weights(nets, src=0):
         for w in n.weights:
             if not w.requires_grad:
                 dist.broadcast(w, src=src)
+        n.mark_updated()
+        n.non_trainable_changed()

@@ -50,18 +50,13 @@ def build_weights(res, latent_dim, rng, dtype=torch.float32):
             shapes = R.discriminator_weight_shapes(res) if k != "latent_regressor" else R.latent_regressor_weight_shapes(latent_dim, res)
             for i in range(5):
                 W[k][2 + 4 * i + 2].fill_(1.0)  # instance-norm gamma = 1
-    enc = []
-    for i, s in enumerate(R.real_encoder_weight_shapes(latent_dim)):
-        # per conv-bn group: kernel, bias, gamma, beta, moving_mean, moving_var
-        enc.append(s)
-    ew = _init(enc, rng, he=True, dtype=dtype)
-    n_bn = (len(ew) - 4) // 6
+    ew = _init(R.real_encoder_weight_shapes(latent_dim), rng, he=True, dtype=dtype)
     with torch.no_grad():
-        for j in range(n_bn):
-            ew[6 * j + 2].fill_(1.0)
-            ew[6 * j + 5].fill_(1.0)
-            ew[6 * j + 4].requires_grad_(False)
-            ew[6 * j + 5].requires_grad_(False)
+        for w, role in zip(ew, R.resnet50_weight_roles()):       # (the 4 head tensors after the ResNet keep their init)
+            if role in ("gamma", "var"):
+                w.fill_(1.0)
+            if role in ("mean", "var"):
+                w.requires_grad_(False)
     W["real_encoder"] = ew
     W["generator_smoothed"] = [w.detach().clone() for w in W["generator"]]
     vgg = _init(R.vgg_weight_shapes(R.VGG19_CFG), rng, he=True, dtype=dtype, grad=False)

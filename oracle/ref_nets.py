@@ -268,8 +268,9 @@ RESNET50_STACKS = [(64, 3, 1), (128, 4, 2), (256, 6, 2), (512, 3, 2)]
 BN_EPS = 1.001e-5
 
 
-def _conv_bn(c, x, stride=1, relu=True, pad7=False):
-    ck, cb, g, b, m, v = c.take(6)
+def _conv_bn(conv, bn, x, stride=1, relu=True, pad7=False):
+    ck, cb = conv
+    g, b, m, v = bn
     if pad7:
         x = O.conv_valid_padded(x, ck, cb, stride, 3)
     else:
@@ -278,39 +279,66 @@ def _conv_bn(c, x, stride=1, relu=True, pad7=False):
     return torch.relu(x) if relu else x
 
 
+def resnet50_layer_order():
+    """Weight-carrying layers of keras.applications ResNet50 (resnet_common.ResNet50, include_top=False) in
+    `model.layers` order [TF-2.1]: a functional model sorts its layers by depth from the output and, inside one depth,
+    by the order of a depth-first walk from the output that visits Add's inputs shortcut first (network.py:
+    _map_graph_network).  In a conv-shortcut block that gives
+        <b>_1_conv, <b>_1_bn, <b>_2_conv, <b>_2_bn, <b>_0_conv, <b>_3_conv, <b>_0_bn, <b>_3_bn
+    (what `ResNet50().summary()` prints), NOT shortcut first.  Returns [(name, kind, cin, cout, k)]."""
+    order = [("conv1_conv", "conv", 3, 64, 7), ("conv1_bn", "bn", 0, 64, 0)]
+    cin = 64
+    for si, (filters, blocks, _) in enumerate(RESNET50_STACKS):
+        for bi in range(blocks):
+            n = "conv%d_block%d" % (si + 2, bi + 1)
+            f = filters
+            order += [(n + "_1_conv", "conv", cin, f, 1), (n + "_1_bn", "bn", 0, f, 0),
+                      (n + "_2_conv", "conv", f, f, 3), (n + "_2_bn", "bn", 0, f, 0)]
+            if bi == 0:
+                order += [(n + "_0_conv", "conv", cin, 4 * f, 1), (n + "_3_conv", "conv", f, 4 * f, 1),
+                          (n + "_0_bn", "bn", 0, 4 * f, 0), (n + "_3_bn", "bn", 0, 4 * f, 0)]
+            else:
+                order += [(n + "_3_conv", "conv", f, 4 * f, 1), (n + "_3_bn", "bn", 0, 4 * f, 0)]
+            cin = 4 * f
+    return order
+
+
 def resnet50_features(w_cursor, x_pre):
     c = w_cursor
-    x = _conv_bn(c, x_pre, stride=2, pad7=True)          # conv1_pad(3) + 7x7 s2 valid + bn + relu
+    L = {}
+    for name, kind, _, _, _ in resnet50_layer_order():      # Conv2D: kernel, bias; BatchNormalization: gamma, beta, mean, var
+        L[name] = c.take(2 if kind == "conv" else 4)
+
+    def cb(prefix, x, **kw):
+        return _conv_bn(L[prefix + "_conv"], L[prefix + "_bn"], x, **kw)
+
+    x = cb("conv1", x_pre, stride=2, pad7=True)          # conv1_pad(3) + 7x7 s2 valid + bn + relu
     x = O.maxpool(x, 3, 2, pad=1)                        # pool1_pad(1) + 3x3 s2
-    for filters, blocks, stride1 in RESNET50_STACKS:
+    for si, (filters, blocks, stride1) in enumerate(RESNET50_STACKS):
         for bi in range(blocks):
+            n = "conv%d_block%d" % (si + 2, bi + 1)
             s = stride1 if bi == 0 else 1
-            if bi == 0:
-                sc = _conv_bn(c, x, stride=s, relu=False)            # 0_conv 1x1 (4f, stride) + 0_bn
-            else:
-                sc = x
-            y = _conv_bn(c, x, stride=s)                             # 1_conv 1x1 (f, stride)
-            y = _conv_bn(c, y)                                       # 2_conv 3x3 same
-            y = _conv_bn(c, y, relu=False)                           # 3_conv 1x1 (4f)
+            sc = cb(n + "_0", x, stride=s, relu=False) if bi == 0 else x     # 0_conv 1x1 (4f, stride) + 0_bn
+            y = cb(n + "_1", x, stride=s)                                    # 1_conv 1x1 (f, stride)
+            y = cb(n + "_2", y)                                              # 2_conv 3x3 same
+            y = cb(n + "_3", y, relu=False)                                  # 3_conv 1x1 (4f)
             x = torch.relu(sc + y)
-    return x.mean(dim=(1, 2))                                        # pooling="avg"
+    return x.mean(dim=(1, 2))                                                # pooling="avg"
 
 
 def resnet50_weight_shapes():
     shp = []
-
-    def cb(k, cin, cout):
-        return [(k, k, cin, cout), (cout,), (cout,), (cout,), (cout,), (cout,)]
-
-    shp += cb(7, 3, 64)
-    cin = 64
-    for filters, blocks, _ in RESNET50_STACKS:
-        for bi in range(blocks):
-            if bi == 0:
-                shp += cb(1, cin, 4 * filters)
-            shp += cb(1, cin, filters) + cb(3, filters, filters) + cb(1, filters, 4 * filters)
-            cin = 4 * filters
+    for _, kind, cin, cout, k in resnet50_layer_order():
+        shp += [(k, k, cin, cout), (cout,)] if kind == "conv" else [(cout,)] * 4
     return shp
+
+
+def resnet50_weight_roles():
+    """Per entry of resnet50_weight_shapes(): 'kernel' | 'bias' | 'gamma' | 'beta' | 'mean' | 'var'."""
+    roles = []
+    for _, kind, _, _, _ in resnet50_layer_order():
+        roles += ["kernel", "bias"] if kind == "conv" else ["gamma", "beta", "mean", "var"]
+    return roles
 
 
 def real_encoder_forward(w, img, rotation_ranges=((-30, 30), (-10, 10), (0, 0))):

@@ -128,42 +128,122 @@ def ema_update(smoothed, training, alpha=0.999):
             s.mul_(alpha).add_(t, alpha=1 - alpha)
 
 
-def second_stage_iteration(W, cfg, batch, d_opt, g_opt, vgg_w):
+def second_stage_iteration(W, cfg, batch, d_opt, g_opt, vgg_w, keep_grads=None, after_discriminator_phase=None):
     """One whole reference training iteration (confignet_second_stage.py:277-288) on explicit
     batches: D step, synth-D step, latent-D step, G step, EMA.  `batch` holds, for a batch size B:
     real_d, enc_in_d (B images each), real_sd, params_sd, rot_sd, real_ld, params_ld, and for the G step
     params_g, rot_g, synth_imgs_g, eye_masks_g (B//2) and real_imgs_g (B - B//2).
-    Used by tests and as bench.py's timed CPU baseline."""
+    Used by tests and as bench.py's timed CPU baseline.  keep_grads: optional dict that receives the gradient lists
+    of the four steps (tests compare the Adam updates where the gradient is significant).  after_discriminator_phase(W):
+    optional hook between step (3) and step (4) (a test checks the three discriminator updates there and then continues
+    from the device path's post-update discriminator weights, so that fp32 sign flips of lr*sign(g) steps on noise-level
+    gradients are not amplified into the generator step's loss scalars)."""
     res = cfg["output_shape"][0]
     out = {}
+    kg = keep_grads if keep_grads is not None else {}
     # (1) discriminator step (confignet_first_stage.py:466-476 ; batch: second_stage:119-130)
     with torch.no_grad():
         lat, rot = R.real_encoder_forward(W["real_encoder"], batch["enc_in_d"], cfg["rotation_ranges"])
         fake = R.generator_forward(W["generator"], lat, rot, res)
     losses = discriminator_loss(W["discriminator"], batch["real_d"], fake)
-    d_opt.apply_gradients(list(zip(grads_of(losses["loss_sum"], W["discriminator"]), W["discriminator"])))
+    kg["discriminator"] = grads_of(losses["loss_sum"], W["discriminator"])
+    d_opt.apply_gradients(list(zip(kg["discriminator"], W["discriminator"])))
     out["d"] = losses
     # (2) synthetic-domain discriminator step (confignet_first_stage.py:478-488,452-464)
     with torch.no_grad():
         lat = R.synthetic_encoder_forward(W["synthetic_encoder"], batch["params_sd"])
         fake = R.generator_forward(W["generator"], lat, batch["rot_sd"], res)
     losses = discriminator_loss(W["synth_discriminator"], batch["real_sd"], fake)
-    d_opt.apply_gradients(list(zip(grads_of(losses["loss_sum"], W["synth_discriminator"]), W["synth_discriminator"])))
+    kg["synth_discriminator"] = grads_of(losses["loss_sum"], W["synth_discriminator"])
+    d_opt.apply_gradients(list(zip(kg["synth_discriminator"], W["synth_discriminator"])))
     out["synth_d"] = losses
     # (3) latent discriminator step (confignet_second_stage.py:132-147)
     with torch.no_grad():
         real_lat, _ = R.real_encoder_forward(W["real_encoder"], batch["real_ld"], cfg["rotation_ranges"])
         fake_lat = R.synthetic_encoder_forward(W["synthetic_encoder"], batch["params_ld"])
     losses = latent_discriminator_loss(W["latent_discriminator"], real_lat, fake_lat)
-    d_opt.apply_gradients(list(zip(grads_of(losses["loss_sum"], W["latent_discriminator"]), W["latent_discriminator"])))
+    kg["latent_discriminator"] = grads_of(losses["loss_sum"], W["latent_discriminator"])
+    d_opt.apply_gradients(list(zip(kg["latent_discriminator"], W["latent_discriminator"])))
     out["latent_d"] = losses
+    if after_discriminator_phase is not None:
+        after_discriminator_phase(W)
     # (4) generator step (confignet_second_stage.py:149-218)
     losses, _ = second_stage_generator_loss(W, cfg, batch["params_g"], batch["rot_g"], batch["synth_imgs_g"],
                                             batch["eye_masks_g"], batch["real_imgs_g"], vgg_w)
     allw = W["generator"] + W["latent_regressor"] + W["synthetic_encoder"] + \
         [w for w in W["real_encoder"] if w.requires_grad]
-    g_opt.apply_gradients(list(zip(grads_of(losses["loss_sum"], allw), allw)))
+    kg["g_step"] = grads_of(losses["loss_sum"], allw)
+    g_opt.apply_gradients(list(zip(kg["g_step"], allw)))
     out["g"] = losses
     # (5) EMA (confignet_first_stage.py:393-400)
     ema_update(W["generator_smoothed"], W["generator"])
     return out
+
+
+def fine_tune_on_img(W, cfg, input_images, n_iters, vgg_w, vggface_w, expr_slice, force_neutral_expression=False,
+                     neutral_expr_latents=None, lr=0.0001):
+    """ConfigNet.fine_tune_on_img (confignet_second_stage.py:321-403) on explicit weights.
+
+    W: generator_smoothed (copied into the fine-tuned generator, l.337), real_encoder, discriminator,
+    latent_discriminator, latent_regressor.  input_images already scaled to [-1, 1], (n_imgs, R, R, 3).
+    expr_slice = (start, stop) of the blendshape_values slice of the latent (l.340).
+    neutral_expr_latents: (1, stop-start) latents of the all-zero blendshape vector (l.328-331) when
+    force_neutral_expression.  Returns (embeddings, rotations, per-step loss dicts, fine-tuned generator weights);
+    the embeddings are the pre/post tiles computed BEFORE the last optimizer step with the updated expr (l.402)."""
+    res = cfg["output_shape"][0]
+    dt = input_images.dtype
+    with torch.no_grad():
+        emb, rot = R.real_encoder_forward(W["real_encoder"], input_images, cfg["rotation_ranges"])     # l.327
+        emb = emb.clone()
+        if force_neutral_expression:
+            emb[:, expr_slice[0]:expr_slice[1]] = neutral_expr_latents.to(dt)
+    gen = [w.detach().clone().requires_grad_(True) for w in W["generator_smoothed"]]                   # l.333-337
+    mean_emb = emb.mean(dim=0, keepdim=True)                                                           # l.341
+    pre = mean_emb[:, :expr_slice[0]].clone().requires_grad_(True)                                     # l.343
+    expr = emb[:, expr_slice[0]:expr_slice[1]].clone().requires_grad_(not force_neutral_expression)    # l.344
+    post = mean_emb[:, expr_slice[1]:].clone().requires_grad_(True)                                    # l.345
+    rotations = rot.clone().requires_grad_(True)                                                       # l.348
+    n_imgs = input_images.shape[0]
+    opt = O.KerasAdam(lr=lr)                                                                           # l.350: default betas 0.9 / 0.999
+    history = []
+    pre_t = post_t = None
+    for _ in range(n_iters):
+        losses = {}
+        pre_t, post_t = pre.repeat(n_imgs, 1), post.repeat(n_imgs, 1)                                  # l.363-364
+        embeddings = torch.cat([pre_t, expr, post_t], dim=1)                                           # l.366
+        out = R.generator_forward(gen, embeddings, rotations, res)                                     # l.368
+        losses["image_loss_real"] = 0.5 * cfg["image_loss_weight"] * R.perceptual_loss(vgg_w, input_images, out)          # l.369
+        losses["face_reco_loss"] = 0.5 * cfg["image_loss_weight"] * R.perceptual_loss(vggface_w, out, input_images, "VGGFace")   # l.370,88-91
+        for i, o in enumerate(R.discriminator_forward(W["discriminator"], out).values()):              # l.373-376
+            losses["GAN_loss_real_%d" % i] = O.gan_g_loss(o)
+        ld_out = O.mlp_simple(embeddings, W["latent_discriminator"], 0.3)                              # l.379
+        ones = torch.ones(1, 1, dtype=dt)                                                              # fake_y_real, l.351
+        losses["latent_GAN_loss"] = cfg["domain_adverserial_loss_weight"] * O.gan_d_loss(ones, ld_out)  # l.380-382
+        labels = torch.cat([embeddings, cfg["latent_regressor_rot_weight"] * rotations], dim=-1)       # l.385
+        losses["latent_regression_loss"] = normalized_latent_regression_loss(W["latent_regressor"], cfg, out, labels)   # l.388
+        losses["loss_sum"] = sum(losses.values())                                                      # l.390
+        tw = gen + [pre, post, rotations] + ([] if force_neutral_expression else [expr])               # l.392-394
+        grads = torch.autograd.grad(losses["loss_sum"], tw, allow_unused=True)                         # l.395
+        opt.apply_gradients(list(zip(grads, tw)))                                                      # l.396
+        history.append({k: float(v.detach()) for k, v in losses.items()})
+    final = torch.cat([pre_t, expr, post_t], dim=1)                                                    # l.402: stale tiles, fresh expr
+    return final.detach(), rotations.detach(), history, [g.detach() for g in gen]
+
+
+def latent_gan_generator_step(g_w, d_w, z, opt):
+    """LatentGAN.generator_training_step (latent_gan.py:151-165): generator MLP (LeakyReLU 0.3) on z, G loss through the
+    discriminator, Adam on the generator's weights."""
+    fake = O.mlp_simple(z, g_w, 0.3)
+    out = O.mlp_simple(fake, d_w, 0.3)
+    loss = O.gan_g_loss(out)
+    opt.apply_gradients(list(zip(grads_of(loss, g_w), g_w)))
+    return {"gan_loss": loss, "loss_sum": loss}
+
+
+def latent_gan_discriminator_step(g_w, d_w, real_latents, z, opt):
+    """LatentGAN.discriminator_training_step (latent_gan.py:117-149): fakes from generator.predict(z) (outside the tape)."""
+    with torch.no_grad():
+        fake = O.mlp_simple(z, g_w, 0.3)
+    losses = latent_discriminator_loss(d_w, real_latents, fake)
+    opt.apply_gradients(list(zip(grads_of(losses["loss_sum"], d_w), d_w)))
+    return losses

@@ -110,22 +110,18 @@ def build_second_stage():
     a real image for the encoder branch; the rest is shared with the first-stage fixture."""
     W, vgg, inp = build()
     enc = seeded_weights(R.real_encoder_weight_shapes(L), 10, he=True)
-    shapes = R.real_encoder_weight_shapes(L)
     rng = np.random.default_rng(11)
-    # every ResNet conv block is [kernel, bias, gamma, beta, moving mean, moving variance]: identity-like BatchNorm
-    # statistics so that 50 layers neither vanish nor explode (SURVEY.md 8d)
-    i = 0
-    while i < len(shapes):
-        if len(shapes[i]) == 4 and i + 5 < len(shapes) and all(len(shapes[i + k]) == 1 for k in range(1, 6)):
-            c = shapes[i + 1][0]
-            enc[i + 1] = (0.05 * rng.standard_normal(c)).astype(np.float32)                      # conv bias
-            enc[i + 2] = (0.5 + 0.05 * rng.standard_normal(c)).astype(np.float32)                # gamma (< 1: keeps 16 residual blocks O(1))
-            enc[i + 3] = (0.05 * rng.standard_normal(c)).astype(np.float32)                      # beta
-            enc[i + 4] = (0.05 * rng.standard_normal(c)).astype(np.float32)                      # moving mean
-            enc[i + 5] = (1.0 + 0.05 * np.abs(rng.standard_normal(c))).astype(np.float32)        # moving variance
-            i += 6
-        else:
-            i += 1
+    # BatchNorm statistics near the identity so that 50 layers neither vanish nor explode (SURVEY.md 8d)
+    for i, role in enumerate(R.resnet50_weight_roles()):
+        c = enc[i].shape[0]
+        if role == "bias":
+            enc[i] = (0.05 * rng.standard_normal(c)).astype(np.float32)
+        elif role == "gamma":
+            enc[i] = (0.5 + 0.05 * rng.standard_normal(c)).astype(np.float32)      # (< 1: keeps 16 residual blocks O(1))
+        elif role in ("beta", "mean"):
+            enc[i] = (0.05 * rng.standard_normal(c)).astype(np.float32)
+        elif role == "var":
+            enc[i] = (1.0 + 0.05 * np.abs(rng.standard_normal(c))).astype(np.float32)
     enc[-4] = (enc[-4] * 0.05).astype(np.float32)      # heads: keep tanh unsaturated and the latents O(1)
     enc[-2] = (enc[-2] * 0.05).astype(np.float32)
     W["real_encoder"] = enc
@@ -147,6 +143,41 @@ def compute_second_stage(W, vgg, inp):
             "enc_grad_norm_total": np.array([float(torch.sqrt(sum((g ** 2).sum() for g in grads if g is not None)))])}
 
 
+# ---- fine_tune_on_img (confignet_second_stage.py:321-403; BASELINE.json configs[3] at 128x128) -----------------------
+FT_EXPR = (7, 37)        # blendshape_values slice of the 43-d latent: after the 7-d beard_style_embedding (sorted keys)
+
+
+def build_fine_tune(n_imgs=1):
+    W, vgg, inp = build_second_stage()
+    # a trained learned_input is not the all-ones initial bias: with a constant 4^3 input most first-layer channels see one sign
+    # only, their bias gradient is exactly zero in exact arithmetic and fp32 noise then decides the sign of an lr*sign(g) step
+    W["generator"][1] = (1.0 + 0.5 * np.random.default_rng(14).standard_normal(32768)).astype(np.float32)
+    W["generator_smoothed"] = [w.copy() for w in W["generator"]]
+    vggface = seeded_weights(R.vgg_weight_shapes(R.VGG16_CFG), 12, he=True)
+    rng = np.random.default_rng(13)
+    inp["ft_imgs"] = rng.uniform(-1, 1, (n_imgs, RES, RES, 3))
+    return W, vgg, vggface, inp
+
+
+FT_CFG = {"output_shape": (RES, RES, 3), "image_loss_weight": 5e-4, "domain_adverserial_loss_weight": 5.0,
+          "latent_regression_weight": 10.0, "latent_regressor_rot_weight": 5.0,
+          "rotation_ranges": ((-30, 30), (-10, 10), (0, 0))}
+
+
+def compute_fine_tune(W, vgg, vggface, inp, n_iters=3):
+    Wt = {k: [t64(w) for w in v] for k, v in W.items()}
+    emb0, rot0 = R.real_encoder_forward(Wt["real_encoder"], t64(inp["ft_imgs"]), FT_CFG["rotation_ranges"])
+    emb, rot, hist, gen = S.fine_tune_on_img(Wt, FT_CFG, t64(inp["ft_imgs"]), n_iters, [t64(w) for w in vgg],
+                                             [t64(w) for w in vggface], FT_EXPR)
+    emb1, rot1, _, _ = S.fine_tune_on_img(Wt, FT_CFG, t64(inp["ft_imgs"]), 1, [t64(w) for w in vgg],
+                                          [t64(w) for w in vggface], FT_EXPR)
+    return {"loss_names": np.array(list(hist[0].keys())),
+            "loss_values": np.array([[h[k] for k in hist[0].keys()] for h in hist]),
+            "emb_encoder": emb0.numpy(), "rot_encoder": rot0.numpy(), "emb": emb.numpy(), "rot": rot.numpy(),
+            "emb_1iter": emb1.numpy(), "rot_1iter": rot1.numpy(),
+            "gen_delta_norms": np.array([float((a - t64(b)).norm()) for a, b in zip(gen, W["generator_smoothed"])])}
+
+
 if __name__ == "__main__":
     W, vgg, inp = build()
     out = compute(W, vgg, inp)
@@ -163,3 +194,10 @@ if __name__ == "__main__":
     print("wrote", path2, os.path.getsize(path2), "bytes")
     for k in ("g_loss_names", "g_loss_values", "enc_rotations", "enc_grad_norm_total"):
         print(k, out2[k])
+    Wf, vggf, vggfacef, inpf = build_fine_tune()
+    out3 = compute_fine_tune(Wf, vggf, vggfacef, inpf)
+    path3 = os.path.join(ROOT, "tests", "golden", "fine_tune_128.npz")
+    np.savez_compressed(path3, **out3)
+    print("wrote", path3, os.path.getsize(path3), "bytes")
+    for k in ("loss_names", "loss_values", "rot_encoder", "rot", "rot_1iter"):
+        print(k, out3[k])

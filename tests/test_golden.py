@@ -133,3 +133,51 @@ def test_hip_path_matches_golden_second_stage():
         assert abs(float(gl[k]) - v) <= 1e-3 * max(1.0, abs(v)), (k, float(gl[k]), v)
     total = float(torch.sqrt(sum((g.double() ** 2).sum() for g in grads)))
     assert abs(total - float(GOLD2["enc_grad_norm_total"][0])) <= 3e-2 * float(GOLD2["enc_grad_norm_total"][0])
+
+
+GOLD3 = np.load(os.path.join(os.path.dirname(__file__), "golden", "fine_tune_128.npz"))
+
+
+def test_oracle_reproduces_fine_tune_golden_and_the_reference_fixture_facts():
+    """(CPU) tests/golden/fine_tune_128.npz comes from oracle/ref_steps.py:fine_tune_on_img.  The facts the reference's own
+    confignet_finetune_ref_*.npz show without weights hold for it: after one iteration exactly the 30
+    blendshape dims (7..36) of the embedding moved, each by lr = 1e-4, and each rotation moved by 1e-4."""
+    W, vgg, vggface, inp = MG.build_fine_tune()
+    out = MG.compute_fine_tune(W, vgg, vggface, inp, n_iters=2)
+    np.testing.assert_allclose(out["loss_values"], GOLD3["loss_values"][:2], rtol=1e-9)
+    np.testing.assert_allclose(out["emb_1iter"], GOLD3["emb_1iter"], atol=1e-12)
+    d = (GOLD3["emb_1iter"] - GOLD3["emb_encoder"])[0]
+    assert np.array_equal(np.nonzero(d)[0], np.arange(7, 37))
+    assert np.all(np.abs(np.abs(d[7:37]) - 1e-4) < 1e-7)
+    assert np.all(np.abs(np.abs((GOLD3["rot_1iter"] - GOLD3["rot_encoder"])[0]) - 1e-4) < 1e-7)
+    assert list(GOLD3["loss_names"]) == ["image_loss_real", "face_reco_loss"] + ["GAN_loss_real_%d" % i for i in range(6)] + \
+        ["latent_GAN_loss", "latent_regression_loss", "loss_sum"]
+
+
+def test_resnet50_weight_order_is_keras_layer_order():
+    """keras.applications ResNet50 lists a conv-shortcut block as 1_conv, 1_bn, 2_conv, 2_bn, 0_conv, 3_conv, 0_bn, 3_bn
+    (depth-sorted functional-model layers, [TF-2.1]); get_weights() follows it with [kernel, bias] per Conv2D and
+    [gamma, beta, moving_mean, moving_variance] per BatchNormalization.  Product and oracle must agree on it, and the
+    shapes of the first conv-shortcut block are pinned here."""
+    from oracle import ref_nets as R
+    from confignet_amd.dnn_models.real_encoder import resnet50_layers
+    prod = list(resnet50_layers())
+    assert prod == R.resnet50_layer_order()
+    names = [n for n, *_ in prod]
+    assert names[:2] == ["conv1_conv", "conv1_bn"]
+    assert names[2:10] == ["conv2_block1_1_conv", "conv2_block1_1_bn", "conv2_block1_2_conv", "conv2_block1_2_bn",
+                           "conv2_block1_0_conv", "conv2_block1_3_conv", "conv2_block1_0_bn", "conv2_block1_3_bn"]
+    assert names[10:16] == ["conv2_block2_1_conv", "conv2_block2_1_bn", "conv2_block2_2_conv", "conv2_block2_2_bn",
+                            "conv2_block2_3_conv", "conv2_block2_3_bn"]
+    assert len(names) == 2 * 53 and names[-1] == "conv5_block3_3_bn"
+    shp = R.resnet50_weight_shapes()
+    assert len(shp) == 53 * 6 and shp[:2] == [(7, 7, 3, 64), (64,)]
+    # conv2_block1: ..., 2_bn x4, then 0_conv (1,1,64,256) BEFORE 3_conv (1,1,64,256), then 0_bn x4, 3_bn x4
+    assert shp[6:8] == [(1, 1, 64, 64), (64,)] and shp[12:14] == [(3, 3, 64, 64), (64,)]
+    assert shp[18:22] == [(1, 1, 64, 256), (256,), (1, 1, 64, 256), (256,)] and shp[22:30] == [(256,)] * 8
+    # conv3_block1 distinguishes the two by shape: 0_conv reads the 256-channel block input, 3_conv the 128-channel branch
+    i = names.index("conv3_block1_0_conv")
+    convs_before = sum(1 for n in names[:i] if n.endswith("_conv"))
+    off = 2 * convs_before + 4 * (i - convs_before)
+    assert shp[off] == (1, 1, 256, 512) and shp[off + 2] == (1, 1, 128, 512)
+    assert sum(int(np.prod(s)) for s in shp) == 23587712           # keras ResNet50(include_top=False) parameter count

@@ -56,12 +56,16 @@ def _worker(rank, world, port, out_dir):
     err = float((flat - g_full).abs().max() / g_full.abs().max())
     # broadcast_weights makes rank 1 adopt rank 0's values
     class _N:
-        pass
+        def mark_updated(self):
+            self.updated = True
+
+        def non_trainable_changed(self):
+            self.stats_dropped = True
     net = _N()
     net.arena = torch.full((8,), float(rank))
     net.weights = []
     parallel.broadcast_weights([net])
-    ok_bcast = bool((net.arena == 0).all())
+    ok_bcast = bool((net.arena == 0).all()) and net.updated and net.stats_dropped   # derived caches are told
     torch.save({"err": err, "bcast": ok_bcast}, os.path.join(out_dir, "r%d.pt" % rank))
     dist.barrier()
     dist.destroy_process_group()

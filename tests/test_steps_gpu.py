@@ -1,0 +1,350 @@
+"""GPU parity of WHOLE step functions against the CPU oracle (round-2 additions):
+
+* fine_tune_on_img (confignet_second_stage.py:321-403; BASELINE.json configs[3]) against the committed golden
+  tests/golden/fine_tune_128.npz (made by scripts/make_golden.py from oracle/ref_steps.py:fine_tune_on_img), eager and
+  HIP-graph dispatch, plus the reference fixture's weight-free fact: after ONE iteration exactly the
+  blendshape slice of the returned embedding has moved, by lr = 1e-4, and the rest is the (stale) encoder output.
+* one whole second-stage training iteration (confignet_second_stage.py:277-288) dispatched as replayed HIP graphs with
+  the concurrent discriminator phase, against oracle/ref_steps.py:second_stage_iteration on the same batches: all four
+  loss dicts, the shared optimizer counter (per-step lr_t), every network's post-update weights and the EMA copy.
+* the LatentGAN discriminator / generator steps + EMA (latent_gan.py:117-174; configs[4]) against the oracle.
+* set_facemodel_param_in_latents values (confignet_first_stage.py:217-239).
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "scripts"))
+import make_golden as MG   # noqa: E402
+
+from oracle import ref_nets as R   # noqa: E402
+from oracle import ref_ops as O   # noqa: E402
+from oracle import ref_steps as S   # noqa: E402
+
+GOLD_FT = np.load(os.path.join(ROOT, "tests", "golden", "fine_tune_128.npz"))
+
+
+def t64(a):
+    if torch.is_tensor(a):
+        a = a.detach().cpu().numpy()
+    return torch.tensor(np.asarray(a), dtype=torch.float64)
+
+
+def w64(net):
+    """Keras-ordered float64 copy of a network's weights; BatchNorm moving statistics stay non-trainable."""
+    return [torch.tensor(a, dtype=torch.float64, requires_grad=bool(p.requires_grad))
+            for a, p in zip(net.get_weights(), net.weights)]
+
+
+def _fine_tune_model():
+    from confignet_amd import ConfigNet
+    W, vgg, vggface, inp = MG.build_fine_tune()
+    cfg = {"output_shape": (MG.RES, MG.RES, 3), "batch_size": 2, "facemodel_inputs": dict(MG.FM)}
+    m = ConfigNet(cfg, seed=0)
+    m.config["image_loss_weight"] *= 10                                    # train_confignet.py:67
+    assert m.config["image_loss_weight"] == MG.FT_CFG["image_loss_weight"]
+    m.generator.set_weights(W["generator"]); m.generator_smoothed.set_weights(W["generator_smoothed"])
+    m.discriminator.set_weights(W["discriminator"]); m.synth_discriminator.set_weights(W["synth_discriminator"])
+    m.latent_discriminator.set_weights(W["latent_discriminator"]); m.latent_regressor.set_weights(W["latent_regressor"])
+    m.synthetic_encoder.set_weights(W["synthetic_encoder"]); m.encoder.set_weights(W["real_encoder"])
+    m.perceptual_loss._pretrained_dnn_activations.set_weights(vgg)
+    m.perceptual_loss_face_reco._pretrained_dnn_activations.set_weights(vggface)
+    assert tuple(m.get_facemodel_param_idxs_in_latent("blendshape_values"))[0] == MG.FT_EXPR[0]
+    return m, W, inp
+
+
+def _check_loss_trajectory(got_steps, ref_steps):
+    """Step 0 (identical weights): every scalar within 1e-3 (north_star).  Later steps follow Adam updates of lr*sign(g) on
+    8 M generator weights; entries whose gradient is at fp32 noise level may step the other way than in the float64 oracle,
+    and these losses move by up to 30 % PER STEP (two runs of the device path differ from each other by as much as either differs
+    from the oracle: fp32 atomics), so from step 1 on the allowance also carries 10 % of the oracle's own accumulated step-to-step
+    change of that scalar.  The sharp checks of the later steps are the embedding / rotation trajectories (steps of 1e-4, compared at
+    5e-5) and the per-tensor update norms of the generator copy."""
+    path = {k: 0.0 for k in ref_steps[0]}
+    for step, (got, ref) in enumerate(zip(got_steps, ref_steps)):
+        assert list(got.keys()) == list(ref.keys())
+        for k, v in ref.items():
+            if step > 0:
+                path[k] += abs(v - ref_steps[step - 1][k])
+            tol = 1e-3 * max(1.0, abs(v)) + 0.1 * path[k]
+            assert abs(got[k] - v) <= tol, ("step %d" % step, k, got[k], v, tol)
+
+
+@pytest.mark.parametrize("graphs", [False, True])
+def test_fine_tune_on_img_matches_oracle_golden(graphs):
+    m, W, inp = _fine_tune_model()
+    m.use_graphs = graphs
+    imgs = inp["ft_imgs"].astype(np.float32)
+    m.fine_tune_loss_log = []
+    emb, rot = m.fine_tune_on_img(imgs, n_iters=3)
+    names = list(GOLD_FT["loss_names"])
+    assert list(m.fine_tune_loss_log[0].keys()) == names
+    _check_loss_trajectory(m.fine_tune_loss_log, [dict(zip(names, row)) for row in GOLD_FT["loss_values"]])
+    # three Adam steps of 1e-4 each: a wrong sign / lr / stale tile would show up at the 1e-4 level
+    assert np.abs(emb - GOLD_FT["emb"]).max() < 5e-5, np.abs(emb - GOLD_FT["emb"]).max()
+    assert np.abs(rot - GOLD_FT["rot"]).max() < 5e-5, (rot, GOLD_FT["rot"])
+    # the fine-tuned generator copy moved like the oracle's (per-tensor update norms; sign flips of noise-level
+    # gradients move single entries by 2 lr)
+    got_norms = np.array([float((torch.as_tensor(a).double() - torch.as_tensor(b).double()).norm())
+                          for a, b in zip(m.generator_fine_tuned.get_weights(), W["generator_smoothed"])])
+    ref = GOLD_FT["gen_delta_norms"]
+    sel = ref > 0
+    assert np.all(np.abs(got_norms[sel] - ref[sel]) <= 0.05 * ref[sel] + 1e-6), (got_norms, ref)
+    assert float(got_norms[0]) == 0.0 and ref[0] == 0.0             # learned_input kernel: zero gradient, never moves
+    # generate_images now decodes with the fine-tuned copy (confignet_second_stage.py:310-319)
+    out = m.generate_images(emb, rot)
+    assert out.shape == (1, MG.RES, MG.RES, 3) and out.dtype == np.uint8
+
+
+def test_fine_tune_one_iteration_moves_exactly_the_expression_slice():
+    """The reference's confignet_finetune_ref_*.npz fact: after n_iters=1 only the 30 expression
+    dims differ from the encoder's embedding, each by lr = 1e-4 (first Adam step = lr*sign(g)); pre/post are returned
+    as tiled BEFORE the step (confignet_second_stage.py:363-364,402); the rotations move by 1e-4."""
+    m, W, inp = _fine_tune_model()
+    imgs = inp["ft_imgs"].astype(np.float32)
+    emb0, rot0 = m.encode_images(imgs)
+    emb, rot = m.fine_tune_on_img(imgs, n_iters=1)
+    d = (emb.astype(np.float64) - emb0.astype(np.float64))[0]
+    lo, hi = MG.FT_EXPR
+    # (the encoder's global average pool sums with fp32 atomics: two runs of encode agree to the last bits, not bitwise)
+    rest = np.r_[0:lo, hi:d.shape[0]]
+    assert np.abs(d[rest]).max() < 1e-6, d[rest]
+    assert np.all(np.abs(np.abs(d[lo:hi]) - 1e-4) < 2e-6), d[lo:hi]
+    assert np.abs(emb - GOLD_FT["emb_1iter"]).max() < 1e-3 and np.abs(emb0 - GOLD_FT["emb_encoder"]).max() < 1e-3
+    assert np.array_equal(np.sign(d[lo:hi]), np.sign((GOLD_FT["emb_1iter"] - GOLD_FT["emb_encoder"])[0, lo:hi]))
+    dr = (rot.astype(np.float64) - rot0.astype(np.float64))[0]
+    assert np.all(np.abs(np.abs(dr) - 1e-4) < 2e-6), dr
+    assert np.abs(rot - GOLD_FT["rot_1iter"]).max() < 1e-4
+
+
+def test_fine_tune_force_neutral_expression_keeps_the_expression_slice_fixed():
+    """force_neutral_expression=True (confignet_second_stage.py:328-331,393-394): the expression latents are replaced by
+    the synthetic encoder's output for all-zero blendshapes and left out of the trainable list."""
+    m, W, inp = _fine_tune_model()
+    imgs = inp["ft_imgs"].astype(np.float32)
+    lo, hi = MG.FT_EXPR
+    neutral = O.mlp_simple(torch.zeros(1, 62, dtype=torch.float64), [t64(w) for w in W["synthetic_encoder"][4:8]], 0.3)
+    Wt = {k: [t64(w) for w in v] for k, v in W.items()}
+    vgg = [t64(w) for w in m.perceptual_loss._pretrained_dnn_activations.get_weights()]
+    vggface = [t64(w) for w in m.perceptual_loss_face_reco._pretrained_dnn_activations.get_weights()]
+    emb_r, rot_r, hist, _ = S.fine_tune_on_img(Wt, MG.FT_CFG, t64(imgs), 2, vgg, vggface, MG.FT_EXPR,
+                                               force_neutral_expression=True, neutral_expr_latents=neutral)
+    m.fine_tune_loss_log = []
+    emb, rot = m.fine_tune_on_img(imgs, n_iters=2, force_neutral_expression=True)
+    assert np.abs(emb[:, lo:hi] - neutral.numpy()).max() < 1e-5           # untouched by the optimizer
+    assert np.abs(emb - emb_r.numpy()).max() < 5e-5 and np.abs(rot - rot_r.numpy()).max() < 5e-5
+    _check_loss_trajectory(m.fine_tune_loss_log, hist)
+
+
+# ------------------------------------------------------------------------------------------------------------
+def _oracle_batch(m, real_set, synth_set, dtype=torch.float64):
+    """The batches of the LAST iteration, rebuilt on the host from the indices / flags / parameters the step functions
+    staged (confignet_amd/graphs.py:StaticBuffers) -- independent of the device gather kernel."""
+    B = {k: v.detach().cpu().numpy() for k, v in m._bufs.bufs.items()}
+    names = list(m.config["facemodel_inputs"].keys())
+
+    def imgs(ds, idx, flip=None):
+        x = ds.imgs[idx].astype(np.float64) / 127.5 - 1.0
+        if flip is not None:
+            for i, f in enumerate(flip):
+                if f:
+                    x[i] = x[i, :, ::-1]
+        return torch.tensor(x, dtype=dtype)
+
+    t = lambda a: torch.tensor(np.asarray(a, dtype=np.float64), dtype=dtype)
+    return {
+        "real_d": imgs(real_set, B["d/real_idx"], B["d/real_flip"]), "enc_in_d": imgs(real_set, B["d/enc_idx"]),
+        "real_sd": imgs(synth_set, B["sd/real_idx"], B["sd/real_flip"]),
+        "params_sd": [t(B["sd/p/" + n]) for n in names], "rot_sd": t(B["sd/rot"]),
+        "real_ld": imgs(real_set, B["ld/real_idx"], B["ld/real_flip"]), "params_ld": [t(B["ld/p/" + n]) for n in names],
+        "params_g": [t(B["g/p/" + n]) for n in names], "rot_g": t(B["g/rot"]),
+        "synth_imgs_g": imgs(synth_set, B["g/synth_idx"]), "eye_masks_g": torch.as_tensor(synth_set.eye_masks[B["g/synth_idx"]]),
+        "real_imgs_g": imgs(real_set, B["g/real_idx"], B["g/real_flip"]),
+    }
+
+
+def test_whole_second_stage_iteration_under_graph_dispatch_matches_oracle():
+    from confignet_amd import ConfigNet, SyntheticFaceDataset, optim
+    from confignet_amd.confignet_first_stage import DEFAULT_CONFIG
+    from confignet_amd.confignet_utils import merge_configs
+    res, batch = 128, 2
+    real_set, synth_set = SyntheticFaceDataset(8, res, seed=5), SyntheticFaceDataset(8, res, seed=6)
+    cfg = merge_configs(DEFAULT_CONFIG, {"batch_size": batch, "output_shape": (res, res, 3),
+                                         "facemodel_inputs": {k: (None, v[1]) for k, v in MG.FM.items()}})
+    cfg["facemodel_inputs"] = {k: v for k, v in cfg["facemodel_inputs"].items() if k in MG.FM}
+    synth_set.process_metadata(cfg, True)
+    cfg["image_loss_weight"] *= 10
+    np.random.seed(3)
+    m = ConfigNet(cfg, seed=4)
+    assert m.config["latent_dim"] == MG.L
+    rng = np.random.default_rng(17)
+    for net in m.all_networks():                               # biases / gammas / betas away from their 0/1 init
+        ws = net.get_weights()
+        net.set_weights([(w + rng.normal(size=w.shape) * 0.05).astype(np.float32) if (w.ndim == 1 and p.requires_grad) else w
+                         for w, p in zip(ws, net.weights)])
+    gw = m.generator.get_weights()                             # a learned input that is not constant (see make_golden.build_fine_tune)
+    gw[1] = (1.0 + 0.5 * rng.standard_normal(32768)).astype(np.float32)
+    m.generator.set_weights(gw)
+    m.generator_smoothed.copy_weights_from(m.generator)
+    m.setup_training(None, synth_set, 0, real_training_set=real_set)
+    m.use_graphs = True
+    d_opt, g_opt = optim.Adam(**m.config["optimizer"]), optim.Adam(**m.config["optimizer"])
+    nets = m.all_networks()
+    start = [n.get_weights() for n in nets]
+    for _ in range(3):                                         # eager warm-up, capture, first replay
+        m.training_iteration(real_set, synth_set, d_opt, g_opt)
+    torch.cuda.synchronize()
+    assert len(m._graphs) == 4 and all(g.graph is not None for g in m._graphs.values())
+    # back to the initial state: weights, Adam moments and the shared step counters (the captured graphs stay)
+    for n, w0 in zip(nets, start):
+        n.set_weights(w0)
+    for o in (d_opt, g_opt):
+        o.iterations = 0
+        for mom, var in o._state.values():
+            mom.zero_(); var.zero_()
+    W = {"generator": w64(m.generator), "generator_smoothed": w64(m.generator_smoothed), "discriminator": w64(m.discriminator),
+         "synth_discriminator": w64(m.synth_discriminator), "latent_discriminator": w64(m.latent_discriminator),
+         "latent_regressor": w64(m.latent_regressor), "synthetic_encoder": w64(m.synthetic_encoder), "real_encoder": w64(m.encoder)}
+    W["generator_smoothed"] = [w.detach() for w in W["generator_smoothed"]]
+    before = {k: [w.detach().clone() for w in v] for k, v in W.items()}
+    vgg_w = [t64(w) for w in m.perceptual_loss._pretrained_dnn_activations.get_weights()]
+
+    got = m.training_iteration(real_set, synth_set, d_opt, g_opt)      # pure replay of the four graphs
+    got = [{k: float(v) for k, v in d.items()} for d in got]
+    assert d_opt.iterations == 3 and g_opt.iterations == 1               # one shared counter for D, synth-D, latent-D (R10)
+
+    ro_d, ro_g = O.KerasAdam(**{k: v for k, v in m.config["optimizer"].items() if k != "amsgrad"}), \
+        O.KerasAdam(**{k: v for k, v in m.config["optimizer"].items() if k != "amsgrad"})
+    grads = {}
+    lr = m.config["optimizer"]["lr"]
+    after = {name: net.get_weights() for name, net in (
+        ("generator", m.generator), ("latent_regressor", m.latent_regressor), ("synthetic_encoder", m.synthetic_encoder),
+        ("real_encoder", m.encoder), ("discriminator", m.discriminator), ("synth_discriminator", m.synth_discriminator),
+        ("latent_discriminator", m.latent_discriminator))}
+
+    def check_updates(name, gl, step_len):
+        """Post-update weights.  beta_1 = 0 and zero moments: |step| = lr*sqrt(1-0.9^t)/sqrt(0.1) whatever |g| is, i.e. 1.000 lr for
+        the discriminator (t=1), 1.378 lr for the synthetic-domain discriminator (t=2), 1.646 lr for the latent discriminator (t=3)
+        and 1.000 lr for the generator step -- a wrong lr_t slot in the concurrent phase shows up as a wrong step length.  The
+        direction is compared where the oracle's gradient is significant (noise-level gradients may take the other sign in fp32)."""
+        for i, (a, w_ref, w0, g) in enumerate(zip(after[name], W[name], before[name], gl)):
+            step = torch.as_tensor(a).double() - w0
+            step_ref = w_ref.detach() - w0
+            if g is None:                                       # BatchNorm moving statistics: never trained
+                assert float(step.abs().max()) == 0.0 and float(step_ref.abs().max()) == 0.0
+                continue
+            if float(g.abs().max()) == 0.0:                     # the learned_input kernel: exactly zero gradient
+                assert float(step.abs().max()) == 0.0, (name, i)
+                continue
+            # fp32 LeakyReLU-branch flips against the float64 oracle move single gradient entries by up to ~30 % of the tensor's
+            # largest one (tests/test_nets_gpu.py:close_grads): above that the step must agree entry by entry
+            sig = g.abs() > 0.3 * g.abs().max()
+            assert float((step - step_ref)[sig].abs().max()) < 0.02 * lr, (name, i, float((step - step_ref)[sig].abs().max()))
+            assert abs(float(step[sig].abs().mean()) - step_len * lr) < 0.01 * lr, (name, i, float(step[sig].abs().mean()) / lr, step_len)
+            live = g.abs() > 1e-4 * g.abs().max()                # (entries with an exactly-zero true gradient step on fp32 noise)
+            wrong = ((step - step_ref)[live].abs() > 0.1 * lr).double().mean()
+            assert float(wrong) < 0.03, (name, i, float(wrong))   # ... and below it all but a few per cent do
+
+    def after_d_phase(Wd):
+        check_updates("discriminator", grads["discriminator"], 1.0)
+        check_updates("synth_discriminator", grads["synth_discriminator"], np.sqrt(1 - 0.9 ** 2) / np.sqrt(0.1))
+        check_updates("latent_discriminator", grads["latent_discriminator"], np.sqrt(1 - 0.9 ** 3) / np.sqrt(0.1))
+        with torch.no_grad():                                   # the generator step continues from the device path's discriminators
+            for name in ("discriminator", "synth_discriminator", "latent_discriminator"):
+                for w, a in zip(Wd[name], after[name]):
+                    w.copy_(torch.as_tensor(a).double())
+
+    ref = S.second_stage_iteration(W, m.config, _oracle_batch(m, real_set, synth_set), ro_d, ro_g, vgg_w, keep_grads=grads,
+                                   after_discriminator_phase=after_d_phase)
+    for g, r, what in zip(got, (ref["d"], ref["synth_d"], ref["latent_d"], ref["g"]), ("D", "synth-D", "latent-D", "G")):
+        assert list(g.keys()) == list(r.keys()), what
+        for k in g:
+            rv = float(r[k].detach())
+            assert abs(g[k] - rv) <= 1e-3 * max(1.0, abs(rv)), (what, k, g[k], rv)
+    cur = 0
+    for name in ("generator", "latent_regressor", "synthetic_encoder", "real_encoder"):
+        n = len([w for w in W[name] if w.requires_grad])
+        it = iter(grads["g_step"][cur:cur + n])
+        check_updates(name, [next(it) if w.requires_grad else None for w in W[name]], 1.0)
+        cur += n
+    # EMA copy of the generator (confignet_first_stage.py:393-400)
+    for a, r in zip(m.generator_smoothed.get_weights(), W["generator_smoothed"]):
+        assert float((torch.as_tensor(a).double() - r).abs().max()) < 2e-6
+
+
+# ------------------------------------------------------------------------------------------------------------
+def test_latent_gan_steps_and_ema_match_oracle():
+    from confignet_amd import LatentGAN, optim
+    L, bs = 145, 128
+    gan = LatentGAN({"latent_dim": L, "batch_size": bs}, seed=1)
+    rng = np.random.default_rng(2)
+    for net in (gan.generator, gan.discriminator):
+        net.set_weights([(w + rng.normal(size=w.shape) * 0.05).astype(np.float32) if w.ndim == 1 else w for w in net.get_weights()])
+    gan.generator_smoothed.copy_weights_from(gan.generator)
+    emb = rng.normal(size=(500, L)).astype(np.float32)
+    opt = optim.Adam(**gan.config["optimizer"])
+    g_w, d_w = w64(gan.generator), w64(gan.discriminator)
+    sm = [w.detach().clone() for w in w64(gan.generator_smoothed)]
+    ropt = O.KerasAdam(lr=gan.config["optimizer"]["lr"], beta_1=0.0, beta_2=0.9)
+    lr = gan.config["optimizer"]["lr"]
+    for it in range(2):
+        # the step functions draw their batches from np.random in the reference's order (latent_gan.py:119-123,152):
+        # replay the same draws for the oracle
+        state = np.random.get_state()
+        d = gan.discriminator_training_step(emb, opt)
+        g = gan.generator_training_step(opt)
+        gan.update_smoothed_weights()
+        after = np.random.get_state()
+        np.random.set_state(state)
+        z_d = np.random.normal(0, 1, (bs, L))
+        idx = np.random.randint(0, emb.shape[0], bs)
+        z_g = np.random.normal(0, 1, (bs, L))
+        np.random.set_state(after)
+        g0, d0 = [w.detach().clone() for w in g_w], [w.detach().clone() for w in d_w]
+        rd = S.latent_gan_discriminator_step(g_w, d_w, t64(emb[idx]), t64(z_d), ropt)
+        rg = S.latent_gan_generator_step(g_w, d_w, t64(z_g), ropt)
+        S.ema_update(sm, g_w)
+        for got, ref, what in ((d, rd, "D"), (g, rg, "G")):
+            assert list(got.keys()) == list(ref.keys()), what
+            for k in got:
+                assert abs(float(got[k]) - float(ref[k])) <= 1e-3 * max(1.0, abs(float(ref[k]))), (what, it, k, float(got[k]), float(ref[k]))
+    assert opt.iterations == 4 and ropt.t == 4                     # ONE optimizer for both networks (latent_gan.py:237)
+    for net, ref in ((gan.generator, g_w), (gan.discriminator, d_w)):
+        for a, r in zip(net.get_weights(), ref):
+            diff = (torch.as_tensor(a).double() - r.detach()).abs()
+            # two Adam steps each; single entries whose gradient is at fp32 noise level may step the other way
+            assert float(diff.mean()) < 0.05 * lr and float(diff.max()) <= 8 * lr, (float(diff.mean()) / lr, float(diff.max()) / lr)
+    for a, r in zip(gan.generator_smoothed.get_weights(), sm):
+        assert float((torch.as_tensor(a).double() - r).abs().max()) < 1e-6
+    lat = gan.generate_latents(7)
+    assert lat.shape == (7, L) and np.isfinite(lat).all()
+
+
+def test_set_facemodel_param_in_latents_values():
+    """confignet_first_stage.py:217-239: the named input's MLP output replaces its slice of every latent row; all other
+    entries are copied."""
+    from confignet_amd import ConfigNetFirstStage
+    cfg = {"output_shape": (128, 128, 3), "batch_size": 2, "facemodel_inputs": dict(MG.FM)}
+    m = ConfigNetFirstStage(cfg, seed=3)
+    rng = np.random.default_rng(4)
+    m.synthetic_encoder.set_weights([(w + rng.normal(size=w.shape) * 0.1).astype(np.float32) for w in m.synthetic_encoder.get_weights()])
+    lat = rng.normal(size=(3, MG.L)).astype(np.float32)
+    val = rng.normal(size=62).astype(np.float32)
+    out = m.set_facemodel_param_in_latents(lat, "blendshape_values", val)
+    ws = [t64(w) for w in m.synthetic_encoder.get_weights()]
+    ref = O.mlp_simple(t64(val[None]), ws[4:8], 0.3).numpy()      # second input in sorted order: 4 tensors per input MLP
+    idx = list(m.get_facemodel_param_idxs_in_latent("blendshape_values"))
+    assert idx == list(range(7, 37))
+    assert np.abs(out[:, idx] - ref).max() < 1e-4
+    keep = [i for i in range(MG.L) if i not in idx]
+    assert np.array_equal(out[:, keep], lat[:, keep]) and out is not lat and np.array_equal(lat, lat.copy())
+    # one row per latent also works (the demo passes (n, dim) values, confignet_demo.py:158)
+    out2 = m.set_facemodel_param_in_latents(lat, "eye_color", np.eye(8, dtype=np.float32)[:3])
+    ref2 = O.mlp_simple(t64(np.eye(8)[:3]), ws[8:12], 0.3).numpy()
+    assert np.abs(out2[:, 37:40] - ref2).max() < 1e-4
