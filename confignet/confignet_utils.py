@@ -1,0 +1,5 @@
+"""Alias of confignet_amd.confignet_utils under the reference's module path."""
+from confignet_amd.confignet_utils import *   # noqa: F401,F403
+from confignet_amd import confignet_utils as _impl
+
+globals().update({k: v for k, v in vars(_impl).items() if not k.startswith("__")})

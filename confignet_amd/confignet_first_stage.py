@@ -6,20 +6,20 @@ TensorBoard/AzureML logging.  `train()` keeps the reference's iteration structur
 import contextlib
 import json
 import os
-import pickle
 import time
 from collections import OrderedDict
 
 import numpy as np
 import torch
 
-from . import confignet_utils, ops, optim
+from . import confignet_utils, ops, optim, parallel
 from .dnn_models.building_blocks import MLPSimple
 from .dnn_models.hologan_discriminator import HologanDiscriminator, HologanLatentRegressor
 from .dnn_models.hologan_generator import HologanGenerator
 from .dnn_models.synthetic_encoder import SyntheticDataEncoder
 from .losses import (GAN_G_loss, compute_discriminator_loss, compute_latent_discriminator_loss,
                      compute_latent_regression_loss, eye_loss)
+from .neural_renderer_dataset import dump_pickle, load_pickle
 from .nn import backward_into_arenas, require_gpu
 from .perceptual_loss import PerceptualLoss
 
@@ -172,8 +172,8 @@ class ConfigNetFirstStage:
         np.savez(os.path.join(output_dir, output_filename + ".npz"), **self._weights_to_npz(self.get_weights()))
         with open(os.path.join(output_dir, output_filename + ".json"), "w") as fp:
             json.dump(self.config, fp, indent=4)
-        with open(os.path.join(output_dir, output_filename + "_facemodel_distr.pck"), "wb") as fp:
-            pickle.dump(self.facemodel_param_distributions, fp)
+        # pickled under the reference's class paths (confignet.neural_renderer_dataset.*), so either side loads the file
+        dump_pickle(self.facemodel_param_distributions, os.path.join(output_dir, output_filename + "_facemodel_distr.pck"))
 
     @classmethod
     def load(cls, file_path):
@@ -187,10 +187,13 @@ class ConfigNetFirstStage:
             with open(log_file, "r") as fp:
                 model.set_logs(json.load(fp))
         distr = os.path.splitext(file_path)[0] + "_facemodel_distr.pck"
+        model.facemodel_param_distributions = None
         if os.path.exists(distr):
-            with open(distr, "rb") as fp:
-                model.facemodel_param_distributions = pickle.load(fp)
-        else:
+            try:
+                model.facemodel_param_distributions = load_pickle(distr)
+            except Exception as e:        # e.g. an sklearn GaussianMixture pickled by an incompatible scikit-learn
+                print("WARNING: facemodel param distributions could not be unpickled (%r)" % (e,))
+        if model.facemodel_param_distributions is None:
             print("WARNING: facemodel param distributions not loaded")
         return model
 
@@ -541,6 +544,7 @@ class ConfigNetFirstStage:
               n_samples_for_metrics=1000, aml_run=None):
         """confignet_first_stage.py:597-626 (checkpoint images / metrics are out of scope)."""
         self.setup_training(log_dir, synth_training_set, n_samples_for_metrics, real_training_set=real_training_set)
+        parallel.broadcast_weights(self.all_networks())       # data-parallel replicas start from rank 0's weights
         start_step = self.get_training_step_number()
         discriminator_optimizer = optim.Adam(**self.config["optimizer"])
         generator_optimizer = optim.Adam(**self.config["optimizer"])
@@ -568,8 +572,8 @@ class ConfigNetFirstStage:
             confignet_utils.update_loss_dict(self.synth_d_losses, synth_d_loss)
             confignet_utils.update_loss_dict(self.latent_d_losses, latent_d_loss)
             step = self.get_training_step_number()
-            if output_dir is not None and step % self.config["metrics_checkpoint_period"] == 0 and step > 0:
-                self.save(os.path.join(output_dir, "checkpoints"), str(step).zfill(6))
+            if output_dir is not None and step % self.config["metrics_checkpoint_period"] == 0 and parallel.rank() == 0:
+                self.save(os.path.join(output_dir, "checkpoints"), str(step).zfill(6))     # (l.349-355; incl. step 0)
 
     # ---- evaluation code ----------------------------------------------------------------------------
     def _generate_images_with(self, generator, latent_vector, rotations):

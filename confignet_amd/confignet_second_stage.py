@@ -6,7 +6,7 @@ import os
 import numpy as np
 import torch
 
-from . import confignet_utils, ops, optim
+from . import confignet_utils, ops, optim, parallel
 from .confignet_first_stage import DEFAULT_CONFIG, ConfigNetFirstStage, frozen
 from .dnn_models.hologan_generator import HologanGenerator
 from .dnn_models.real_encoder import RealEncoder
@@ -187,6 +187,7 @@ class ConfigNet(ConfigNetFirstStage):
         """confignet_second_stage.py:268-299 (metrics / image checkpoints are out of scope)."""
         self.setup_training(log_dir, synth_training_set, n_samples_for_metrics, attribute_classifier,
                             real_training_set=real_training_set, validation_set=validation_set)
+        parallel.broadcast_weights(self.all_networks())       # data-parallel replicas start from rank 0's weights
         start_step = self.get_training_step_number()
         discriminator_optimizer = optim.Adam(**self.config["optimizer"])
         generator_optimizer = optim.Adam(**self.config["optimizer"])
@@ -207,8 +208,8 @@ class ConfigNet(ConfigNetFirstStage):
             confignet_utils.update_loss_dict(self.synth_d_losses, synth_d_loss)
             confignet_utils.update_loss_dict(self.latent_d_losses, latent_d_loss)
             step = self.get_training_step_number()
-            if output_dir is not None and step % self.config["metrics_checkpoint_period"] == 0 and step > 0:
-                self.save(os.path.join(output_dir, "checkpoints"), str(step).zfill(6))
+            if output_dir is not None and step % self.config["metrics_checkpoint_period"] == 0 and parallel.rank() == 0:
+                self.save(os.path.join(output_dir, "checkpoints"), str(step).zfill(6))     # (first_stage l.349-355; incl. step 0)
 
     # ---- inference ----------------------------------------------------------------------------------
     def encode_images(self, input_images):

@@ -130,13 +130,19 @@ class LatentGAN:
         return embeddings
 
     def train(self, training_set, confignet_model, output_dir, log_dir, n_iters):
+        """latent_gan.py:234-247; of write_logs (l.176-200) the periodic checkpoint is kept (TensorBoard images and FID/KID
+        are out of scope)."""
+        from . import parallel
         gt_embeddings = self.extract_embeddings(confignet_model, training_set)
+        parallel.broadcast_weights([self.generator, self.generator_smoothed, self.discriminator])
         optimizer = optim.Adam(**self.config["optimizer"])
         for step_number in range(n_iters):
             d_loss = self.discriminator_training_step(gt_embeddings, optimizer)
             g_loss = self.generator_training_step(optimizer)
             self.update_smoothed_weights()
             print("[step: %d] [D loss: %f] [G loss: %f]" % (step_number, d_loss["loss_sum"], g_loss["loss_sum"]))
+            if output_dir is not None and step_number % self.config["verbose_log_period"] == 0 and parallel.rank() == 0:
+                self.save(os.path.join(output_dir, "checkpoints"), str(step_number).zfill(6))
 
     def generate_latents(self, n_samples, truncation=1.0):
         z = self.sample_input_latent_vector(n_samples) * truncation

@@ -5,6 +5,8 @@ read (reference: confignet/neural_renderer_dataset.py:71-100,150-228): `.imgs` u
 FFHQ or the synthetic renders, so images are seeded noise (conv cost is data independent)."""
 import numpy as np
 
+from .neural_renderer_dataset import ExemplarDistribution, OneHotDistribution
+
 # face-model input dimensionalities of the reference's test dataset (SURVEY.md section 4)
 FACEMODEL_INPUT_DIMS = {
     "beard_style_embedding": 9, "blendshape_values": 62, "bone_rotations:left_eye": 3, "eye_color": 8,
@@ -12,17 +14,6 @@ FACEMODEL_INPUT_DIMS = {
     "head_hair_style_embedding": 18, "lower_eyelash_style": 4, "texture_embedding": 50, "upper_eyelash_style": 4,
 }
 ONE_HOT_INPUTS = ("eye_color", "lower_eyelash_style", "upper_eyelash_style")
-
-
-class ExemplarDistribution:
-    """sample(n) -> (values, indices) like neural_renderer_dataset.py:34-39."""
-
-    def __init__(self, exemplars):
-        self.exemplars = exemplars
-
-    def sample(self, n_samples):
-        idx = np.random.randint(0, self.exemplars.shape[0], n_samples)
-        return self.exemplars[idx], idx
 
 
 class SyntheticFaceDataset:
@@ -53,7 +44,11 @@ class SyntheticFaceDataset:
         rot[:, 0] = np.pi * rng.uniform(-30, 30, n_imgs) / 180
         rot[:, 1] = np.pi * rng.uniform(-10, 10, n_imgs) / 180
         self.metadata_inputs["rotations"] = rot
-        self.metadata_input_distributions = {n: ExemplarDistribution(self.metadata_inputs[n]) for n in FACEMODEL_INPUT_DIMS}
+        self.metadata_input_distributions = {}
+        for n in FACEMODEL_INPUT_DIMS:                      # (neural_renderer_dataset.py:189-207: strings -> one-hot, else exemplars)
+            dist = OneHotDistribution() if n in ONE_HOT_INPUTS else ExemplarDistribution()
+            dist.fit(self.metadata_inputs[n])
+            self.metadata_input_distributions[n] = dist
 
     def process_metadata(self, config, update_config=False):
         """Fills the input dimensionality of every face-model input (neural_renderer_dataset.py:150-228)."""

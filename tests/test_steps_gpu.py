@@ -348,3 +348,26 @@ def test_set_facemodel_param_in_latents_values():
     out2 = m.set_facemodel_param_in_latents(lat, "eye_color", np.eye(8, dtype=np.float32)[:3])
     ref2 = O.mlp_simple(t64(np.eye(8)[:3]), ws[8:12], 0.3).numpy()
     assert np.abs(out2[:, 37:40] - ref2).max() < 1e-4
+
+
+def test_train_scripts_run_on_the_reference_dataset_files(tmp_path):
+    """The reference's own smoke tests (tests/training_test.py:13-31): train_confignet.py with the 2-image dataset, 1 + 1
+    steps, batch 4; then train_latent_gan.py on the model it wrote."""
+    import train_confignet
+    import train_latent_gan
+    asset = os.path.join(ROOT, "tests", "golden", "reference_assets", "test_dataset_res_256.pck")
+    out = str(tmp_path / "run")
+    model = train_confignet.parse_args(["--output_dir", out, "--real_training_set_path", asset, "--synth_training_set_path", asset,
+                                        "--validation_set_path", asset, "--attribute_classifier_path", "none",
+                                        "--batch_size", "4", "--stage_1_training_steps", "1", "--n_samples_for_metrics", "10"])
+    assert model.config["latent_dim"] == 145 and tuple(model.config["output_shape"]) == (256, 256, 3)
+    assert model.config["facemodel_inputs"]["blendshape_values"][0] == 62
+    assert np.isfinite(model.g_losses["loss_sum"]).all() and len(model.g_losses["loss_sum"]) == 1
+    for f in ("000000.npz", "000000.json", "000000_facemodel_distr.pck"):
+        assert os.path.exists(os.path.join(out, "checkpoints", f)) and os.path.exists(os.path.join(out, "first_stage", "checkpoints", f))
+    import confignet
+    m2 = confignet.load_confignet(os.path.join(out, "checkpoints", "000000.json"))
+    assert type(m2).__name__ == "ConfigNet" and set(m2.facemodel_param_distributions) == set(model.config["facemodel_inputs"])
+    gan = train_latent_gan.parse_args(["--confignet_path", os.path.join(out, "checkpoints", "000000.json"), "--training_set_path", asset,
+                                       "--output_dir", str(tmp_path / "lg"), "--n_training_steps", "1", "--batch_size", "8"])
+    assert os.path.exists(str(tmp_path / "lg" / "checkpoints" / "000000.npz")) and gan.generate_latents(3).shape == (3, 145)
