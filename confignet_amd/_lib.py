@@ -15,6 +15,10 @@ class CnConvGeom(ctypes.Structure):
         "k_d", "k_h", "k_w", "s_d", "s_h", "s_w", "dl_d", "dl_h", "dl_w", "p_d", "p_h", "p_w", "up")]
 
 
+CN_F32, CN_BF16 = 0, 1          # dtype codes of activation tensors (include/confignet_hip.h)
+CN_EUNSUPPORTED = -3
+
+
 class ConfigNetHipError(RuntimeError):
     pass
 
@@ -39,25 +43,25 @@ SIGNATURES = {
     "cn_conv_weight_tflip": [_p, _p, _i, _i, _i, _p],
     "cn_conv_dgrad": [_G, _p, _p, _p, _p],
     "cn_conv_wgrad": [_G, _p, _p, _p, _i, _p],
-    "cn_sumpool2": [_p, _p, _i, _i, _i, _i, _i, _i, _p],
+    "cn_sumpool2": [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "cn_gemm": [_i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _p, _i, _f, _p],
-    "cn_nc_reduce": [_p, _p, _p, _p, _i, _i, _i, _i, _f, _p],
-    "cn_nc_lin2": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p],
+    "cn_nc_reduce": [_p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _p],
+    "cn_nc_lin2": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _p],
     "cn_norm_coef_fwd": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _p],
     "cn_norm_coef_bwd": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _p],
     "cn_dual_tail_coef_fwd": [_p] * 13 + [_i, _i, _i, _f, _p],
     "cn_dual_tail_coef_bwd": [_p] * 13 + [ctypes.POINTER(ctypes.c_void_p), _i, _i, _i, _f, _p],
-    "cn_dual_tail_gx": [_p] * 12 + [_i, _i, _i, _f, _p],
-    "cn_act_fwd": [_p, _p, _z, _i, _f, _p],
-    "cn_act_bwd": [_p, _p, _p, _z, _i, _f, _p],
-    "cn_axpby": [_p, _p, _p, _z, _f, _f, _p],
-    "cn_mul": [_p, _p, _p, _z, _p],
-    "cn_sqdiff_sum": [_p, _p, _p, _z, _f, _p],
+    "cn_dual_tail_gx": [_p] * 12 + [_i, _i, _i, _f, _i, _p],
+    "cn_act_fwd": [_p, _p, _z, _i, _f, _i, _p],
+    "cn_act_bwd": [_p, _p, _p, _z, _i, _f, _i, _p],
+    "cn_axpby": [_p, _p, _p, _z, _f, _f, _i, _p],
+    "cn_mul": [_p, _p, _p, _z, _i, _p],
+    "cn_sqdiff_sum": [_p, _p, _p, _z, _f, _i, _p],
     "cn_row_sumsq": [_p, _p, _i, _z, _p],
-    "cn_row_scale": [_p, _p, _p, _i, _z, _f, _p],
+    "cn_row_scale": [_p, _p, _p, _i, _z, _f, _i, _p],
     "cn_masked_diff": [_p, _p, _p, _p, _z, _i, _p],
-    "cn_maxpool_fwd": [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
-    "cn_maxpool_bwd": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
+    "cn_maxpool_fwd": [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
+    "cn_maxpool_bwd": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "cn_chan_affine3_fwd": [_p, _p, _z, ctypes.POINTER(_i), _f, ctypes.POINTER(_f), _p],
     "cn_chan_affine3_bwd": [_p, _p, _z, ctypes.POINTER(_i), _f, _p],
     "cn_gan_loss_fwd": [_p, _p, _i, _f, _p],
@@ -69,9 +73,11 @@ SIGNATURES = {
     "cn_gather_images_u8": [_p, _p, _p, _p, _i, _i, _i, _i, _p],
     "cn_to_uint8": [_p, _p, _z, _p],
     "cn_spin": [ctypes.c_ulonglong, _p],
-    "cn_conv_weight_split_bf16": [_p, _p, _i, _i, _i, _i, _p],
-    "cn_conv_fwd_bf16x3": [_G, _p, _p, _i, _p, _p, _i, _f, _p],
-    "cn_conv_dgrad_bf16x3": [_G, _p, _p, _i, _p, _p],
+    "cn_conv_weight_prep_bf16": [_p, _p, _p, _i, _i, _i, _p],
+    "cn_conv_fwd_bf16": [_G, _p, _p, _p, _p, _i, _f, _p],
+    "cn_conv_dgrad_bf16": [_G, _p, _p, _p, _p],
+    "cn_conv_wgrad_bf16": [_G, _p, _p, _p, _i, _p],
+    "cn_cast": [_p, _i, _p, _i, _z, _p],
     "cn_prof_enable": [_i],
     "cn_prof_reset": [],
     "cn_prof_collect": [ctypes.POINTER(_i), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)],

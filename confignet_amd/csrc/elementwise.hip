@@ -3,6 +3,7 @@
 // average pool), activations, pooling, loss reductions, image pre/post-processing, Adam+EMA.
 // All are single-pass, float4-vectorised over the channel (fastest) axis where C % 4 == 0.
 #include "common.h"
+#include "typed.h"
 #include <stdlib.h>
 
 namespace {
@@ -13,8 +14,8 @@ __device__ __forceinline__ float4 lrelu4(float4 v, float s) {
 }
 
 // ---- nc_reduce: (N,S,C) -> (N,C) sums.  grid (cblk, sblk, n); block (TX c-groups, TY rows) ----
-template <int V>   // V = 4: float4 channel groups, V = 1: scalar channels
-__global__ __launch_bounds__(256) void nc_reduce_kernel(const float* __restrict__ x1, const float* __restrict__ x2,
+template <int V, typename T>   // V = 4: 4-wide channel groups, V = 1: scalar channels; T: storage type of x1 / x2
+__global__ __launch_bounds__(256) void nc_reduce_kernel(const T* __restrict__ x1, const T* __restrict__ x2,
                                                         float* __restrict__ s1, float* __restrict__ s2, int S, int C,
                                                         int rows_per_block, int flags, float slope) {
     const int CG = C / V;                          // channel groups
@@ -30,19 +31,19 @@ __global__ __launch_bounds__(256) void nc_reduce_kernel(const float* __restrict_
         for (int s = sbeg + ty; s < send; s += TY) {
             float a[V], b[V];
             if (V == 4) {
-                float4 va = *reinterpret_cast<const float4*>(x1 + base + (long)s * C);
+                float4 va = ld4<T>(x1 + base + (long)s * C);
                 if (flags & 1) va = lrelu4(va, slope);
                 a[0] = va.x; a[1 % V] = va.y; a[2 % V] = va.z; a[3 % V] = va.w;
                 if (x2) {
-                    float4 vb = *reinterpret_cast<const float4*>(x2 + base + (long)s * C);
+                    float4 vb = ld4<T>(x2 + base + (long)s * C);
                     if (flags & 2) vb = lrelu4(vb, slope);
                     b[0] = vb.x; b[1 % V] = vb.y; b[2 % V] = vb.z; b[3 % V] = vb.w;
                 }
             } else {
-                a[0] = x1[base + (long)s * C];
+                a[0] = ldf<T>(x1 + base + (long)s * C);
                 if (flags & 1) a[0] = lrelu(a[0], slope);
                 if (x2) {
-                    b[0] = x2[base + (long)s * C];
+                    b[0] = ldf<T>(x2 + base + (long)s * C);
                     if (flags & 2) b[0] = lrelu(b[0], slope);
                 }
             }
@@ -76,11 +77,11 @@ __global__ __launch_bounds__(256) void nc_reduce_kernel(const float* __restrict_
 }
 
 // ---- nc_lin2: y = A1*f1(x1) + A2*f2(x2) + B ----
-template <int V>
-__global__ __launch_bounds__(256) void nc_lin2_kernel(const float* __restrict__ x1, const float* __restrict__ a1,
-                                                      const float* __restrict__ x2, const float* __restrict__ a2,
+template <int V, typename T>
+__global__ __launch_bounds__(256) void nc_lin2_kernel(const T* __restrict__ x1, const float* __restrict__ a1,
+                                                      const T* __restrict__ x2, const float* __restrict__ a2,
                                                       const float* __restrict__ bb, const float* __restrict__ a3,
-                                                      const float* __restrict__ b3, float* __restrict__ y, long total_g,
+                                                      const float* __restrict__ b3, T* __restrict__ y, long total_g,
                                                       int S, int C, int cstride, int flags, float slope) {
     const int CG = C / V;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total_g; i += (long)gridDim.x * blockDim.x) {
@@ -95,7 +96,7 @@ __global__ __launch_bounds__(256) void nc_lin2_kernel(const float* __restrict__ 
         if (x1) {
 #pragma unroll
             for (int e = 0; e < V; ++e) {
-                float v = x1[i * V + e];
+                float v = ldf<T>(x1 + i * V + e);
                 if (flags & 1) v = lrelu(v, slope);
                 r[e] += (a1 ? a1[ci + e] : 1.f) * v;
             }
@@ -103,7 +104,7 @@ __global__ __launch_bounds__(256) void nc_lin2_kernel(const float* __restrict__ 
         if (x2) {
 #pragma unroll
             for (int e = 0; e < V; ++e) {
-                raw2[e] = x2[i * V + e];
+                raw2[e] = ldf<T>(x2 + i * V + e);
                 float v = raw2[e];
                 if (flags & 2) v = lrelu(v, slope);
                 r[e] += (a2 ? a2[ci + e] : 1.f) * v;
@@ -121,8 +122,8 @@ __global__ __launch_bounds__(256) void nc_lin2_kernel(const float* __restrict__ 
 #pragma unroll
             for (int e = 0; e < V; ++e) r[e] = fmaxf(r[e], 0.f);
         }
-        if (V == 4) *reinterpret_cast<float4*>(y + i * 4) = make_float4(r[0], r[1 % V], r[2 % V], r[3 % V]);
-        else y[i] = r[0];
+        if (V == 4) st4<T>(y + i * 4, make_float4(r[0], r[1 % V], r[2 % V], r[3 % V]));
+        else stf<T>(y + i, r[0]);
     }
 }
 
@@ -130,11 +131,11 @@ __global__ __launch_bounds__(256) void nc_lin2_kernel(const float* __restrict__ 
 // thread keeps ONE channel group for its whole grid-stride walk through a sample: no per-element div/mod (the
 // 64-bit ones of the generic kernel cost more than the 48 bytes they index) and the (n, c) coefficients live in
 // registers.  G = float4 groups per sample.
-template <int V>
-__global__ __launch_bounds__(256) void nc_lin2_rows_kernel(const float* __restrict__ x1, const float* __restrict__ a1,
-                                                           const float* __restrict__ x2, const float* __restrict__ a2,
+template <int V, typename T>
+__global__ __launch_bounds__(256) void nc_lin2_rows_kernel(const T* __restrict__ x1, const float* __restrict__ a1,
+                                                           const T* __restrict__ x2, const float* __restrict__ a2,
                                                            const float* __restrict__ bb, const float* __restrict__ a3,
-                                                           const float* __restrict__ b3, float* __restrict__ y, int G,
+                                                           const float* __restrict__ b3, T* __restrict__ y, int G,
                                                            int CG, int cstride, int flags, float slope) {
     const int t0 = blockIdx.x * 256 + threadIdx.x;
     const int adv = gridDim.x * 256;
@@ -156,16 +157,16 @@ __global__ __launch_bounds__(256) void nc_lin2_rows_kernel(const float* __restri
         float v1[V], v2[V], r[V];
         if (V == 4) {
             if (x1) {
-                const float4 t = *reinterpret_cast<const float4*>(x1 + i);
+                const float4 t = ld4<T>(x1 + i);
                 v1[0] = t.x; v1[1 % V] = t.y; v1[2 % V] = t.z; v1[3 % V] = t.w;
             }
             if (x2) {
-                const float4 t = *reinterpret_cast<const float4*>(x2 + i);
+                const float4 t = ld4<T>(x2 + i);
                 v2[0] = t.x; v2[1 % V] = t.y; v2[2 % V] = t.z; v2[3 % V] = t.w;
             }
         } else {
-            if (x1) v1[0] = x1[i];
-            if (x2) v2[0] = x2[i];
+            if (x1) v1[0] = ldf<T>(x1 + i);
+            if (x2) v2[0] = ldf<T>(x2 + i);
         }
 #pragma unroll
         for (int e = 0; e < V; ++e) {
@@ -178,8 +179,8 @@ __global__ __launch_bounds__(256) void nc_lin2_rows_kernel(const float* __restri
             }
             if (fr) r[e] = fmaxf(r[e], 0.f);
         }
-        if (V == 4) *reinterpret_cast<float4*>(y + i) = make_float4(r[0], r[1 % V], r[2 % V], r[3 % V]);
-        else y[i] = r[0];
+        if (V == 4) st4<T>(y + i, make_float4(r[0], r[1 % V], r[2 % V], r[3 % V]));
+        else stf<T>(y + i, r[0]);
     }
 }
 
@@ -192,69 +193,81 @@ __device__ __forceinline__ float act_deriv(float o, int act, float slope) {
     return 1.f;
 }
 
-template <bool VEC>
-__global__ void act_fwd_kernel(const float* x, float* y, size_t n, int act, float slope) {   // may run in place
+template <bool VEC, typename T>
+__global__ void act_fwd_kernel(const T* x, T* y, size_t n, int act, float slope) {   // may run in place
     const size_t stride = (size_t)gridDim.x * blockDim.x, t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (VEC) {
         for (size_t i = t; i < n / 4; i += stride) {
-            float4 v = reinterpret_cast<const float4*>(x)[i];
+            float4 v = ld4<T>(x + 4 * i);
             v.x = cn_apply_act(v.x, act, slope); v.y = cn_apply_act(v.y, act, slope);
             v.z = cn_apply_act(v.z, act, slope); v.w = cn_apply_act(v.w, act, slope);
-            reinterpret_cast<float4*>(y)[i] = v;
+            st4<T>(y + 4 * i, v);
         }
-        for (size_t i = (n / 4) * 4 + t; i < n; i += stride) y[i] = cn_apply_act(x[i], act, slope);
+        for (size_t i = (n / 4) * 4 + t; i < n; i += stride) stf<T>(y + i, cn_apply_act(ldf<T>(x + i), act, slope));
     } else {
-        for (size_t i = t; i < n; i += stride) y[i] = cn_apply_act(x[i], act, slope);
+        for (size_t i = t; i < n; i += stride) stf<T>(y + i, cn_apply_act(ldf<T>(x + i), act, slope));
     }
 }
 
-template <bool VEC>
-__global__ void act_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ y, float* __restrict__ gx,
+template <bool VEC, typename T>
+__global__ void act_bwd_kernel(const T* __restrict__ gy, const T* __restrict__ y, T* __restrict__ gx,
                                size_t n, int act, float slope) {
     const size_t stride = (size_t)gridDim.x * blockDim.x, t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (VEC) {
         for (size_t i = t; i < n / 4; i += stride) {
-            const float4 o = reinterpret_cast<const float4*>(y)[i], g = reinterpret_cast<const float4*>(gy)[i];
-            reinterpret_cast<float4*>(gx)[i] = make_float4(g.x * act_deriv(o.x, act, slope), g.y * act_deriv(o.y, act, slope),
-                                                           g.z * act_deriv(o.z, act, slope), g.w * act_deriv(o.w, act, slope));
+            const float4 o = ld4<T>(y + 4 * i), g = ld4<T>(gy + 4 * i);
+            st4<T>(gx + 4 * i, make_float4(g.x * act_deriv(o.x, act, slope), g.y * act_deriv(o.y, act, slope),
+                                           g.z * act_deriv(o.z, act, slope), g.w * act_deriv(o.w, act, slope)));
         }
-        for (size_t i = (n / 4) * 4 + t; i < n; i += stride) gx[i] = gy[i] * act_deriv(y[i], act, slope);
+        for (size_t i = (n / 4) * 4 + t; i < n; i += stride) stf<T>(gx + i, ldf<T>(gy + i) * act_deriv(ldf<T>(y + i), act, slope));
     } else {
-        for (size_t i = t; i < n; i += stride) gx[i] = gy[i] * act_deriv(y[i], act, slope);
+        for (size_t i = t; i < n; i += stride) stf<T>(gx + i, ldf<T>(gy + i) * act_deriv(ldf<T>(y + i), act, slope));
     }
 }
 
-template <bool VEC>
-__global__ void axpby_kernel(const float* __restrict__ x, const float* __restrict__ y, float* __restrict__ o, size_t n,
+template <bool VEC, typename T>
+__global__ void axpby_kernel(const T* __restrict__ x, const T* __restrict__ y, T* __restrict__ o, size_t n,
                              float a, float b) {
     const size_t stride = (size_t)gridDim.x * blockDim.x, t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (VEC) {
         for (size_t i = t; i < n / 4; i += stride) {
-            const float4 u = reinterpret_cast<const float4*>(x)[i];
+            const float4 u = ld4<T>(x + 4 * i);
             float4 r = make_float4(a * u.x, a * u.y, a * u.z, a * u.w);
             if (y) {
-                const float4 w = reinterpret_cast<const float4*>(y)[i];
+                const float4 w = ld4<T>(y + 4 * i);
                 r.x += b * w.x; r.y += b * w.y; r.z += b * w.z; r.w += b * w.w;
             }
-            reinterpret_cast<float4*>(o)[i] = r;
+            st4<T>(o + 4 * i, r);
         }
-        for (size_t i = (n / 4) * 4 + t; i < n; i += stride) o[i] = a * x[i] + (y ? b * y[i] : 0.f);
+        for (size_t i = (n / 4) * 4 + t; i < n; i += stride) stf<T>(o + i, a * ldf<T>(x + i) + (y ? b * ldf<T>(y + i) : 0.f));
     } else {
-        for (size_t i = t; i < n; i += stride) o[i] = a * x[i] + (y ? b * y[i] : 0.f);
+        for (size_t i = t; i < n; i += stride) stf<T>(o + i, a * ldf<T>(x + i) + (y ? b * ldf<T>(y + i) : 0.f));
     }
 }
 
-template <bool VEC>
-__global__ void mul_kernel(const float* __restrict__ x, const float* __restrict__ y, float* __restrict__ o, size_t n) {
+template <bool VEC, typename T>
+__global__ void mul_kernel(const T* __restrict__ x, const T* __restrict__ y, T* __restrict__ o, size_t n) {
     const size_t stride = (size_t)gridDim.x * blockDim.x, t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (VEC) {
         for (size_t i = t; i < n / 4; i += stride) {
-            const float4 u = reinterpret_cast<const float4*>(x)[i], w = reinterpret_cast<const float4*>(y)[i];
-            reinterpret_cast<float4*>(o)[i] = make_float4(u.x * w.x, u.y * w.y, u.z * w.z, u.w * w.w);
+            const float4 u = ld4<T>(x + 4 * i), w = ld4<T>(y + 4 * i);
+            st4<T>(o + 4 * i, make_float4(u.x * w.x, u.y * w.y, u.z * w.z, u.w * w.w));
         }
-        for (size_t i = (n / 4) * 4 + t; i < n; i += stride) o[i] = x[i] * y[i];
+        for (size_t i = (n / 4) * 4 + t; i < n; i += stride) stf<T>(o + i, ldf<T>(x + i) * ldf<T>(y + i));
     } else {
-        for (size_t i = t; i < n; i += stride) o[i] = x[i] * y[i];
+        for (size_t i = t; i < n; i += stride) stf<T>(o + i, ldf<T>(x + i) * ldf<T>(y + i));
+    }
+}
+
+// dst[i] = (TD) src[i]: storage-type conversion (fp32 <-> bf16, round to nearest even)
+template <typename TS, typename TD>
+__global__ void cast_kernel(const TS* __restrict__ src, TD* __restrict__ dst, size_t n, int vec) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x, t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (vec) {
+        for (size_t i = t; i < n / 4; i += stride) st4<TD>(dst + 4 * i, ld4<TS>(src + 4 * i));
+        for (size_t i = (n / 4) * 4 + t; i < n; i += stride) stf<TD>(dst + i, ldf<TS>(src + i));
+    } else {
+        for (size_t i = t; i < n; i += stride) stf<TD>(dst + i, ldf<TS>(src + i));
     }
 }
 
@@ -269,23 +282,24 @@ __device__ __forceinline__ float block_sum(float v) {
     return sh[0] + sh[1] + sh[2] + sh[3];
 }
 
-__global__ __launch_bounds__(256) void sqdiff_sum_kernel(const float* __restrict__ a, const float* __restrict__ b,
+template <typename T>
+__global__ __launch_bounds__(256) void sqdiff_sum_kernel(const T* __restrict__ a, const T* __restrict__ b,
                                                          float* __restrict__ out, size_t n, float scale, int vec) {
     float acc = 0.f;
     const size_t stride = (size_t)gridDim.x * blockDim.x, t0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (vec) {
         for (size_t i = t0; i < n / 4; i += stride) {
-            const float4 u = reinterpret_cast<const float4*>(a)[i], w = reinterpret_cast<const float4*>(b)[i];
+            const float4 u = ld4<T>(a + 4 * i), w = ld4<T>(b + 4 * i);
             const float d0 = u.x - w.x, d1 = u.y - w.y, d2 = u.z - w.z, d3 = u.w - w.w;
             acc += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
         }
         for (size_t i = (n / 4) * 4 + t0; i < n; i += stride) {
-            const float d = a[i] - b[i];
+            const float d = ldf<T>(a + i) - ldf<T>(b + i);
             acc += d * d;
         }
     } else {
         for (size_t i = t0; i < n; i += stride) {
-            const float d = a[i] - b[i];
+            const float d = ldf<T>(a + i) - ldf<T>(b + i);
             acc += d * d;
         }
     }
@@ -311,18 +325,19 @@ __global__ __launch_bounds__(256) void row_sumsq_kernel(const float* __restrict_
     if (threadIdx.x == 0) unsafeAtomicAdd(&out[blockIdx.y], t);
 }
 
-__global__ void row_scale_kernel(const float* __restrict__ x, const float* __restrict__ s, float* __restrict__ o,
+template <typename T>
+__global__ void row_scale_kernel(const T* __restrict__ x, const float* __restrict__ s, T* __restrict__ o,
                                  size_t row, float k, int vec) {
     const float f = s[blockIdx.y] * k;
     const size_t base = (size_t)blockIdx.y * row;
     const size_t stride = (size_t)gridDim.x * blockDim.x, t0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (vec) {
         for (size_t i = t0; i < row / 4; i += stride) {
-            const float4 u = reinterpret_cast<const float4*>(x + base)[i];
-            reinterpret_cast<float4*>(o + base)[i] = make_float4(u.x * f, u.y * f, u.z * f, u.w * f);
+            const float4 u = ld4<T>(x + base + 4 * i);
+            st4<T>(o + base + 4 * i, make_float4(u.x * f, u.y * f, u.z * f, u.w * f));
         }
     } else {
-        for (size_t i = t0; i < row; i += stride) o[base + i] = x[base + i] * f;
+        for (size_t i = t0; i < row; i += stride) stf<T>(o + base + i, ldf<T>(x + base + i) * f);
     }
 }
 
@@ -334,7 +349,8 @@ __global__ void masked_diff_kernel(const float* __restrict__ a, const float* __r
     }
 }
 
-__global__ void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int n, int h, int w, int c,
+template <typename T>
+__global__ void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int n, int h, int w, int c,
                                    int oh, int ow, int k, int s, int pad) {
     const long total = (long)n * oh * ow * c;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -348,38 +364,51 @@ __global__ void maxpool_fwd_kernel(const float* __restrict__ x, float* __restric
         for (int dy = 0; dy < k; ++dy)
             for (int dx = 0; dx < k; ++dx) {
                 const int iy = oy * s - pad + dy, ix = ox * s - pad + dx;
-                const float v = (iy >= 0 && iy < h && ix >= 0 && ix < w) ? x[(((long)b * h + iy) * w + ix) * c + ch] : 0.f;
-                if ((iy >= 0 && iy < h && ix >= 0 && ix < w) || pad > 0) best = fmaxf(best, v);
+                const bool in = iy >= 0 && iy < h && ix >= 0 && ix < w;
+                const float v = in ? ldf<T>(x + (((long)b * h + iy) * w + ix) * c + ch) : 0.f;
+                if (in || pad > 0) best = fmaxf(best, v);
             }
-        y[i] = best;
+        stf<T>(y + i, best);
     }
 }
 
-// gradient goes to the first maximum of the window in row-major window order
-__global__ void maxpool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gy, float* __restrict__ gx,
+// Gradient goes to the first maximum of each window in row-major window order (a zero-padding cell that wins takes it
+// nowhere).  Written as a GATHER over input elements -- every element re-evaluates the (at most ceil(k/s)^2) windows
+// that contain it -- so there are no atomics: deterministic, and gx may be stored in bf16.
+template <typename T>
+__global__ void maxpool_bwd_kernel(const T* __restrict__ x, const T* __restrict__ gy, T* __restrict__ gx,
                                    int n, int h, int w, int c, int oh, int ow, int k, int s, int pad) {
-    const long total = (long)n * oh * ow * c;
+    const long total = (long)n * h * w * c;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int ch = (int)(i % c);
         long t = i / c;
-        const int ox = (int)(t % ow);
-        t /= ow;
-        const int oy = (int)(t % oh);
-        const int b = (int)(t / oh);
-        float best = -INFINITY;
-        long arg = -1;
-        for (int dy = 0; dy < k; ++dy)
-            for (int dx = 0; dx < k; ++dx) {
-                const int iy = oy * s - pad + dy, ix = ox * s - pad + dx;
-                const bool in = iy >= 0 && iy < h && ix >= 0 && ix < w;
-                if (!in && pad == 0) continue;
-                const float v = in ? x[(((long)b * h + iy) * w + ix) * c + ch] : 0.f;
-                if (v > best) {
-                    best = v;
-                    arg = in ? (((long)b * h + iy) * w + ix) * c + ch : -1;
-                }
+        const int ix0 = (int)(t % w);
+        t /= w;
+        const int iy0 = (int)(t % h);
+        const int b = (int)(t / h);
+        float acc = 0.f;
+        // windows (oy, ox) with oy*s - pad <= iy0 < oy*s - pad + k
+        const int oy_lo = max(0, (iy0 + pad - k + s) / s), oy_hi = min(oh - 1, (iy0 + pad) / s);
+        const int ox_lo = max(0, (ix0 + pad - k + s) / s), ox_hi = min(ow - 1, (ix0 + pad) / s);
+        for (int oy = oy_lo; oy <= oy_hi; ++oy)
+            for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+                float best = -INFINITY;
+                int ay = -1, ax = -1;
+                bool arg_in = false;
+                for (int dy = 0; dy < k; ++dy)
+                    for (int dx = 0; dx < k; ++dx) {
+                        const int iy = oy * s - pad + dy, ix = ox * s - pad + dx;
+                        const bool in = iy >= 0 && iy < h && ix >= 0 && ix < w;
+                        if (!in && pad == 0) continue;
+                        const float v = in ? ldf<T>(x + (((long)b * h + iy) * w + ix) * c + ch) : 0.f;
+                        if (v > best) {
+                            best = v;
+                            ay = iy; ax = ix; arg_in = in;
+                        }
+                    }
+                if (arg_in && ay == iy0 && ax == ix0) acc += ldf<T>(gy + (((long)b * oh + oy) * ow + ox) * c + ch);
             }
-        if (arg >= 0) unsafeAtomicAdd(&gx[arg], gy[i]);
+        stf<T>(gx + i, acc);
     }
 }
 
@@ -475,9 +504,9 @@ inline int ew_blocks(size_t n) {
 
 }  // namespace
 
-extern "C" int cn_nc_reduce(const float* x1, const float* x2, float* s1, float* s2, int n, int s, int c, int flags,
-                            float slope, void* stream) {
-    CN_CHECK_ARG(x1 && (s1 || s2) && n > 0 && s > 0 && c > 0, "nc_reduce: bad args");
+extern "C" int cn_nc_reduce(const void* x1, const void* x2, float* s1, float* s2, int n, int s, int c, int flags,
+                            float slope, int dt, void* stream) {
+    CN_CHECK_ARG(x1 && (s1 || s2) && n > 0 && s > 0 && c > 0 && (dt == CN_F32 || dt == CN_BF16), "nc_reduce: bad args");
     hipStream_t st = (hipStream_t)stream;
     if (flags & 16) {
         // outputs were cleared by the caller (per-step zero pool: one clearing launch per step, not per call)
@@ -506,16 +535,19 @@ extern "C" int cn_nc_reduce(const float* x1, const float* x2, float* s1, float* 
     if (rpb < 4 * TY) rpb = 4 * TY;
     const int sblk = cn_cdiv(s, rpb);
     dim3 grid(cblk, sblk, n), block(TX, TY);
-    if (V == 4) hipLaunchKernelGGL(nc_reduce_kernel<4>, grid, block, 0, st, x1, x2, s1, s2, s, c, (int)rpb, flags, slope);
-    else hipLaunchKernelGGL(nc_reduce_kernel<1>, grid, block, 0, st, x1, x2, s1, s2, s, c, (int)rpb, flags, slope);
+    CN_DISPATCH_DT(dt, {
+        const T* p1 = (const T*)x1; const T* p2 = (const T*)x2;
+        if (V == 4) hipLaunchKernelGGL((nc_reduce_kernel<4, T>), grid, block, 0, st, p1, p2, s1, s2, s, c, (int)rpb, flags, slope);
+        else hipLaunchKernelGGL((nc_reduce_kernel<1, T>), grid, block, 0, st, p1, p2, s1, s2, s, c, (int)rpb, flags, slope);
+    });
     CN_LAUNCH_CHECK();
     return CN_OK;
 }
 
-extern "C" int cn_nc_lin2(const float* x1, const float* a1, const float* x2, const float* a2, const float* bb,
-                          const float* a3, const float* b3, float* y, int n, int s, int c, int cstride, int flags,
-                          float slope, void* stream) {
-    CN_CHECK_ARG(y && n > 0 && s > 0 && c > 0 && (cstride == 0 || cstride == c), "nc_lin2: bad args");
+extern "C" int cn_nc_lin2(const void* x1, const float* a1, const void* x2, const float* a2, const float* bb,
+                          const float* a3, const float* b3, void* y, int n, int s, int c, int cstride, int flags,
+                          float slope, int dt, void* stream) {
+    CN_CHECK_ARG(y && n > 0 && s > 0 && c > 0 && (cstride == 0 || cstride == c) && (dt == CN_F32 || dt == CN_BF16), "nc_lin2: bad args");
     CN_CHECK_ARG(x1 || x2 || bb, "nc_lin2: nothing to compute");
     const int V = (c % 4 == 0) ? 4 : 1;
     const long total = (long)n * s * (c / V);
@@ -533,14 +565,18 @@ extern "C" int cn_nc_lin2(const float* x1, const float* a1, const float* x2, con
             if (gx * ny > 8192) gx = 8192 / ny;
             if (gx < 1) gx = 1;
             gx = (gx + q - 1) / q * q;
-            if (V == 4) hipLaunchKernelGGL(nc_lin2_rows_kernel<4>, dim3((unsigned)gx, ny), dim3(256), 0, st, x1, a1, x2, a2, bb, a3, b3, y, (int)G, CG, cstride, flags, slope);
-            else hipLaunchKernelGGL(nc_lin2_rows_kernel<1>, dim3((unsigned)gx, ny), dim3(256), 0, st, x1, a1, x2, a2, bb, a3, b3, y, (int)G, CG, cstride, flags, slope);
+            CN_DISPATCH_DT(dt, {
+                if (V == 4) hipLaunchKernelGGL((nc_lin2_rows_kernel<4, T>), dim3((unsigned)gx, ny), dim3(256), 0, st, (const T*)x1, a1, (const T*)x2, a2, bb, a3, b3, (T*)y, (int)G, CG, cstride, flags, slope);
+                else hipLaunchKernelGGL((nc_lin2_rows_kernel<1, T>), dim3((unsigned)gx, ny), dim3(256), 0, st, (const T*)x1, a1, (const T*)x2, a2, bb, a3, b3, (T*)y, (int)G, CG, cstride, flags, slope);
+            });
             CN_LAUNCH_CHECK();
             return CN_OK;
         }
     }
-    if (V == 4) hipLaunchKernelGGL(nc_lin2_kernel<4>, dim3(ew_blocks(total)), dim3(256), 0, st, x1, a1, x2, a2, bb, a3, b3, y, total, s, c, cstride, flags, slope);
-    else hipLaunchKernelGGL(nc_lin2_kernel<1>, dim3(ew_blocks(total)), dim3(256), 0, st, x1, a1, x2, a2, bb, a3, b3, y, total, s, c, cstride, flags, slope);
+    CN_DISPATCH_DT(dt, {
+        if (V == 4) hipLaunchKernelGGL((nc_lin2_kernel<4, T>), dim3(ew_blocks(total)), dim3(256), 0, st, (const T*)x1, a1, (const T*)x2, a2, bb, a3, b3, (T*)y, total, s, c, cstride, flags, slope);
+        else hipLaunchKernelGGL((nc_lin2_kernel<1, T>), dim3(ew_blocks(total)), dim3(256), 0, st, (const T*)x1, a1, (const T*)x2, a2, bb, a3, b3, (T*)y, total, s, c, cstride, flags, slope);
+    });
     CN_LAUNCH_CHECK();
     return CN_OK;
 }
@@ -551,39 +587,55 @@ extern "C" int cn_nc_lin2(const float* x1, const float* a1, const float* x2, con
     return CN_OK;
 
 static inline bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
-// float4 form of a streaming map when every pointer is 16-byte aligned (quarter the grid: one float4 per lane per trip)
-#define EW_LAUNCH_V(kernel, n, vec, ...)                                                                                   \
-    if (vec) hipLaunchKernelGGL(kernel<true>, dim3(ew_blocks(((n) + 3) / 4)), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); \
-    else hipLaunchKernelGGL(kernel<false>, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__);             \
-    CN_LAUNCH_CHECK();                                                                                                     \
+// 4-wide access of a tensor stored as `dt` needs 16-byte (fp32) / 8-byte (bf16) alignment (NULL counts as aligned)
+static inline bool alv(const void* p, int dt) { return ((uintptr_t)p & (dt == CN_BF16 ? 7 : 15)) == 0; }
+// 4-wide form of a streaming map when every pointer is aligned (quarter the grid: four elements per lane per trip)
+#define EW_LAUNCH_VT(kernel, n, vec, dt, ...)                                                                                    \
+    CN_CHECK_ARG((dt) == CN_F32 || (dt) == CN_BF16, "bad dtype code %d", (int)(dt));                                                \
+    CN_DISPATCH_DT(dt, {                                                                                                          \
+        if (vec) hipLaunchKernelGGL((kernel<true, T>), dim3(ew_blocks(((n) + 3) / 4)), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); \
+        else hipLaunchKernelGGL((kernel<false, T>), dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__);             \
+    });                                                                                                                           \
+    CN_LAUNCH_CHECK();                                                                                                            \
     return CN_OK;
 
-extern "C" int cn_act_fwd(const float* x, float* y, size_t numel, int act, float slope, void* stream) {
+extern "C" int cn_act_fwd(const void* x, void* y, size_t numel, int act, float slope, int dt, void* stream) {
     CN_CHECK_ARG(x && y, "act_fwd: NULL");
     if (!numel) return CN_OK;
-    EW_LAUNCH_V(act_fwd_kernel, numel, al16(x) && al16(y), x, y, numel, act, slope)
+    EW_LAUNCH_VT(act_fwd_kernel, numel, alv(x, dt) && alv(y, dt), dt, (const T*)x, (T*)y, numel, act, slope)
 }
-extern "C" int cn_act_bwd(const float* gy, const float* y, float* gx, size_t numel, int act, float slope, void* stream) {
+extern "C" int cn_act_bwd(const void* gy, const void* y, void* gx, size_t numel, int act, float slope, int dt, void* stream) {
     CN_CHECK_ARG(gy && y && gx, "act_bwd: NULL");
     if (!numel) return CN_OK;
-    EW_LAUNCH_V(act_bwd_kernel, numel, al16(gy) && al16(y) && al16(gx), gy, y, gx, numel, act, slope)
+    EW_LAUNCH_VT(act_bwd_kernel, numel, alv(gy, dt) && alv(y, dt) && alv(gx, dt), dt, (const T*)gy, (const T*)y, (T*)gx, numel, act, slope)
 }
-extern "C" int cn_axpby(const float* x, const float* y, float* out, size_t numel, float a, float b, void* stream) {
+extern "C" int cn_axpby(const void* x, const void* y, void* out, size_t numel, float a, float b, int dt, void* stream) {
     CN_CHECK_ARG(x && out, "axpby: NULL");
     if (!numel) return CN_OK;
-    EW_LAUNCH_V(axpby_kernel, numel, al16(x) && al16(y) && al16(out), x, y, out, numel, a, b)
+    EW_LAUNCH_VT(axpby_kernel, numel, alv(x, dt) && alv(y, dt) && alv(out, dt), dt, (const T*)x, (const T*)y, (T*)out, numel, a, b)
 }
-extern "C" int cn_mul(const float* x, const float* y, float* out, size_t numel, void* stream) {
+extern "C" int cn_mul(const void* x, const void* y, void* out, size_t numel, int dt, void* stream) {
     CN_CHECK_ARG(x && y && out, "mul: NULL");
     if (!numel) return CN_OK;
-    EW_LAUNCH_V(mul_kernel, numel, al16(x) && al16(y) && al16(out), x, y, out, numel)
+    EW_LAUNCH_VT(mul_kernel, numel, alv(x, dt) && alv(y, dt) && alv(out, dt), dt, (const T*)x, (const T*)y, (T*)out, numel)
 }
-extern "C" int cn_sqdiff_sum(const float* a, const float* b, float* out, size_t numel, float scale, void* stream) {
-    CN_CHECK_ARG(a && b && out, "sqdiff_sum: NULL");
+extern "C" int cn_cast(const void* src, int src_dt, void* dst, int dst_dt, size_t numel, void* stream) {
+    CN_CHECK_ARG(src && dst && (src_dt == CN_F32 || src_dt == CN_BF16) && (dst_dt == CN_F32 || dst_dt == CN_BF16) && src_dt != dst_dt,
+                 "cast: bad args");
     if (!numel) return CN_OK;
-    const int vec = al16(a) && al16(b);
+    const int vec = alv(src, src_dt) && alv(dst, dst_dt);
+    const dim3 grid(ew_blocks(vec ? (numel + 3) / 4 : numel));
+    if (src_dt == CN_F32) hipLaunchKernelGGL((cast_kernel<float, bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, (const float*)src, (bf16_t*)dst, numel, vec);
+    else hipLaunchKernelGGL((cast_kernel<bf16_t, float>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, (float*)dst, numel, vec);
+    CN_LAUNCH_CHECK();
+    return CN_OK;
+}
+extern "C" int cn_sqdiff_sum(const void* a, const void* b, float* out, size_t numel, float scale, int dt, void* stream) {
+    CN_CHECK_ARG(a && b && out && (dt == CN_F32 || dt == CN_BF16), "sqdiff_sum: bad args");
+    if (!numel) return CN_OK;
+    const int vec = alv(a, dt) && alv(b, dt);
     const int blocks = ew_blocks(numel / (vec ? 4 : 1) + 1) > 512 ? 512 : ew_blocks(numel / (vec ? 4 : 1) + 1);   // one atomic each
-    hipLaunchKernelGGL(sqdiff_sum_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, b, out, numel, scale, vec);
+    CN_DISPATCH_DT(dt, hipLaunchKernelGGL((sqdiff_sum_kernel<T>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const T*)a, (const T*)b, out, numel, scale, vec));
     CN_LAUNCH_CHECK();
     return CN_OK;
 }
@@ -597,12 +649,12 @@ extern "C" int cn_row_sumsq(const float* x, float* out, int n, size_t row, void*
     CN_LAUNCH_CHECK();
     return CN_OK;
 }
-extern "C" int cn_row_scale(const float* x, const float* s, float* out, int n, size_t row, float k, void* stream) {
-    CN_CHECK_ARG(x && s && out && n > 0 && row > 0, "row_scale: bad args");
-    const int vec = al16(x) && al16(out) && row % 4 == 0;
+extern "C" int cn_row_scale(const void* x, const float* s, void* out, int n, size_t row, float k, int dt, void* stream) {
+    CN_CHECK_ARG(x && s && out && n > 0 && row > 0 && (dt == CN_F32 || dt == CN_BF16), "row_scale: bad args");
+    const int vec = alv(x, dt) && alv(out, dt) && row % 4 == 0;
     int bpr = (int)((row + 256 * 16 - 1) / (256 * 16));
     if (bpr > 512) bpr = 512;
-    hipLaunchKernelGGL(row_scale_kernel, dim3(bpr, n), dim3(256), 0, (hipStream_t)stream, x, s, out, row, k, vec);
+    CN_DISPATCH_DT(dt, hipLaunchKernelGGL((row_scale_kernel<T>), dim3(bpr, n), dim3(256), 0, (hipStream_t)stream, (const T*)x, s, (T*)out, row, k, vec));
     CN_LAUNCH_CHECK();
     return CN_OK;
 }
@@ -611,18 +663,21 @@ extern "C" int cn_masked_diff(const float* a, const float* b, const uint8_t* mas
     if (!pixels) return CN_OK;
     EW_LAUNCH(masked_diff_kernel, pixels, a, b, mask, out, pixels, c)
 }
-extern "C" int cn_maxpool_fwd(const float* x, float* y, int n, int h, int w, int c, int k, int s, int pad, void* stream) {
-    CN_CHECK_ARG(x && y && n > 0 && h > 0 && w > 0 && c > 0 && k > 0 && s > 0 && pad >= 0, "maxpool: bad args");
+extern "C" int cn_maxpool_fwd(const void* x, void* y, int n, int h, int w, int c, int k, int s, int pad, int dt, void* stream) {
+    CN_CHECK_ARG(x && y && n > 0 && h > 0 && w > 0 && c > 0 && k > 0 && s > 0 && pad >= 0 && (dt == CN_F32 || dt == CN_BF16), "maxpool: bad args");
     const int oh = (h + 2 * pad - k) / s + 1, ow = (w + 2 * pad - k) / s + 1;
     const size_t total = (size_t)n * oh * ow * c;
-    EW_LAUNCH(maxpool_fwd_kernel, total, x, y, n, h, w, c, oh, ow, k, s, pad)
+    CN_DISPATCH_DT(dt, hipLaunchKernelGGL((maxpool_fwd_kernel<T>), dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (T*)y, n, h, w, c, oh, ow, k, s, pad));
+    CN_LAUNCH_CHECK();
+    return CN_OK;
 }
-extern "C" int cn_maxpool_bwd(const float* x, const float* gy, float* gx, int n, int h, int w, int c, int k, int s, int pad, void* stream) {
-    CN_CHECK_ARG(x && gy && gx && n > 0 && h > 0 && w > 0 && c > 0 && k > 0 && s > 0 && pad >= 0, "maxpool_bwd: bad args");
+extern "C" int cn_maxpool_bwd(const void* x, const void* gy, void* gx, int n, int h, int w, int c, int k, int s, int pad, int dt, void* stream) {
+    CN_CHECK_ARG(x && gy && gx && n > 0 && h > 0 && w > 0 && c > 0 && k > 0 && s > 0 && pad >= 0 && (dt == CN_F32 || dt == CN_BF16), "maxpool_bwd: bad args");
     const int oh = (h + 2 * pad - k) / s + 1, ow = (w + 2 * pad - k) / s + 1;
-    if (int ez__ = cn_zero_async(gx, sizeof(float) * (size_t)n * h * w * c, (hipStream_t)stream)) return ez__;
-    const size_t total = (size_t)n * oh * ow * c;
-    EW_LAUNCH(maxpool_bwd_kernel, total, x, gy, gx, n, h, w, c, oh, ow, k, s, pad)
+    const size_t total = (size_t)n * h * w * c;
+    CN_DISPATCH_DT(dt, hipLaunchKernelGGL((maxpool_bwd_kernel<T>), dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)gy, (T*)gx, n, h, w, c, oh, ow, k, s, pad));
+    CN_LAUNCH_CHECK();
+    return CN_OK;
 }
 extern "C" int cn_chan_affine3_fwd(const float* x, float* y, size_t pixels, const int* perm, float scale, const float* off, void* stream) {
     CN_CHECK_ARG(x && y && perm && off, "chan_affine3: NULL");

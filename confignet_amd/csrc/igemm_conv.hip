@@ -16,90 +16,10 @@
 #include "common.h"
 
 #include "mma_tile.h"
+#include "typed.h"
+#include "conv_geom.h"
 
 namespace {
-
-struct RowInfo {
-    int nbase, vd, vh, vw;
-    bool ok;
-};
-
-__device__ __forceinline__ RowInfo decode_row(const CnConvGeom& g, int m, int M) {
-    RowInfo r;
-    r.ok = m < M;
-    if (!r.ok) m = 0;
-    int ow = m % g.out_w;
-    int t = m / g.out_w;
-    int oh = t % g.out_h;
-    t /= g.out_h;
-    int od = t % g.out_d;
-    int n = t / g.out_d;
-    r.nbase = n * g.in_d;
-    r.vd = od * g.s_d - g.p_d;
-    r.vh = oh * g.s_h - g.p_h;
-    r.vw = ow * g.s_w - g.p_w;
-    return r;
-}
-
-// Parity-class row order for the data-gradient of a strided convolution (dl > 1, stride 1 on the output
-// side, out % dl == 0): rows are enumerated class-major, class = (od % dl_d, oh % dl_h, ow % dl_w), so
-// that all rows of a tile hit the zero-stuffed positions for the SAME taps and those taps are skipped as a
-// whole (4x fewer MFMAs for the 2-D stride-2 discriminator blocks).  Returns the true output row.
-__device__ __forceinline__ int par_row(const CnConvGeom& g, int mp, int M, int& cls) {
-    const int qd = g.out_d / g.dl_d, qh = g.out_h / g.dl_h, qw = g.out_w / g.dl_w;
-    const int per = g.n * qd * qh * qw;
-    if (mp >= M) { cls = -1; return M; }
-    cls = mp / per;
-    int rem = mp - cls * per;
-    const int cw = cls % g.dl_w, ch = (cls / g.dl_w) % g.dl_h, cd = cls / (g.dl_w * g.dl_h);
-    const int xw = rem % qw; rem /= qw;
-    const int xh = rem % qh; rem /= qh;
-    const int xd = rem % qd;
-    const int n = rem / qd;
-    return ((n * g.out_d + xd * g.dl_d + cd) * g.out_h + xh * g.dl_h + ch) * g.out_w + xw * g.dl_w + cw;
-}
-
-__device__ __forceinline__ unsigned long long par_tap_mask(const CnConvGeom& g, int cls) {
-    const int cw = cls % g.dl_w, ch = (cls / g.dl_w) % g.dl_h, cd = cls / (g.dl_w * g.dl_h);
-    unsigned long long mask = 0ull;
-    int tap = 0;
-    for (int kd = 0; kd < g.k_d; ++kd)
-        for (int kh = 0; kh < g.k_h; ++kh)
-            for (int kw = 0; kw < g.k_w; ++kw, ++tap) {
-                const int vd = cd - g.p_d + kd, vh = ch - g.p_h + kh, vw = cw - g.p_w + kw;
-                const bool ok = ((vd % g.dl_d) == 0) && ((vh % g.dl_h) == 0) && ((vw % g.dl_w) == 0);
-                if (ok) mask |= 1ull << tap;
-            }
-    return mask;
-}
-
-__device__ __forceinline__ bool map1(int v, int dl, int ext, int up, int& q) {
-    if (v < 0) return false;
-    if (dl > 1) {
-        if (v % dl) return false;
-        v /= dl;
-    }
-    if (v >= ext) return false;
-    q = v >> up;
-    return true;
-}
-
-// element offset (channel 0) of the stored input element read by row r at tap (kd,kh,kw), or -1
-__device__ __forceinline__ int src_off(const CnConvGeom& g, const RowInfo& r, int kd, int kh, int kw) {
-    int qd, qh, qw;
-    if (!r.ok) return -1;
-    if (!map1(r.vd + kd, g.dl_d, g.in_d << g.up, g.up, qd)) return -1;
-    if (!map1(r.vh + kh, g.dl_h, g.in_h << g.up, g.up, qh)) return -1;
-    if (!map1(r.vw + kw, g.dl_w, g.in_w << g.up, g.up, qw)) return -1;
-    return (((r.nbase + qd) * g.in_h + qh) * g.in_w + qw) * g.cin;
-}
-
-__device__ __forceinline__ void tap_decode(const CnConvGeom& g, int tap, int& kd, int& kh, int& kw) {
-    kw = tap % g.k_w;
-    int t = tap / g.k_w;
-    kh = t % g.k_h;
-    kd = t / g.k_h;
-}
 
 // ---------------------------------------------------------------------------------------------
 // forward / data-gradient:  Y[m, co] = act( sum_{t,ci} X[src(m,t), ci] * W[t, ci, co] + bias[co] )
@@ -747,8 +667,8 @@ __global__ void weight_tflip_kernel(const float* __restrict__ W, float* __restri
     }
 }
 
-template <int ND>
-__global__ void sumpool2_kernel(const float* __restrict__ GU, float* __restrict__ GX, int n, int d, int h, int w, int c4) {
+template <int ND, typename T>
+__global__ void sumpool2_kernel(const T* __restrict__ GU, T* __restrict__ GX, int n, int d, int h, int w, int c4) {
     const long total = (long)n * d * h * w * c4;
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
@@ -762,7 +682,6 @@ __global__ void sumpool2_kernel(const float* __restrict__ GU, float* __restrict_
     const int b = (int)(t / d);
     const int H2 = 2 * h, W2 = 2 * w, D2 = ND == 3 ? 2 * d : 1;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    const float4* src = reinterpret_cast<const float4*>(GU);
 #pragma unroll
     for (int dz = 0; dz < (ND == 3 ? 2 : 1); ++dz)
 #pragma unroll
@@ -770,51 +689,10 @@ __global__ void sumpool2_kernel(const float* __restrict__ GU, float* __restrict_
 #pragma unroll
             for (int dx = 0; dx < 2; ++dx) {
                 const int zz = ND == 3 ? 2 * z + dz : 0;
-                const float4 v = src[((((long)b * D2 + zz) * H2 + 2 * y + dy) * W2 + 2 * x + dx) * c4 + cc];
+                const float4 v = ld4<T>(GU + 4 * (((((long)b * D2 + zz) * H2 + 2 * y + dy) * W2 + 2 * x + dx) * c4 + cc));
                 s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
             }
-    reinterpret_cast<float4*>(GX)[i] = s;
-}
-
-// exact number of (output position, tap) pairs that touch a stored element, per spatial axis
-double valid_pairs_1d(int out, int k, int s, int dl, int p, int in, int up) {
-    long cnt = 0;
-    for (int o = 0; o < out; ++o)
-        for (int kk = 0; kk < k; ++kk) {
-            int v = o * s - p + kk;
-            if (v < 0 || v % dl) continue;
-            if (v / dl >= (in << up)) continue;
-            ++cnt;
-        }
-    return (double)cnt;
-}
-
-double conv_flops(const CnConvGeom& g) {
-    return 2.0 * g.n * valid_pairs_1d(g.out_d, g.k_d, g.s_d, g.dl_d, g.p_d, g.in_d, g.up) *
-           valid_pairs_1d(g.out_h, g.k_h, g.s_h, g.dl_h, g.p_h, g.in_h, g.up) *
-           valid_pairs_1d(g.out_w, g.k_w, g.s_w, g.dl_w, g.p_w, g.in_w, g.up) * g.cin * g.cout;
-}
-
-// parity-class row order applies to data-gradient geometries of strided convolutions
-bool parity_ordered(const CnConvGeom& g) {
-    if (g.s_d != 1 || g.s_h != 1 || g.s_w != 1 || g.up) return false;
-    if (g.dl_d * g.dl_h * g.dl_w == 1) return false;
-    return g.out_d % g.dl_d == 0 && g.out_h % g.dl_h == 0 && g.out_w % g.dl_w == 0;
-}
-
-int check_geom(const CnConvGeom* g) {
-    CN_CHECK_ARG(g != nullptr, "geom is NULL");
-    CN_CHECK_ARG(g->nd == 2 || g->nd == 3, "nd must be 2 or 3 (got %d)", g->nd);
-    CN_CHECK_ARG(g->n > 0 && g->cin > 0 && g->cout > 0, "empty batch/channels");
-    CN_CHECK_ARG(g->in_d > 0 && g->in_h > 0 && g->in_w > 0 && g->out_d > 0 && g->out_h > 0 && g->out_w > 0, "empty extent");
-    CN_CHECK_ARG(g->k_d > 0 && g->k_h > 0 && g->k_w > 0 && g->s_d > 0 && g->s_h > 0 && g->s_w > 0, "bad kernel/stride");
-    CN_CHECK_ARG(g->dl_d > 0 && g->dl_h > 0 && g->dl_w > 0, "bad dilation divisor");
-    CN_CHECK_ARG(g->up == 0 || g->up == 1, "up must be 0/1");
-    CN_CHECK_ARG(g->nd == 3 || (g->in_d == 1 && g->out_d == 1 && g->k_d == 1), "2-D geometry must have depth 1");
-    const double in_el = (double)g->n * g->in_d * g->in_h * g->in_w * g->cin;
-    const double out_el = (double)g->n * g->out_d * g->out_h * g->out_w * g->cout;
-    CN_CHECK_ARG(in_el < 2147483647.0 && out_el < 2147483647.0, "tensor exceeds 2^31 elements (32-bit offsets)");
-    return CN_OK;
+    st4<T>(GX + 4 * i, s);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1077,164 +955,6 @@ __global__ __launch_bounds__(256) void up2k4_rgb_fwd_kernel(CnConvGeom g, const 
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// EXPERIMENTAL (CN_BF16X3=1, off by default; not the product path of round 1): the same implicit GEMM with every fp32
-// operand split into two bf16 terms, x = hi + lo (+ 2^-17 |x|), and  a*b ~= a_hi*b_hi + a_hi*b_lo + a_lo*b_hi  evaluated by
-// three v_mfma_f32_32x32x16_bf16 with fp32 accumulation (relative error ~2^-16 per product against 2^-24 for the fp32
-// MFMA; the bf16 pipe is 16x wider).  128 x 128 tile, 16-deep stages (48 KB of LDS: 3 workgroups per CU), operands stored k-contiguous in LDS so that a lane
-// fetches its 8 bf16 of one MFMA with one ds_read_b128.  Forward geometry only (no parity order, no split-K).
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-
-// n-way bf16 split of an fp32 value: x = t[0] + t[1] (+ t[2]) + O(2^-(8 n + 1) |x|); every difference below is exact in fp32
-template <int NS>
-__device__ __forceinline__ void split_bf16_n(float x, unsigned short (&t)[NS]) {
-#pragma unroll
-    for (int i = 0; i < NS; ++i) {
-        const unsigned u = __float_as_uint(x);
-        const unsigned h = (u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u;       // round to nearest even
-        t[i] = (unsigned short)(h >> 16);
-        x -= __uint_as_float(h);
-    }
-}
-
-// filter pre-split for the experimental path: W[tap][ci][co] (fp32) -> NS arrays [tap][co][ci] (bf16, k contiguous)
-template <int NS>
-__global__ void wsplit_bf16_kernel(const float* __restrict__ W, unsigned short* __restrict__ Ws, int T, int cin, int cout) {
-    const long total = (long)T * cin * cout;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int ci = (int)(i % cin);
-        const long r = i / cin;
-        const int co = (int)(r % cout), tap = (int)(r / cout);
-        unsigned short t[NS];
-        split_bf16_n<NS>(W[((long)tap * cin + ci) * cout + co], t);
-#pragma unroll
-        for (int q = 0; q < NS; ++q) Ws[q * total + i] = t[q];
-    }
-}
-
-// NS = 2: a*b ~= a0 b0 + a0 b1 + a1 b0 (3 MFMAs, 16 operand bits); NS = 3: + a0 b2 + a2 b0 + a1 b1 (6 MFMAs: every dropped term
-// is <= 2^-24 of the product, the size of one fp32 rounding).  TN: output columns per workgroup = 64 * TN.
-template <int TN, int NS>
-__global__ __launch_bounds__(256) void igemm_fwd_bf16x3_kernel(CnConvGeom g, const float* __restrict__ X,
-                                                               const unsigned short* __restrict__ Ws, long wstride,
-                                                               const float* __restrict__ bias, float* __restrict__ Y, int act,
-                                                               float slope) {
-    constexpr int BM = 128, BN = 64 * TN, KB = 16, LD = KB + 8;             // LD in bf16 elements (48-byte rows, 16-byte aligned)
-    constexpr int KQ = KB / 4, RPP = 256 / KQ, AP = BM / RPP;
-    __shared__ __attribute__((aligned(16))) unsigned short As[NS][2][BM][LD], Bs[NS][2][BN][LD];
-    __shared__ int rowmap[BM];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1, half = lane >> 5, l31 = lane & 31;
-    const int M = g.n * g.out_d * g.out_h * g.out_w;
-    const int T = g.k_d * g.k_h * g.k_w;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-    const int kq = tid % KQ, arow = tid / KQ;
-    RowInfo ri[AP];
-#pragma unroll
-    for (int i = 0; i < AP; ++i) {
-        const int mrow = m0 + arow + RPP * i;
-        ri[i] = decode_row(g, mrow, M);
-        if (kq == 0) rowmap[arow + RPP * i] = ri[i].ok ? mrow : -1;
-    }
-    f32x16 acc[2][TN];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    const int cpb = g.cin / KB, nks = T * cpb;
-    float4 ra[AP];
-    uint4 rbs[NS];                                                    // one (column, 8 k) piece of each filter term per thread
-    int aoff[AP];
-    int cur_tap = -1;
-    auto load_tiles = [&](int ks) {
-        const int tap = ks / cpb, c0 = (ks - tap * cpb) * KB;
-        if (tap != cur_tap) {
-            cur_tap = tap;
-            int kd, kh, kw;
-            tap_decode(g, tap, kd, kh, kw);
-#pragma unroll
-            for (int i = 0; i < AP; ++i) aoff[i] = src_off(g, ri[i], kd, kh, kw);
-        }
-#pragma unroll
-        for (int i = 0; i < AP; ++i)
-            ra[i] = aoff[i] >= 0 ? *reinterpret_cast<const float4*>(X + aoff[i] + c0 + kq * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-        {
-            const int bn = tid >> 1, k8 = tid & 1;                       // KB = 16: two 8-element pieces per column
-            const int col = n0 + bn;
-            const long off = ((long)tap * g.cout + col) * g.cin + c0 + 8 * k8;
-            const bool on = bn < BN && col < g.cout;
-#pragma unroll
-            for (int q = 0; q < NS; ++q)
-                rbs[q] = on ? *reinterpret_cast<const uint4*>(Ws + q * wstride + off) : make_uint4(0, 0, 0, 0);
-        }
-    };
-    auto store_tiles = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < AP; ++i) {
-            const float v[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
-            unsigned short t[4][NS];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) split_bf16_n<NS>(v[e], t[e]);
-            const int r = arow + RPP * i;
-#pragma unroll
-            for (int q = 0; q < NS; ++q)
-                *reinterpret_cast<uint2*>(&As[q][buf][r][kq * 4]) =
-                    make_uint2(t[0][q] | ((unsigned)t[1][q] << 16), t[2][q] | ((unsigned)t[3][q] << 16));
-        }
-        if ((tid >> 1) < BN) {
-#pragma unroll
-            for (int q = 0; q < NS; ++q) *reinterpret_cast<uint4*>(&Bs[q][buf][tid >> 1][8 * (tid & 1)]) = rbs[q];
-        }
-    };
-    load_tiles(0);
-    store_tiles(0);
-    __syncthreads();
-    for (int ks = 0; ks < nks; ++ks) {
-        const int buf = ks & 1;
-        if (ks + 1 < nks) load_tiles(ks + 1);
-        {
-            union U { uint4 u; bf16x8 v; };
-            U a[NS][2], b[NS][TN];
-#pragma unroll
-            for (int q = 0; q < NS; ++q) {
-#pragma unroll
-                for (int i = 0; i < 2; ++i) a[q][i].u = *reinterpret_cast<const uint4*>(&As[q][buf][wm * 64 + 32 * i + l31][8 * half]);
-#pragma unroll
-                for (int j = 0; j < TN; ++j) b[q][j].u = *reinterpret_cast<const uint4*>(&Bs[q][buf][wn * 32 * TN + 32 * j + l31][8 * half]);
-            }
-            // smallest terms first; every (qa, qb) with qa + qb < NS, spelled out so that all indices are compile-time
-#define CN_BFX_TERM(QA, QB)                                                                                              \
-    _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j)                         \
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[QA][i].v, b[QB][j].v, acc[i][j], 0, 0, 0);
-            if constexpr (NS == 3) {
-                CN_BFX_TERM(0, 2) CN_BFX_TERM(2, 0) CN_BFX_TERM(1, 1)
-            }
-            CN_BFX_TERM(0, 1) CN_BFX_TERM(1, 0) CN_BFX_TERM(0, 0)
-#undef CN_BFX_TERM
-        }
-        if (ks + 1 < nks) store_tiles(buf ^ 1);
-        __syncthreads();
-    }
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int col = n0 + wn * 32 * TN + 32 * j + l31;
-        if (col >= g.cout) continue;
-        const float bv = bias ? bias[col] : 0.f;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int rbase = wm * 64 + 32 * i + 4 * half;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = rowmap[rbase + (r & 3) + 8 * (r >> 2)];
-                if (row >= 0) Y[(long)row * g.cout + col] = cn_apply_act(acc[i][j][r] + bv, act, slope);
-            }
-        }
-    }
-}
-
 static int g_force_kb16 = -1;
 static int g_xcd = getenv("CN_NO_XCD") ? 0 : 1;
 
@@ -1432,7 +1152,7 @@ extern "C" int cn_conv_fwd(const CnConvGeom* gp, const float* x, const float* w,
         default: e = launch_fwd<2, 2, 1, 1>(g, vec, par, splits, x, w, bias, y, kact, slope, s); break;  // 64 x 64
     }
     cn_prof_end(s);
-    if (e == CN_OK && splits > 1 && act != CN_ACT_NONE) e = cn_act_fwd(y, y, (size_t)M * g.cout, act, slope, stream);
+    if (e == CN_OK && splits > 1 && act != CN_ACT_NONE) e = cn_act_fwd(y, y, (size_t)M * g.cout, act, slope, CN_F32, stream);
     return e;
 }
 
@@ -1495,59 +1215,16 @@ extern "C" int cn_conv_wgrad(const CnConvGeom* gp, const float* x, const float* 
     return e;
 }
 
-extern "C" int cn_sumpool2(const float* gu, float* gx, int nd, int n, int d, int h, int w, int c, void* stream) {
-    CN_CHECK_ARG(gu && gx && (nd == 2 || nd == 3) && c % 4 == 0, "sumpool2: bad args (c must be a multiple of 4)");
+extern "C" int cn_sumpool2(const void* gu, void* gx, int nd, int n, int d, int h, int w, int c, int dt, void* stream) {
+    CN_CHECK_ARG(gu && gx && (nd == 2 || nd == 3) && c % 4 == 0 && (dt == CN_F32 || dt == CN_BF16), "sumpool2: bad args (c must be a multiple of 4)");
     if (nd == 2) d = 1;
     const long total = (long)n * d * h * w * (c / 4);
-    if (nd == 3)
-        hipLaunchKernelGGL(sumpool2_kernel<3>, dim3(cn_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, gu, gx, n, d, h, w, c / 4);
-    else
-        hipLaunchKernelGGL(sumpool2_kernel<2>, dim3(cn_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, gu, gx, n, d, h, w, c / 4);
+    CN_DISPATCH_DT(dt, {
+        if (nd == 3)
+            hipLaunchKernelGGL((sumpool2_kernel<3, T>), dim3(cn_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, (const T*)gu, (T*)gx, n, d, h, w, c / 4);
+        else
+            hipLaunchKernelGGL((sumpool2_kernel<2, T>), dim3(cn_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, (const T*)gu, (T*)gx, n, d, h, w, c / 4);
+    });
     CN_LAUNCH_CHECK();
     return CN_OK;
-}
-
-// ---- EXPERIMENTAL error-compensated bf16 convolution (never called unless CN_BF16X3=1) ----
-extern "C" int cn_conv_weight_split_bf16(const float* w, uint16_t* ws, int terms, int taps, int cin, int cout, void* stream) {
-    CN_CHECK_ARG(w && ws && (terms == 2 || terms == 3) && taps > 0 && cin > 0 && cout > 0, "bad weight_split args");
-    if (terms == 2) hipLaunchKernelGGL(wsplit_bf16_kernel<2>, dim3(1024), dim3(256), 0, (hipStream_t)stream, w, ws, taps, cin, cout);
-    else hipLaunchKernelGGL(wsplit_bf16_kernel<3>, dim3(1024), dim3(256), 0, (hipStream_t)stream, w, ws, taps, cin, cout);
-    CN_LAUNCH_CHECK();
-    return CN_OK;
-}
-
-extern "C" int cn_conv_fwd_bf16x3(const CnConvGeom* gp, const float* x, const uint16_t* ws, int terms, const float* bias,
-                                  float* y, int act, float slope, void* stream) {
-    if (int e = check_geom(gp)) return e;
-    CN_CHECK_ARG(x && ws && y && (terms == 2 || terms == 3), "bad bf16-split convolution args");
-    const CnConvGeom g = *gp;
-    const long M = (long)g.n * g.out_d * g.out_h * g.out_w;
-    const bool narrow = g.cout <= 64 || (long)cn_cdiv(M, 128) * cn_cdiv(g.cout, 128) < 512;      // 128 x 64 tiles
-    const long tiles = (long)cn_cdiv(M, 128) * cn_cdiv(g.cout, narrow ? 64 : 128);
-    if (g.dl_d * g.dl_h * g.dl_w != 1 || g.cin % 16 || g.cout % 4 || tiles < 256)
-        return CN_EUNSUPPORTED;                     // outside the prototype's envelope: nothing was launched
-    hipStream_t s = (hipStream_t)stream;
-    dim3 grid(cn_cdiv(M, 128), cn_cdiv(g.cout, narrow ? 64 : 128));
-    const long wstride = (long)g.k_d * g.k_h * g.k_w * g.cin * g.cout;
-    cn_prof_begin(s, conv_flops(g));
-#define BFX(TN_, NS_) hipLaunchKernelGGL((igemm_fwd_bf16x3_kernel<TN_, NS_>), grid, dim3(256), 0, s, g, x, ws, wstride, bias, y, act, slope)
-    if (terms == 2) { if (narrow) BFX(1, 2); else BFX(2, 2); }
-    else { if (narrow) BFX(1, 3); else BFX(2, 3); }
-#undef BFX
-    cn_prof_end(s);
-    CN_LAUNCH_CHECK();
-    return CN_OK;
-}
-
-extern "C" int cn_conv_dgrad_bf16x3(const CnConvGeom* gp, const float* gy, const uint16_t* wts, int terms, float* gu, void* stream) {
-    if (int e = check_geom(gp)) return e;
-    if (gp->s_d != 1 || gp->s_h != 1 || gp->s_w != 1) return CN_EUNSUPPORTED;      // strided: parity-ordered fp32 path
-    CnConvGeom d = *gp;
-    d.in_d = gp->out_d; d.in_h = gp->out_h; d.in_w = gp->out_w; d.cin = gp->cout;
-    d.out_d = gp->in_d << gp->up; d.out_h = gp->in_h << gp->up; d.out_w = gp->in_w << gp->up;
-    if (gp->nd == 2) d.out_d = 1;
-    d.cout = gp->cin;
-    d.p_d = gp->k_d - 1 - gp->p_d; d.p_h = gp->k_h - 1 - gp->p_h; d.p_w = gp->k_w - 1 - gp->p_w;
-    d.up = 0;
-    return cn_conv_fwd_bf16x3(&d, gy, wts, terms, nullptr, gu, CN_ACT_NONE, 0.f, stream);
 }

@@ -1,6 +1,7 @@
 // norm_coef.hip -- the O(N*C) coefficient algebra of AdaIN / instance norm / style statistics as single
 // tiny kernels (one thread per (n,c), or per c for the parameter gradients that reduce over n).
 #include "common.h"
+#include "typed.h"
 
 namespace {
 
@@ -211,22 +212,23 @@ __global__ void dual_coef_bwd_kernel(const float* __restrict__ H1, const float* 
 }
 
 // g_x = lrelu'(x) (kh*h + kt*ta + ka*lrelu(x) + kc) + et*tx + ex*x + e0 ; any of the two groups may be absent
-__global__ void dual_gx_kernel(const float* __restrict__ h, const float* __restrict__ ta, const float* __restrict__ tx,
-                               const float* __restrict__ x, const float* __restrict__ kh, const float* __restrict__ kt,
+template <typename T>
+__global__ void dual_gx_kernel(const T* __restrict__ h, const T* __restrict__ ta, const T* __restrict__ tx,
+                               const T* __restrict__ x, const float* __restrict__ kh, const float* __restrict__ kt,
                                const float* __restrict__ ka, const float* __restrict__ kc, const float* __restrict__ et,
-                               const float* __restrict__ ex, const float* __restrict__ e0, float* __restrict__ out,
+                               const float* __restrict__ ex, const float* __restrict__ e0, T* __restrict__ out,
                                long total4, int S, int C, float slope) {
     const int C4 = C / 4;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
         const int cg = (int)(i % C4);
         const int n = (int)((i / C4) / S);
         const long ci = (long)n * C + (long)cg * 4;
-        const float4 xv = reinterpret_cast<const float4*>(x)[i];
+        const float4 xv = ld4<T>(x + 4 * i);
         const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
         float r[4] = {0.f, 0.f, 0.f, 0.f};
         if (kh) {
-            const float4 hv = reinterpret_cast<const float4*>(h)[i];
-            const float4 tv = reinterpret_cast<const float4*>(ta)[i];
+            const float4 hv = ld4<T>(h + 4 * i);
+            const float4 tv = ld4<T>(ta + 4 * i);
             const float hs[4] = {hv.x, hv.y, hv.z, hv.w}, ts[4] = {tv.x, tv.y, tv.z, tv.w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -235,12 +237,12 @@ __global__ void dual_gx_kernel(const float* __restrict__ h, const float* __restr
             }
         }
         if (et) {
-            const float4 tv = reinterpret_cast<const float4*>(tx)[i];
+            const float4 tv = ld4<T>(tx + 4 * i);
             const float ts[4] = {tv.x, tv.y, tv.z, tv.w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) r[e] += et[ci + e] * ts[e] + ex[ci + e] * xs[e] + e0[ci + e];
         }
-        reinterpret_cast<float4*>(out)[i] = make_float4(r[0], r[1], r[2], r[3]);
+        st4<T>(out + 4 * i, make_float4(r[0], r[1], r[2], r[3]));
     }
 }
 
@@ -280,17 +282,17 @@ extern "C" int cn_dual_tail_coef_bwd(const float* H1, const float* H2p, const fl
     return CN_OK;
 }
 
-extern "C" int cn_dual_tail_gx(const float* h, const float* ta, const float* tx, const float* x, const float* kh,
+extern "C" int cn_dual_tail_gx(const void* h, const void* ta, const void* tx, const void* x, const float* kh,
                                const float* kt, const float* ka, const float* kc, const float* et, const float* ex,
-                               const float* e0, float* out, int n, int s, int c, float slope, void* stream) {
-    CN_CHECK_ARG(x && out && n > 0 && s > 0 && c > 0 && c % 4 == 0 && (kh || et), "dual_tail_gx: bad args");
+                               const float* e0, void* out, int n, int s, int c, float slope, int dt, void* stream) {
+    CN_CHECK_ARG(x && out && n > 0 && s > 0 && c > 0 && c % 4 == 0 && (kh || et) && (dt == CN_F32 || dt == CN_BF16), "dual_tail_gx: bad args");
     CN_CHECK_ARG(!kh || (h && ta && kt && ka && kc), "dual_tail_gx: missing instance-norm tensors");
     CN_CHECK_ARG(!et || (tx && ex && e0), "dual_tail_gx: missing style tensors");
     const long total4 = (long)n * s * (c / 4);
     long blocks = (total4 + 255) / 256;
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(dual_gx_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, h, ta, tx, x, kh, kt, ka, kc, et, ex,
-                       e0, out, total4, s, c, slope);
+    CN_DISPATCH_DT(dt, hipLaunchKernelGGL((dual_gx_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const T*)h,
+                                          (const T*)ta, (const T*)tx, (const T*)x, kh, kt, ka, kc, et, ex, e0, (T*)out, total4, s, c, slope));
     CN_LAUNCH_CHECK();
     return CN_OK;
 }

@@ -35,23 +35,6 @@ def _cg(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
-def _tflip_cached(w):
-    """weight_tflip(w), cached on the tensor until the weights change (nn.WEIGHTS_EPOCH) or, for
-    non-parameter tensors, until torch's version counter moves."""
-    from .nn import WEIGHTS_EPOCH
-    # (per stream: a forked step computes it once on each branch instead of sharing a tensor across streams)
-    key = (WEIGHTS_EPOCH[0], w._version, w.data_ptr(), torch.cuda.current_stream().cuda_stream if w.is_cuda else 0)
-    c = getattr(w, "_cn_tflip", None)
-    if c is not None and c[0] == key:
-        return c[1]
-    wt = ops.weight_tflip(w.detach())
-    try:
-        w._cn_tflip = (key, wt)
-    except Exception:
-        pass
-    return wt
-
-
 # =============================================================================================
 # convolution family
 # =============================================================================================
@@ -93,7 +76,7 @@ class ConvDgradFn(Function):
     @staticmethod
     def forward(ctx, gy, w, g):
         gy = _cg(gy)
-        gu = ops.conv_dgrad(gy, _tflip_cached(w), g)
+        gu = ops.conv_dgrad(gy, w, g)
         ctx.save_for_backward(gy, w)
         ctx.g = g
         return ops.sumpool2(gu) if g.up else gu

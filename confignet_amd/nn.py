@@ -35,14 +35,18 @@ def he_normal(rng, shape):
     return (rng.standard_normal(size=shape) * math.sqrt(2.0 / (rf * shape[-2]))).astype(np.float32)
 
 
-WEIGHTS_EPOCH = [0]     # bumped whenever any network's weights change in place (optimizer, set_weights, EMA)
+WEIGHTS_EPOCH = [0]     # global generation of derived weight caches: bumped when a HIP-graph capture starts / ends (copies made
+                        # inside a capture live in that graph's pool)
 
 
 class Net:
+    epoch = 0           # bumped whenever THIS network's weights change in place (optimizer, set_weights, EMA, broadcast)
+
     def mark_updated(self):
-        """Raw-pointer kernels (Adam, EMA) do not bump torch's version counters: derived caches (the
-        tap-flipped filters of the data-gradient GEMM) are keyed on this epoch instead."""
-        WEIGHTS_EPOCH[0] += 1
+        """Raw-pointer kernels (Adam, EMA) do not bump torch's version counters: derived caches (the tap-flipped fp32 filter
+        of the data-gradient GEMM, the bf16 operand copies) are keyed on this per-network epoch instead, so an update of one
+        network does not invalidate the copies of the others (the frozen VGG stacks keep theirs for the whole run)."""
+        self.epoch += 1
 
     def non_trainable_changed(self):
         """Hook: the non-trainable tensors (BatchNorm moving statistics) were rewritten in place."""
@@ -83,6 +87,7 @@ class Net:
                 self._trainable_idx.append(i)
             else:
                 p = torch.from_numpy(a).to(self.device)
+            p._cn_owner = self
             self.weights.append(p)
         self.n_trainable = n_train
         return self

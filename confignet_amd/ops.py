@@ -6,9 +6,25 @@ import os
 
 import torch
 
-from ._lib import CnConvGeom, check, lib
+from ._lib import CN_BF16, CN_EUNSUPPORTED, CN_F32, CnConvGeom, check, lib
 
 ACT_NONE, ACT_LRELU, ACT_RELU, ACT_TANH = 0, 1, 2, 3
+
+# Storage type of ACTIVATION tensors (channels-last tensors with more than 4 channels).  fp32 is the reference's arithmetic
+# (BASELINE.json configs[1]); bf16 is configs[2]: bf16 activations and bf16 filter copies on v_mfma_f32_32x32x16_bf16 with
+# fp32 accumulation, while 3-channel images, (N, F) latent-sized tensors, statistics, coefficients, losses, master weights,
+# their gradients and the optimizer state stay fp32.
+ACT_DTYPE = torch.float32
+
+
+def set_activation_dtype(dtype):
+    """dtype: torch.float32 / torch.bfloat16 (or "f32" / "bf16").  Process-wide; switch only between steps."""
+    global ACT_DTYPE
+    if isinstance(dtype, str):
+        dtype = {"f32": torch.float32, "fp32": torch.float32, "float32": torch.float32, "bf16": torch.bfloat16,
+                 "bfloat16": torch.bfloat16}[dtype]
+    assert dtype in (torch.float32, torch.bfloat16)
+    ACT_DTYPE = dtype
 
 
 def _stream():
@@ -18,13 +34,48 @@ def _stream():
 def _ptr(t):
     if t is None:
         return None
-    assert t.is_cuda and t.dtype in (torch.float32, torch.uint8, torch.int64, torch.int16) and t.is_contiguous(), \
+    assert t.is_cuda and t.dtype in (torch.float32, torch.bfloat16, torch.uint8, torch.int64, torch.int16) and t.is_contiguous(), \
         "confignet_amd ops need contiguous CUDA tensors (got %s %s contiguous=%s)" % (t.device, t.dtype, t.is_contiguous())
     return ctypes.c_void_p(t.data_ptr())
 
 
+def _fptr(t):
+    """Pointer of a tensor the ABI declares as float*."""
+    assert t is None or t.dtype == torch.float32, "fp32 tensor expected, got %s" % (t.dtype,)
+    return _ptr(t)
+
+
 def _c(t):
     return t if t.is_contiguous() else t.contiguous()
+
+
+def _dt(t):
+    return CN_BF16 if t.dtype == torch.bfloat16 else CN_F32
+
+
+def cast(x, dtype):
+    """Storage-type conversion fp32 <-> bf16 (round to nearest even) by a HIP kernel."""
+    if x.dtype == dtype:
+        return x
+    x = _c(x)
+    out = torch.empty(x.shape, device=x.device, dtype=dtype)
+    check(lib.cn_cast(_ptr(x), _dt(x), _ptr(out), _dt(out), x.numel(), _stream()), "cn_cast")
+    return out
+
+
+def f32(x):
+    return x if x is None else cast(x, torch.float32)
+
+
+def _unify(*ts):
+    """Activation operands of one elementwise call share a storage type: bf16 as soon as one of them is (an fp32 gradient
+    arriving from a dense layer meets a bf16 activation)."""
+    dt = torch.bfloat16 if any(t is not None and t.dtype == torch.bfloat16 for t in ts) else torch.float32
+    return [None if t is None else cast(t, dt) for t in ts]
+
+
+def _act_out_dtype(channels):
+    return ACT_DTYPE if channels > 4 else torch.float32
 
 
 # ---------------------------------------------------------------------------------------------
@@ -81,63 +132,92 @@ def geom_in_shape(g, upsampled=False):
     return (g.n, g.in_h << u, g.in_w << u, g.cin)
 
 
-# EXPERIMENTAL (DESIGN.md section 9 item 8): error-compensated bf16 convolution, only with CN_BF16X3=1
-BF16X3 = os.environ.get("CN_BF16X3") in ("1", "2", "3")
-BF16_TERMS = 3 if os.environ.get("CN_BF16X3") == "3" else 2      # 2: 16 operand bits, 3 MFMAs; 3: all 24 bits, 6 MFMAs
-CN_EUNSUPPORTED = -3
-
-
-def _bf16x3_rows_cout(rows, cout, cin, dilated):
-    return (not dilated) and cin % 16 == 0 and cout % 4 == 0 and ((rows + 127) // 128) * ((cout + 63) // 64) >= 256
-
-
-def weight_split_bf16(w):
-    """[terms][taps][cout][cin] bf16 terms of w [..taps.., cin, cout], cached on the tensor per weights epoch / stream."""
+def _weight_cache(w, slot, make):
+    """Derived forms of a filter (tap-flipped fp32 copy, bf16 operand copies), cached on the tensor.  A weight of a network
+    (nn.Net tags its tensors with their owner) is re-derived when THAT network's epoch moves; other tensors (the cotangent
+    "filters" of double-backward calls) when torch's version counter does.  The key also holds the stream (a forked step
+    derives on each branch instead of sharing a tensor across streams) and the global generation, which a HIP-graph capture
+    bumps so that copies used inside a graph are made inside it -- except for FROZEN networks (no trainable weight: the VGG
+    stacks), whose copies are made once, outside any capture, and then referenced by every graph."""
     from .nn import WEIGHTS_EPOCH
-    key = (WEIGHTS_EPOCH[0], w._version, w.data_ptr(), torch.cuda.current_stream().cuda_stream, BF16_TERMS)
-    c = getattr(w, "_cn_wsplit", None)
+    owner = getattr(w, "_cn_owner", None)
+    frozen = owner is not None and getattr(owner, "n_trainable", 1) == 0
+    if frozen:
+        key = (owner.epoch, w.data_ptr())
+        c = getattr(w, slot, None)
+        if c is not None and c[0] == key:
+            return c[1]
+        if not torch.cuda.is_current_stream_capturing():
+            val = make(w.detach())
+            torch.cuda.current_stream().synchronize()   # once per frozen filter: any stream may read the copy from now on
+            setattr(w, slot, (key, val))
+            return val
+        return make(w.detach())                    # first use happens inside a capture: a graph-private copy
+    key = (WEIGHTS_EPOCH[0], owner.epoch if owner is not None else -1, w._version, w.data_ptr(),
+           torch.cuda.current_stream().cuda_stream if w.is_cuda else 0)
+    c = getattr(w, slot, None)
     if c is not None and c[0] == key:
         return c[1]
-    taps, cin, cout = int(math.prod(w.shape[:-2])), w.shape[-2], w.shape[-1]
-    halves = torch.empty((BF16_TERMS, taps, cout, cin), device=w.device, dtype=torch.int16)
-    check(lib.cn_conv_weight_split_bf16(_ptr(w), _ptr(halves), BF16_TERMS, taps, cin, cout, _stream()), "cn_conv_weight_split_bf16")
+    val = make(w.detach())
     try:
-        w._cn_wsplit = (key, halves)
+        setattr(w, slot, (key, val))
     except Exception:
         pass
-    return halves
+    return val
+
+
+def weight_prep_bf16(w):
+    """(wf [t][co][ci], wd [t][ci][co]) bf16 operand copies of the fp32 filter w [..taps.., cin, cout]."""
+    def make(wd_):
+        taps, cin, cout = int(math.prod(wd_.shape[:-2])), wd_.shape[-2], wd_.shape[-1]
+        both = torch.empty((2, taps * cin * cout), device=wd_.device, dtype=torch.bfloat16)
+        check(lib.cn_conv_weight_prep_bf16(_fptr(_c(wd_)), _ptr(both[0]), _ptr(both[1]), taps, cin, cout, _stream()),
+              "cn_conv_weight_prep_bf16")
+        return both[0], both[1]
+    return _weight_cache(w, "_cn_wbf16", make)
+
+
+def _bf16_conv_ok(g):
+    return ACT_DTYPE == torch.bfloat16 and g.cin % 8 == 0 and g.cout % 8 == 0 and g.dl_d * g.dl_h * g.dl_w == 1
 
 
 def conv_fwd(x, w, bias, g, act=ACT_NONE, slope=0.0):
+    out_dtype = _act_out_dtype(g.cout)
+    if _bf16_conv_ok(g):
+        x = cast(x, torch.bfloat16)
+        y = torch.empty(geom_out_shape(g), device=x.device, dtype=torch.bfloat16)
+        wf, _ = weight_prep_bf16(w)
+        check(lib.cn_conv_fwd_bf16(ctypes.byref(g), _ptr(x), _ptr(wf), _fptr(bias), _ptr(y), act, slope, _stream()), "cn_conv_fwd_bf16")
+        return y
+    x = f32(x)                                  # 3-channel image layers (and everything in fp32 mode): fp32 MFMA family
     y = torch.empty(geom_out_shape(g), device=x.device, dtype=torch.float32)
-    if BF16X3 and _bf16x3_rows_cout(y.numel() // g.cout, g.cout, g.cin, g.dl_d * g.dl_h * g.dl_w != 1):
-        halves = weight_split_bf16(w)
-        rc = lib.cn_conv_fwd_bf16x3(ctypes.byref(g), _ptr(x), _ptr(halves), BF16_TERMS, _ptr(bias), _ptr(y), act, slope, _stream())
-        if rc != CN_EUNSUPPORTED:
-            check(rc, "cn_conv_fwd_bf16x3")
-            return y
-    check(lib.cn_conv_fwd(ctypes.byref(g), _ptr(x), _ptr(w), _ptr(bias), _ptr(y), act, slope, _stream()), "cn_conv_fwd")
-    return y
+    check(lib.cn_conv_fwd(ctypes.byref(g), _ptr(x), _fptr(w), _fptr(bias), _ptr(y), act, slope, _stream()), "cn_conv_fwd")
+    return cast(y, out_dtype)
 
 
 def weight_tflip(w):
+    w = _c(w)
     taps = int(math.prod(w.shape[:-2]))
     wt = torch.empty(w.shape[:-2] + (w.shape[-1], w.shape[-2]), device=w.device, dtype=torch.float32)
-    check(lib.cn_conv_weight_tflip(_ptr(w), _ptr(wt), taps, w.shape[-2], w.shape[-1], _stream()), "cn_conv_weight_tflip")
+    check(lib.cn_conv_weight_tflip(_fptr(w), _ptr(wt), taps, w.shape[-2], w.shape[-1], _stream()), "cn_conv_weight_tflip")
     return wt
 
 
-def conv_dgrad(gy, wt, g):
-    """Gradient w.r.t. the (virtually upsampled) input of the conv described by g."""
-    gu = torch.empty(geom_in_shape(g, upsampled=True), device=gy.device, dtype=torch.float32)
-    if BF16X3 and g.s_d * g.s_h * g.s_w == 1 and _bf16x3_rows_cout(gu.numel() // g.cin, g.cin, g.cout, False):
-        halves = weight_split_bf16(wt)
-        rc = lib.cn_conv_dgrad_bf16x3(ctypes.byref(g), _ptr(gy), _ptr(halves), BF16_TERMS, _ptr(gu), _stream())
-        if rc != CN_EUNSUPPORTED:
-            check(rc, "cn_conv_dgrad_bf16x3")
-            return gu
-    check(lib.cn_conv_dgrad(ctypes.byref(g), _ptr(gy), _ptr(wt), _ptr(gu), _stream()), "cn_conv_dgrad")
-    return gu
+def conv_dgrad(gy, w, g):
+    """Gradient w.r.t. the (virtually upsampled) input of the conv described by g; w is the filter itself (the operand
+    copies the kernels want are derived and cached here)."""
+    shape = geom_in_shape(g, upsampled=True)
+    if _bf16_conv_ok(g):
+        gy = cast(gy, torch.bfloat16)
+        gu = torch.empty(shape, device=gy.device, dtype=torch.bfloat16)
+        _, wd = weight_prep_bf16(w)
+        check(lib.cn_conv_dgrad_bf16(ctypes.byref(g), _ptr(gy), _ptr(wd), _ptr(gu), _stream()), "cn_conv_dgrad_bf16")
+        return gu
+    gy = f32(gy)
+    gu = torch.empty(shape, device=gy.device, dtype=torch.float32)
+    wt = _weight_cache(w, "_cn_tflip", weight_tflip)
+    check(lib.cn_conv_dgrad(ctypes.byref(g), _ptr(gy), _fptr(wt), _ptr(gu), _stream()), "cn_conv_dgrad")
+    return cast(gu, _act_out_dtype(g.cin))
 
 
 def conv_wgrad(x, gy, g, w_shape):
@@ -145,7 +225,12 @@ def conv_wgrad(x, gy, g, w_shape):
     pre = gw is not None
     if not pre:
         gw = torch.empty(w_shape, device=x.device, dtype=torch.float32)
-    check(lib.cn_conv_wgrad(ctypes.byref(g), _ptr(x), _ptr(gy), _ptr(gw), int(pre), _stream()), "cn_conv_wgrad")
+    if _bf16_conv_ok(g):
+        x, gy = cast(x, torch.bfloat16), cast(gy, torch.bfloat16)
+        check(lib.cn_conv_wgrad_bf16(ctypes.byref(g), _ptr(x), _ptr(gy), _fptr(gw), int(pre), _stream()), "cn_conv_wgrad_bf16")
+        return gw
+    x, gy = f32(x), f32(gy)
+    check(lib.cn_conv_wgrad(ctypes.byref(g), _ptr(x), _ptr(gy), _fptr(gw), int(pre), _stream()), "cn_conv_wgrad")
     return gw
 
 
@@ -200,9 +285,9 @@ def zero_pool_alloc(shape, device):
 def sumpool2(gu):
     nd = gu.dim() - 2
     sp = [s // 2 for s in gu.shape[1:-1]]
-    gx = torch.empty((gu.shape[0], *sp, gu.shape[-1]), device=gu.device, dtype=torch.float32)
+    gx = torch.empty((gu.shape[0], *sp, gu.shape[-1]), device=gu.device, dtype=gu.dtype)
     d, h, w = ([1] + sp) if nd == 2 else sp
-    check(lib.cn_sumpool2(_ptr(gu), _ptr(gx), nd, gu.shape[0], d, h, w, gu.shape[-1], _stream()), "cn_sumpool2")
+    check(lib.cn_sumpool2(_ptr(gu), _ptr(gx), nd, gu.shape[0], d, h, w, gu.shape[-1], _dt(gu), _stream()), "cn_sumpool2")
     return gx
 
 
@@ -214,6 +299,7 @@ def gemm(a, b, trans_a=False, trans_b=False, bias=None, act=ACT_NONE, slope=0.0)
     n = b.shape[0] if trans_b else b.shape[1]
     kb = b.shape[1] if trans_b else b.shape[0]
     assert k == kb, "gemm inner dims %d vs %d" % (k, kb)
+    a, b = f32(a), f32(b)                      # dense layers compute in fp32 (a flattened bf16 feature map is converted)
     c = torch.empty((m, n), device=a.device, dtype=torch.float32)
     check(lib.cn_gemm(int(trans_a), int(trans_b), m, n, k, _ptr(a), a.shape[1], _ptr(b), b.shape[1], _ptr(c), n,
                       _ptr(bias), act, slope, _stream()), "cn_gemm")
@@ -227,6 +313,7 @@ def _nsc(x):
 
 def nc_reduce(x1, x2=None, want_sum=True, want_dot=True, flags=0, slope=0.0, per_channel=False):
     """(sum_s f1(x1), sum_s f1(x1)*f2(x2 or x1)) per (n, c); per_channel folds n into s."""
+    x1, x2 = _unify(x1, x2)
     n, s, c = _nsc(x1)
     rep = 1
     if per_channel:
@@ -250,7 +337,7 @@ def nc_reduce(x1, x2=None, want_sum=True, want_dot=True, flags=0, slope=0.0, per
         else:
             one = torch.empty((n, c), device=x1.device, dtype=torch.float32)
         s1, s2 = (one, None) if want_sum else (None, one)
-    check(lib.cn_nc_reduce(_ptr(x1), _ptr(x2), _ptr(s1), _ptr(s2), n, s, c, flags, slope, _stream()), "cn_nc_reduce")
+    check(lib.cn_nc_reduce(_ptr(x1), _ptr(x2), _ptr(s1), _ptr(s2), n, s, c, flags, slope, _dt(x1), _stream()), "cn_nc_reduce")
     if rep > 1:
         if want_sum and want_dot:
             s12 = s12.sum(1, keepdim=True)
@@ -264,10 +351,12 @@ def nc_lin2(shape, x1=None, a1=None, x2=None, a2=None, b=None, flags=0, slope=0.
     """y = a1*f1(x1) + a2*f2(x2) + b with (n,c) [or (c,)] coefficients broadcast over space."""
     n, c = shape[0], shape[-1]
     s = int(math.prod(shape)) // (n * c)
+    x1, x2 = _unify(x1, x2)
     ref = x1 if x1 is not None else (x2 if x2 is not None else b)
-    y = torch.empty(shape, device=ref.device, dtype=torch.float32)
-    check(lib.cn_nc_lin2(_ptr(x1), _ptr(a1), _ptr(x2), _ptr(a2), _ptr(b), _ptr(a3), _ptr(b3), _ptr(y), n, s, c,
-                         0 if per_channel else c, flags, slope, _stream()), "cn_nc_lin2")
+    dtype = ref.dtype if (x1 is not None or x2 is not None) else _act_out_dtype(c)
+    y = torch.empty(shape, device=ref.device, dtype=dtype)
+    check(lib.cn_nc_lin2(_ptr(x1), _fptr(a1), _ptr(x2), _fptr(a2), _fptr(b), _fptr(a3), _fptr(b3), _ptr(y), n, s, c,
+                         0 if per_channel else c, flags, slope, _dt(y), _stream()), "cn_nc_lin2")
     return y
 
 
@@ -345,45 +434,51 @@ def dual_tail_coef_bwd(H, E, u, T, U, mean, q, sm, ssd, gamma, spatial, eps=1e-3
 
 
 def dual_tail_gx(h, ta, tx, x, co, slope):
+    h, ta, tx, x = _unify(h, ta, tx, x)
     n, s, c = _nsc(x)
     out = torch.empty_like(x)
     check(lib.cn_dual_tail_gx(_ptr(h), _ptr(ta), _ptr(tx), _ptr(x), _ptr(co["kh"]), _ptr(co["kt"]), _ptr(co["ka"]),
                               _ptr(co["kc"]), _ptr(co["et"]), _ptr(co["ex"]), _ptr(co["e0"]), _ptr(out), n, s, c, slope,
-                              _stream()), "cn_dual_tail_gx")
+                              _dt(x), _stream()), "cn_dual_tail_gx")
     return out
 
 
 def act_fwd(x, act, slope=0.0):
     y = torch.empty_like(x)
-    check(lib.cn_act_fwd(_ptr(x), _ptr(y), x.numel(), act, slope, _stream()), "cn_act_fwd")
+    check(lib.cn_act_fwd(_ptr(x), _ptr(y), x.numel(), act, slope, _dt(x), _stream()), "cn_act_fwd")
     return y
 
 
 def act_bwd(gy, y, act, slope=0.0):
+    gy, y = _unify(gy, y)
     gx = torch.empty_like(gy)
-    check(lib.cn_act_bwd(_ptr(gy), _ptr(y), _ptr(gx), gy.numel(), act, slope, _stream()), "cn_act_bwd")
+    check(lib.cn_act_bwd(_ptr(gy), _ptr(y), _ptr(gx), gy.numel(), act, slope, _dt(gy), _stream()), "cn_act_bwd")
     return gx
 
 
 def axpby(x, y, a, b):
+    x, y = _unify(x, y)
     out = torch.empty_like(x)
-    check(lib.cn_axpby(_ptr(x), _ptr(y), _ptr(out), x.numel(), a, b, _stream()), "cn_axpby")
+    check(lib.cn_axpby(_ptr(x), _ptr(y), _ptr(out), x.numel(), a, b, _dt(x), _stream()), "cn_axpby")
     return out
 
 
 def mul(x, y):
+    x, y = _unify(x, y)
     out = torch.empty_like(x)
-    check(lib.cn_mul(_ptr(x), _ptr(y), _ptr(out), x.numel(), _stream()), "cn_mul")
+    check(lib.cn_mul(_ptr(x), _ptr(y), _ptr(out), x.numel(), _dt(x), _stream()), "cn_mul")
     return out
 
 
 def sqdiff_sum(a, b, scale):
+    a, b = _unify(a, b)
     out = torch.zeros((1,), device=a.device, dtype=torch.float32)
-    check(lib.cn_sqdiff_sum(_ptr(a), _ptr(b), _ptr(out), a.numel(), scale, _stream()), "cn_sqdiff_sum")
+    check(lib.cn_sqdiff_sum(_ptr(a), _ptr(b), _ptr(out), a.numel(), scale, _dt(a), _stream()), "cn_sqdiff_sum")
     return out
 
 
 def row_sumsq(x):
+    x = f32(x)
     n = x.shape[0]
     out = torch.empty((n,), device=x.device, dtype=torch.float32)
     check(lib.cn_row_sumsq(_ptr(x), _ptr(out), n, x.numel() // n, _stream()), "cn_row_sumsq")
@@ -392,11 +487,12 @@ def row_sumsq(x):
 
 def row_scale(x, s, k):
     out = torch.empty_like(x)
-    check(lib.cn_row_scale(_ptr(x), _ptr(s), _ptr(out), x.shape[0], x.numel() // x.shape[0], k, _stream()), "cn_row_scale")
+    check(lib.cn_row_scale(_ptr(x), _fptr(s), _ptr(out), x.shape[0], x.numel() // x.shape[0], k, _dt(x), _stream()), "cn_row_scale")
     return out
 
 
 def masked_diff(a, b, mask):
+    a, b = f32(a), f32(b)
     out = torch.empty_like(a)
     check(lib.cn_masked_diff(_ptr(a), _ptr(b), _ptr(mask), _ptr(out), mask.numel(), a.shape[-1], _stream()), "cn_masked_diff")
     return out
@@ -405,19 +501,21 @@ def masked_diff(a, b, mask):
 def maxpool_fwd(x, k, s, pad):
     n, h, w, c = x.shape
     oh, ow = (h + 2 * pad - k) // s + 1, (w + 2 * pad - k) // s + 1
-    y = torch.empty((n, oh, ow, c), device=x.device, dtype=torch.float32)
-    check(lib.cn_maxpool_fwd(_ptr(x), _ptr(y), n, h, w, c, k, s, pad, _stream()), "cn_maxpool_fwd")
+    y = torch.empty((n, oh, ow, c), device=x.device, dtype=x.dtype)
+    check(lib.cn_maxpool_fwd(_ptr(x), _ptr(y), n, h, w, c, k, s, pad, _dt(x), _stream()), "cn_maxpool_fwd")
     return y
 
 
 def maxpool_bwd(x, gy, k, s, pad):
     n, h, w, c = x.shape
+    x, gy = _unify(x, gy)
     gx = torch.empty_like(x)
-    check(lib.cn_maxpool_bwd(_ptr(x), _ptr(gy), _ptr(gx), n, h, w, c, k, s, pad, _stream()), "cn_maxpool_bwd")
+    check(lib.cn_maxpool_bwd(_ptr(x), _ptr(gy), _ptr(gx), n, h, w, c, k, s, pad, _dt(x), _stream()), "cn_maxpool_bwd")
     return gx
 
 
 def chan_affine3_fwd(x, perm, scale, off):
+    x = f32(x)
     y = torch.empty_like(x)
     check(lib.cn_chan_affine3_fwd(_ptr(x), _ptr(y), x.numel() // 3, (ctypes.c_int * 3)(*perm), scale,
                                   (ctypes.c_float * 3)(*off), _stream()), "cn_chan_affine3_fwd")
@@ -425,6 +523,7 @@ def chan_affine3_fwd(x, perm, scale, off):
 
 
 def chan_affine3_bwd(gy, perm, scale):
+    gy = f32(gy)
     gx = torch.empty_like(gy)
     check(lib.cn_chan_affine3_bwd(_ptr(gy), _ptr(gx), gy.numel() // 3, (ctypes.c_int * 3)(*perm), scale, _stream()),
           "cn_chan_affine3_bwd")
@@ -444,19 +543,23 @@ def gan_loss_bwd(s, gout, label):
 
 
 def rotate3d_fwd(grid, rot):
+    keep = grid.dtype
+    grid = f32(grid)                           # fp32 kernel; a bf16 grid is converted on the way in and out
     out = torch.empty_like(grid)
     n, g, c = grid.shape[0], grid.shape[1], grid.shape[-1]
-    check(lib.cn_rotate3d_fwd(_ptr(grid), _ptr(rot), _ptr(out), n, g, c, _stream()), "cn_rotate3d_fwd")
-    return out
+    check(lib.cn_rotate3d_fwd(_ptr(grid), _fptr(rot), _ptr(out), n, g, c, _stream()), "cn_rotate3d_fwd")
+    return cast(out, keep)
 
 
 def rotate3d_bwd(grid, rot, gout, need_rot):
     n, g, c = grid.shape[0], grid.shape[1], grid.shape[-1]
+    keep = grid.dtype
+    grid, gout = f32(grid), f32(gout)
     ggrid = torch.empty_like(grid)
     grot = torch.empty((n, 3, 3), device=grid.device, dtype=torch.float32) if need_rot else None
-    check(lib.cn_rotate3d_bwd(_ptr(grid), _ptr(rot), _ptr(gout), _ptr(ggrid), _ptr(grot), n, g, c, _stream()),
+    check(lib.cn_rotate3d_bwd(_ptr(grid), _fptr(rot), _ptr(gout), _ptr(ggrid), _ptr(grot), n, g, c, _stream()),
           "cn_rotate3d_bwd")
-    return ggrid, grot
+    return cast(ggrid, keep), grot
 
 
 def adam_step(theta, grad, m, v, ema, lr_t, beta1, beta2, eps, ema_alpha=0.999):
@@ -479,6 +582,7 @@ def gather_images_u8(pool, idx, flip):
 
 
 def to_uint8(x):
+    x = f32(x)
     out = torch.empty(x.shape, device=x.device, dtype=torch.uint8)
     check(lib.cn_to_uint8(_ptr(x), _ptr(out), x.numel(), _stream()), "cn_to_uint8")
     return out

@@ -3,8 +3,12 @@
  * The reference (microsoft/ConfigNet) has no FFI boundary: its per-layer arithmetic is
  * reached through tensorflow.keras calls (tensorflow-gpu==2.1.0).  Each entry point below
  * replaces the TF op(s) issued by the cited reference line(s); paths are relative to the
- * reference root.  All pointers are DEVICE pointers owned by the caller, fp32, channels-last
+ * reference root.  All pointers are DEVICE pointers owned by the caller, channels-last
  * (N, [D,] H, W, C); kernels use the Keras layouts (kd,kh,kw,cin,cout) / Dense (in,out).
+ * Storage types: `float*` arguments are fp32.  ACTIVATION tensors that may be stored in bf16 are passed as
+ * `void*` together with a dtype code `dt` (CN_F32 / CN_BF16) that applies to every `void*` tensor of that
+ * call; statistics, (n,c) coefficients, loss sums, biases, master weights, weight gradients and optimizer
+ * state are fp32 in either mode, and all arithmetic accumulates in fp32.
  * Every call enqueues on `stream` (a hipStream_t passed as void*) and returns 0 on success
  * or a negative CN_E* code; cn_last_error_string() describes the last failure of the
  * calling thread.  No exceptions cross the ABI.  No global state except a profiling event
@@ -22,7 +26,11 @@ extern "C" {
 #define CN_OK 0
 #define CN_EINVAL (-1)   /* bad argument / unsupported geometry */
 #define CN_EHIP (-2)     /* HIP runtime error */
-#define CN_EUNSUPPORTED (-3) /* experimental entry points only: geometry outside the envelope, nothing launched */
+#define CN_EUNSUPPORTED (-3) /* geometry outside the envelope of a specialised entry point: nothing was launched */
+
+/* storage type of activation tensors (the `dt` arguments) */
+#define CN_F32 0
+#define CN_BF16 1        /* bfloat16 bits, round-to-nearest-even on store */
 
 /* activation codes for fused epilogues */
 #define CN_ACT_NONE 0
@@ -66,7 +74,23 @@ int cn_conv_dgrad(const CnConvGeom* g, const float* gy, const float* w_tflip, fl
  * or accumulated into when `accumulate` != 0 (the caller guarantees its previous content, e.g. zeros). */
 int cn_conv_wgrad(const CnConvGeom* g, const float* x, const float* gy, float* gw, int accumulate, void* stream);
 /* Backward of the folded nearest x2 upsample: out[n,p,c] = sum of the 2^nd children of p. */
-int cn_sumpool2(const float* gu, float* gx, int nd, int n, int d, int h, int w, int c, void* stream);
+int cn_sumpool2(const void* gu, void* gx, int nd, int n, int d, int h, int w, int c, int dt, void* stream);
+
+/* ---- bf16 convolution family (implicit GEMM on v_mfma_f32_32x32x16_bf16, fp32 accumulate) -- the compute path of
+ * BASELINE.json configs[2] (bf16 compute, fp32 master weights).  Same geometry and reference lines as the fp32 family.
+ * Activations x / y / gy / gu are bf16; bias and the filter gradient are fp32.  Filters are bf16 copies prepared once per
+ * weight update by cn_conv_weight_prep_bf16 from the fp32 master filter w[t][ci][co]:
+ *     wf[t][co][ci]  (forward operand: reduction index ci contiguous)
+ *     wd[t][ci][co]  (data-gradient operand: reduction index co contiguous; the tap flip is index arithmetic)
+ * Requirements: cin % 8 == 0 and cout % 8 == 0 (16-byte operand pieces); other shapes return CN_EUNSUPPORTED without
+ * launching (the caller converts and uses the fp32 family: 3-channel image layers). */
+int cn_conv_weight_prep_bf16(const float* w, uint16_t* wf, uint16_t* wd, int taps, int cin, int cout, void* stream);
+int cn_conv_fwd_bf16(const CnConvGeom* g, const uint16_t* x, const uint16_t* wf, const float* bias, uint16_t* y,
+                     int act, float slope, void* stream);
+int cn_conv_dgrad_bf16(const CnConvGeom* g, const uint16_t* gy, const uint16_t* wd, uint16_t* gu, void* stream);
+int cn_conv_wgrad_bf16(const CnConvGeom* g, const uint16_t* x, const uint16_t* gy, float* gw, int accumulate, void* stream);
+/* dst = (dst_dt) src : storage-type conversion between fp32 and bf16 tensors */
+int cn_cast(const void* src, int src_dt, void* dst, int dst_dt, size_t numel, void* stream);
 
 /* ---- dense GEMM: C = act(op(A) op(B) + bias) (keras Dense: building_blocks.py:152-173,
  * hologan_discriminator.py:34,46,97 ; real_encoder.py:16,18 ; latent_gan.py:88-109) ---------*/
@@ -81,16 +105,16 @@ int cn_gemm(int trans_a, int trans_b, int m, int n, int k, const float* a, int l
  *   a = f1(x1), b = x2 ? f2(x2) : a ;  sum1[n,c] = sum_s a ; sum2[n,c] = sum_s a*b
  *   flags: bit0 leaky-relu(slope) on x1, bit1 leaky-relu(slope) on x2, bit4: the outputs are already zero
  *   (skip the clearing launch).  Outputs are overwritten. */
-int cn_nc_reduce(const float* x1, const float* x2, float* sum1, float* sum2, int n, int s, int c,
-                 int flags, float slope, void* stream);
+int cn_nc_reduce(const void* x1, const void* x2, float* sum1, float* sum2, int n, int s, int c,
+                 int flags, float slope, int dt, void* stream);
 /* y = A1*f1(x1) + A2*f2(x2) + B, coefficient tensors indexed [n*cstride + c] (cstride = c, or 0 for
  * per-channel coefficients).  flags: bit0/bit1 as above, bit2: multiply the result by lrelu'(x2),
  * bit3: relu on the result.  x1, x2 and B are each optional (NULL); a NULL coefficient of a present
  * x means 1.  If a3 != NULL, a3*x2 + b3 (raw x2) is added after the bit2 mask -- the style-statistics
  * gradient that joins the instance-norm gradient in DiscrBlock (building_blocks.py:100-106). */
-int cn_nc_lin2(const float* x1, const float* a1, const float* x2, const float* a2, const float* bb,
-               const float* a3, const float* b3, float* y, int n, int s, int c, int cstride, int flags,
-               float slope, void* stream);
+int cn_nc_lin2(const void* x1, const float* a1, const void* x2, const float* a2, const float* bb,
+               const float* a3, const float* b3, void* y, int n, int s, int c, int cstride, int flags,
+               float slope, int dt, void* stream);
 
 /* Per-(n,c) coefficient kernels of the normalisation layers (tiny: N*C threads).
  * mode 0 AdaIN (building_blocks.py:132-144): p1 = [s|b] (N,2C); mu = s1/S, var = s2/S - mu^2,
@@ -122,27 +146,28 @@ int cn_dual_tail_coef_bwd(const float* H1, const float* H2p, const float* E, con
                           const float* T2, const float* U1, const float* U2, const float* mean, const float* q,
                           const float* sm, const float* ssd, const float* gamma, float* const* out13, int n, int c,
                           int S, float eps, void* stream);
-int cn_dual_tail_gx(const float* h, const float* ta, const float* tx, const float* x, const float* kh,
+int cn_dual_tail_gx(const void* h, const void* ta, const void* tx, const void* x, const float* kh,
                     const float* kt, const float* ka, const float* kc, const float* et, const float* ex,
-                    const float* e0, float* out, int n, int s, int c, float slope, void* stream);
+                    const float* e0, void* out, int n, int s, int c, float slope, int dt, void* stream);
 
 /* ---- elementwise / small ops ------------------------------------------------------------------*/
-int cn_act_fwd(const float* x, float* y, size_t numel, int act, float slope, void* stream);
+int cn_act_fwd(const void* x, void* y, size_t numel, int act, float slope, int dt, void* stream);
 /* gx = gy * act'(.) evaluated from the activation OUTPUT (lrelu/relu: sign of y; tanh: 1-y^2). */
-int cn_act_bwd(const float* gy, const float* y, float* gx, size_t numel, int act, float slope, void* stream);
-int cn_axpby(const float* x, const float* y, float* out, size_t numel, float a, float b, void* stream);
-int cn_mul(const float* x, const float* y, float* out, size_t numel, void* stream);
+int cn_act_bwd(const void* gy, const void* y, void* gx, size_t numel, int act, float slope, int dt, void* stream);
+int cn_axpby(const void* x, const void* y, void* out, size_t numel, float a, float b, int dt, void* stream);
+int cn_mul(const void* x, const void* y, void* out, size_t numel, int dt, void* stream);
 /* out[0] += scale * sum (a-b)^2  (perceptual_loss.py:74-80); out must be initialised by the caller */
-int cn_sqdiff_sum(const float* a, const float* b, float* out, size_t numel, float scale, void* stream);
+int cn_sqdiff_sum(const void* a, const void* b, float* out, size_t numel, float scale, int dt, void* stream);
 /* out[n] = sum_row x^2 (R1: losses.py:77-79 ; eye loss: losses.py:16) */
 int cn_row_sumsq(const float* x, float* out, int n, size_t row, void* stream);
 /* out[n,:] = x[n,:] * s[n] * k */
-int cn_row_scale(const float* x, const float* s, float* out, int n, size_t row, float k, void* stream);
+int cn_row_scale(const void* x, const float* s, void* out, int n, size_t row, float k, int dt, void* stream);
 /* out = (a - b) * mask[n,h,w] broadcast over c (b optional) (losses.py:14) */
 int cn_masked_diff(const float* a, const float* b, const uint8_t* mask, float* out, size_t pixels, int c, void* stream);
-/* 2-D max pooling, zero padding (keras MaxPooling2D after ZeroPadding2D) */
-int cn_maxpool_fwd(const float* x, float* y, int n, int h, int w, int c, int k, int s, int pad, void* stream);
-int cn_maxpool_bwd(const float* x, const float* gy, float* gx, int n, int h, int w, int c, int k, int s, int pad, void* stream);
+/* 2-D max pooling, zero padding (keras MaxPooling2D after ZeroPadding2D); bwd: the gradient of a window goes to its
+ * first maximum in row-major window order (computed as a gather: no atomics) */
+int cn_maxpool_fwd(const void* x, void* y, int n, int h, int w, int c, int k, int s, int pad, int dt, void* stream);
+int cn_maxpool_bwd(const void* x, const void* gy, void* gx, int n, int h, int w, int c, int k, int s, int pad, int dt, void* stream);
 /* y[...,j] = scale * x[...,perm[j]] + off[j] on 3-channel images: (x+1)*127.5 + "caffe"/VGGFace
  * preprocessing (perceptual_loss.py:52-61 ; real_encoder.py:24-25); bwd scatters back. */
 int cn_chan_affine3_fwd(const float* x, float* y, size_t pixels, const int* perm, float scale, const float* off, void* stream);
@@ -179,17 +204,6 @@ int cn_prof_enable(int on);
 int cn_prof_reset(void);
 /* synchronises the recorded events; returns launches, summed kernel ms and algorithmic flops */
 int cn_prof_collect(int* launches, double* total_ms, double* total_flops);
-
-/* ---- EXPERIMENTAL, not part of the round-1 product path (reached only with CN_BF16X3=1):
- * convolution with every fp32 operand split into 2 (or 3) bf16 terms, x = t0 + t1 (+ t2), and the product expanded into 3
- * (or 6) bf16 MFMAs with fp32 accumulation: terms = 2 keeps 16 operand bits, terms = 3 all 24 (every dropped cross term is
- * <= 2^-24 of the product).  w [taps][cin][cout] -> ws [terms][taps][cout][cin]; fwd/dgrad return
- * CN_EUNSUPPORTED without launching when the geometry is outside the prototype's envelope ------------------------*/
-int cn_conv_weight_split_bf16(const float* w, uint16_t* ws /* [terms][taps][cout][cin] */, int terms /* 2 or 3 */,
-                              int taps, int cin, int cout, void* stream);
-int cn_conv_fwd_bf16x3(const CnConvGeom* g, const float* x, const uint16_t* ws, int terms, const float* bias,
-                       float* y, int act, float slope, void* stream);
-int cn_conv_dgrad_bf16x3(const CnConvGeom* g, const float* gy, const uint16_t* wts, int terms, float* gu, void* stream);
 
 /* ---- stream calibration: one wave busy-waits `ticks` of the 100 MHz wall clock on `stream`.  Two such launches on
  * streams that share a hardware queue run back to back, on independent queues side by side: graphs.py uses that to

@@ -17,8 +17,7 @@ wt = torch.randn(k, k, cin, cout, device="cuda")
 b = torch.randn(cout, device="cuda")
 g = spec.geom(tuple(x.shape), cout)
 gy = torch.randn(n, g.out_h, g.out_w, cout, device="cuda")
-wf = ops.weight_tflip(wt)
-fn = {"fwd": lambda: ops.conv_fwd(x, wt, b, g, 1, 0.2), "dgrad": lambda: ops.conv_dgrad(gy, wf, g),
+fn = {"fwd": lambda: ops.conv_fwd(x, wt, b, g, 1, 0.2), "dgrad": lambda: ops.conv_dgrad(gy, wt, g),
       "wgrad": lambda: ops.conv_wgrad(x, gy, g, tuple(wt.shape))}[kind]
 for _ in range(3):
     fn()

@@ -93,8 +93,7 @@ for kk, cnt in calls.items():
     if kind == "fwd":
         fn = lambda: ops.conv_fwd(xin, w, bias, g, 1, 0.3)
     elif kind == "dgrad":
-        wt = ops.weight_tflip(w)
-        fn = lambda: ops.conv_dgrad(yout, wt, g)
+        fn = lambda: ops.conv_dgrad(yout, w, g)
     else:
         fn = lambda: ops.conv_wgrad(xin, yout, g, wshape)
     for _ in range(2):

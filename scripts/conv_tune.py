@@ -20,8 +20,8 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
         x = torch.randn(n, h, w, cin, device="cuda"); wt = torch.randn(k, k, cin, cout, device="cuda"); b = torch.randn(cout, device="cuda")
         g = spec.geom(tuple(x.shape), cout)
         if KIND == "dgrad":
-            gy = torch.randn(n, g.out_h, g.out_w, cout, device="cuda"); wf = ops.weight_tflip(wt)
-            fn = lambda: ops.conv_dgrad(gy, wf, g)
+            gy = torch.randn(n, g.out_h, g.out_w, cout, device="cuda")
+            fn = lambda: ops.conv_dgrad(gy, wt, g)
         else:
             fn = lambda: ops.conv_fwd(x, wt, b, g, 2, 0.0)
         for _ in range(3): fn()

@@ -89,7 +89,7 @@ def test_conv_fwd_dgrad_wgrad(case):
     yr0 = _oracle_conv(xu, wr, None, stride, 0, epad, 0, 0.0)
     gy = rng.normal(size=tuple(yr0.shape))
     (yr0 * t64(gy)).sum().backward()
-    gu = ops.conv_dgrad(dev(gy), ops.weight_tflip(dev(w)), g)
+    gu = ops.conv_dgrad(dev(gy), dev(w), g)
     close(gu, xu.grad, what="dgrad")
     if up:
         close(ops.sumpool2(gu), xr.grad, what="sumpool2(dgrad)")
@@ -131,7 +131,7 @@ def test_conv_adjoint_identities_full_size(case):
     gy = rnd(*y.shape)
     dot = lambda a, b: float((a.double() * b.double()).sum())
     lhs = dot(y, gy)
-    gu = ops.conv_dgrad(gy, ops.weight_tflip(w), g)                    # gradient at the (upsampled) input extent
+    gu = ops.conv_dgrad(gy, w, g)                    # gradient at the (upsampled) input extent
     gx = ops.sumpool2(gu) if up else gu
     gw = ops.conv_wgrad(x, gy, g, tuple(w.shape))
     scale = math.sqrt(dot(y, y) * dot(gy, gy))                         # Cauchy-Schwarz bound of the inner product
