@@ -27,6 +27,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+BF16_MFMA_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16 dense peak (~2.5 PF; the 5 PF figure is 2:1 sparsity)
 
 
 def main():
@@ -42,8 +43,9 @@ def main():
     ap.add_argument("--serial", action="store_true",
                     help="one stream, eager dispatch: no kernel overlaps another (the form to trace for per-kernel durations)")
     ap.add_argument("--cpu-batch", type=int, default=16)
-    ap.add_argument("--bf16x3", action="store_true",
-                    help="EXPERIMENTAL, not the headline: error-compensated bf16 MFMA convolutions (DESIGN.md section 9 item 8)")
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+                    help="f32: the reference's arithmetic (BASELINE.json configs[1], the headline).  bf16: configs[2]'s compute type "
+                         "(bf16 activations / filter copies on bf16 MFMA, fp32 accumulate, fp32 master weights) -- a separate line")
     args = ap.parse_args()
 
     import torch
@@ -52,8 +54,7 @@ def main():
     from confignet_amd.confignet_first_stage import DEFAULT_CONFIG
     from confignet_amd.confignet_utils import merge_configs
 
-    if args.bf16x3:
-        ops.BF16X3 = True
+    ops.set_activation_dtype(args.dtype)
     world = parallel.init_from_env()
     rank = parallel.rank()
     if world > 1:                                     # N processes share the host: keep each rank's CPU thread pool small
@@ -155,24 +156,28 @@ def main():
         ms_per_step = 1e3 * elapsed / args.steps
         value = args.batch * world / (elapsed / args.steps)
         achieved = kernel_flops / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
+        peak = FP32_MFMA_PEAK_TFLOPS if args.dtype == "f32" else BF16_MFMA_PEAK_TFLOPS
         out = {
             "metric": "train-step images/sec at 256x256 (G+D fwd+bwd)",
             "value": round(value, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if not args.bf16x3 else "f32 emulated: bf16x3-split MFMA, fp32 accumulate (EXPERIMENTAL, not the headline)",
+            "dtype": args.dtype,
             "data": "synthetic",
             "config": {"workload": "ConfigNet second-stage iteration (D + synth-D + latent-D + G + EMA), %dx%d, "
-                                   "batch %d per GPU, fp32, Keras-Adam" % (args.res, args.res, args.batch),
+                                   "batch %d per GPU, %s, Keras-Adam" % (args.res, args.res, args.batch,
+                                                                          "fp32" if args.dtype == "f32" else "bf16 compute / fp32 master weights"),
                        "global_batch": args.batch * world, "resolution": args.res, "latent_dim": cfg_latent(model),
                        "parallelism": "dp%d" % world, "losses_finite": bool(finite),
                        "dispatch": ("eager, one stream" if args.serial else "eager" if args.no_graphs else
                                     "hip-graph replay per step function, D-type steps concurrent, G step forked over 2 streams" +
                                     ("" if not parallel.active() else " (fwd+bwd), eager RCCL all-reduce + Adam"))},
             "step_functions_ms": step_ms,
-            "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": pmc_traffic(),
-                         "mfma_busy_pmc": pmc_mfma_busy(),
-                         "kernel": "igemm_fwd/igemm_wgrad (implicit-GEMM conv, v_mfma_f32_32x32x2_f32)",
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
+                         "frac": round(achieved / peak, 4), "traffic": pmc_traffic() if args.dtype == "f32" else None,
+                         "mfma_busy_pmc": pmc_mfma_busy() if args.dtype == "f32" else None,
+                         "kernel": ("igemm_fwd/igemm_wgrad (implicit-GEMM conv, v_mfma_f32_32x32x2_f32)" if args.dtype == "f32" else
+                                    "igemm_bf16/igemm_bf16_wgrad (implicit-GEMM conv, v_mfma_f32_32x32x16_bf16) + the fp32 kernels of the "
+                                    "3-channel image layers"),
                          "launches_per_step": launches / max(args.steps, 1),
                          "kernel_ms_per_step": round(kernel_ms / max(args.steps, 1), 3),
                          "measured": "HIP events around every launch of the class, same K iterations run serially (eager, one stream)",

@@ -89,7 +89,7 @@ def test_fine_tune_on_img_matches_oracle_golden(graphs):
     # three Adam steps of ~1e-4 each: a wrong lr_t / moment / stale tile shifts EVERY entry at the 1e-4 level; a single entry whose
     # gradient changes sign near zero in a later step may take that one step the other way (<= 2e-4)
     err = np.abs(emb - GOLD_FT["emb"]).ravel()
-    assert np.quantile(err, 0.9) < 2e-5 and err.max() < 2.5e-4, (np.quantile(err, 0.9), err.max())
+    assert np.quantile(err, 0.9) < 4e-5 and err.max() < 2.5e-4, (np.quantile(err, 0.9), err.max())
     assert np.abs(rot - GOLD_FT["rot"]).max() < 1e-4, (rot, GOLD_FT["rot"])
     # the fine-tuned generator copy moved like the oracle's (per-tensor update norms; sign flips of noise-level
     # gradients move single entries by 2 lr)
@@ -141,7 +141,7 @@ def test_fine_tune_force_neutral_expression_keeps_the_expression_slice_fixed():
     emb, rot = m.fine_tune_on_img(imgs, n_iters=2, force_neutral_expression=True)
     assert np.abs(emb[:, lo:hi] - neutral.numpy()).max() < 1e-5           # untouched by the optimizer
     err = np.abs(emb - emb_r.numpy()).ravel()
-    assert np.quantile(err, 0.9) < 2e-5 and err.max() < 2.5e-4 and np.abs(rot - rot_r.numpy()).max() < 1e-4
+    assert np.quantile(err, 0.9) < 4e-5 and err.max() < 2.5e-4 and np.abs(rot - rot_r.numpy()).max() < 1e-4
     _check_loss_trajectory(m.fine_tune_loss_log, hist)
 
 
