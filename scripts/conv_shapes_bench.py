@@ -42,6 +42,8 @@ def conv_wgrad(x, gy, g, ws):
 
 ops.conv_fwd, ops.conv_dgrad, ops.conv_wgrad = conv_fwd, conv_dgrad, conv_wgrad
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+DTYPE = sys.argv[2] if len(sys.argv) > 2 else "f32"          # "bf16": activation tensors with more than 4 channels in bf16
+ops.set_activation_dtype(DTYPE)
 np.random.seed(0)
 ds = SyntheticFaceDataset(64, 256, seed=1)
 cfg = merge_configs(DEFAULT_CONFIG, {"batch_size": B, "output_shape": (256, 256, 3)})
@@ -87,6 +89,10 @@ for kk, cnt in calls.items():
     T = g.k_d * g.k_h * g.k_w
     xin = torch.randn((g.n, g.in_d, g.in_h, g.in_w, g.cin) if g.nd == 3 else (g.n, g.in_h, g.in_w, g.cin), device="cuda")
     yout = torch.randn((g.n, g.out_d, g.out_h, g.out_w, g.cout) if g.nd == 3 else (g.n, g.out_h, g.out_w, g.cout), device="cuda")
+    if g.cin > 4:
+        xin = xin.to(ops.ACT_DTYPE)
+    if g.cout > 4:
+        yout = yout.to(ops.ACT_DTYPE)
     wshape = ((g.k_d, g.k_h, g.k_w) if g.nd == 3 else (g.k_h, g.k_w)) + (g.cin, g.cout)
     w = torch.randn(wshape, device="cuda")
     bias = torch.randn(g.cout, device="cuda")
