@@ -78,6 +78,8 @@ SIGNATURES = {
     "cn_conv_dgrad_bf16": [_G, _p, _p, _p, _p],
     "cn_conv_wgrad_bf16": [_G, _p, _p, _p, _i, _p],
     "cn_cast": [_p, _i, _p, _i, _z, _p],
+    "cn_upfold_weights": [_p, _p, _p, _i, ctypes.POINTER(_i), ctypes.POINTER(_i), _i, _i, ctypes.POINTER(_i), ctypes.POINTER(_i), _p],
+    "cn_upfold_wgrad": [_p, _p, _i, ctypes.POINTER(_i), ctypes.POINTER(_i), _i, _i, _i, _p],
     "cn_prof_enable": [_i],
     "cn_prof_reset": [],
     "cn_prof_collect": [ctypes.POINTER(_i), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)],

@@ -45,7 +45,12 @@ class ConvFn(Function):
     def forward(ctx, x, w, bias, spec, act, slope):
         x, w = _cg(x), _cg(w)
         g = spec.geom(tuple(x.shape), w.shape[-1])
-        y = ops.conv_fwd(x, w, bias, g, act, slope)
+        if ops.upfold_ok(g):
+            # UpSampling + Conv collapsed per output-parity class: 8/27 (3-D k3) or 6.25/16 (2-D k4) of the multiply-adds
+            wf, _, gd, _ = ops.upfold_prepare(w, g)
+            y = ops.conv_fwd(x, wf, bias, gd, act, slope)
+        else:
+            y = ops.conv_fwd(x, w, bias, g, act, slope)
         ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
         ctx.g, ctx.act, ctx.slope, ctx.has_bias = g, act, slope, bias is not None
         return y
@@ -60,6 +65,18 @@ class ConvFn(Function):
                                    "use conv(..., act=ACT_NONE) + lrelu()")
             gy = ops.act_bwd(gy, y, ctx.act, ctx.slope)
         gx = gw = gb = None
+        if ops.upfold_ok(ctx.g) and not torch.is_grad_enabled():
+            # first-order backward of the collapsed form: data gradient straight at the stored extent (no upsampled gradient,
+            # no sum-pool pass), filter gradient of the class filters scattered back to the k taps
+            _, wd, _, g2 = ops.upfold_prepare(w, ctx.g)
+            if ctx.needs_input_grad[0]:
+                gx = ops.conv_fwd(gy, wd, None, g2)
+            if not _INPUT_GRADS_ONLY:
+                if ctx.needs_input_grad[1]:
+                    gw = ops.upfold_wgrad(ops.conv_wgrad(gy, x, g2, tuple(wd.shape)), ctx.g, tuple(w.shape))
+                if ctx.has_bias and ctx.needs_input_grad[2]:
+                    gb = ops.nc_reduce(gy.detach(), None, want_dot=False, per_channel=True)[0].reshape(-1)
+            return gx, gw, gb, None, None, None
         if ctx.needs_input_grad[0]:
             gx = ConvDgradFn.apply(gy, w, ctx.g)
         if not _INPUT_GRADS_ONLY:

@@ -178,7 +178,65 @@ def weight_prep_bf16(w):
 
 
 def _bf16_conv_ok(g):
-    return ACT_DTYPE == torch.bfloat16 and g.cin % 8 == 0 and g.cout % 8 == 0 and g.dl_d * g.dl_h * g.dl_w == 1
+    return ACT_DTYPE == torch.bfloat16 and g.cin % 8 == 0 and g.cout % 8 == 0
+
+
+# ---------------------------------------------------------------------------------------------
+# x2-upsample-folded convolutions collapsed per output-parity class (include/confignet_hip.h: cn_upfold_*)
+# ---------------------------------------------------------------------------------------------
+UPFOLD = os.environ.get("CN_NO_UPFOLD") is None
+
+
+def upfold_ok(g):
+    """Generator layers UpSampling + Conv(k3 / k4, SAME, stride 1) with wide channels (map_final keeps its own kernel)."""
+    return (UPFOLD and g.up == 1 and g.cin > 4 and g.cout > 4 and g.s_d * g.s_h * g.s_w == 1 and g.dl_d * g.dl_h * g.dl_w == 1
+            and all(2 <= k <= 4 for k in ((g.k_d, g.k_h, g.k_w) if g.nd == 3 else (g.k_h, g.k_w)))
+            and g.out_h == 2 * g.in_h and g.out_w == 2 * g.in_w and (g.nd == 2 or g.out_d == 2 * g.in_d))
+
+
+def _copy_geom(g, **kw):
+    out = CnConvGeom()
+    for name, _ in CnConvGeom._fields_:
+        setattr(out, name, getattr(g, name))
+    for k, v in kw.items():
+        setattr(out, k, v)
+    return out
+
+
+def upfold_prepare(w, g):
+    """(wf, wd, gd, g2): class filters (fp32, cached on the filter per weight epoch) and the two geometries they are used
+    with (rebuilt per call: batch and extents belong to the call, not to the filter)."""
+    def make(wd_):
+        k3 = (ctypes.c_int * 3)(g.k_d, g.k_h, g.k_w)
+        p3 = (ctypes.c_int * 3)(g.p_d, g.p_h, g.p_w)
+        k2, p2 = (ctypes.c_int * 3)(), (ctypes.c_int * 3)()
+        wd_ = _c(wd_)
+        ks = [g.k_d, g.k_h, g.k_w]
+        sizes = [1 if (g.nd == 2 and i == 0) else (ks[i] + 1 if ks[i] >= 3 else 3) for i in range(3)]   # k2 per axis
+        t2 = sizes[0] * sizes[1] * sizes[2]
+        both = torch.empty((2, t2 * g.cin * g.cout), device=wd_.device, dtype=torch.float32)
+        check(lib.cn_upfold_weights(_fptr(wd_), _ptr(both[0]), _ptr(both[1]), g.nd, k3, p3, g.cin, g.cout, k2, p2, _stream()),
+              "cn_upfold_weights")
+        assert list(k2) == sizes, (list(k2), sizes)
+        return both[0], both[1], tuple(k2), tuple(p2)
+    wf, wd, (kd, kh, kw), (pd, ph, pw) = _weight_cache(w, "_cn_upfold_%d_%d%d%d_%d%d%d" % (g.nd, g.k_d, g.k_h, g.k_w, g.p_d, g.p_h, g.p_w), make)
+    # forward: zero-stuffed (dl = 2) convolution on the stored grid, parity-ordered rows, dead taps skipped
+    gd = _copy_geom(g, k_d=kd, k_h=kh, k_w=kw, dl_d=(2 if g.nd == 3 else 1), dl_h=2, dl_w=2,
+                    p_d=kd - 1 - pd, p_h=kh - 1 - ph, p_w=kw - 1 - pw, up=0)
+    # conv2: from the output grid (cout channels) to the stored grid (cin channels), stride 2
+    g2 = _copy_geom(g, in_d=g.out_d, in_h=g.out_h, in_w=g.out_w, cin=g.cout, out_d=g.in_d, out_h=g.in_h, out_w=g.in_w,
+                    cout=g.cin, k_d=kd, k_h=kh, k_w=kw, s_d=(2 if g.nd == 3 else 1), s_h=2, s_w=2, p_d=pd, p_h=ph, p_w=pw, up=0)
+    taps = (kd, kh, kw) if g.nd == 3 else (kh, kw)
+    return wf.view(taps + (g.cin, g.cout)), wd.view(taps + (g.cout, g.cin)), gd, g2
+
+
+def upfold_wgrad(gw2, g, w_shape):
+    """gw[kk][ci][co] from the conv2 filter gradient gw2[a][co][ci]."""
+    gw = torch.empty(w_shape, device=gw2.device, dtype=torch.float32)
+    k3 = (ctypes.c_int * 3)(g.k_d, g.k_h, g.k_w)
+    p3 = (ctypes.c_int * 3)(g.p_d, g.p_h, g.p_w)
+    check(lib.cn_upfold_wgrad(_fptr(_c(gw2)), _ptr(gw), g.nd, k3, p3, g.cin, g.cout, 0, _stream()), "cn_upfold_wgrad")
+    return gw
 
 
 def conv_fwd(x, w, bias, g, act=ACT_NONE, slope=0.0):

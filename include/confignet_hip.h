@@ -89,6 +89,19 @@ int cn_conv_fwd_bf16(const CnConvGeom* g, const uint16_t* x, const uint16_t* wf,
                      int act, float slope, void* stream);
 int cn_conv_dgrad_bf16(const CnConvGeom* g, const uint16_t* gy, const uint16_t* wd, uint16_t* gu, void* stream);
 int cn_conv_wgrad_bf16(const CnConvGeom* g, const uint16_t* x, const uint16_t* gy, float* gw, int accumulate, void* stream);
+/* ---- convolution after a x2 nearest upsample, collapsed per output-parity class (exact; hologan_generator.py:139-170 +
+ * building_blocks.py:29,65).  Along one axis output o = 2 s + tau reads stored row s through Wc(tau) = the sum of the taps kk
+ * with floor((o - pad_lo + kk) / 2) = s: k2 = 4 (k = 3) or 5 (k = 4) values of tau, 2-3 of them live per output parity.  With
+ * "conv2" = the stride-2 convolution (kernel k2, low padding pad2) from the output grid to the stored grid:
+ *   forward       = cn_conv_fwd of the geometry {in = stored, out = 2 in, k = k2, s = 1, dl = 2, p = k2-1-pad2, up = 0} with wf,
+ *   data gradient = cn_conv_fwd of conv2 {in = 2 in (cout channels), out = in (cin channels), k = k2, s = 2, p = pad2} with wd,
+ *   filter grad.  = cn_conv_wgrad of conv2 (x := gy, gy := x) -> gw2[a][co][ci], then cn_upfold_wgrad -> gw[kk][ci][co].
+ * cn_upfold_weights: w[kk][ci][co] (k3 = {k_d,k_h,k_w}, k_d = 1 for nd = 2; pad_lo3 = SAME low paddings) ->
+ *   wf[a'][ci][co] and/or wd[a][co][ci]; returns k2 and pad2 per axis in k2_out3 / pad2_out3 (host arrays, may be NULL). */
+int cn_upfold_weights(const float* w, float* wf, float* wd, int nd, const int* k3, const int* pad_lo3, int cin, int cout,
+                      int* k2_out3, int* pad2_out3, void* stream);
+int cn_upfold_wgrad(const float* gw2, float* gw, int nd, const int* k3, const int* pad_lo3, int cin, int cout,
+                    int accumulate, void* stream);
 /* dst = (dst_dt) src : storage-type conversion between fp32 and bf16 tensors */
 int cn_cast(const void* src, int src_dt, void* dst, int dst_dt, size_t numel, void* stream);
 

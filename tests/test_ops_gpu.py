@@ -360,3 +360,59 @@ def test_adam_ema():
         ops.adam_step(dth, dev(gt), m, v, ema, dev([lr_t]), 0.0, 0.9, 1e-7, 0.999)
     close(dth, p, tol=1e-6)
     close(ema, ema_ref, tol=1e-6)
+
+
+UPFOLD_CASES = [
+    # (x shape, kernel, cout): UpSampling + Conv(SAME) layers of the generator (hologan_generator.py:139-170)
+    ((2, 4, 4, 4, 512), (3, 3, 3), 256),     # map_3d_0
+    ((1, 8, 8, 8, 256), (3, 3, 3), 128),     # map_3d_1
+    ((2, 16, 16, 256), (4, 4), 64),          # map_2d_1
+    ((2, 32, 32, 64), (4, 4), 32),           # map_2d_2
+    ((1, 5, 7, 16), (4, 4), 8),              # odd extents
+    ((1, 3, 5, 4, 8), (3, 3, 3), 8),         # odd extents, 3-D
+    ((2, 6, 6, 16), (3, 3), 16),             # k3 in 2-D
+]
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("case", UPFOLD_CASES, ids=[str(i) for i in range(len(UPFOLD_CASES))])
+def test_upsample_folded_conv_collapsed_per_parity_class(case, dtype):
+    """F.conv with a folded x2 upsample runs as per-parity-class filters (cn_upfold_*): forward (+ bias + LeakyReLU), data
+    gradient at the stored extent and filter gradient against the float64 oracle of UpSampling -> Conv(SAME).
+    fp32: 2e-4 like every other convolution.  bf16: the oracle on the bf16-rounded x; the class filters are sums of up to 8 taps
+    rounded to bf16 AFTER summing, so |err| <= 2^-8 (|y| + sum |terms|) -- asserted as 1.5e-2 of the output scale."""
+    from confignet_amd import functional as F
+    from confignet_amd import ops
+    xs, k, cout = case
+    rng = np.random.default_rng(abs(hash(case)) % 2 ** 31)
+    cin = xs[-1]
+    x = rng.normal(size=xs)
+    w = rng.normal(size=(*k, cin, cout)) / math.sqrt(np.prod(k) * cin)
+    b = rng.normal(size=cout)
+    ops.set_activation_dtype(dtype)
+    try:
+        spec = ops.ConvSpec(k, up=1)
+        assert ops.upfold_ok(spec.geom(xs, cout))
+        xt = dev(x)
+        if dtype == "bf16":
+            xt = xt.to(torch.bfloat16)
+        xt.requires_grad_(True)
+        wt, bt = dev(w).requires_grad_(True), dev(b).requires_grad_(True)
+        xr = (xt.detach().double().cpu()).requires_grad_(True)
+        wr, br = t64(w).requires_grad_(True), t64(b).requires_grad_(True)
+        tol = 2e-4 if dtype == "f32" else 1.5e-2
+        # forward with the fused bias + LeakyReLU epilogue
+        close(F.conv(xt, wt, bt, spec, 1, 0.3).float(), O.leaky_relu(O.conv_same(O.upsample2(xr), wr, br), 0.3), tol=tol, what="upfold fwd")
+        # gradients of the linear layer (no activation in between: a LeakyReLU whose input is within rounding of zero takes
+        # the other branch than in the oracle, which is a property of the comparison, not of the kernels)
+        y = F.conv(xt, wt, bt, spec)
+        yr = O.conv_same(O.upsample2(xr), wr, br)
+        cot = rng.normal(size=tuple(yr.shape))
+        cot_t = dev(cot).to(y.dtype)
+        gx, gw, gb = torch.autograd.grad((y * cot_t).float().sum(), [xt, wt, bt])
+        gxr, gwr, gbr = torch.autograd.grad((yr * cot_t.double().cpu()).sum(), [xr, wr, br])
+        close(gx.float(), gxr, tol=tol, what="upfold dgrad")
+        close(gw, gwr, tol=5e-4 if dtype == "f32" else 1.5e-2, what="upfold wgrad")
+        close(gb, gbr, tol=5e-4 if dtype == "f32" else 1.5e-2, what="upfold bias grad")
+    finally:
+        ops.set_activation_dtype("f32")
