@@ -88,22 +88,16 @@ def main():
         args.no_graphs = True
         model.fork_generator_step = False
     model.use_graphs = not args.no_graphs
-    try:
-        # graph mode needs three untimed iterations whatever W says: eager call, capture, first replay (which still
-        # pays the graph's one-off upload); the JSON reports the number actually run
-        args.warmup = max(args.warmup, 3 if model.use_graphs else 0)
-        for _ in range(args.warmup):
-            model.training_iteration(real_set, synth_set, d_opt, g_opt)
-        sync()
-    except RuntimeError as e:                          # deterministic on every rank: all fall back together
-        if not (model.use_graphs and parallel.active()):
-            raise
-        print("[bench] graph capture next to the process group failed (%s); eager dispatch" % str(e).splitlines()[0],
-              file=sys.stderr, flush=True)
-        args.no_graphs, model.use_graphs, model._graphs = True, False, {}
-        for _ in range(max(args.warmup, 1)):
-            model.training_iteration(real_set, synth_set, d_opt, g_opt)
-        sync()
+    # graph mode needs three untimed iterations whatever W says: eager call, capture, first replay (which still pays the
+    # graph's one-off upload); the JSON reports the number actually run.  A capture that fails next to the process group is
+    # FATAL (no silent eager fallback: an eager multi-GPU number would not be the configuration this benchmark names);
+    # --no-graphs asks for eager dispatch explicitly and says so in config.dispatch.
+    args.warmup = max(args.warmup, 3 if model.use_graphs else 0)
+    for _ in range(args.warmup):
+        model.training_iteration(real_set, synth_set, d_opt, g_opt)
+    sync()
+    if model.use_graphs:
+        assert len(model._graphs) == 4 and all(g.graph is not None for g in model._graphs.values()), "step graphs were not captured"
     t0 = time.perf_counter()
     for _ in range(args.steps):
         losses = model.training_iteration(real_set, synth_set, d_opt, g_opt)

@@ -407,7 +407,7 @@ class ConfigNetFirstStage:
             for g in pending:
                 g.stream.wait_stream(cur)
                 with torch.cuda.stream(g.stream):
-                    g.graph.replay()
+                    g.replay()
                     g.finish()
             for g in pending:
                 cur.wait_stream(g.stream)
@@ -515,8 +515,22 @@ class ConfigNetFirstStage:
         losses["loss_sum"] = sum(losses.values())
         return losses
 
-    def _generator_update(self, losses, nets, optimizer):
-        backward_into_arenas(losses["loss_sum"], nets)
+    def _generator_update(self, losses, nets, optimizer, cut=None):
+        """tape.gradient + apply_gradients of the generator step.  Data parallel with `cut` = (tensors, late_nets): the
+        networks in late_nets (the real encoder) are reached only through `tensors` (its outputs), so the backward pass
+        is taken in two parts -- everything down to `tensors` first, whose gradient arenas (generator, latent regressor,
+        synthetic encoder: 62 MB) then start their RCCL all-reduce while the second part (the ResNet-50 backward, the last
+        and longest stretch of the tape) is still computing; only the encoder's arena is exchanged after it."""
+        if cut is None or not parallel.active():
+            backward_into_arenas(losses["loss_sum"], nets)
+        else:
+            from .graphs import segment_break
+            tensors, late = cut
+            early = [n for n in nets if all(n is not m for m in late)]
+            cut_grads = backward_into_arenas(losses["loss_sum"], early, extra=tensors)
+            segment_break(lambda: parallel.begin_allreduce(early))
+            live = [(t, g) for t, g in zip(tensors, cut_grads) if g is not None]
+            backward_into_arenas([t for t, _ in live], late, grad_outputs=[g for _, g in live])
         optimizer.apply_gradients(nets, advance=False, slot="g")
 
     def generator_training_step(self, real_training_set, synth_training_set, optimizer):

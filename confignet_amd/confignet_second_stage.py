@@ -116,6 +116,7 @@ class ConfigNet(ConfigNetFirstStage):
             side.wait_stream(main)
         with torch.cuda.stream(side):
             real_latents, real_rotations = self.encoder(real_imgs)
+            self._g_cut = ([real_latents, real_rotations], [self.encoder])     # the encoder hangs on the tape by these two only
             generator_output_real = self.generator((real_latents, real_rotations))
             image_loss_real = cfg["image_loss_weight"] * self.perceptual_loss.loss(real_imgs, generator_output_real)
             gan_real = [GAN_G_loss(o) for o in self.discriminator(generator_output_real).values()]
@@ -159,7 +160,8 @@ class ConfigNet(ConfigNetFirstStage):
             real_imgs = self._real_imgs("g", real_training_set)
             with frozen(self.discriminator, self.synth_discriminator, self.latent_discriminator):
                 losses = self._generator_loss(params, synth_rot, synth_imgs, eye_masks, real_imgs)
-                self._generator_update(losses, nets, optimizer)
+                self._generator_update(losses, nets, optimizer, cut=self._g_cut)
+                self._g_cut = None
             return losses
         return self._run_step("g", (real_training_set, synth_training_set), optimizer, device)
 

@@ -13,6 +13,21 @@ from . import parallel
 from .nn import WEIGHTS_EPOCH
 
 
+_recording = None        # the StepGraph whose fn is being captured right now
+
+
+def segment_break(action):
+    """Called by a step function between two parts of its device half.  `action()` is an eager launch that cannot live inside
+    a HIP graph (an RCCL all-reduce) and that should start as soon as the first part has run while the second part goes on:
+    eager dispatch runs it on the spot; under capture the graph is cut here -- replay = segment, action, segment, ... --
+    (data-parallel generator step: the generator / regressor gradient arenas are exchanged under the encoder's backward)."""
+    g = _recording
+    if g is None:
+        action()
+    else:
+        g._cut(action)
+
+
 class StepGraph:
     """fn() -> dict of detached device scalars.  Call 1..warmup run eagerly ON THE CAPTURE STREAM (autograd's
     per-leaf AccumulateGrad nodes are bound to the stream they are created on, so the leaves must first be
@@ -20,7 +35,8 @@ class StepGraph:
 
     Data-parallel runs (parallel.active()): the graph holds forward + backward only; the optimizer calls made by
     fn are recorded (optim.deferred_updates) and issued eagerly after every replay by `finish()` -- gradient
-    all-reduce over RCCL, then Adam -- on whatever stream the replay was issued on."""
+    all-reduce over RCCL, then Adam -- on whatever stream the replay was issued on.  fn may also cut itself into several
+    graph segments with eager launches in between (segment_break)."""
 
     def __init__(self, fn, warmup=1, stream=None):
         self.fn, self.warmup = fn, warmup
@@ -28,6 +44,7 @@ class StepGraph:
         self.stream = stream if stream is not None else torch.cuda.Stream()
         self.split = parallel.active()
         self.tail = []
+        self.segments = []           # [(CUDAGraph, action run after it | None)]; self.graph is the last segment
 
     def _run_fn(self):
         if not self.split:
@@ -42,7 +59,32 @@ class StepGraph:
         if self.tail:
             optim.run_deferred(self.tail)
 
+    # RCCL's watchdog thread polls events while a process group exists: keep its calls out of the capture
+    def _mode(self):
+        return "thread_local" if self.split else "global"
+
+    def _begin(self):
+        g = torch.cuda.CUDAGraph()
+        pool = self.segments[0][0].pool() if self.segments else None
+        if pool is not None:
+            g.capture_begin(pool=pool, capture_error_mode=self._mode())
+        else:
+            g.capture_begin(capture_error_mode=self._mode())
+        self._cur = g
+
+    def _cut(self, action):
+        self._cur.capture_end()
+        self.segments.append((self._cur, action))
+        self._begin()
+
+    def replay(self):
+        for g, action in self.segments:
+            g.replay()
+            if action is not None:
+                action()
+
     def __call__(self):
+        global _recording
         if self.graph is None:
             cur = torch.cuda.current_stream()
             if self.calls < self.warmup:
@@ -56,13 +98,20 @@ class StepGraph:
             torch.cuda.synchronize()
             ops.prof_enable(False)                 # no event records inside a capture
             WEIGHTS_EPOCH[0] += 1                  # derived caches must be rebuilt INSIDE this graph
-            self.graph = torch.cuda.CUDAGraph()
-            # RCCL's watchdog thread polls events while a process group exists: keep its calls out of the capture
-            mode = "thread_local" if self.split else "global"
-            with torch.cuda.graph(self.graph, stream=self.stream, capture_error_mode=mode):
-                self.out = self._run_fn()
+            self.stream.wait_stream(cur)
+            with torch.cuda.stream(self.stream):
+                self._begin()
+                _recording = self
+                try:
+                    self.out = self._run_fn()
+                finally:
+                    _recording = None
+                    self._cur.capture_end()
+                self.segments.append((self._cur, None))
+            cur.wait_stream(self.stream)
+            self.graph = self._cur
             WEIGHTS_EPOCH[0] += 1
-        self.graph.replay()
+        self.replay()
         self.finish()
         return self.out
 

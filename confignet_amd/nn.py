@@ -138,16 +138,22 @@ class Net:
         raise NotImplementedError
 
 
-def backward_into_arenas(loss, nets):
+def backward_into_arenas(loss, nets, extra=(), grad_outputs=None):
     """tape.gradient(loss, trainable_weights) written into the networks' gradient arenas.
     Uses autograd.grad + one multi-tensor copy instead of .backward(): AccumulateGrad nodes are bound to the
     stream they were created on, which breaks HIP-graph capture of a step on a capture stream.
     Weights switched off with requires_grad_(False) (a variable the caller leaves out of the reference's
     trainable list, e.g. the expression slice of fine_tune_on_img(force_neutral_expression=True)) get a zero
-    gradient: Keras-Adam on a zero gradient with zero moments leaves them unchanged."""
+    gradient: Keras-Adam on a zero gradient with zero moments leaves them unchanged.
+    `extra`: further tensors of the tape whose gradients are returned (a list, None where unused) -- with `grad_outputs` and
+    `loss` a list of such tensors a later call continues the backward pass from them (two-part backward, see
+    ConfigNetFirstStage._generator_update)."""
     every = [p for n in nets for p in n.trainable_weights]
     params = [p for p in every if p.requires_grad]
-    grads = torch.autograd.grad(loss, params, allow_unused=True)
+    extra = list(extra)
+    grads = torch.autograd.grad(loss, params + extra, grad_outputs=grad_outputs, allow_unused=True)
+    extra_grads = list(grads[len(params):])
+    grads = grads[:len(params)]
     dst = [p.grad for p, g in zip(params, grads) if g is not None]
     src = [g.reshape(p.shape) for p, g in zip(params, grads) if g is not None]
     if dst:
@@ -158,3 +164,4 @@ def backward_into_arenas(loss, nets):
     for p in every:
         if not p.requires_grad:
             p.grad.zero_()
+    return extra_grads

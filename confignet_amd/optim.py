@@ -53,7 +53,7 @@ class Adam:
         step function owns a `slot` (its own scalar), so several captured steps that share this optimizer can
         be in flight at once, each with the lr_t of ITS position in the shared step count."""
         if slot not in self._lr_dev:
-            self._lr_dev[slot] = torch.zeros(1, device="cuda", dtype=torch.float32)
+            self._lr_dev[slot] = torch.zeros(1, device="cuda" if torch.cuda.is_available() else "cpu", dtype=torch.float32)
         self.iterations += 1
         self._lr_dev[slot].fill_(self.lr_t())
 

@@ -63,9 +63,41 @@ def allreduce_flat_(buffers):
             b.mul_(1.0 / ws)
 
 
+_pending = {}        # id(net) -> async work handle of an all-reduce of its gradient arena that is in flight
+
+
+def begin_allreduce(nets):
+    """Start the mean all-reduce of these networks' gradient arenas WITHOUT waiting for it: RCCL runs it on torch's
+    communication stream, ordered after everything already queued on the calling stream, while the calling stream goes on
+    with compute (the rest of the backward pass).  `allreduce_gradients` later waits for it instead of reducing again."""
+    if not active():
+        return
+    ws = world_size()
+    for n in nets:
+        assert id(n) not in _pending, "gradient all-reduce already in flight"
+        if n.grad_arena.is_cuda:
+            _pending[id(n)] = (dist.all_reduce(n.grad_arena, op=dist.ReduceOp.AVG, async_op=True), None)
+        else:                                      # gloo (CPU tests): no AVG
+            _pending[id(n)] = (dist.all_reduce(n.grad_arena, op=dist.ReduceOp.SUM, async_op=True), 1.0 / ws)
+
+
 def allreduce_gradients(nets):
-    if active():
-        allreduce_flat_([n.grad_arena for n in nets])
+    """Mean over ranks of every network's gradient arena: waits for the ones `begin_allreduce` already started (the calling
+    stream is ordered after the collective), reduces the others now."""
+    if not active():
+        return
+    rest = []
+    for n in nets:
+        pend = _pending.pop(id(n), None)
+        if pend is None:
+            rest.append(n.grad_arena)
+        else:
+            work, scale = pend
+            work.wait()
+            if scale is not None:
+                n.grad_arena.mul_(scale)
+    if rest:
+        allreduce_flat_(rest)
 
 
 def broadcast_weights(nets, src=0):

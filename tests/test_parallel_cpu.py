@@ -66,7 +66,40 @@ def _worker(rank, world, port, out_dir):
     net.weights = []
     parallel.broadcast_weights([net])
     ok_bcast = bool((net.arena == 0).all()) and net.updated and net.stats_dropped   # derived caches are told
-    torch.save({"err": err, "bcast": ok_bcast}, os.path.join(out_dir, "r%d.pt" % rank))
+    # optim.Adam.apply_gradients over two "networks" with one arena exchanged early (parallel.begin_allreduce, the overlapped
+    # generator / regressor buckets of the data-parallel generator step) and one at apply time: every rank must end with the
+    # SAME weights = one Keras-Adam step on the rank-mean gradient.  (The Adam launch itself is a HIP kernel: replaced by its
+    # formula here, the ordering / exchange logic is what runs.)
+    from confignet_amd import ops, optim
+
+    def adam_step_cpu(theta, grad, m, v, ema, lr_t, b1, b2, eps, ema_alpha=0.999):
+        m.mul_(b1).add_(grad, alpha=1 - b1)
+        v.mul_(b2).addcmul_(grad, grad, value=1 - b2)
+        theta.sub_(lr_t * m / (v.sqrt() + eps))
+    ops.adam_step = adam_step_cpu
+
+    class _Net(_N):
+        def __init__(self, n, seed):
+            g = torch.Generator().manual_seed(seed)
+            self.arena = torch.randn(n, generator=g)                                   # identical on every rank
+            self.grad_arena = torch.randn(n, generator=torch.Generator().manual_seed(seed + 100 * (rank + 1)))   # per rank
+    early, late = _Net(64, 1), _Net(32, 2)
+    want = []
+    for net in (early, late):
+        gs = [torch.randn(net.arena.numel(), generator=torch.Generator().manual_seed((1 if net is early else 2) + 100 * (r + 1)))
+              for r in range(world)]
+        gm = sum(gs) / world
+        want.append(net.arena - 4e-4 * (0.1 ** 0.5) * gm / ((0.1 * gm * gm).sqrt() + 1e-7))    # t = 1, beta_1 = 0, beta_2 = 0.9
+    opt = optim.Adam(lr=4e-4, beta_1=0.0, beta_2=0.9)
+    with optim.deferred_updates() as items:                       # what a captured step records ...
+        opt.apply_gradients([early, late], advance=False, slot="g")
+    assert len(items) == 1 and torch.equal(early.arena, _Net(64, 1).arena)      # nothing applied yet
+    opt.advance("g")
+    parallel.begin_allreduce([early])                             # ... the cut inside the step starts the early bucket ...
+    optim.run_deferred(items)                                     # ... and StepGraph.finish() waits for it, reduces the rest, applies
+    ok_adam = all(float((n.arena - w).abs().max()) < 1e-6 for n, w in zip((early, late), want)) and not parallel._pending
+    torch.save({"err": err, "bcast": ok_bcast, "adam": ok_adam, "theta": torch.cat([early.arena, late.arena])},
+               os.path.join(out_dir, "r%d.pt" % rank))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -77,4 +110,6 @@ def test_dp_gradient_identity_and_collectives_gloo(tmp_path):
     for r in range(2):
         res = torch.load(os.path.join(str(tmp_path), "r%d.pt" % r))
         assert res["err"] < 1e-10, "DP-averaged gradient != global-batch gradient (%.3e)" % res["err"]
-        assert res["bcast"]
+        assert res["bcast"] and res["adam"]
+    a, b = (torch.load(os.path.join(str(tmp_path), "r%d.pt" % r))["theta"] for r in range(2))
+    assert torch.equal(a, b), "replicated Adam must give bit-identical weights on every rank"
