@@ -590,15 +590,41 @@ class ConfigNetFirstStage:
                 self.save(os.path.join(output_dir, "checkpoints"), str(step).zfill(6))     # (l.349-355; incl. step 0)
 
     # ---- evaluation code ----------------------------------------------------------------------------
+    use_inference_graphs = True      # generate_images: one replayed HIP graph per (generator, batch) instead of ~60 eager launches
+
     def _generate_images_with(self, generator, latent_vector, rotations):
         inp = self.generator.build_input_dict(latent_vector, rotations)
         n = len(inp["rotation"])
+        host = {}
+        for k, v in inp.items():                                            # one float32 host array per DISTINCT input object
+            if id(v) not in host:
+                host[id(v)] = v if torch.is_tensor(v) else np.ascontiguousarray(v, dtype=np.float32)
+        inp = {k: host[id(v)] for k, v in inp.items()}
         outs = []
         with torch.no_grad():
             for s in range(0, n, 32):                                       # keras predict batch 32 (R11)
-                chunk = {k: (v[s:s + 32] if not isinstance(v, list) else v) for k, v in inp.items()}
-                outs.append(ops.to_uint8(generator(chunk)).cpu().numpy())   # clip + (x+1)*127.5 -> uint8
-        return np.concatenate(outs, axis=0)
+                chunk = {k: (v if n <= 32 else v[s:s + 32]) for k, v in inp.items()}
+                if self.use_inference_graphs:
+                    img = self._replay_generator(generator, chunk)
+                else:
+                    img = ops.to_uint8(generator(chunk))                    # clip + (x+1)*127.5 -> uint8
+                outs.append(img.cpu().numpy())
+        return outs[0] if len(outs) == 1 else np.concatenate(outs, axis=0)
+
+    def _replay_generator(self, generator, chunk):
+        """uint8 images of one <= 32 chunk through a cached InferenceGraph (generator forward + to_uint8)."""
+        from .graphs import InferenceGraph
+        cache = self.__dict__.setdefault("_infer_graphs", {})
+        key = (id(generator), len(chunk["rotation"]), generator.epoch, ops.ACT_DTYPE)
+        g = cache.get(key)
+        if g is None:
+            for k in [k for k in cache if k[0] == key[0] and k[2] != key[2]]:      # stale weights epoch
+                del cache[k]
+            if len(cache) >= 8:
+                cache.pop(next(iter(cache)))
+            dev_chunk = {k: generator.to_device(v) for k, v in chunk.items()}
+            g = cache[key] = InferenceGraph(lambda **kw: ops.to_uint8(generator(kw)), dev_chunk, self._work_stream("main"))
+        return g(**chunk)
 
     def generate_images(self, latent_vector, rotations):
         """confignet_first_stage.py:633-639."""

@@ -51,3 +51,13 @@ def update_loss_dict(main_loss_dict, new_loss_dict):
     for key, val in new_loss_dict.items():
         val = float(val)
         main_loss_dict.setdefault(key, []).append(val)
+
+
+def build_image_matrix(images, n_rows, n_cols):
+    """confignet_utils.py:182-190: tiles images[j * n_cols + i] into an (n_rows*H, n_cols*W, 3) uint8 canvas."""
+    h, w = images.shape[1:3]
+    out = np.zeros((n_rows * h, n_cols * w, 3), dtype=np.uint8)
+    for i in range(n_cols):
+        for j in range(n_rows):
+            out[j * h:(j + 1) * h, i * w:(i + 1) * w] = images[j * n_cols + i]
+    return out

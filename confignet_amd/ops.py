@@ -132,7 +132,17 @@ def geom_in_shape(g, upsampled=False):
     return (g.n, g.in_h << u, g.in_w << u, g.cin)
 
 
+_keepalive = None        # a list while an InferenceGraph is captured: every derived filter copy the capture references
+
+
 def _weight_cache(w, slot, make):
+    val = _weight_cache_lookup(w, slot, make)
+    if _keepalive is not None:
+        _keepalive.append(val)
+    return val
+
+
+def _weight_cache_lookup(w, slot, make):
     """Derived forms of a filter (tap-flipped fp32 copy, bf16 operand copies), cached on the tensor.  A weight of a network
     (nn.Net tags its tensors with their owner) is re-derived when THAT network's epoch moves; other tensors (the cotangent
     "filters" of double-backward calls) when torch's version counter does.  The key also holds the stream (a forked step

@@ -12,6 +12,7 @@
 """
 import os
 import sys
+from collections import OrderedDict
 
 import numpy as np
 import pytest
@@ -374,3 +375,121 @@ def test_train_scripts_run_on_the_reference_dataset_files(tmp_path):
     gan = train_latent_gan.parse_args(["--confignet_path", os.path.join(out, "checkpoints", "000000.json"), "--training_set_path", asset,
                                        "--output_dir", str(tmp_path / "lg"), "--n_training_steps", "1", "--batch_size", "8"])
     assert os.path.exists(str(tmp_path / "lg" / "checkpoints" / "000000.npz")) and gan.generate_latents(3).shape == (3, 145)
+
+
+FM_DEMO = OrderedDict(sorted(dict(MG.FM, **{"bone_rotations:left_eye": (3, 2), "hdri_embedding": (50, 20)}).items()))
+L_DEMO = sum(v[1] for v in FM_DEMO.values())
+
+
+def _write_reference_checkpoint(tmp_path, res=128):
+    """A checkpoint in the reference's on-disk format made WITHOUT this package's save(): model.npz = np.savez of one object
+    array per network holding the Keras get_weights() list (confignet_first_stage.py:129-140,173-180, second stage :35-43),
+    shapes from the oracle's Keras-ordered shape lists; model.json = the config dict; model_facemodel_distr.pck."""
+    import json
+    from confignet_amd.confignet_first_stage import DEFAULT_CONFIG
+    from confignet_amd.neural_renderer_dataset import ExemplarDistribution, OneHotDistribution, dump_pickle
+    L = L_DEMO
+    lists = {
+        "generator_weights": MG.seeded_weights(R.generator_weight_shapes(L, res), 21),
+        "generator_smoothed_weights": MG.seeded_weights(R.generator_weight_shapes(L, res), 22),
+        "discriminator_weights": MG.seeded_weights(R.discriminator_weight_shapes(res), 23),
+        "latent_regressor_weights": MG.seeded_weights(R.latent_regressor_weight_shapes(L, res), 24),
+        "synthetic_encoder_weights": MG.seeded_weights(R.synthetic_encoder_weight_shapes(list(FM_DEMO.values())), 25),
+        "latent_discriminator_weights": MG.seeded_weights(R.mlp_weight_shapes(4, L, L, 1), 26),
+        "synth_discriminator_weights": MG.seeded_weights(R.discriminator_weight_shapes(res), 27),
+        "real_encoder_weights": MG.seeded_weights(R.real_encoder_weight_shapes(L), 28, he=True),
+    }
+    for i, role in enumerate(R.resnet50_weight_roles()):                   # sane BatchNorm statistics
+        if role == "var":
+            lists["real_encoder_weights"][i] = (1.0 + np.abs(lists["real_encoder_weights"][i])).astype(np.float32)
+        elif role == "gamma":
+            lists["real_encoder_weights"][i] = (0.5 + lists["real_encoder_weights"][i]).astype(np.float32)
+    for k in ("real_encoder_weights",):
+        lists[k][-4] *= 0.05
+        lists[k][-2] *= 0.05
+    arrays = {}
+    for k, lst in lists.items():
+        a = np.empty(len(lst), dtype=object)
+        a[:] = lst
+        arrays[k] = a
+    np.savez(str(tmp_path / "model.npz"), **arrays)
+    cfg = dict(DEFAULT_CONFIG, model_type="ConfigNet", output_shape=[res, res, 3], latent_dim=L,
+               facemodel_inputs={k: list(v) for k, v in FM_DEMO.items()})
+    with open(str(tmp_path / "model.json"), "w") as fp:
+        json.dump(cfg, fp)
+    rng = np.random.default_rng(3)
+    distr = {}
+    for k, (din, _) in FM_DEMO.items():
+        distr[k] = OneHotDistribution() if k == "eye_color" else ExemplarDistribution()
+        distr[k].fit(np.eye(din, dtype=np.float32) if k == "eye_color" else rng.standard_normal((5, din)).astype(np.float32))
+    dump_pickle(distr, str(tmp_path / "model_facemodel_distr.pck"))
+    lg = {}
+    for k, seed, nout in (("generator_weights", 31, L), ("smoothed_generator_weights", 32, L), ("discriminator_weights", 33, 1)):
+        lst = MG.seeded_weights(R.mlp_weight_shapes(3, L, int(L * 1.5), nout), seed)
+        a = np.empty(len(lst), dtype=object)
+        a[:] = lst
+        lg[k] = a
+    os.makedirs(str(tmp_path / "lg"))
+    np.savez(str(tmp_path / "lg" / "model.npz"), **lg)
+    with open(str(tmp_path / "lg" / "model.json"), "w") as fp:
+        json.dump({"latent_dim": L, "optimizer": {"lr": 5e-5, "beta_1": 0.0, "beta_2": 0.9, "amsgrad": False}, "batch_size": 32,
+                   "num_mlp_layers": 3, "latent_distribution_type": "normal", "hidden_layer_size_multiplier": 1.5,
+                   "n_samples_for_metrics": 1000, "verbose_log_period": 500, "logging_img_square_size": 6}, fp)
+    return lists, lg
+
+
+def test_reference_format_checkpoint_loads_and_the_demo_loop_runs(tmp_path):
+    """f1 + f3 of SURVEY.md section 8: a model.json / model.npz / _facemodel_distr.pck triple in the reference's layout loads
+    through load_confignet (weights land in the right tensors: generate_images / encode_images match the oracle evaluated on
+    the file's own Keras-ordered lists), LatentGAN.load likewise, and the headless demo loop (evaluation/confignet_demo.py
+    --test_mode, the reference's tests/evaluation_test.py:30-48) runs in both of its modes on top of them."""
+    import confignet
+    from confignet_amd import ops
+    sys.path.insert(0, os.path.join(ROOT, "evaluation"))
+    import confignet_demo
+    lists, lg = _write_reference_checkpoint(tmp_path)
+    m = confignet.load_confignet(str(tmp_path / "model.json"))
+    assert type(m).__name__ == "ConfigNet" and m.config["latent_dim"] == L_DEMO and set(m.facemodel_param_distributions) == set(FM_DEMO)
+    for key, net in (("generator_weights", m.generator), ("generator_smoothed_weights", m.generator_smoothed),
+                     ("real_encoder_weights", m.encoder), ("latent_regressor_weights", m.latent_regressor)):
+        got = net.get_weights()
+        assert len(got) == len(lists[key]) and all(np.array_equal(a, b) for a, b in zip(got, lists[key])), key
+    rng = np.random.default_rng(9)
+    z, rot = rng.standard_normal((3, L_DEMO)), rng.uniform(-0.3, 0.3, (3, 3))
+    imgs = m.generate_images(z, rot)                                        # smoothed generator, replayed HIP graph
+    ref = R.generator_forward([t64(w) for w in lists["generator_smoothed_weights"]], t64(z), t64(rot), 128)
+    ref_u8 = ((ref.clamp(-1, 1) + 1) * 127.5).numpy()
+    assert imgs.dtype == np.uint8 and np.abs(imgs.astype(np.float64) - ref_u8).max() <= 1.0 + 127.5e-3     # truncation + 1e-3
+    m.use_inference_graphs = False
+    assert np.abs(m.generate_images(z, rot).astype(int) - imgs.astype(int)).max() <= 1                     # eager dispatch
+    m.use_inference_graphs = True
+    assert np.abs(m.generate_images(z[:1], rot[:1]).astype(int) - imgs[:1].astype(int)).max() <= 1         # another batch size
+    face = rng.integers(0, 256, (2, 128, 128, 3), dtype=np.uint8)
+    emb, r = m.encode_images(face)
+    emb_r, rot_r = R.real_encoder_forward([t64(w) for w in lists["real_encoder_weights"]], t64(face.astype(np.float64) / 127.5 - 1.0))
+    assert np.abs(emb - emb_r.numpy()).max() <= 1e-3 * max(1.0, float(emb_r.abs().max())) and np.abs(r - rot_r.numpy()).max() < 1e-4
+    gan = confignet.LatentGAN.load(str(tmp_path / "lg" / "model.json"))
+    assert all(np.array_equal(a, b) for a, b in zip(gan.generator_smoothed.get_weights(), lg["smoothed_generator_weights"]))
+    np.random.seed(0)
+    lat = gan.generate_latents(1)
+    np.random.seed(0)
+    zz = np.random.normal(0, 1, (1, L_DEMO))
+    assert np.abs(lat - O.mlp_simple(t64(zz), [t64(w) for w in lg["smoothed_generator_weights"]], 0.3).numpy()).max() < 1e-4
+    # the demo: sampled from the LatentGAN (6 faces), and on one input image (incl. the one-shot fine-tune key)
+    np.save(str(tmp_path / "face.npy"), face[0])
+    frames = []
+    s1 = confignet_demo.run(["--confignet_model_path", str(tmp_path / "model.json"), "--latent_gan_model_path", str(tmp_path / "lg" / "model.json"),
+                             "--output_dir", str(tmp_path / "frames"), "--test_mode"])
+    canvas = np.load(str(tmp_path / "frames" / "frame_0000.npy"))
+    assert canvas.shape == (2 * 128, 3 * (2 * 128 + 20), 3) and canvas.dtype == np.uint8 and s1.exit
+    s2 = confignet_demo.run(["--confignet_model_path", str(tmp_path / "model.json"), "--image_path", str(tmp_path / "face.npy"), "--test_mode"])
+    assert s2.n_rows == s2.n_cols == 1 and s2.model.generator_fine_tuned is not None and s2.exit
+    # a keyed session: head pose / gaze / attribute keys change the rendering, 'v' restores the embedding target
+    s3 = confignet_demo.DemoSession(m, gan, None, 1, 2)
+    a = s3.frame()
+    for k in "ddwix":
+        s3.key(k)
+    b = s3.frame()
+    assert a.shape == b.shape == (128, 2 * 276, 3) and np.abs(a.astype(int) - b.astype(int)).max() > 0
+    assert abs(s3.rotation_offset[0, 0] - 0.1) < 1e-12 and abs(s3.eye_rotation_offset[0, 0] + 0.05) < 1e-12
+    assert ops.ACT_DTYPE == torch.float32
