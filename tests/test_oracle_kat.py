@@ -165,3 +165,133 @@ def test_reference_golden_weight_free_facts():
     moved = np.nonzero(np.abs(emb_b[0] - emb_f[0]) > 1e-5)[0]
     assert moved.min() == 7 and moved.max() == 36 and len(moved) == 30
     np.testing.assert_allclose(np.abs(emb_b[0, moved] - emb_f[0, moved]), 1e-4, rtol=2e-2)
+
+
+def test_oracle_matches_tensorflow_pins():
+    """Consumes tests/golden/tf_pins.npz -- written OUT OF LOOP by scripts/tf_pin_dump.py on a machine that has TensorFlow
+    2.x and the reference checkout -- and checks every [TF-2.1] rule the oracle hard-codes against executed TensorFlow:
+    Conv2dAdaIn / Conv3dAdaIn / DiscrBlock outputs (SAME padding split, LeakyReLU 0.3 / 0.2, LayerNormalization eps 1e-3,
+    eps-on-std instance norm, style eps), the 3-D resampling incl. both gradients, the shared-counter Keras-Adam trace and
+    the keras.applications weight orders.  Skipped while the file does not exist (TensorFlow cannot be installed here):
+    until someone commits it, parity is against this repository's own restatement."""
+    import os
+    import pytest
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tf_pins.npz")
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/tf_pins.npz not present: run scripts/tf_pin_dump.py where TensorFlow is available")
+    _check_pins(np.load(path, allow_pickle=False))
+
+
+def _check_pins(P):
+    files = P.files if hasattr(P, "files") else list(P.keys())
+    t = lambda a: torch.tensor(np.asarray(a), dtype=torch.float64)
+    unpack = lambda prefix: [t(P["%s_%d" % (prefix, i)]) for i in range(int(P[prefix + "_n"]))]
+    for name in ("conv2d_adain", "conv3d_adain"):
+        ck, cb, *mlp = unpack(name + "_w")
+        y = O.adain(O.leaky_relu(O.conv_same(t(P[name + "_x"]), ck, cb), 0.3), t(P[name + "_z"]), mlp, 0.2)
+        assert float((y - t(P[name + "_y"])).abs().max()) < 1e-4, name
+    for tag in ("even", "odd"):
+        w = unpack("discr_block_%s_w" % tag)                               # conv kernel, bias, gamma, beta
+        y, st = R.discr_block(t(P["discr_block_%s_x" % tag]), *w, return_styles=True)
+        assert float((y - t(P["discr_block_%s_y" % tag])).abs().max()) < 1e-4 and float((st - t(P["discr_block_%s_style" % tag])).abs().max()) < 1e-4
+    grid, ang = t(P["rot_grid"]).requires_grad_(True), t(P["rot_angles"]).requires_grad_(True)
+    Rm = O.euler_angles_to_matrix(ang)
+    out = O.transform_3d_grid(grid, Rm)
+    g_grid, g_ang = torch.autograd.grad((out * t(P["rot_cot"])).sum(), [grid, ang])
+    assert float((Rm - t(P["rot_matrix"])).abs().max()) < 1e-6 and float((out - t(P["rot_out"])).abs().max()) < 1e-4
+    assert float((g_grid - t(P["rot_g_grid"])).abs().max()) < 1e-4
+    assert float((g_ang - t(P["rot_g_angles"])).abs().max()) < 1e-3 * max(1.0, float(t(P["rot_g_angles"]).abs().max()))
+    gamma, beta = unpack("inorm_w")
+    assert float((O.instance_norm(t(P["inorm_x"]), gamma, beta) - t(P["inorm_y"])).abs().max()) < 1e-5
+    mu, sd = O.layer_style(t(P["inorm_x"]))
+    assert float((mu - t(P["style_mean"])).abs().max()) < 1e-6 and float((sd - t(P["style_std"])).abs().max()) < 1e-6
+    # one optimizer, three variables in turn, two rounds: t = 1..6 (R10)
+    opt = O.KerasAdam(lr=4e-4, beta_1=0.0, beta_2=0.9)
+    vs = [t(v).clone() for v in P["adam_theta0"]]
+    k = 0
+    for it in range(2):
+        for j, v in enumerate(vs):
+            opt.apply_gradients([(t(P["adam_grads"][3 * it + j]), v)])
+            assert float((v - t(P["adam_trace"][k])).abs().max()) < 1e-7, (it, j)
+            k += 1
+    assert int(P["adam_iterations"]) == 6 == opt.t
+    opt2, v = O.KerasAdam(lr=1e-4), t(P["adam_theta0"][0]).clone()
+    for it in range(3):
+        opt2.apply_gradients([(t(P["adam_grads"][it]), v)])
+        assert float((v - t(P["adam_default_trace"][it])).abs().max()) < 1e-7
+    for k_, s_, n_ in ((4, 1, 8), (3, 2, 8), (3, 2, 9), (3, 1, 8)):
+        x = torch.zeros(1, n_, n_, 1, dtype=torch.float64)
+        x[0, 0, 0, 0], x[0, n_ - 1, n_ - 1, 0] = 1.0, 2.0
+        y = O.conv_same(x, torch.ones(k_, k_, 1, 1, dtype=torch.float64), None, stride=s_)
+        assert torch.equal(y, t(P["same_k%d_s%d_n%d" % (k_, s_, n_)])), (k_, s_, n_)
+    assert abs(float(P["keras_leakyrelu_of_minus1"][0]) + 0.3) < 1e-7 and abs(float(P["tf_nn_leaky_relu_of_minus1"][0]) + 0.2) < 1e-7
+    assert abs(float(P["layernorm_default_eps"]) - 1e-3) < 1e-12
+    if "resnet50_weight_names" in files:
+        names = [str(n) for n in P["resnet50_weight_names"]]
+        want = []
+        for lname, kind, *_ in R.resnet50_layer_order():
+            want += [lname + "/kernel:0", lname + "/bias:0"] if kind == "conv" else \
+                [lname + "/gamma:0", lname + "/beta:0", lname + "/moving_mean:0", lname + "/moving_variance:0"]
+        assert names == want, "keras ResNet50 get_weights() order differs from oracle/ref_nets.py:resnet50_layer_order"
+        assert [eval(s) for s in P["resnet50_weight_shapes"]] == [tuple(s) for s in R.resnet50_weight_shapes()]
+        assert abs(float(P["resnet50_bn_eps"][0]) - R.BN_EPS) < 1e-12
+        assert np.allclose(P["caffe_preprocess_probe"][0, 0, 0], [30.0 - 103.939, 20.0 - 116.779, 10.0 - 123.68])
+
+
+def test_pin_checker_runs_on_a_self_made_file():
+    """The checker above is exercised here on a pins dictionary produced BY THE ORACLE in the layout scripts/tf_pin_dump.py
+    writes (so a typo in a key or a shape convention shows up now, not on the day a TensorFlow-made file arrives).  This
+    pins nothing: it only proves the consumer works."""
+    rng = np.random.default_rng(0)
+    t = lambda a: torch.tensor(np.asarray(a), dtype=torch.float64)
+    P = {}
+
+    def pack(prefix, arrays):
+        P[prefix + "_n"] = np.array(len(arrays))
+        for i, a in enumerate(arrays):
+            P["%s_%d" % (prefix, i)] = np.asarray(a)
+    for name, xs, k in (("conv2d_adain", (2, 9, 8, 6), (4, 4)), ("conv3d_adain", (2, 5, 4, 6, 3), (3, 3, 3))):
+        x, z = rng.standard_normal(xs), rng.standard_normal((2, 7))
+        ws = [rng.standard_normal(sh) * 0.3 for sh in ((*k, xs[-1], 8), (8,), (7, 5), (5,), (5, 16), (16,))]
+        P[name + "_x"], P[name + "_z"] = x, z
+        P[name + "_y"] = O.adain(O.leaky_relu(O.conv_same(t(x), t(ws[0]), t(ws[1])), 0.3), t(z), [t(w) for w in ws[2:]], 0.2).numpy()
+        pack(name + "_w", ws)
+    for tag, hw in (("even", (8, 10)), ("odd", (9, 7))):
+        x = rng.standard_normal((2, *hw, 5))
+        ws = [rng.standard_normal(sh) * 0.3 for sh in ((3, 3, 5, 6), (6,), (6,), (6,))]
+        y, st = R.discr_block(t(x), *[t(w) for w in ws], return_styles=True)
+        P["discr_block_%s_x" % tag], P["discr_block_%s_y" % tag], P["discr_block_%s_style" % tag] = x, y.numpy(), st.numpy()
+        pack("discr_block_%s_w" % tag, ws)
+    grid = t(rng.standard_normal((2, 16, 16, 16, 3))).requires_grad_(True)
+    ang = t([[0.3, -0.1, 0.05], [-0.45, 0.15, 0.0]]).requires_grad_(True)
+    cot = rng.standard_normal((2, 16, 16, 16, 3))
+    Rm = O.euler_angles_to_matrix(ang)
+    out = O.transform_3d_grid(grid, Rm)
+    gg, ga = torch.autograd.grad((out * t(cot)).sum(), [grid, ang])
+    P.update(rot_grid=grid.detach().numpy(), rot_angles=ang.detach().numpy(), rot_matrix=Rm.detach().numpy(), rot_out=out.detach().numpy(),
+             rot_cot=cot, rot_g_grid=gg.numpy(), rot_g_angles=ga.numpy())
+    x = rng.standard_normal((2, 6, 5, 4))
+    ws = [rng.standard_normal(4), rng.standard_normal(4)]
+    P["inorm_x"], P["inorm_y"] = x, O.instance_norm(t(x), t(ws[0]), t(ws[1])).numpy()
+    pack("inorm_w", ws)
+    mu, sd = O.layer_style(t(x))
+    P["style_mean"], P["style_std"] = mu.numpy(), sd.numpy()
+    th, gs = rng.standard_normal((3, 50)), rng.standard_normal((6, 50))
+    P["adam_theta0"], P["adam_grads"] = th, gs
+    opt, vs, trace = O.KerasAdam(lr=4e-4, beta_1=0.0, beta_2=0.9), [t(v).clone() for v in th], []
+    for it in range(2):
+        for j, v in enumerate(vs):
+            opt.apply_gradients([(t(gs[3 * it + j]), v)])
+            trace.append(v.numpy().copy())
+    P["adam_trace"], P["adam_iterations"] = np.stack(trace), np.array(6)
+    opt2, v, t2 = O.KerasAdam(lr=1e-4), t(th[0]).clone(), []
+    for it in range(3):
+        opt2.apply_gradients([(t(gs[it]), v)])
+        t2.append(v.numpy().copy())
+    P["adam_default_trace"] = np.stack(t2)
+    for k_, s_, n_ in ((4, 1, 8), (3, 2, 8), (3, 2, 9), (3, 1, 8)):
+        x = torch.zeros(1, n_, n_, 1, dtype=torch.float64)
+        x[0, 0, 0, 0], x[0, n_ - 1, n_ - 1, 0] = 1.0, 2.0
+        P["same_k%d_s%d_n%d" % (k_, s_, n_)] = O.conv_same(x, torch.ones(k_, k_, 1, 1, dtype=torch.float64), None, stride=s_).numpy()
+    P["keras_leakyrelu_of_minus1"], P["tf_nn_leaky_relu_of_minus1"], P["layernorm_default_eps"] = np.array([-0.3]), np.array([-0.2]), np.array(1e-3)
+    _check_pins(P)
