@@ -175,7 +175,11 @@ def main():
                          "launches_per_step": launches / max(args.steps, 1),
                          "kernel_ms_per_step": round(kernel_ms / max(args.steps, 1), 3),
                          "measured": "HIP events around every launch of the class, same K iterations run serially (eager, one stream)",
-                         "algorithmic_gflop_per_step": round(kernel_flops / max(args.steps, 1) / 1e9, 2)},
+                         "algorithmic_gflop_per_step": round(kernel_flops / max(args.steps, 1) / 1e9, 2),
+                         "recorded": "traffic / mfma_busy_pmc come from committed rocprofv3 PMC passes and are quoted only when "
+                                     "profiles/round2_pmc_*.json carry this kernels_hash",
+                         "kernels_hash": kernels_hash()},
+            "torch_kernel_time_share": torch_kernel_share(),
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
@@ -185,39 +189,65 @@ def main():
         dist.destroy_process_group()
 
 
-def pmc_traffic():
-    """HBM bytes per launch of the dominant kernel class from the committed rocprofv3 PMC passes of this same
-    command (profiles/round1_pmc_traffic.json: FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE);
-    hardware counters cannot be read from inside the benchmark process, hence a recorded measurement."""
+def kernels_hash():
+    """sha1 over the HIP sources: recorded counter measurements are only quoted for the kernels they were taken on."""
+    import hashlib
+    h = hashlib.sha1()
+    d = os.path.join(ROOT, "confignet_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:12]
+
+
+def _recorded(name, key):
+    """A counter-derived figure from the committed rocprofv3 PMC passes of this same command (hardware counters cannot be
+    read from inside the benchmark process).  Returned only if the file was recorded on the CURRENT kernel sources
+    (`kernels_hash`), else None: a stale measurement is not quoted."""
     try:
-        with open(os.path.join(ROOT, "profiles", "round1_pmc_traffic.json")) as fp:
-            return round(json.load(fp)["hbm_bytes_per_launch"])
+        with open(os.path.join(ROOT, "profiles", name)) as fp:
+            rec = json.load(fp)
+        if rec.get("kernels_hash") != kernels_hash():
+            return None
+        return rec[key]
     except Exception:
         return None
+
+
+def pmc_traffic():
+    """HBM bytes per launch of the dominant kernel class (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE;
+    scripts/pmc_summary.py, scripts/pmc_traffic_json.py)."""
+    v = _recorded("round2_pmc_traffic.json", "hbm_bytes_per_launch")
+    return None if v is None else round(v)
 
 
 def pmc_mfma_busy():
-    """MFMA-pipe busy fraction of the class from the committed PMC pass (profiles/round1_pmc_mfma.json:
-    SQ_VALU_MFMA_BUSY_CYCLES against GRBM_GUI_ACTIVE; scripts/pmc_mfma.py states the normalisation)."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "round1_pmc_mfma.json")) as fp:
-            return round(json.load(fp)["mfma_busy_fraction"], 4)
-    except Exception:
-        return None
+    """MFMA-pipe busy fraction of the class (SQ_VALU_MFMA_BUSY_CYCLES against GRBM_GUI_ACTIVE; scripts/pmc_mfma.py)."""
+    v = _recorded("round2_pmc_mfma.json", "mfma_busy_fraction")
+    return None if v is None else round(v, 4)
+
+
+def torch_kernel_share():
+    """Share of the GPU time of one iteration spent in PyTorch's own kernels (autograd's gradient accumulation adds, cat,
+    fills, small (N, L) algebra) from the committed kernel trace of this command -- north_star: torch is plumbing."""
+    v = _recorded("round2_torch_share.json", "torch_kernel_time_share")
+    return None if v is None else round(v, 4)
 
 
 def cpu_baseline(args):
-    """The oracle's restatement of one whole second-stage iteration, timed on the host cores in a
-    subprocess with a hard time limit (a bounded sample: batch 4 instead of 16)."""
+    """The oracle's restatement of one whole second-stage iteration, timed on the host cores in a subprocess with a hard
+    time limit: thread count = the fastest of {16, 64, all} in a one-iteration probe at batch 2, then 1 warm-up + the median
+    of 3 iterations at the benchmark's batch."""
     import subprocess
     cmd = [sys.executable, "-m", "oracle.cpu_baseline", str(args.cpu_batch), str(args.res)]
     try:
-        p = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=240)
+        p = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=420)
         r = json.loads(p.stdout.strip().splitlines()[-1])
         return {"value": round(r["value"], 4), "unit": "images/sec", "cores": r["cores"], "kind": "port",
-                "sample": "1 second-stage iteration at %dx%d, batch %d (%.1f s) on %d of %d host cores; torch-CPU fp32 "
-                          "restatement of the reference (oracle/) -- TensorFlow 2.1 itself cannot be installed here"
-                          % (args.res, args.res, args.cpu_batch, r["seconds"], r["cores"], r["host_cores"])}
+                "sample": "second-stage iteration at %dx%d, batch %d: 1 warm-up + median of 3 (%.1f s each) on %d of %d host cores "
+                          "(fastest of a {16, 64, all}-thread probe: %s s per batch-2 iteration); torch-CPU fp32 restatement of the "
+                          "reference (oracle/) -- TensorFlow 2.1 itself cannot be installed here"
+                          % (args.res, args.res, args.cpu_batch, r["seconds"], r["cores"], r["host_cores"], r["thread_probe_seconds"])}
     except Exception as e:   # timeout / crash: report it, never block the GPU result
         return {"value": None, "unit": "images/sec", "cores": None, "kind": "port", "sample": "failed: %r" % (e,)}
 

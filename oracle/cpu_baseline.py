@@ -81,10 +81,8 @@ def make_batch(res, b, rng, dtype=torch.float32):
             "eye_masks_g": torch.as_tensor(masks), "real_imgs_g": img(nr)}
 
 
-def time_second_stage_iteration(res=256, batch=2, repeats=1, threads=None):
-    """Returns (images_per_sec, seconds_per_iteration, cores_used)."""
-    # torch-CPU eager on these op sizes stops scaling (and collapses from oversubscription) beyond a few
-    # dozen threads: use at most 16 of the host's cores and report that number as `cores`
+def time_second_stage_iteration(res=256, batch=2, repeats=1, threads=None, warmup=0):
+    """Returns (images_per_sec, median seconds per iteration, threads used)."""
     threads = threads or min(os.cpu_count() or 1, 16)
     torch.set_num_threads(threads)
     rng = np.random.default_rng(0)
@@ -96,13 +94,26 @@ def time_second_stage_iteration(res=256, batch=2, repeats=1, threads=None):
     d_opt = O.KerasAdam(lr=4e-4, beta_1=0.0, beta_2=0.9)
     g_opt = O.KerasAdam(lr=4e-4, beta_1=0.0, beta_2=0.9)
     times = []
-    for _ in range(repeats):
+    for i in range(warmup + repeats):
         b = make_batch(res, batch, rng)
         t0 = time.perf_counter()
         S.second_stage_iteration(W, cfg, b, d_opt, g_opt, vgg)
-        times.append(time.perf_counter() - t0)
+        if i >= warmup:
+            times.append(time.perf_counter() - t0)
     sec = float(np.median(times))
     return batch / sec, sec, threads
+
+
+def best_thread_count(res, candidates, probe_batch=2):
+    """torch-CPU eager on these op sizes stops scaling (and can collapse from oversubscription) beyond a few dozen threads:
+    one probe iteration at a small batch per candidate, the fastest wins."""
+    best, best_ips, seen = None, -1.0, {}
+    for c in candidates:
+        ips, sec, _ = time_second_stage_iteration(res, probe_batch, repeats=1, threads=c)
+        seen[c] = round(sec, 2)
+        if ips > best_ips:
+            best, best_ips = c, ips
+    return best, seen
 
 
 if __name__ == "__main__":
@@ -110,5 +121,8 @@ if __name__ == "__main__":
     import sys
     b = int(sys.argv[1]) if len(sys.argv) > 1 else 2
     r = int(sys.argv[2]) if len(sys.argv) > 2 else 256
-    v, sec, cores = time_second_stage_iteration(r, b)
-    print(json.dumps({"value": v, "seconds": sec, "cores": cores, "host_cores": os.cpu_count()}))
+    host = os.cpu_count() or 1
+    cands = sorted({min(16, host), min(64, host), host})
+    threads, probe = best_thread_count(r, cands)
+    v, sec, cores = time_second_stage_iteration(r, b, repeats=3, threads=threads, warmup=1)     # 1 warm-up + median of 3
+    print(json.dumps({"value": v, "seconds": sec, "cores": cores, "host_cores": host, "thread_probe_seconds": probe}))
