@@ -43,6 +43,7 @@ SIGNATURES = {
     "cn_conv_weight_tflip": [_p, _p, _i, _i, _i, _p],
     "cn_conv_dgrad": [_G, _p, _p, _p, _p],
     "cn_conv_wgrad": [_G, _p, _p, _p, _i, _p],
+    "cn_conv_tune": [_i, _i, ctypes.c_long],
     "cn_sumpool2": [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "cn_gemm": [_i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _p, _i, _f, _p],
     "cn_nc_reduce": [_p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _p],

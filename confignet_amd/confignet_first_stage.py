@@ -382,36 +382,61 @@ class ConfigNetFirstStage:
             from .graphs import StepGraph
             self._graphs = {k: v for k, v in self._graphs.items() if k[3] == self._bufs.generation}
             g = self._graphs[key] = StepGraph(device_fn, stream=self._work_stream(name))
-        if self._deferred is not None and g.graph is not None:
-            self._deferred.append(g)           # replayed together with its independent sibling steps
-            return g.out
+        if self._deferred is not None:
+            if g.graph is not None:
+                self._deferred.append(g)       # replayed together with its independent sibling steps
+                return g.out
+            self._flush_deferred()             # not captured yet: everything collected before it runs first, in order
         return g()
 
-    def run_concurrently(self, step_calls):
+    def run_concurrently(self, step_calls, then=None):
         """Runs step functions that do not depend on each other (the three discriminator-type steps of one
         iteration: each updates only its own network and reads generator/encoder weights that stay fixed until
         the generator step) as HIP graphs replayed on separate streams, so their many small launches overlap on
-        the 256 CUs.  Host halves (sampling, staging, step counters) still run in the reference's order."""
+        the 256 CUs.  Host halves (sampling, staging, step counters) still run in the reference's order.
+        `then`: the step that follows them (the generator step).  Its graph is cut where it first needs a discriminator
+        (graphs.segment_break(early=True)); the part before the cut -- generator, encoder and VGG forward passes, heavy
+        MFMA-bound kernels -- is replayed NEXT TO the discriminator-type graphs (latency-bound small launches), the rest after
+        them: same values as the reference's order, since the early part reads nothing the discriminator steps write."""
         if not self.use_graphs:
-            return [c() for c in step_calls]
+            outs = [c() for c in step_calls]
+            return outs + [then()] if then is not None else outs
         self._deferred = []
         try:
             outs = [c() for c in step_calls]
-            pending, self._deferred = self._deferred, None
+            n_siblings = len(self._deferred)
+            if then is not None:
+                self._deferred_then = n_siblings == len(step_calls)      # (else: warm-up / capture iteration, strictly in order)
+                outs.append(then())
+            self._flush_deferred()
         finally:
-            self._deferred = None
-        if pending:
-            # every graph is replayed on the stream it was captured on: one of the model's measured-independent
-            # work streams (see _work_stream)
-            cur = torch.cuda.current_stream()
-            for g in pending:
-                g.stream.wait_stream(cur)
-                with torch.cuda.stream(g.stream):
-                    g.replay()
-                    g.finish()
-            for g in pending:
-                cur.wait_stream(g.stream)
+            self._deferred, self._deferred_then = None, False
         return outs
+
+    _deferred_then = False
+
+    def _flush_deferred(self):
+        """Launch the graphs collected so far: each on the stream it was captured on (one of the model's measured-independent
+        work streams, see _work_stream), a trailing generator-step graph's early segments on the calling stream beside them."""
+        pending, self._deferred = self._deferred, []
+        if not pending:
+            return
+        follower = pending.pop() if (self._deferred_then and len(pending) > 1 and pending[-1].early_cut) else None
+        cur = torch.cuda.current_stream()
+        for g in pending:
+            g.stream.wait_stream(cur)
+            with torch.cuda.stream(g.stream):
+                g.replay()
+                g.finish()
+        if follower is not None and self.early_generator_forward:
+            follower.replay(0, follower.early_cut)
+        for g in pending:
+            cur.wait_stream(g.stream)
+        if follower is not None:
+            follower.replay(follower.early_cut if self.early_generator_forward else 0)
+            follower.finish()
+
+    early_generator_forward = os.environ.get("CN_NO_EARLY_G") is None
 
     def _discriminator_update(self, net, real_imgs, fake_imgs, optimizer, slot="default"):
         losses = compute_discriminator_loss(net, real_imgs, fake_imgs)
@@ -491,13 +516,20 @@ class ConfigNetFirstStage:
         side = self._branch_stream if self.fork_generator_step else main
         if side is not main:
             side.wait_stream(main)
+        from .graphs import segment_break
         with torch.cuda.stream(side):
             generator_output_real = self.generator((real_latents, real_rotations))
-            gan_real = [GAN_G_loss(o) for o in self.discriminator(generator_output_real).values()]
         synth_latents = self.synthetic_encoder(facemodel_params)
         generator_output_synth = self.generator((synth_latents, synth_rotations))
         losses["image_loss"] = cfg["image_loss_weight"] * self.perceptual_loss.loss(gt_imgs, generator_output_synth)
         losses["eye_loss"] = cfg["eye_loss_weight"] * eye_loss(gt_imgs, generator_output_synth, eye_masks)
+        if side is not main:
+            main.wait_stream(side)
+        segment_break(early=True)              # nothing above reads a discriminator weight
+        if side is not main:
+            side.wait_stream(main)
+        with torch.cuda.stream(side):
+            gan_real = [GAN_G_loss(o) for o in self.discriminator(generator_output_real).values()]
         for i, o in enumerate(self.synth_discriminator(generator_output_synth).values()):
             losses["GAN_loss_synth_" + str(i)] = GAN_G_loss(o)
         if side is not main:
@@ -569,13 +601,18 @@ class ConfigNetFirstStage:
         for _ in range(start_step, n_steps):
             t0 = time.perf_counter()
             with self._main_line():
-                for _ in range(self.config["n_discriminator_updates"]):
-                    d_loss, synth_d_loss, latent_d_loss = self.run_concurrently([
-                        lambda: self.discriminator_training_step(real_training_set, discriminator_optimizer),
-                        lambda: self.synth_discriminator_training_step(synth_training_set, discriminator_optimizer),
-                        lambda: self.latent_discriminator_training_step(synth_training_set, discriminator_optimizer)])
-                for _ in range(self.config["n_generator_updates"]):
-                    g_loss = self.generator_training_step(real_training_set, synth_training_set, generator_optimizer)
+                d_steps = [lambda: self.discriminator_training_step(real_training_set, discriminator_optimizer),
+                           lambda: self.synth_discriminator_training_step(synth_training_set, discriminator_optimizer),
+                           lambda: self.latent_discriminator_training_step(synth_training_set, discriminator_optimizer)]
+                g_step = lambda: self.generator_training_step(real_training_set, synth_training_set, generator_optimizer)
+                nd, ng = self.config["n_discriminator_updates"], self.config["n_generator_updates"]
+                for i in range(nd):
+                    out = self.run_concurrently(d_steps, then=g_step if (i == nd - 1 and ng >= 1) else None)
+                    d_loss, synth_d_loss, latent_d_loss = out[:3]
+                    if len(out) > 3:
+                        g_loss = out[3]
+                for _ in range(ng - 1 if nd >= 1 else ng):
+                    g_loss = g_step()
                 self.update_smoothed_weights()
             torch.cuda.synchronize()
             self.last_iteration_time = time.perf_counter() - t0

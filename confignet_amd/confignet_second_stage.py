@@ -114,18 +114,28 @@ class ConfigNet(ConfigNetFirstStage):
         side = self._branch_stream if self.fork_generator_step else main
         if side is not main:
             side.wait_stream(main)
+        from .graphs import segment_break
         with torch.cuda.stream(side):
             real_latents, real_rotations = self.encoder(real_imgs)
             self._g_cut = ([real_latents, real_rotations], [self.encoder])     # the encoder hangs on the tape by these two only
             generator_output_real = self.generator((real_latents, real_rotations))
             image_loss_real = cfg["image_loss_weight"] * self.perceptual_loss.loss(real_imgs, generator_output_real)
-            gan_real = [GAN_G_loss(o) for o in self.discriminator(generator_output_real).values()]
-            out_real = self.latent_discriminator(real_latents)
         synth_latents = self.synthetic_encoder(facemodel_params)
         generator_output_synth = self.generator((synth_latents, synth_rotations))
         losses["image_loss_synth"] = cfg["image_loss_weight"] * self.perceptual_loss.loss(synth_imgs, generator_output_synth)
         losses["image_loss_real"] = None                      # (keeps the reference's key order; filled after the join)
         losses["eye_loss"] = cfg["eye_loss_weight"] * eye_loss(synth_imgs, generator_output_synth, eye_masks)
+        # Everything above -- encoder, both generator passes, the four VGG-19 passes: the heavy MFMA-bound half of the step's
+        # forward -- reads no discriminator weight, so in graph mode the iteration replays it NEXT TO the three discriminator-
+        # type steps (run_concurrently(..., then=)); below this point the step needs their updated weights.
+        if side is not main:
+            main.wait_stream(side)
+        segment_break(early=True)
+        if side is not main:
+            side.wait_stream(main)
+        with torch.cuda.stream(side):
+            gan_real = [GAN_G_loss(o) for o in self.discriminator(generator_output_real).values()]
+            out_real = self.latent_discriminator(real_latents)
         for i, o in enumerate(self.synth_discriminator(generator_output_synth).values()):
             losses["GAN_loss_synth_" + str(i)] = GAN_G_loss(o)
         out_synth = self.latent_discriminator(synth_latents)
@@ -169,14 +179,18 @@ class ConfigNet(ConfigNetFirstStage):
         """One reference training iteration (confignet_second_stage.py:277-288): D, synth-D, latent-D,
         G, EMA.  Returns the four loss dicts (device scalars; no host sync here)."""
         with self._main_line():
-            for _ in range(self.config["n_discriminator_updates"]):
-                d_loss, synth_d_loss, latent_d_loss = self.run_concurrently([
-                    lambda: self.discriminator_training_step(real_training_set, discriminator_optimizer),
-                    lambda: self.synth_discriminator_training_step(synth_training_set, discriminator_optimizer),
-                    lambda: self.latent_discriminator_training_step(real_training_set, synth_training_set,
-                                                                    discriminator_optimizer)])
-            for _ in range(self.config["n_generator_updates"]):
-                g_loss = self.generator_training_step(real_training_set, synth_training_set, generator_optimizer)
+            d_steps = [lambda: self.discriminator_training_step(real_training_set, discriminator_optimizer),
+                       lambda: self.synth_discriminator_training_step(synth_training_set, discriminator_optimizer),
+                       lambda: self.latent_discriminator_training_step(real_training_set, synth_training_set, discriminator_optimizer)]
+            g_step = lambda: self.generator_training_step(real_training_set, synth_training_set, generator_optimizer)
+            nd, ng = self.config["n_discriminator_updates"], self.config["n_generator_updates"]
+            for i in range(nd):
+                out = self.run_concurrently(d_steps, then=g_step if (i == nd - 1 and ng >= 1) else None)
+                d_loss, synth_d_loss, latent_d_loss = out[:3]
+                if len(out) > 3:
+                    g_loss = out[3]
+            for _ in range(ng - 1 if nd >= 1 else ng):
+                g_loss = g_step()
             self.update_smoothed_weights()
         return d_loss, synth_d_loss, latent_d_loss, g_loss
 

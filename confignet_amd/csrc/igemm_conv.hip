@@ -956,6 +956,9 @@ __global__ __launch_bounds__(256) void up2k4_rgb_fwd_kernel(CnConvGeom g, const 
 }
 
 static int g_force_kb16 = -1;
+static int g_tune_cfg = getenv("CN_CFG") ? atoi(getenv("CN_CFG")) : -1;          // read once (not per launch)
+static int g_tune_splits = getenv("CN_SPLITS") ? atoi(getenv("CN_SPLITS")) : 0;
+static long g_tune_wg_blocks = getenv("CN_WG_BLOCKS") ? atol(getenv("CN_WG_BLOCKS")) : 0;
 static int g_xcd = getenv("CN_NO_XCD") ? 0 : 1;
 
 template <int WM, int WN, int TM, int TN>
@@ -997,7 +1000,7 @@ int launch_wgrad(const CnConvGeom& g, const float* x, const float* gy, float* gw
     const long M = (long)g.n * g.out_d * g.out_h * g.out_w;
     const long Ktot = (long)g.k_d * g.k_h * g.k_w * g.cin;
     const long tiles = (long)cn_cdiv(Ktot, BMt) * cn_cdiv(g.cout, BNt);
-    static const long wg_blocks = getenv("CN_WG_BLOCKS") ? atol(getenv("CN_WG_BLOCKS")) : 2048;   // sweep 256..4096: flat from 1536 up
+    const long wg_blocks = g_tune_wg_blocks > 0 ? g_tune_wg_blocks : 2048;   // sweep 256..4096: flat from 1536 up
     long splits = (wg_blocks + tiles - 1) / tiles;
     long rows = (M + splits - 1) / splits;
     if (rows < 256) rows = 256;
@@ -1136,8 +1139,8 @@ extern "C" int cn_conv_fwd(const CnConvGeom* gp, const float* x, const float* w,
         if (want > nks / min_steps) want = nks / min_steps;
         if (want > 1) splits = (int)want;
     }
-    if (const char* e = getenv("CN_CFG")) cfg = atoi(e);          // tuning overrides (scripts/conv_tune.py)
-    if (const char* e = getenv("CN_SPLITS")) splits = atoi(e);
+    if (g_tune_cfg >= 0) cfg = g_tune_cfg;                        // tuning overrides (cn_conv_tune; scripts/conv_sweep.py)
+    if (g_tune_splits > 0) splits = g_tune_splits;
     const int kact = splits > 1 ? CN_ACT_NONE : act;
     if (splits > 1) {
         if (int ez__ = cn_zero_async(y, sizeof(float) * M * g.cout, s)) return ez__;
@@ -1226,5 +1229,15 @@ extern "C" int cn_sumpool2(const void* gu, void* gx, int nd, int n, int d, int h
             hipLaunchKernelGGL((sumpool2_kernel<2, T>), dim3(cn_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, (const T*)gu, (T*)gx, n, d, h, w, c / 4);
     });
     CN_LAUNCH_CHECK();
+    return CN_OK;
+}
+
+// Tuning hook (scripts/conv_sweep.py): force the tile configuration (0 = 128x128, 1 = 128x64, 2 = 64x64, 3 = 128x32, 4 = 128x96;
+// -1 = heuristic), the split-K factor of cn_conv_fwd / cn_conv_dgrad (0 = heuristic) and the workgroup target of cn_conv_wgrad
+// (0 = default).  Process-wide; not for production use.
+extern "C" int cn_conv_tune(int cfg, int splits, long wg_blocks) {
+    g_tune_cfg = cfg;
+    g_tune_splits = splits;
+    g_tune_wg_blocks = wg_blocks;
     return CN_OK;
 }

@@ -16,16 +16,23 @@ from .nn import WEIGHTS_EPOCH
 _recording = None        # the StepGraph whose fn is being captured right now
 
 
-def segment_break(action):
-    """Called by a step function between two parts of its device half.  `action()` is an eager launch that cannot live inside
-    a HIP graph (an RCCL all-reduce) and that should start as soon as the first part has run while the second part goes on:
-    eager dispatch runs it on the spot; under capture the graph is cut here -- replay = segment, action, segment, ... --
-    (data-parallel generator step: the generator / regressor gradient arenas are exchanged under the encoder's backward)."""
+def segment_break(action=None, early=False):
+    """Called by a step function between two parts of its device half; under capture the step's graph is cut here (replay =
+    segment, action, segment, ...), eager dispatch just runs `action` on the spot.
+    * `action()`: an eager launch that cannot live inside a HIP graph (an RCCL all-reduce) and that should start as soon as the
+      first part has run while the second part goes on (data-parallel generator step: the generator / regressor gradient
+      arenas are exchanged under the encoder's backward).
+    * early=True marks that everything BEFORE this point reads nothing the sibling steps of the iteration write (the
+      generator step's generator / encoder / VGG forward passes do not touch discriminator weights): the iteration replays
+      those segments next to the discriminator-type graphs instead of after them (ConfigNetFirstStage._flush_deferred)."""
     g = _recording
     if g is None:
-        action()
+        if action is not None:
+            action()
     else:
         g._cut(action)
+        if early:
+            g.early_cut = len(g.segments)
 
 
 class StepGraph:
@@ -45,6 +52,7 @@ class StepGraph:
         self.split = parallel.active()
         self.tail = []
         self.segments = []           # [(CUDAGraph, action run after it | None)]; self.graph is the last segment
+        self.early_cut = 0           # segments[:early_cut] may run concurrently with the iteration's sibling steps
 
     def _run_fn(self):
         if not self.split:
@@ -77,8 +85,8 @@ class StepGraph:
         self.segments.append((self._cur, action))
         self._begin()
 
-    def replay(self):
-        for g, action in self.segments:
+    def replay(self, start=0, stop=None):
+        for g, action in self.segments[start:stop]:
             g.replay()
             if action is not None:
                 action()

@@ -73,6 +73,9 @@ int cn_conv_dgrad(const CnConvGeom* g, const float* gy, const float* w_tflip, fl
 /* Filter gradient (Conv*DBackpropFilter): gw[(t,ci),co] (+)= sum_m x[src(m,t),ci]*gy[m,co]; gw is overwritten,
  * or accumulated into when `accumulate` != 0 (the caller guarantees its previous content, e.g. zeros). */
 int cn_conv_wgrad(const CnConvGeom* g, const float* x, const float* gy, float* gw, int accumulate, void* stream);
+/* Tuning hook: force the tile configuration (0 = 128x128, 1 = 128x64, 2 = 64x64, 3 = 128x32, 4 = 128x96; -1 = heuristic), the
+ * split-K factor of cn_conv_fwd / cn_conv_dgrad (0 = heuristic) and the workgroup target of cn_conv_wgrad (0 = default). */
+int cn_conv_tune(int cfg, int splits, long wg_blocks);
 /* Backward of the folded nearest x2 upsample: out[n,p,c] = sum of the 2^nd children of p. */
 int cn_sumpool2(const void* gu, void* gx, int nd, int n, int d, int h, int w, int c, int dt, void* stream);
 
