@@ -17,7 +17,7 @@ __device__ __forceinline__ float4 lrelu4(float4 v, float s) {
 template <int V, typename T>   // V = 4: 4-wide channel groups, V = 1: scalar channels; T: storage type of x1 / x2
 __global__ __launch_bounds__(256) void nc_reduce_kernel(const T* __restrict__ x1, const T* __restrict__ x2,
                                                         float* __restrict__ s1, float* __restrict__ s2, int S, int C,
-                                                        int rows_per_block, int flags, float slope) {
+                                                        int rows_per_block, int flags, float slope, int period2) {
     const int CG = C / V;                          // channel groups
     const int tx = threadIdx.x, ty = threadIdx.y, TX = blockDim.x, TY = blockDim.y;
     const int cg = blockIdx.x * TX + tx;
@@ -28,6 +28,7 @@ __global__ __launch_bounds__(256) void nc_reduce_kernel(const T* __restrict__ x1
     for (int e = 0; e < V; ++e) a1[e] = a2[e] = 0.f;
     if (cg < CG) {
         const long base = (long)n * S * C + (long)cg * V;
+        const long base2 = (long)(period2 ? n % period2 : n) * S * C + (long)cg * V;     // x2 may hold fewer samples (tiled)
         for (int s = sbeg + ty; s < send; s += TY) {
             float a[V], b[V];
             if (V == 4) {
@@ -35,7 +36,7 @@ __global__ __launch_bounds__(256) void nc_reduce_kernel(const T* __restrict__ x1
                 if (flags & 1) va = lrelu4(va, slope);
                 a[0] = va.x; a[1 % V] = va.y; a[2 % V] = va.z; a[3 % V] = va.w;
                 if (x2) {
-                    float4 vb = ld4<T>(x2 + base + (long)s * C);
+                    float4 vb = ld4<T>(x2 + base2 + (long)s * C);
                     if (flags & 2) vb = lrelu4(vb, slope);
                     b[0] = vb.x; b[1 % V] = vb.y; b[2 % V] = vb.z; b[3 % V] = vb.w;
                 }
@@ -43,7 +44,7 @@ __global__ __launch_bounds__(256) void nc_reduce_kernel(const T* __restrict__ x1
                 a[0] = ldf<T>(x1 + base + (long)s * C);
                 if (flags & 1) a[0] = lrelu(a[0], slope);
                 if (x2) {
-                    b[0] = ldf<T>(x2 + base + (long)s * C);
+                    b[0] = ldf<T>(x2 + base2 + (long)s * C);
                     if (flags & 2) b[0] = lrelu(b[0], slope);
                 }
             }
@@ -82,13 +83,14 @@ __global__ __launch_bounds__(256) void nc_lin2_kernel(const T* __restrict__ x1, 
                                                       const T* __restrict__ x2, const float* __restrict__ a2,
                                                       const float* __restrict__ bb, const float* __restrict__ a3,
                                                       const float* __restrict__ b3, T* __restrict__ y, long total_g,
-                                                      int S, int C, int cstride, int flags, float slope) {
+                                                      int S, int C, int cstride, int flags, float slope, int period2) {
     const int CG = C / V;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total_g; i += (long)gridDim.x * blockDim.x) {
         const int cg = (int)(i % CG);
         const long row = i / CG;
         const int n = (int)(row / S);
         const long ci = (long)n * cstride + (long)cg * V;
+        const long i2 = period2 ? (((long)(n % period2) * S + (row - (long)n * S)) * CG + cg) : i;   // x2 tiled over samples
         float r[V];
 #pragma unroll
         for (int e = 0; e < V; ++e) r[e] = bb ? bb[ci + e] : 0.f;
@@ -104,7 +106,7 @@ __global__ __launch_bounds__(256) void nc_lin2_kernel(const T* __restrict__ x1, 
         if (x2) {
 #pragma unroll
             for (int e = 0; e < V; ++e) {
-                raw2[e] = ldf<T>(x2 + i * V + e);
+                raw2[e] = ldf<T>(x2 + i2 * V + e);
                 float v = raw2[e];
                 if (flags & 2) v = lrelu(v, slope);
                 r[e] += (a2 ? a2[ci + e] : 1.f) * v;
@@ -136,7 +138,7 @@ __global__ __launch_bounds__(256) void nc_lin2_rows_kernel(const T* __restrict__
                                                            const T* __restrict__ x2, const float* __restrict__ a2,
                                                            const float* __restrict__ bb, const float* __restrict__ a3,
                                                            const float* __restrict__ b3, T* __restrict__ y, int G,
-                                                           int CG, int cstride, int flags, float slope) {
+                                                           int CG, int cstride, int flags, float slope, int period2) {
     const int t0 = blockIdx.x * 256 + threadIdx.x;
     const int adv = gridDim.x * 256;
     const int cg = t0 % CG;
@@ -151,9 +153,11 @@ __global__ __launch_bounds__(256) void nc_lin2_rows_kernel(const T* __restrict__
         kb3[e] = (a3 && b3) ? b3[ci + e] : 0.f;
     }
     const long base = (long)blockIdx.y * G;
+    const long base2 = (long)(period2 ? blockIdx.y % period2 : blockIdx.y) * G;      // x2 tiled over samples
     const bool f1 = flags & 1, f2 = flags & 2, fm = flags & 4, fr = flags & 8;
     for (int j = t0; j < G; j += adv) {
         const long i = (base + j) * V;
+        const long i2 = (base2 + j) * V;
         float v1[V], v2[V], r[V];
         if (V == 4) {
             if (x1) {
@@ -161,12 +165,12 @@ __global__ __launch_bounds__(256) void nc_lin2_rows_kernel(const T* __restrict__
                 v1[0] = t.x; v1[1 % V] = t.y; v1[2 % V] = t.z; v1[3 % V] = t.w;
             }
             if (x2) {
-                const float4 t = ld4<T>(x2 + i);
+                const float4 t = ld4<T>(x2 + i2);
                 v2[0] = t.x; v2[1 % V] = t.y; v2[2 % V] = t.z; v2[3 % V] = t.w;
             }
         } else {
             if (x1) v1[0] = ldf<T>(x1 + i);
-            if (x2) v2[0] = ldf<T>(x2 + i);
+            if (x2) v2[0] = ldf<T>(x2 + i2);
         }
 #pragma unroll
         for (int e = 0; e < V; ++e) {
@@ -535,10 +539,12 @@ extern "C" int cn_nc_reduce(const void* x1, const void* x2, float* s1, float* s2
     if (rpb < 4 * TY) rpb = 4 * TY;
     const int sblk = cn_cdiv(s, rpb);
     dim3 grid(cblk, sblk, n), block(TX, TY);
+    const int period2 = flags >> 8;                 // bits 8..: x2 holds `period2` samples, used for sample n as n % period2
+    CN_CHECK_ARG(period2 == 0 || (x2 && n % period2 == 0), "nc_reduce: bad x2 period %d for n = %d", period2, n);
     CN_DISPATCH_DT(dt, {
         const T* p1 = (const T*)x1; const T* p2 = (const T*)x2;
-        if (V == 4) hipLaunchKernelGGL((nc_reduce_kernel<4, T>), grid, block, 0, st, p1, p2, s1, s2, s, c, (int)rpb, flags, slope);
-        else hipLaunchKernelGGL((nc_reduce_kernel<1, T>), grid, block, 0, st, p1, p2, s1, s2, s, c, (int)rpb, flags, slope);
+        if (V == 4) hipLaunchKernelGGL((nc_reduce_kernel<4, T>), grid, block, 0, st, p1, p2, s1, s2, s, c, (int)rpb, flags & 255, slope, period2);
+        else hipLaunchKernelGGL((nc_reduce_kernel<1, T>), grid, block, 0, st, p1, p2, s1, s2, s, c, (int)rpb, flags & 255, slope, period2);
     });
     CN_LAUNCH_CHECK();
     return CN_OK;
@@ -552,6 +558,9 @@ extern "C" int cn_nc_lin2(const void* x1, const float* a1, const void* x2, const
     const int V = (c % 4 == 0) ? 4 : 1;
     const long total = (long)n * s * (c / V);
     hipStream_t st = (hipStream_t)stream;
+    const int period2 = flags >> 8;                 // bits 8..: x2 holds `period2` samples, used for sample n as n % period2
+    CN_CHECK_ARG(period2 == 0 || (x2 && cstride && n % period2 == 0), "nc_lin2: bad x2 period %d for n = %d", period2, n);
+    flags &= 255;
     {
         // big tensors: per-sample grid with a fixed channel group per thread (nc_lin2_rows_kernel)
         const int CG = c / V;
@@ -566,16 +575,16 @@ extern "C" int cn_nc_lin2(const void* x1, const float* a1, const void* x2, const
             if (gx < 1) gx = 1;
             gx = (gx + q - 1) / q * q;
             CN_DISPATCH_DT(dt, {
-                if (V == 4) hipLaunchKernelGGL((nc_lin2_rows_kernel<4, T>), dim3((unsigned)gx, ny), dim3(256), 0, st, (const T*)x1, a1, (const T*)x2, a2, bb, a3, b3, (T*)y, (int)G, CG, cstride, flags, slope);
-                else hipLaunchKernelGGL((nc_lin2_rows_kernel<1, T>), dim3((unsigned)gx, ny), dim3(256), 0, st, (const T*)x1, a1, (const T*)x2, a2, bb, a3, b3, (T*)y, (int)G, CG, cstride, flags, slope);
+                if (V == 4) hipLaunchKernelGGL((nc_lin2_rows_kernel<4, T>), dim3((unsigned)gx, ny), dim3(256), 0, st, (const T*)x1, a1, (const T*)x2, a2, bb, a3, b3, (T*)y, (int)G, CG, cstride, flags, slope, period2);
+                else hipLaunchKernelGGL((nc_lin2_rows_kernel<1, T>), dim3((unsigned)gx, ny), dim3(256), 0, st, (const T*)x1, a1, (const T*)x2, a2, bb, a3, b3, (T*)y, (int)G, CG, cstride, flags, slope, period2);
             });
             CN_LAUNCH_CHECK();
             return CN_OK;
         }
     }
     CN_DISPATCH_DT(dt, {
-        if (V == 4) hipLaunchKernelGGL((nc_lin2_kernel<4, T>), dim3(ew_blocks(total)), dim3(256), 0, st, (const T*)x1, a1, (const T*)x2, a2, bb, a3, b3, (T*)y, total, s, c, cstride, flags, slope);
-        else hipLaunchKernelGGL((nc_lin2_kernel<1, T>), dim3(ew_blocks(total)), dim3(256), 0, st, (const T*)x1, a1, (const T*)x2, a2, bb, a3, b3, (T*)y, total, s, c, cstride, flags, slope);
+        if (V == 4) hipLaunchKernelGGL((nc_lin2_kernel<4, T>), dim3(ew_blocks(total)), dim3(256), 0, st, (const T*)x1, a1, (const T*)x2, a2, bb, a3, b3, (T*)y, total, s, c, cstride, flags, slope, period2);
+        else hipLaunchKernelGGL((nc_lin2_kernel<1, T>), dim3(ew_blocks(total)), dim3(256), 0, st, (const T*)x1, a1, (const T*)x2, a2, bb, a3, b3, (T*)y, total, s, c, cstride, flags, slope, period2);
     });
     CN_LAUNCH_CHECK();
     return CN_OK;

@@ -71,11 +71,12 @@ def discr_block(x, w4, return_styles, twice_differentiable=False, intermediates=
     twice_differentiable=True every op is twice differentiable (composite path, kept as the cross-check of
     the tangent-pass R1).  `intermediates` (a list) receives the primal tensors the tangent pass reuses."""
     ck, cb, gamma, beta = w4
+    in_shape = tuple(x.shape)
     x = F.conv(x, ck, cb, DISCR_CONV)
     if not twice_differentiable:
         y, style, mean, q, smean, ssd = F.DiscrTailFn.apply(x, gamma, beta, return_styles, KERAS_LRELU)
         if intermediates is not None:
-            intermediates.append({"x": x, "mean": mean, "q": q, "smean": smean, "ssd": ssd})
+            intermediates.append({"x": x, "mean": mean, "q": q, "smean": smean, "ssd": ssd, "in_shape": in_shape})
         return y, style
     styles = F.layer_style(x) if return_styles else None
     x = F.instance_norm(F.lrelu(x, KERAS_LRELU), gamma, beta)

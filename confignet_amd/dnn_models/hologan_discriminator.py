@@ -60,6 +60,45 @@ class HologanDiscriminator(Net):
         out["discr_final"] = F.linear(x, w[-2], w[-1])
         return out
 
+    def input_gradients(self, intermediates):
+        """[d sum_n out_i / d image for every head i] -- what losses.py:75-82 asks the inner tape for, head by head
+        (`tape.gradient(out_i, real_imgs)`) -- computed for ALL heads in ONE backward sweep without a tape: the cotangents of
+        the heads still "above" a block are stacked along the batch axis (head b joins at block b through its style
+        statistics), so every block runs one statistics pass, one affine pass and ONE data-gradient convolution on
+        (6 - b) * N samples instead of 6 - b separate launches on N (the activations are read through a sample period, not
+        copied).  Constants of the outer tape: the callers detach these gradients anyway (the penalty's weight gradient
+        flows through `tangent`)."""
+        from .. import ops
+        from .building_blocks import DISCR_CONV, KERAS_LRELU
+        w, nr = self.weights, self.num_resample
+        heads = 2 + 4 * nr
+        n = intermediates[0]["x"].shape[0]
+        with torch.no_grad():
+            last = intermediates[-1]["x"]
+            # final head: out = flatten(y_last) @ W + b  ->  d out / d y_last = W, the same for every sample
+            G = w[-2].detach().reshape(1, *last.shape[1:]).expand(n, *last.shape[1:]).contiguous()
+            for b in reversed(range(nr)):
+                it = intermediates[b]
+                x = it["x"]
+                sp, c = x.numel() // (x.shape[0] * x.shape[-1]), x.shape[-1]
+                h = G.shape[0] // n                                   # heads above this block
+                out = torch.empty(((h + 1) * n, *x.shape[1:]), device=x.device, dtype=x.dtype)
+                # heads above: instance norm + LeakyReLU backward (building_blocks.py:105-106), all of them at once
+                t1, t2 = ops.nc_reduce(G, x, flags=2, slope=KERAS_LRELU, x2_period=n)
+                c1, c2, c0, _, _ = ops.norm_coef_bwd(ops.NORM_INSTANCE, t1, t2, it["mean"].repeat(h, 1), it["q"].repeat(h, 1),
+                                                     w[4 + 4 * b].detach(), sp, 1e-3)
+                ops.nc_lin2((h * n, *x.shape[1:]), G, c1, x, c2, c0, flags=2 | 4, slope=KERAS_LRELU, x2_period=n, out=out[n:])
+                # head b enters through the style statistics of this block's pre-activation (building_blocks.py:100-102)
+                gstyle = w[heads + 2 * b].detach().reshape(1, 2 * c).expand(n, 2 * c).contiguous()
+                _, d2, d0, _, _ = ops.norm_coef_bwd(ops.NORM_STYLE, gstyle, None, it["smean"], it["ssd"], None, sp, 1e-6)
+                ops.nc_lin2(tuple(x.shape), x, d2, b=d0, out=out[:n])
+                # the block's stride-2 convolution: one data-gradient launch for every head
+                k = w[2 + 4 * b]
+                in_shape = (out.shape[0],) + tuple(it["in_shape"][1:])
+                G = ops.conv_dgrad(out, k.detach(), DISCR_CONV.geom(in_shape, c))
+            g_img = ops.conv_dgrad(G, w[0].detach(), C1.geom(tuple(G.shape), 3))     # from-RGB 1x1 convolution
+        return [g_img[i * n:(i + 1) * n] for i in range(nr + 1)]
+
     def tangent(self, v, intermediates, head):
         """JVP of output `head` (0..n-1 style heads, n = final head) w.r.t. the input image in direction v,
         evaluated at the primal pass that filled `intermediates`.  Linear layers act on the tangent without

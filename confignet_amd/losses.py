@@ -1,8 +1,12 @@
 """Losses (reference: confignet/losses.py) on HIP kernels."""
+import os
+
 import numpy as np
 import torch
 
 from . import functional as F
+
+BATCHED_R1 = os.environ.get("CN_NO_BATCHED_R1") is None
 
 
 def GAN_G_loss(scores):
@@ -63,9 +67,12 @@ def compute_discriminator_loss(discriminator, real_imgs, fake_imgs, second_order
         losses["GAN_loss_real_" + str(i)] = GAN_D_loss(1.0, o)
     for i, o in enumerate(out_fake.values()):
         losses["GAN_loss_fake_" + str(i)] = GAN_D_loss(0.0, o)
-    with F.input_grads_only():
-        gs = [torch.autograd.grad(o, real_imgs, grad_outputs=torch.ones_like(o), retain_graph=True)[0]
-              for o in out_real.values()]
+    if BATCHED_R1 and hasattr(discriminator, "input_gradients"):
+        gs = discriminator.input_gradients(inter)              # all six heads in one tape-free backward sweep
+    else:
+        with F.input_grads_only():
+            gs = [torch.autograd.grad(o, real_imgs, grad_outputs=torch.ones_like(o), retain_graph=True)[0]
+                  for o in out_real.values()]
     for i, g in enumerate(gs):
         g = g.detach()
         jvp = discriminator.tangent(g, inter, i).reshape(-1)          # == |g_n|^2, carries d/dtheta

@@ -379,10 +379,13 @@ def _nsc(x):
     return n, x.numel() // (n * c), c
 
 
-def nc_reduce(x1, x2=None, want_sum=True, want_dot=True, flags=0, slope=0.0, per_channel=False):
-    """(sum_s f1(x1), sum_s f1(x1)*f2(x2 or x1)) per (n, c); per_channel folds n into s."""
+def nc_reduce(x1, x2=None, want_sum=True, want_dot=True, flags=0, slope=0.0, per_channel=False, x2_period=0):
+    """(sum_s f1(x1), sum_s f1(x1)*f2(x2 or x1)) per (n, c); per_channel folds n into s.
+    x2_period: x2 holds only that many samples and sample n of x1 pairs with x2[n % x2_period]."""
     x1, x2 = _unify(x1, x2)
     n, s, c = _nsc(x1)
+    assert not (x2_period and per_channel)
+    flags |= x2_period << 8
     rep = 1
     if per_channel:
         # every workgroup ends in one atomic per channel: spread a long reduction over `rep` partial rows (as if
@@ -415,14 +418,23 @@ def nc_reduce(x1, x2=None, want_sum=True, want_dot=True, flags=0, slope=0.0, per
     return s1, s2
 
 
-def nc_lin2(shape, x1=None, a1=None, x2=None, a2=None, b=None, flags=0, slope=0.0, per_channel=False, a3=None, b3=None):
-    """y = a1*f1(x1) + a2*f2(x2) + b with (n,c) [or (c,)] coefficients broadcast over space."""
+def nc_lin2(shape, x1=None, a1=None, x2=None, a2=None, b=None, flags=0, slope=0.0, per_channel=False, a3=None, b3=None,
+            x2_period=0, out=None):
+    """y = a1*f1(x1) + a2*f2(x2) + b with (n,c) [or (c,)] coefficients broadcast over space.
+    x2_period: as in nc_reduce.  out: write into this (contiguous) tensor instead of a new one."""
     n, c = shape[0], shape[-1]
     s = int(math.prod(shape)) // (n * c)
     x1, x2 = _unify(x1, x2)
     ref = x1 if x1 is not None else (x2 if x2 is not None else b)
     dtype = ref.dtype if (x1 is not None or x2 is not None) else _act_out_dtype(c)
-    y = torch.empty(shape, device=ref.device, dtype=dtype)
+    if out is not None:
+        assert out.is_contiguous() and out.numel() == int(math.prod(shape))
+        if out.dtype != dtype:                     # the caller's buffer decides the storage type
+            x1, x2 = (None if x1 is None else cast(x1, out.dtype)), (None if x2 is None else cast(x2, out.dtype))
+        y = out
+    else:
+        y = torch.empty(shape, device=ref.device, dtype=dtype)
+    flags |= x2_period << 8
     check(lib.cn_nc_lin2(_ptr(x1), _fptr(a1), _ptr(x2), _fptr(a2), _fptr(b), _fptr(a3), _fptr(b3), _ptr(y), n, s, c,
                          0 if per_channel else c, flags, slope, _dt(y), _stream()), "cn_nc_lin2")
     return y

@@ -120,12 +120,14 @@ int cn_gemm(int trans_a, int trans_b, int m, int n, int k, const float* a, int l
  * (keras ResNet50), global average pooling and every bias gradient.
  *   a = f1(x1), b = x2 ? f2(x2) : a ;  sum1[n,c] = sum_s a ; sum2[n,c] = sum_s a*b
  *   flags: bit0 leaky-relu(slope) on x1, bit1 leaky-relu(slope) on x2, bit4: the outputs are already zero
- *   (skip the clearing launch).  Outputs are overwritten. */
+ *   (skip the clearing launch); bits 8..: x2 holds only (flags >> 8) samples and sample n reads x2[n % period] (the batched
+ *   R1 input-gradient pass stacks the cotangents of several heads along n against ONE copy of the activations).
+ *   Outputs are overwritten. */
 int cn_nc_reduce(const void* x1, const void* x2, float* sum1, float* sum2, int n, int s, int c,
                  int flags, float slope, int dt, void* stream);
 /* y = A1*f1(x1) + A2*f2(x2) + B, coefficient tensors indexed [n*cstride + c] (cstride = c, or 0 for
  * per-channel coefficients).  flags: bit0/bit1 as above, bit2: multiply the result by lrelu'(x2),
- * bit3: relu on the result.  x1, x2 and B are each optional (NULL); a NULL coefficient of a present
+ * bit3: relu on the result, bits 8..: x2 sample period as in cn_nc_reduce.  x1, x2 and B are each optional (NULL); a NULL coefficient of a present
  * x means 1.  If a3 != NULL, a3*x2 + b3 (raw x2) is added after the bit2 mask -- the style-statistics
  * gradient that joins the instance-norm gradient in DiscrBlock (building_blocks.py:100-106). */
 int cn_nc_lin2(const void* x1, const float* a1, const void* x2, const float* a2, const float* bb,

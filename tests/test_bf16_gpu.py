@@ -206,7 +206,7 @@ def test_bf16_generator_and_discriminator_loss_against_the_fp32_oracle():
         assert rel <= 0.3 and cos >= 0.95, "bf16 discriminator (R1) grad[%d] %s: rel-L2 %.3e cos %.4f" % (i, tuple(p.shape), rel, cos)
     got = torch.cat([p.grad.detach().cpu().double().reshape(-1) for p in d.weights])
     ref = torch.cat([r.reshape(-1) for r in gr])
-    assert float((got - ref).norm() / ref.norm()) <= 0.2 and float((got * ref).sum() / (got.norm() * ref.norm())) >= 0.98
+    assert float((got - ref).norm() / ref.norm()) <= 0.3 and float((got * ref).sum() / (got.norm() * ref.norm())) >= 0.98
 
 
 def test_bf16_second_stage_iteration_runs_under_graph_dispatch_and_tracks_the_fp32_run():
