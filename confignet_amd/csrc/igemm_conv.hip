@@ -94,7 +94,10 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(CnConvGeom g, const floa
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    float4 ra[AP], rb[BP];
+    // two register sets: loads of K step s+2 are issued while step s is multiplied and step s+1 is still in flight, so a
+    // gathered operand has two steps of MFMA time to arrive (small tiles give a workgroup only 512 MFMA cycles per step and
+    // small problems only 1-2 workgroups per CU: one step did not cover the L2/HBM latency -- MFMA-busy 0.41 on the 64x64 tile)
+    float4 ra0[AP], rb0[BP], ra1[AP], rb1[BP];
     const int cpb = VEC ? g.cin / KB : 1;
     const int nks_all = VEC ? __popcll(tapmask) * cpb : (Ktot + BK - 1) / BK;
     // split-K over gridDim.z (small-M problems): this workgroup walks K steps [ks_beg, ks_end)
@@ -116,7 +119,7 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(CnConvGeom g, const floa
     // Tap-minor (tap_minor != 0: all taps of a channel chunk, then the next chunk) recomputes them every step but keeps
     // the XCD's working set at (tiles in flight) x (rows) x KB channels, so the taps' shifted re-reads of a chunk hit
     // the 4 MiB L2 instead of going back to the fabric (stride-1 layers with many channels).
-    auto load_tiles = [&](int ks) {
+    auto load_tiles = [&](int ks, float4 (&ra)[AP], float4 (&rb)[BP]) {
         if (VEC) {
             int c0;
             if (tap_minor) {
@@ -188,7 +191,7 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(CnConvGeom g, const floa
             }
         }
     };
-    auto store_tiles = [&](int buf) {
+    auto store_tiles = [&](int buf, const float4 (&ra)[AP], const float4 (&rb)[BP]) {
 #pragma unroll
         for (int i = 0; i < AP; ++i) {
             const int r = arow + RPP * i;
@@ -207,17 +210,25 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(CnConvGeom g, const floa
 
     const int a_col = wm * 32 * TM + l31, b_col = wn * 32 * TN + l31;
     if (ks_beg < ks_end) {
-        load_tiles(ks_beg);
-        store_tiles(0);
+        load_tiles(ks_beg, ra0, rb0);
+        store_tiles(0, ra0, rb0);
     }
+    if (ks_beg + 1 < ks_end) load_tiles(ks_beg + 1, ra1, rb1);
     __syncthreads();
-    for (int ks = ks_beg; ks < ks_end; ++ks) {
-        const int buf = (ks - ks_beg) & 1;
-        if (ks + 1 < ks_end) load_tiles(ks + 1);
-        mma_step<TM, TN, LDA, LDB, KB>(As[buf], Bs[buf], acc, a_col, b_col, half);
-        if (ks + 1 < ks_end) store_tiles(buf ^ 1);
+    int ks = ks_beg;
+    for (; ks + 1 < ks_end; ks += 2) {
+        // even step: LDS buffer 0 holds step ks, set 1 holds step ks+1 (in flight), step ks+2 goes to set 0
+        if (ks + 2 < ks_end) load_tiles(ks + 2, ra0, rb0);
+        mma_step<TM, TN, LDA, LDB, KB>(As[0], Bs[0], acc, a_col, b_col, half);
+        store_tiles(1, ra1, rb1);
+        __syncthreads();
+        // odd step: buffer 1 holds step ks+1, set 0 holds step ks+2, step ks+3 goes to set 1
+        if (ks + 3 < ks_end) load_tiles(ks + 3, ra1, rb1);
+        mma_step<TM, TN, LDA, LDB, KB>(As[1], Bs[1], acc, a_col, b_col, half);
+        if (ks + 2 < ks_end) store_tiles(0, ra0, rb0);
         __syncthreads();
     }
+    if (ks < ks_end) mma_step<TM, TN, LDA, LDB, KB>(As[0], Bs[0], acc, a_col, b_col, half);   // odd number of steps: the last one
 
     // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     const bool split = gridDim.z > 1;

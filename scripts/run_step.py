@@ -11,6 +11,7 @@ cfg = merge_configs(DEFAULT_CONFIG, {"batch_size": 16, "output_shape": (256, 256
 ds.process_metadata(cfg, True)
 m = ConfigNet(cfg, seed=0)
 m.setup_training(None, ds, 0, real_training_set=ds)
+m.use_graphs = os.environ.get("CN_USE_GRAPHS") == "1"
 dopt, gopt = optim.Adam(**cfg["optimizer"]), optim.Adam(**cfg["optimizer"])
 fn = {"d": lambda: m.discriminator_training_step(ds, dopt), "sd": lambda: m.synth_discriminator_training_step(ds, dopt),
       "ld": lambda: m.latent_discriminator_training_step(ds, ds, dopt), "g": lambda: m.generator_training_step(ds, ds, gopt)}[which]
