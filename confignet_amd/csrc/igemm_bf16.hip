@@ -99,11 +99,11 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(CnConvGeom g, const bf1
 
     const int cpb = (g.cin + KS - 1) / KS;         // stages per tap (the last one may be partly zero: cin = 48)
     const int nks = __popcll(tapmask) * cpb;
-    uint4 ra[AP], rb[BP];
+    uint4 ra0[AP], rb0[BP], ra1[AP], rb1[BP];      // two register sets: operands of stage s+2 in flight while stage s is multiplied
     int aoff[AP];
     int cur_ord = -1, cur_tap = -1;
 
-    auto load_tiles = [&](int ks) {
+    auto load_tiles = [&](int ks, uint4 (&ra)[AP], uint4 (&rb)[BP]) {
         const int ord = ks / cpb;
         const int c0 = (ks - ord * cpb) * KS + kq * 8;
         if (ord != cur_ord) {
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(CnConvGeom g, const bf1
                                                        : make_uint4(0, 0, 0, 0);
         }
     };
-    auto store_tiles = [&](int buf) {
+    auto store_tiles = [&](int buf, const uint4 (&ra)[AP], const uint4 (&rb)[BP]) {
 #pragma unroll
         for (int i = 0; i < AP; ++i)
             *reinterpret_cast<uint4*>(As + ((size_t)buf * BM + arow + 64 * i) * LDK + kq * 8) = ra[i];
@@ -140,15 +140,8 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(CnConvGeom g, const bf1
         }
     };
 
-    if (nks > 0) {
-        load_tiles(0);
-        store_tiles(0);
-    }
-    __syncthreads();
     const int a_row = wm * 32 * TM + l31, b_row = wn * 32 * TN + l31;
-    for (int ks = 0; ks < nks; ++ks) {
-        const int buf = ks & 1;
-        if (ks + 1 < nks) load_tiles(ks + 1);
+    auto mma_stage = [&](int buf) {
         Frag a[2][TM], b[2][TN];
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
@@ -166,9 +159,26 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(CnConvGeom g, const bf1
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s][i].v, b[s][j].v, acc[i][j], 0, 0, 0);
-        if (ks + 1 < nks) store_tiles(buf ^ 1);
+    };
+    if (nks > 0) {
+        load_tiles(0, ra0, rb0);
+        store_tiles(0, ra0, rb0);
+    }
+    if (nks > 1) load_tiles(1, ra1, rb1);
+    __syncthreads();
+    int ks = 0;
+    for (; ks + 1 < nks; ks += 2) {
+        if (ks + 2 < nks) load_tiles(ks + 2, ra0, rb0);
+        mma_stage(0);
+        store_tiles(1, ra1, rb1);
+        __syncthreads();
+        if (ks + 3 < nks) load_tiles(ks + 3, ra1, rb1);
+        mma_stage(1);
+        if (ks + 2 < nks) store_tiles(0, ra0, rb0);
         __syncthreads();
     }
+    if (ks < nks) mma_stage(0);
+    __syncthreads();
 
     // epilogue: bias + activation in fp32, bf16 tile through LDS, 16-byte row pieces out.
     // C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
