@@ -385,7 +385,7 @@ class ConfigNetFirstStage:
         if self._deferred is not None:
             if g.graph is not None:
                 self._deferred.append(g)       # replayed together with its independent sibling steps
-                return g.out
+                return g.result()              # (filled by g.finish() right after the replay)
             self._flush_deferred()             # not captured yet: everything collected before it runs first, in order
         return g()
 

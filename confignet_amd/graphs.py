@@ -51,6 +51,7 @@ class StepGraph:
         self.stream = stream if stream is not None else torch.cuda.Stream()
         self.split = parallel.active()
         self.tail = []
+        self.packed, self._result = None, None      # all loss scalars of the step in one static tensor / this call's copy
         self.segments = []           # [(CUDAGraph, action run after it | None)]; self.graph is the last segment
         self.early_cut = 0           # segments[:early_cut] may run concurrently with the iteration's sibling steps
 
@@ -63,9 +64,23 @@ class StepGraph:
         return out
 
     def finish(self):
-        """Eager tail of one execution (no-op for single-rank graphs, whose Adam launches are graph nodes)."""
+        """Eager tail of one execution: the optimizer calls of a data-parallel step (no-op for single-rank graphs, whose Adam
+        launches are graph nodes), then the copy of the step's loss scalars out of the graph's static buffers into the
+        tensor handed to the caller for THIS execution (one small launch)."""
         if self.tail:
             optim.run_deferred(self.tail)
+        if self._result is not None and self.packed is not None:
+            self._result.copy_(self.packed)
+            self._result = None
+
+    def result(self):
+        """The loss dict of the NEXT execution: scalars that are views of a fresh tensor, filled by `finish()` right after
+        the replay -- so a caller may keep last step's dict while the next step runs (the graph's own outputs are static
+        buffers that every replay overwrites)."""
+        if self.packed is None:
+            return self.out
+        self._result = torch.empty_like(self.packed)
+        return {k: self._result[i] for i, k in enumerate(self.out.keys())}
 
     # RCCL's watchdog thread polls events while a process group exists: keep its calls out of the capture
     def _mode(self):
@@ -112,6 +127,8 @@ class StepGraph:
                 _recording = self
                 try:
                     self.out = self._run_fn()
+                    if isinstance(self.out, dict) and self.out and all(torch.is_tensor(v) and v.numel() == 1 for v in self.out.values()):
+                        self.packed = torch.stack([v.reshape(()).float() for v in self.out.values()])
                 finally:
                     _recording = None
                     self._cur.capture_end()
@@ -119,9 +136,10 @@ class StepGraph:
             cur.wait_stream(self.stream)
             self.graph = self._cur
             WEIGHTS_EPOCH[0] += 1
+        res = self.result()
         self.replay()
         self.finish()
-        return self.out
+        return res
 
 
 class InferenceGraph:

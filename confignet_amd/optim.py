@@ -66,7 +66,23 @@ class Adam:
 
     def apply_gradients(self, nets, advance=True, slot="default"):
         """One Keras apply_gradients call over the flat arenas of `nets` (a Net or a list of Nets):
-        data-parallel gradient all-reduce first, then one fused Adam launch per arena."""
+        data-parallel gradient all-reduce first, then one fused Adam launch per arena.
+        Also accepts the Keras form `apply_gradients(zip(gradients, variables))` (confignet_first_stage.py:472-474) when the
+        variables are weights of confignet_amd networks: the gradients are copied into the owners' gradient arenas (weights
+        of those networks that are not listed get a zero gradient, which Keras-Adam with zero moments leaves unchanged)."""
+        if not isinstance(nets, (list, tuple)) and not hasattr(nets, "arena"):
+            nets = list(nets)
+        if isinstance(nets, (list, tuple)) and nets and isinstance(nets[0], (list, tuple)):
+            pairs, nets = nets, []
+            for _, var in pairs:
+                owner = getattr(var, "_cn_owner", None)
+                assert owner is not None, "apply_gradients(zip(grads, vars)): variables must be weights of a confignet_amd network"
+                if all(owner is not n for n in nets):
+                    nets.append(owner)
+                    owner.grad_arena.zero_()
+            for g, var in pairs:
+                if g is not None:
+                    var.grad.copy_(g.reshape(var.shape))
         if not isinstance(nets, (list, tuple)):
             nets = [nets]
         if _deferred is not None:

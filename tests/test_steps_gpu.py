@@ -493,3 +493,43 @@ def test_reference_format_checkpoint_loads_and_the_demo_loop_runs(tmp_path):
     assert a.shape == b.shape == (128, 2 * 276, 3) and np.abs(a.astype(int) - b.astype(int)).max() > 0
     assert abs(s3.rotation_offset[0, 0] - 0.1) < 1e-12 and abs(s3.eye_rotation_offset[0, 0] + 0.05) < 1e-12
     assert ops.ACT_DTYPE == torch.float32
+
+
+def test_loss_dicts_survive_the_next_replay_and_keras_style_apply_gradients():
+    """Boundary details of the step API: (1) in HIP-graph mode the returned loss scalars are copies taken
+    right after the replay, so a caller may keep last iteration's dicts (the reference returns fresh tensors every step);
+    (2) optimizer.apply_gradients(zip(gradients, variables)) -- the Keras call shape of confignet_first_stage.py:472-474 -- works
+    on the weights of a network and equals the arena form."""
+    from confignet_amd import ConfigNet, SyntheticFaceDataset, optim
+    from confignet_amd.confignet_first_stage import DEFAULT_CONFIG
+    from confignet_amd.confignet_utils import merge_configs
+    from confignet_amd.dnn_models.building_blocks import MLPSimple
+    ds = SyntheticFaceDataset(16, 128, seed=3)
+    cfg = merge_configs(DEFAULT_CONFIG, {"batch_size": 4, "output_shape": (128, 128, 3)})
+    ds.process_metadata(cfg, True)
+    np.random.seed(1)
+    m = ConfigNet(cfg, seed=0)
+    m.setup_training(None, ds, 0, real_training_set=ds)
+    m.use_graphs = True
+    dopt, gopt = optim.Adam(**m.config["optimizer"]), optim.Adam(**m.config["optimizer"])
+    for _ in range(3):
+        m.training_iteration(ds, ds, dopt, gopt)
+    kept = m.training_iteration(ds, ds, dopt, gopt)
+    torch.cuda.synchronize()
+    before = [{k: float(v) for k, v in d.items()} for d in kept]
+    nxt = m.training_iteration(ds, ds, dopt, gopt)
+    torch.cuda.synchronize()
+    after = [{k: float(v) for k, v in d.items()} for d in kept]
+    assert before == after                                                     # untouched by the following replay
+    assert any(abs(float(a["loss_sum"]) - b["loss_sum"]) > 0 for a, b in zip(nxt, before))   # ... which produced new numbers
+    # Keras-style call
+    rng = np.random.default_rng(0)
+    a, b = MLPSimple(3, 8, 12, 4, rng=np.random.default_rng(5)), MLPSimple(3, 8, 12, 4, rng=np.random.default_rng(5))
+    grads = [torch.tensor(rng.standard_normal(tuple(w.shape)), dtype=torch.float32, device="cuda") for w in a.weights]
+    o1, o2 = optim.Adam(lr=1e-3), optim.Adam(lr=1e-3)
+    o1.apply_gradients(zip(grads, a.trainable_weights))
+    for p, g in zip(b.weights, grads):
+        p.grad.copy_(g)
+    o2.apply_gradients(b)
+    assert o1.iterations == o2.iterations == 1 and torch.equal(a.arena, b.arena)
+    assert float((a.arena - MLPSimple(3, 8, 12, 4, rng=np.random.default_rng(5)).arena).abs().max()) > 5e-4
