@@ -249,8 +249,41 @@ def upfold_wgrad(gw2, g, w_shape):
     return gw
 
 
+# ---------------------------------------------------------------------------------------------
+# Winograd F(2x2, 3x3) for the wide 2-D 3x3 stride-1 SAME layers (fp32 mode): include/confignet_hip.h: cn_conv_fwd_wino
+# ---------------------------------------------------------------------------------------------
+WINOGRAD = os.environ.get("CN_NO_WINOGRAD") is None
+WINO_MIN_WGS = 192          # below ~one workgroup per CU the direct kernel with split-K wins
+
+
+def _wino_ok(g, cin, cout):
+    """cin / cout: reduction / output channels of the convolution actually run (swapped for a data gradient)."""
+    if not (WINOGRAD and g.nd == 2 and g.k_h == 3 and g.k_w == 3 and g.s_h == 1 and g.s_w == 1 and g.dl_h == 1 and g.dl_w == 1
+            and g.up == 0 and g.p_h == 1 and g.p_w == 1 and g.out_h == g.in_h and g.out_w == g.in_w):
+        return False
+    if cin % 8 or cout % 64:
+        return False
+    tiles = g.n * ((g.in_h + 1) // 2) * ((g.in_w + 1) // 2)
+    return ((tiles + 63) // 64) * (cout // 64) >= WINO_MIN_WGS
+
+
+def _wino_filter(w, dgrad):
+    def make(wd_):
+        wd_ = _c(wd_)
+        cin, cout = wd_.shape[-2], wd_.shape[-1]
+        u = torch.empty((16, cout, cin) if dgrad else (16, cin, cout), device=wd_.device, dtype=torch.float32)
+        check(lib.cn_conv_wino_filter(_fptr(wd_), _ptr(u), cin, cout, int(dgrad), _stream()), "cn_conv_wino_filter")
+        return u
+    return _weight_cache(w, "_cn_wino_d" if dgrad else "_cn_wino_f", make)
+
+
 def conv_fwd(x, w, bias, g, act=ACT_NONE, slope=0.0):
     out_dtype = _act_out_dtype(g.cout)
+    if ACT_DTYPE == torch.float32 and x.dtype == torch.float32 and _wino_ok(g, g.cin, g.cout):
+        y = torch.empty(geom_out_shape(g), device=x.device, dtype=torch.float32)
+        check(lib.cn_conv_fwd_wino(g.n, g.in_h, g.in_w, g.cin, g.cout, _ptr(x), _ptr(_wino_filter(w, False)), _fptr(bias), _ptr(y),
+                                   act, slope, _stream()), "cn_conv_fwd_wino")
+        return y
     if _bf16_conv_ok(g):
         x = cast(x, torch.bfloat16)
         y = torch.empty(geom_out_shape(g), device=x.device, dtype=torch.bfloat16)
@@ -283,6 +316,10 @@ def conv_dgrad(gy, w, g):
         return gu
     gy = f32(gy)
     gu = torch.empty(shape, device=gy.device, dtype=torch.float32)
+    if ACT_DTYPE == torch.float32 and _wino_ok(g, g.cout, g.cin):
+        check(lib.cn_conv_fwd_wino(g.n, g.in_h, g.in_w, g.cout, g.cin, _ptr(gy), _ptr(_wino_filter(w, True)), None, _ptr(gu),
+                                   ACT_NONE, 0.0, _stream()), "cn_conv_fwd_wino")
+        return gu
     wt = _weight_cache(w, "_cn_tflip", weight_tflip)
     check(lib.cn_conv_dgrad(ctypes.byref(g), _ptr(gy), _fptr(wt), _ptr(gu), _stream()), "cn_conv_dgrad")
     return cast(gu, _act_out_dtype(g.cin))

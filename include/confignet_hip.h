@@ -73,6 +73,16 @@ int cn_conv_dgrad(const CnConvGeom* g, const float* gy, const float* w_tflip, fl
 /* Filter gradient (Conv*DBackpropFilter): gw[(t,ci),co] (+)= sum_m x[src(m,t),ci]*gy[m,co]; gw is overwritten,
  * or accumulated into when `accumulate` != 0 (the caller guarantees its previous content, e.g. zeros). */
 int cn_conv_wgrad(const CnConvGeom* g, const float* x, const float* gy, float* gw, int accumulate, void* stream);
+/* 3x3 stride-1 SAME 2-D convolution as Winograd F(2x2, 3x3) on the fp32 matrix cores: 16 GEMMs in the transform domain,
+ * 4/9 of the multiply-adds of the direct form (exact in real arithmetic).  The same reference lines as cn_conv_fwd /
+ * cn_conv_dgrad for the layers it fits (keras.applications VGG19/VGG16 and the 3x3 convolutions of ResNet50:
+ * perceptual_loss.py:19,35 ; real_encoder.py:13).  u = cn_conv_wino_filter(w): [16][cin][cout] (dgrad = 0), or the filter
+ * of the data-gradient convolution [16][cout][cin] (dgrad = 1: flipped taps, channels swapped), made once per weight update.
+ * cn_conv_fwd_wino: x (n,h,w,cin) -> y (n,h,w,cout) with fused bias + activation; CN_EUNSUPPORTED (nothing launched)
+ * unless cin % 8 == 0 and cout % 64 == 0. */
+int cn_conv_wino_filter(const float* w, float* u, int cin, int cout, int dgrad, void* stream);
+int cn_conv_fwd_wino(int n, int h, int w, int cin, int cout, const float* x, const float* u, const float* bias, float* y,
+                     int act, float slope, void* stream);
 /* Tuning hook: force the tile configuration (0 = 128x128, 1 = 128x64, 2 = 64x64, 3 = 128x32, 4 = 128x96; -1 = heuristic), the
  * split-K factor of cn_conv_fwd / cn_conv_dgrad (0 = heuristic) and the workgroup target of cn_conv_wgrad (0 = default). */
 int cn_conv_tune(int cfg, int splits, long wg_blocks);

@@ -416,3 +416,42 @@ def test_upsample_folded_conv_collapsed_per_parity_class(case, dtype):
         close(gb, gbr, tol=5e-4 if dtype == "f32" else 1.5e-2, what="upfold bias grad")
     finally:
         ops.set_activation_dtype("f32")
+
+
+WINO_CASES = [
+    # (x shape, cout): 3x3 stride-1 SAME layers routed to cn_conv_fwd_wino (threshold lowered for the small cases)
+    ((2, 16, 16, 64), 64),
+    ((1, 32, 32, 128), 256),
+    ((2, 9, 7, 16), 64),          # odd extents: partial tiles on both axes
+    ((1, 5, 6, 8), 128),
+    ((3, 8, 8, 256), 512),
+    ((1, 37, 21, 64), 64),
+]
+
+
+@pytest.mark.parametrize("case", WINO_CASES, ids=[str(i) for i in range(len(WINO_CASES))])
+def test_winograd_3x3_forward_and_data_gradient(case):
+    """Winograd F(2x2, 3x3) forward (+ bias + ReLU epilogue) and data gradient against the float64 oracle of the direct
+    convolution, at the same 2e-4 bar as the implicit-GEMM kernels (fp32: the transforms add a few roundings, ~1e-6)."""
+    from confignet_amd import ops
+    xs, cout = case
+    rng = np.random.default_rng(abs(hash(case)) % 2 ** 31)
+    cin = xs[-1]
+    x = rng.normal(size=xs)
+    w = rng.normal(size=(3, 3, cin, cout)) / math.sqrt(9 * cin)
+    b = rng.normal(size=cout)
+    g = ops.ConvSpec((3, 3)).geom(xs, cout)
+    keep, ops.WINO_MIN_WGS = ops.WINO_MIN_WGS, 0
+    try:
+        assert ops._wino_ok(g, cin, cout)
+        y = ops.conv_fwd(dev(x), dev(w), dev(b), g, 2, 0.0)
+        xr, wr = t64(x).requires_grad_(True), t64(w)
+        close(y, torch.relu(O.conv_same(xr, wr, t64(b))), what="winograd fwd")
+        yr0 = O.conv_same(xr, wr, None)
+        gy = rng.normal(size=tuple(yr0.shape))
+        (yr0 * t64(gy)).sum().backward()
+        if cin % 64 == 0:
+            assert ops._wino_ok(g, cout, cin)
+        close(ops.conv_dgrad(dev(gy), dev(w), g), xr.grad, what="winograd dgrad")
+    finally:
+        ops.WINO_MIN_WGS = keep
