@@ -254,6 +254,7 @@ def upfold_wgrad(gw2, g, w_shape):
 # ---------------------------------------------------------------------------------------------
 WINOGRAD = os.environ.get("CN_NO_WINOGRAD") is None
 WINO_MIN_WGS = 192          # below ~one workgroup per CU the direct kernel with split-K wins
+WINO_MIN_FILL = 0.7         # fraction of the 8 x 8-tile blocks that must lie inside the image
 
 
 def _wino_ok(g, cin, cout):
@@ -261,10 +262,15 @@ def _wino_ok(g, cin, cout):
     if not (WINOGRAD and g.nd == 2 and g.k_h == 3 and g.k_w == 3 and g.s_h == 1 and g.s_w == 1 and g.dl_h == 1 and g.dl_w == 1
             and g.up == 0 and g.p_h == 1 and g.p_w == 1 and g.out_h == g.in_h and g.out_w == g.in_w):
         return False
-    if cin % 8 or cout % 64:
+    if cin % 16 or cout % 64:
         return False
-    tiles = g.n * ((g.in_h + 1) // 2) * ((g.in_w + 1) // 2)
-    return ((tiles + 63) // 64) * (cout // 64) >= WINO_MIN_WGS
+    # workgroup = 8 x 8 tiles (16 x 16 output pixels) x 64 channels: most of the block must be image, and there must be
+    # enough workgroups to fill the chip (below that the direct kernel with split-K wins)
+    th, tw = (g.in_h + 1) // 2, (g.in_w + 1) // 2
+    bh, bw = (th + 7) // 8, (tw + 7) // 8
+    if th * tw < WINO_MIN_FILL * (bh * bw * 64):
+        return False
+    return g.n * bh * bw * (cout // 64) >= WINO_MIN_WGS
 
 
 def _wino_filter(w, dgrad):

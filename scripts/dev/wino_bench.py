@@ -11,6 +11,7 @@ def t(fn, reps=5):
     for _ in range(reps): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) * 1e3 / reps
+if os.environ.get('WINO_SHAPE'): shapes = [shapes[int(os.environ['WINO_SHAPE'])]]
 for xs, cout in shapes:
     x = torch.randn(xs, device="cuda"); w = torch.randn(3, 3, xs[-1], cout, device="cuda") * 0.05; b = torch.randn(cout, device="cuda")
     g = ops.ConvSpec((3, 3)).geom(xs, cout)

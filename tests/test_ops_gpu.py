@@ -423,7 +423,8 @@ WINO_CASES = [
     ((2, 16, 16, 64), 64),
     ((1, 32, 32, 128), 256),
     ((2, 9, 7, 16), 64),          # odd extents: partial tiles on both axes
-    ((1, 5, 6, 8), 128),
+    ((1, 5, 6, 16), 128),
+    ((2, 40, 24, 32), 64),        # several blocks per image, ragged on one axis
     ((3, 8, 8, 256), 512),
     ((1, 37, 21, 64), 64),
 ]
@@ -441,7 +442,7 @@ def test_winograd_3x3_forward_and_data_gradient(case):
     w = rng.normal(size=(3, 3, cin, cout)) / math.sqrt(9 * cin)
     b = rng.normal(size=cout)
     g = ops.ConvSpec((3, 3)).geom(xs, cout)
-    keep, ops.WINO_MIN_WGS = ops.WINO_MIN_WGS, 0
+    keep, ops.WINO_MIN_WGS, ops.WINO_MIN_FILL = (ops.WINO_MIN_WGS, ops.WINO_MIN_FILL), 0, 0.0
     try:
         assert ops._wino_ok(g, cin, cout)
         y = ops.conv_fwd(dev(x), dev(w), dev(b), g, 2, 0.0)
@@ -454,4 +455,4 @@ def test_winograd_3x3_forward_and_data_gradient(case):
             assert ops._wino_ok(g, cout, cin)
         close(ops.conv_dgrad(dev(gy), dev(w), g), xr.grad, what="winograd dgrad")
     finally:
-        ops.WINO_MIN_WGS = keep
+        ops.WINO_MIN_WGS, ops.WINO_MIN_FILL = keep
