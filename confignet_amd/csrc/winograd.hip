@@ -117,10 +117,14 @@ __global__ __launch_bounds__(256, 1) void wino_fwd_kernel(WinoGeom g, const floa
         const bool in = slot < RAW_SLOTS && yy >= 0 && yy < g.h && xx >= 0 && xx < g.w;
         xoff[j] = in ? (unsigned)(((img * g.h + yy) * g.w + xx) * g.cin + (q & 1) * 4) * 4u : 0x80000000u;
     }
-    auto load_filter_piece = [&](int j, int ks, int buf) {
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    f32x4 ru[8];
+    auto load_filter_piece = [&](int j, int ks) {
+        ru[j] = __builtin_amdgcn_raw_buffer_load_b128(ures, uoff[j], ks * WKB * g.cout * 4, 0);
+    };
+    auto store_filter_piece = [&](int j, int buf) {
         const int piece = wave * 8 + j, p = piece >> 1, k0 = (piece & 1) * 4;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(ures, (__attribute__((address_space(3))) float*)&Us[buf][p][k0][0], 16, uoff[j],
-                                                 ks * WKB * g.cout * 4, 0, 0);
+        *reinterpret_cast<f32x4*>(&Us[buf][p][k0 + (lane >> 4)][(lane & 15) * 4]) = ru[j];
     };
     auto load_input_piece = [&](int j, int ks, int rbuf) {   // rbuf = ks & 1, as a literal
         __builtin_amdgcn_raw_ptr_buffer_load_lds(xres, (__attribute__((address_space(3))) float*)&(rbuf ? Raw1 : Raw0)[(wave * 3 + j) * 256], 16,
@@ -187,18 +191,21 @@ __global__ __launch_bounds__(256, 1) void wino_fwd_kernel(WinoGeom g, const floa
                 b[cur ^ 1][e] = Us[buf][pn][kk + half][ccol];
             }
             transform_piece(buf ^ 1, buf ^ 1, m);
-            if (m < 8) load_filter_piece(m, ksf, buf ^ 1);
+            if (m < 8) load_filter_piece(m, ksf);
+            else if (m >= 56) store_filter_piece(m - 56, buf ^ 1);
             else if (m < 11) load_input_piece(m - 8, ksx, buf);
         }
         __builtin_amdgcn_sched_barrier(0);
     };
 
 #pragma unroll
-    for (int j = 0; j < 8; ++j) load_filter_piece(j, 0, 0);
+    for (int j = 0; j < 8; ++j) load_filter_piece(j, 0);
 #pragma unroll
     for (int j = 0; j < 3; ++j) load_input_piece(j, 0, 0);
 #pragma unroll
     for (int j = 0; j < 3; ++j) load_input_piece(j, 1, 1);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) store_filter_piece(j, 0);
     __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();
 #pragma unroll
