@@ -59,9 +59,9 @@ __global__ void wino_filter_kernel(const float* __restrict__ W, float* __restric
     }
 }
 
-__global__ __launch_bounds__(256, 1) void wino_fwd_kernel(WinoGeom g, const float* __restrict__ X, const float* __restrict__ U,
+__global__ __launch_bounds__(512, 1) void wino_fwd_kernel(WinoGeom g, const float* __restrict__ X, const float* __restrict__ U,
                                                           const float* __restrict__ bias, float* __restrict__ Y, int act, float slope) {
-    constexpr int BT = 64, BC = 64, LDV = BT + 4, LDU = BC;    // Us / Raw unpadded: filled by LDS-DMA loads (wave-contiguous)
+    constexpr int BT = 64, BC = 64, LDV = BT + 4, LDU = BC;
     constexpr int RAW_SLOTS = 324, RAW_FLOATS = 12 * 64 * 4;    // 18 x 18 pixels x 8 channels, rounded up to 12 wave loads
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float (*Vs)[16][WKB][LDV] = reinterpret_cast<float (*)[16][WKB][LDV]>(smem);                                   // [2]
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256, 1) void wino_fwd_kernel(WinoGeom g, const floa
     int* tilebase = reinterpret_cast<int*>(smem + 2 * 16 * WKB * (LDV + LDU));                                      // [BT] pixel index of output (2th, 2tw), or -1
     int* tilehw = tilebase + BT;                                                                                    // [BT] (2th << 16) | 2tw
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wt = wave >> 1, wc = wave & 1, half = lane >> 5, l31 = lane & 31;
+    const int ph = wave >> 2, wt = (wave >> 1) & 1, wc = wave & 1, half = lane >> 5, l31 = lane & 31;
 
     // Workgroup -> (8 x 8 block of tiles, 64 output channels).  Logically consecutive workgroups (same channel block = same
     // filter tile, neighbouring pixels) are sent to the same XCD so that they share its L2.
@@ -83,133 +83,130 @@ __global__ __launch_bounds__(256, 1) void wino_fwd_kernel(WinoGeom g, const floa
     const int blk = wg % nblk, c0 = (wg / nblk) * BC;
     const int img = blk / (g.bh * g.bw), brem = blk - img * (g.bh * g.bw), bty = brem / g.bw, btx = brem - bty * g.bw;
 
-    // this thread's transform task: tile (tid >> 2) = (ty, tx) of the block, channel pair (tid & 3) of every step
-    const int gt = tid >> 2, cp = tid & 3, ty = gt >> 3, tx = gt & 7;
-    if (cp == 0) {
+    // this thread's transform task: tile (tid >> 3) = (ty, tx) of the block, channel (tid & 7) of every step
+    const int gt = tid >> 3, ch = tid & 7, ty = gt >> 3, tx = gt & 7;
+    if (ch == 0) {
         const int th = bty * 8 + ty, tw = btx * 8 + tx;
         const bool valid = th < g.th && tw < g.tw;
         tilebase[gt] = valid ? (img * g.h + 2 * th) * g.w + 2 * tw : -1;
         tilehw[gt] = ((2 * th) << 16) | (2 * tw);
     }
-    // Both operands arrive by LDS-DMA through buffer descriptors: one instruction per 1 KB piece (per-lane byte offset in a
-    // VGPR, the step's advance in an SGPR), no staging registers (16 accumulators leave none to spare), and an offset
-    // beyond the descriptor's range reads as zero -- the zero padding of the image border costs nothing.
+    // Both operands are fetched through buffer descriptors: one instruction per 1 KB piece (per-lane byte offset in a VGPR,
+    // the step's advance in an SGPR), and an offset beyond the descriptor's range reads as zero -- the zero padding of the
+    // image border costs nothing.
     const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X), 0, g.n * g.h * g.w * g.cin * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t ures = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(U), 0, 16 * g.cin * g.cout * 4, 0x00020000);
     // Filter tile: one piece = 4 k rows x 64 channels of one position (lane = (k & 3) * 16 + float4 column); 16 positions x
-    // 2 k halves = 32 pieces per step, 8 per wave.
-    unsigned uoff[8];
+    // 2 k halves = 32 pieces per step, 4 per wave, through registers (a load early in the step, a ds_write_b128 late).
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    unsigned uoff[4];
+    f32x4 ru[4];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int piece = wave * 8 + j, p = piece >> 1, k0 = (piece & 1) * 4;
+    for (int j = 0; j < 4; ++j) {
+        const int piece = wave * 4 + j, p = piece >> 1, k0 = (piece & 1) * 4;
         uoff[j] = (unsigned)((p * g.cin + k0 + (lane >> 4)) * g.cout + c0 + (lane & 15) * 4) * 4u;
     }
-    // Input block: the 18 x 18 pixels under the 8 x 8 tiles (each pixel once, not once per tile that covers it) x 8 channels.
-    // Slot of pixel (r, c): ((2r + (c & 1)) * 9 + (c >> 1)) -- even and odd columns apart, so that the 8 tiles of a block row
-    // read 8 consecutive 32-byte slots (conflict-free ds_read_b64).  A piece is 32 slots; lane -> slot (lane >> 1), channel
-    // half (lane & 1); 3 pieces per wave.
-    unsigned xoff[3];
+    auto load_filter_piece = [&](int j, int ks) { ru[j] = __builtin_amdgcn_raw_buffer_load_b128(ures, uoff[j], ks * WKB * g.cout * 4, 0); };
+    auto store_filter_piece = [&](int j, int buf) {
+        const int piece = wave * 4 + j, p = piece >> 1, k0 = (piece & 1) * 4;
+        *reinterpret_cast<f32x4*>(&Us[buf][p][k0 + (lane >> 4)][(lane & 15) * 4]) = ru[j];
+    };
+    // Input block: the 18 x 18 pixels under the 8 x 8 tiles (each pixel once, not once per tile that covers it) x 8 channels,
+    // by LDS-DMA (no registers).  Slot of pixel (r, c): ((2r + (c & 1)) * 9 + (c >> 1)) -- even and odd columns apart, so that
+    // the tiles of a block row read consecutive 32-byte slots (conflict-free).  A piece is 32 slots; lane -> slot (lane >> 1),
+    // channel half (lane & 1); pieces 0..7 by the 8 waves, 8..11 by waves 0..3.
+    unsigned xoff[2];
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        const int q = (wave * 3 + j) * 64 + lane, slot = q >> 1;
+    for (int j = 0; j < 2; ++j) {
+        const int q = (j * 8 + wave) * 64 + lane, slot = q >> 1;
         const int r = slot / 18, rem = slot - r * 18, par = rem >= 9, c = 2 * (rem - 9 * par) + par;
         const int yy = bty * 16 - 1 + r, xx = btx * 16 - 1 + c;
         const bool in = slot < RAW_SLOTS && yy >= 0 && yy < g.h && xx >= 0 && xx < g.w;
         xoff[j] = in ? (unsigned)(((img * g.h + yy) * g.w + xx) * g.cin + (q & 1) * 4) * 4u : 0x80000000u;
     }
-    typedef float f32x4 __attribute__((ext_vector_type(4)));
-    f32x4 ru[8];
-    auto load_filter_piece = [&](int j, int ks) {
-        ru[j] = __builtin_amdgcn_raw_buffer_load_b128(ures, uoff[j], ks * WKB * g.cout * 4, 0);
-    };
-    auto store_filter_piece = [&](int j, int buf) {
-        const int piece = wave * 8 + j, p = piece >> 1, k0 = (piece & 1) * 4;
-        *reinterpret_cast<f32x4*>(&Us[buf][p][k0 + (lane >> 4)][(lane & 15) * 4]) = ru[j];
-    };
     auto load_input_piece = [&](int j, int ks, int rbuf) {   // rbuf = ks & 1, as a literal
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(xres, (__attribute__((address_space(3))) float*)&(rbuf ? Raw1 : Raw0)[(wave * 3 + j) * 256], 16,
+        if (j == 1 && wave >= 4) return;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xres, (__attribute__((address_space(3))) float*)&(rbuf ? Raw1 : Raw0)[(j * 8 + wave) * 256], 16,
                                                  xoff[j], ks * WKB * 4, 0, 0);
     };
-    // V = B^T d B of the thread's two channels, cut into 64 pieces so that the step below can put one behind each MFMA:
-    // 16 patch reads (both channels in one ds_read_b64), 16 results of the column pass, 32 results written to their V planes
-    float2 dd[16], tt[16];
-    const int rawt = ((4 * ty) * 9 + tx) * 8 + cp * 2;
-    auto transform_piece = [&](int rbuf, int vbuf, int m) {
-        if (m < 16) {
-            const int i = m >> 2, j = m & 3;
-            dd[m] = *reinterpret_cast<const float2*>(&(rbuf ? Raw1 : Raw0)[rawt + (i * 18 + (j & 1) * 9 + (j >> 1)) * 8]);
-        } else if (m < 32) {
-            const int j = (m - 16) >> 2, s_ = m & 3;
-            auto d = [&](int i) { return dd[i * 4 + j]; };
-            float2 v;
-            if (s_ == 0) v = make_float2(d(0).x - d(2).x, d(0).y - d(2).y);
-            else if (s_ == 1) v = make_float2(d(1).x + d(2).x, d(1).y + d(2).y);
-            else if (s_ == 2) v = make_float2(d(2).x - d(1).x, d(2).y - d(1).y);
-            else v = make_float2(d(1).x - d(3).x, d(1).y - d(3).y);
-            tt[s_ * 4 + j] = v;
+    // V = B^T d B of the thread's channel, cut into 64 items (16 patch reads, 16 results of the column pass, 16 results each
+    // followed by its write to a V plane) so that the step below can put two behind each MFMA
+    float dd[16], tt[16], vv = 0.f;
+    const int rawt = ((4 * ty) * 9 + tx) * 8 + ch;
+    auto transform_item = [&](int rbuf, int vbuf, int it) {
+        if (it < 16) {
+            const int i = it >> 2, j = it & 3;
+            dd[it] = (rbuf ? Raw1 : Raw0)[rawt + (i * 18 + (j & 1) * 9 + (j >> 1)) * 8];
+        } else if (it < 32) {
+            const int j = (it - 16) >> 2, s_ = it & 3;
+            tt[s_ * 4 + j] = s_ == 0 ? dd[0 * 4 + j] - dd[2 * 4 + j] : s_ == 1 ? dd[1 * 4 + j] + dd[2 * 4 + j]
+                           : s_ == 2 ? dd[2 * 4 + j] - dd[1 * 4 + j] : dd[1 * 4 + j] - dd[3 * 4 + j];
         } else {
-            const int idx = m - 32, e = idx & 1, i = idx >> 3, s_ = (idx >> 1) & 3;
-            auto t = [&](int c) { return e ? tt[i * 4 + c].y : tt[i * 4 + c].x; };
-            const float v = s_ == 0 ? t(0) - t(2) : s_ == 1 ? t(1) + t(2) : s_ == 2 ? t(2) - t(1) : t(1) - t(3);
-            Vs[vbuf][i * 4 + s_][2 * cp + e][gt] = v;
+            const int k = (it - 32) >> 1, i = k >> 2, s_ = k & 3;
+            if ((it & 1) == 0)
+                vv = s_ == 0 ? tt[i * 4 + 0] - tt[i * 4 + 2] : s_ == 1 ? tt[i * 4 + 1] + tt[i * 4 + 2]
+                   : s_ == 2 ? tt[i * 4 + 2] - tt[i * 4 + 1] : tt[i * 4 + 1] - tt[i * 4 + 3];
+            else
+                Vs[vbuf][k][ch][gt] = vv;
         }
     };
 
-    f32x16 acc[16];
+    f32x16 acc[8];
 #pragma unroll
-    for (int p = 0; p < 16; ++p)
+    for (int p = 0; p < 8; ++p)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
 
     const int nks = g.cin / WKB;                 // even (cin % 16 == 0)
     const int trow = wt * 32 + l31, ccol = wc * 32 + l31;
-    // One step: the matrix cores work on (V, U)(ks) in LDS buffer `buf` while, one small piece behind each of the 64 MFMAs
-    // (a wave has its SIMD to itself: whatever is not issued in an MFMA's 64-cycle shadow stalls the matrix pipe),
-    //   * the filter tile of step ks+1 and the input block of step ks+2 are requested (8 + 3 instructions),
-    //   * the input block of step ks+1 (in LDS since the previous step) is transformed into the other V buffer,
-    //   * the operands of the next group of 4 MFMAs are read from LDS.
-    // The loads have most of a step (> 3000 cycles) to land before the barrier that opens the next step.
+    // One step: the wave's 32 MFMAs on (V, U)(ks) in LDS buffer `buf` (positions 8 ph .. 8 ph + 7, 4 k pairs), and a few small
+    // items behind each of them:
+    //   * the filter tile of step ks+1 (4 loads early, 4 LDS writes late) and the input block of step ks+2 (LDS-DMA),
+    //   * the input block of step ks+1 (in LDS since the previous step) transformed into the other V buffer,
+    //   * the operands of the next group of 4 MFMAs read from LDS.
+    // Two waves share a SIMD (the two position halves): what one wave issues besides MFMAs runs under the other's MFMAs.
     auto step = [&](int ks, int buf) {
         const int ksf = ks + 1 < nks ? ks + 1 : nks - 1, ksx = ks + 2 < nks ? ks + 2 : nks - 2 + buf;   // (the tail re-fetches, unused)
-        __builtin_amdgcn_s_waitcnt(0x0F70);              // vmcnt(0): this step's filter tile and the next input block are in LDS
+        __builtin_amdgcn_s_waitcnt(0x0F70);              // vmcnt(0): the next input block is in LDS
         __syncthreads();
         float a[2][4], b[2][4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            a[0][e] = Vs[buf][e][half][trow];
-            b[0][e] = Us[buf][e][half][ccol];
+            a[0][e] = Vs[buf][8 * ph + e][half][trow];
+            b[0][e] = Us[buf][8 * ph + e][half][ccol];
         }
 #pragma unroll
-        for (int m = 0; m < 64; ++m) {
-            // MFMA m: k pair (m >> 4), position 4 * ((m >> 2) & 3) + (m & 3); its operands were read one group (4 MFMAs) ago
-            const int grp = m >> 2, e = m & 3, cur = grp & 1, p = 4 * (grp & 3) + e;
+        for (int m = 0; m < 32; ++m) {
+            // MFMA m: k pair (m >> 3), position 8 ph + (m & 7); its operands were read one group (4 MFMAs) ago
+            const int grp = m >> 2, e = m & 3, cur = grp & 1, q = m & 7;
             __builtin_amdgcn_sched_barrier(0);
-            acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][e], b[cur][e], acc[p], 0, 0, 0);
-            if (grp + 1 < 16) {
-                const int kk = ((grp + 1) >> 2) * 2, pn = 4 * ((grp + 1) & 3) + e;
+            acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][e], b[cur][e], acc[q], 0, 0, 0);
+            if (grp + 1 < 8) {
+                const int kk = ((grp + 1) >> 1) * 2, pn = 8 * ph + 4 * ((grp + 1) & 1) + e;
                 a[cur ^ 1][e] = Vs[buf][pn][kk + half][trow];
                 b[cur ^ 1][e] = Us[buf][pn][kk + half][ccol];
             }
-            transform_piece(buf ^ 1, buf ^ 1, m);
-            if (m < 8) load_filter_piece(m, ksf);
-            else if (m >= 56) store_filter_piece(m - 56, buf ^ 1);
-            else if (m < 11) load_input_piece(m - 8, ksx, buf);
+            transform_item(buf ^ 1, buf ^ 1, 2 * m);
+            transform_item(buf ^ 1, buf ^ 1, 2 * m + 1);
+            if (m < 4) load_filter_piece(m, ksf);
+            else if (m < 6) load_input_piece(m - 4, ksx, buf);
+            else if (m >= 28) store_filter_piece(m - 28, buf ^ 1);
         }
         __builtin_amdgcn_sched_barrier(0);
     };
 
 #pragma unroll
-    for (int j = 0; j < 8; ++j) load_filter_piece(j, 0);
+    for (int j = 0; j < 4; ++j) load_filter_piece(j, 0);
 #pragma unroll
-    for (int j = 0; j < 3; ++j) load_input_piece(j, 0, 0);
+    for (int j = 0; j < 2; ++j) load_input_piece(j, 0, 0);
 #pragma unroll
-    for (int j = 0; j < 3; ++j) load_input_piece(j, 1, 1);
+    for (int j = 0; j < 2; ++j) load_input_piece(j, 1, 1);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) store_filter_piece(j, 0);
+    for (int j = 0; j < 4; ++j) store_filter_piece(j, 0);
     __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();
 #pragma unroll
-    for (int m = 0; m < 64; ++m) transform_piece(0, 0, m);
+    for (int it = 0; it < 64; ++it) transform_item(0, 0, it);
     for (int ks = 0; ks < nks; ks += 2) {
         step(ks, 0);
         step(ks + 1, 1);
@@ -217,31 +214,49 @@ __global__ __launch_bounds__(256, 1) void wino_fwd_kernel(WinoGeom g, const floa
     __builtin_amdgcn_s_waitcnt(0x0F70);                  // nothing may still be writing LDS when the workgroup retires
     __syncthreads();
 
-    // output transform Y = A^T M A per (tile, co): the 16 positions of one element sit in the same lane / register index.
+    // Output transform Y = A^T M A per (tile, co), A^T = [1 1 1 0; 0 1 -1 -1].  A wave holds rows a = 2 ph, 2 ph + 1 of M (the 8
+    // positions of one element in the same lane / register index): it forms its part of both output rows, keeps the part
+    // of output row ph, hands the other to its partner wave through LDS (over the operand buffers, no longer read), adds
+    // what it receives and stores output row ph.
     // C/D layout: col = lane&31 -> co, row = (r&3) + 8*(r>>2) + 4*(lane>>5) -> tile
+    float* xchg = smem + ((wt * 2 + wc) * 2) * 16 * 2 * 64;      // [sender ph][r][j][lane]
+    float keep[16][2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        __builtin_amdgcn_sched_barrier(0);      // one element's 8 accumulator reads at a time
+        float tm[2][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float m0 = acc[j][r], m1 = acc[4 + j][r];
+            tm[0][j] = ph ? m0 : m0 + m1;
+            tm[1][j] = ph ? -m0 - m1 : m1;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const float y0 = tm[i][0] + tm[i][1] + tm[i][2], y1 = tm[i][1] - tm[i][2] - tm[i][3];
+            if (i == ph) {
+                keep[r][0] = y0;
+                keep[r][1] = y1;
+            } else {
+                xchg[((ph * 16 + r) * 2 + 0) * 64 + lane] = y0;
+                xchg[((ph * 16 + r) * 2 + 1) * 64 + lane] = y1;
+            }
+        }
+    }
+    __syncthreads();
     const int co = c0 + wc * 32 + l31;
     const float bv = bias ? bias[co] : 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        __builtin_amdgcn_sched_barrier(0);      // one element's 16 accumulator reads at a time (hoisting all 256 exhausts the VGPRs)
         const int tl = wt * 32 + 4 * half + (r & 3) + 8 * (r >> 2);
         const int base = tilebase[tl];
-        if (base < 0) continue;
         const int hw = tilehw[tl], oy = hw >> 16, ox = hw & 0xffff;
-        float tm[2][4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            tm[0][j] = acc[0 * 4 + j][r] + acc[1 * 4 + j][r] + acc[2 * 4 + j][r];
-            tm[1][j] = acc[1 * 4 + j][r] - acc[2 * 4 + j][r] - acc[3 * 4 + j][r];
-        }
-#pragma unroll
-        for (int a = 0; a < 2; ++a) {
-            if (oy + a >= g.h) continue;
-            const float y0 = tm[a][0] + tm[a][1] + tm[a][2], y1 = tm[a][1] - tm[a][2] - tm[a][3];
-            float* dst = Y + ((long)base + a * g.w) * g.cout + co;
-            dst[0] = cn_apply_act(y0 + bv, act, slope);
-            if (ox + 1 < g.w) dst[g.cout] = cn_apply_act(y1 + bv, act, slope);
-        }
+        const float y0 = keep[r][0] + xchg[(((ph ^ 1) * 16 + r) * 2 + 0) * 64 + lane];
+        const float y1 = keep[r][1] + xchg[(((ph ^ 1) * 16 + r) * 2 + 1) * 64 + lane];
+        if (base < 0 || oy + ph >= g.h) continue;
+        float* dst = Y + ((long)base + ph * g.w) * g.cout + co;
+        dst[0] = cn_apply_act(y0 + bv, act, slope);
+        if (ox + 1 < g.w) dst[g.cout] = cn_apply_act(y1 + bv, act, slope);
     }
 }
 
@@ -274,7 +289,7 @@ extern "C" int cn_conv_fwd_wino(int n, int h, int w, int cin, int cout, const fl
     hipStream_t s = (hipStream_t)stream;
     // MFMA work that contributes to the result: 16 products per 2x2 output tile and (ci, co) pair
     cn_prof_begin(s, 2.0 * 16.0 * (double)ntiles * cin * cout);
-    hipLaunchKernelGGL(wino_fwd_kernel, dim3((unsigned)(nblk * (cout / 64))), dim3(256), lds, s, g, x, u, bias, y, act, slope);
+    hipLaunchKernelGGL(wino_fwd_kernel, dim3((unsigned)(nblk * (cout / 64))), dim3(512), lds, s, g, x, u, bias, y, act, slope);
     cn_prof_end(s);
     CN_LAUNCH_CHECK();
     return CN_OK;

@@ -253,7 +253,7 @@ def upfold_wgrad(gw2, g, w_shape):
 # Winograd F(2x2, 3x3) for the wide 2-D 3x3 stride-1 SAME layers (fp32 mode): include/confignet_hip.h: cn_conv_fwd_wino
 # ---------------------------------------------------------------------------------------------
 WINOGRAD = os.environ.get("CN_NO_WINOGRAD") is None
-WINO_MIN_WGS = 192          # below ~one workgroup per CU the direct kernel with split-K wins
+WINO_MIN_WGS = 128          # below ~half a workgroup per CU the direct kernel with split-K wins
 WINO_MIN_FILL = 0.7         # fraction of the 8 x 8-tile blocks that must lie inside the image
 
 

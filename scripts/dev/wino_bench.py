@@ -13,7 +13,7 @@ def t(fn, reps=5):
     return e0.elapsed_time(e1) * 1e3 / reps
 if os.environ.get('WINO_SHAPE'): shapes = [shapes[int(os.environ['WINO_SHAPE'])]]
 for xs, cout in shapes:
-    x = torch.randn(xs, device="cuda"); w = torch.randn(3, 3, xs[-1], cout, device="cuda") * 0.05; b = torch.randn(cout, device="cuda")
+    x = torch.randn(xs, device="cuda") * float(os.environ.get("WINO_XSCALE", "1")); w = torch.randn(3, 3, xs[-1], cout, device="cuda") * 0.05; b = torch.randn(cout, device="cuda")
     g = ops.ConvSpec((3, 3)).geom(xs, cout)
     fl = 2.0 * xs[0] * xs[1] * xs[2] * 9 * xs[-1] * cout
     ops.WINOGRAD = False
