@@ -57,6 +57,7 @@ SIGNATURES = {
     "cn_dual_tail_gx": [_p] * 12 + [_i, _i, _i, _f, _i, _p],
     "cn_act_fwd": [_p, _p, _z, _i, _f, _i, _p],
     "cn_act_bwd": [_p, _p, _p, _z, _i, _f, _i, _p],
+    "cn_act_bwd_bias": [_p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _i, _p],
     "cn_axpby": [_p, _p, _p, _z, _f, _f, _i, _p],
     "cn_mul": [_p, _p, _p, _z, _i, _p],
     "cn_sqdiff_sum": [_p, _p, _p, _z, _f, _i, _p],

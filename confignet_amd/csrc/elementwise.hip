@@ -13,11 +13,22 @@ __device__ __forceinline__ float4 lrelu4(float4 v, float s) {
     return make_float4(lrelu(v.x, s), lrelu(v.y, s), lrelu(v.z, s), lrelu(v.w, s));
 }
 
+// derivative of an activation evaluated from its OUTPUT o
+__device__ __forceinline__ float act_deriv(float o, int act, float slope) {
+    if (act == CN_ACT_LRELU) return o > 0.f ? 1.f : slope;
+    if (act == CN_ACT_RELU) return o > 0.f ? 1.f : 0.f;
+    if (act == CN_ACT_TANH) return 1.f - o * o;
+    return 1.f;
+}
+
 // ---- nc_reduce: (N,S,C) -> (N,C) sums.  grid (cblk, sblk, n); block (TX c-groups, TY rows) ----
 template <int V, typename T>   // V = 4: 4-wide channel groups, V = 1: scalar channels; T: storage type of x1 / x2
 __global__ __launch_bounds__(256) void nc_reduce_kernel(const T* __restrict__ x1, const T* __restrict__ x2,
                                                         float* __restrict__ s1, float* __restrict__ s2, int S, int C,
-                                                        int rows_per_block, int flags, float slope, int period2) {
+                                                        int rows_per_block, int flags, float slope, int period2,
+                                                        T* __restrict__ dact_out = nullptr, int dact = 0) {
+    // dact_out: fused activation backward -- the reduced quantity is x1 * act'(x2) (x2 = the activation's OUTPUT), which is
+    // also written to dact_out; only s1 (its sum) is produced.
     const int CG = C / V;                          // channel groups
     const int tx = threadIdx.x, ty = threadIdx.y, TX = blockDim.x, TY = blockDim.y;
     const int cg = blockIdx.x * TX + tx;
@@ -40,12 +51,21 @@ __global__ __launch_bounds__(256) void nc_reduce_kernel(const T* __restrict__ x1
                     if (flags & 2) vb = lrelu4(vb, slope);
                     b[0] = vb.x; b[1 % V] = vb.y; b[2 % V] = vb.z; b[3 % V] = vb.w;
                 }
+                if (dact_out) {
+#pragma unroll
+                    for (int e = 0; e < V; ++e) a[e] *= act_deriv(b[e], dact, slope);
+                    st4<T>(dact_out + base + (long)s * C, make_float4(a[0], a[1 % V], a[2 % V], a[3 % V]));
+                }
             } else {
                 a[0] = ldf<T>(x1 + base + (long)s * C);
                 if (flags & 1) a[0] = lrelu(a[0], slope);
                 if (x2) {
                     b[0] = ldf<T>(x2 + base2 + (long)s * C);
                     if (flags & 2) b[0] = lrelu(b[0], slope);
+                }
+                if (dact_out) {
+                    a[0] *= act_deriv(b[0], dact, slope);
+                    stf<T>(dact_out + base + (long)s * C, a[0]);
                 }
             }
 #pragma unroll
@@ -190,12 +210,6 @@ __global__ __launch_bounds__(256) void nc_lin2_rows_kernel(const T* __restrict__
 
 // ---- streaming maps: one float4 per lane per trip when the pointers are 16-byte aligned (they are for every tensor
 // the host side allocates), scalar tail / fallback otherwise.  VEC is decided by the launcher. ----
-__device__ __forceinline__ float act_deriv(float o, int act, float slope) {
-    if (act == CN_ACT_LRELU) return o > 0.f ? 1.f : slope;
-    if (act == CN_ACT_RELU) return o > 0.f ? 1.f : 0.f;
-    if (act == CN_ACT_TANH) return 1.f - o * o;
-    return 1.f;
-}
 
 template <bool VEC, typename T>
 __global__ void act_fwd_kernel(const T* x, T* y, size_t n, int act, float slope) {   // may run in place
@@ -508,8 +522,8 @@ inline int ew_blocks(size_t n) {
 
 }  // namespace
 
-extern "C" int cn_nc_reduce(const void* x1, const void* x2, float* s1, float* s2, int n, int s, int c, int flags,
-                            float slope, int dt, void* stream) {
+static int nc_reduce_launch(const void* x1, const void* x2, float* s1, float* s2, int n, int s, int c, int flags,
+                            float slope, int dt, void* stream, void* dact_out, int dact) {
     CN_CHECK_ARG(x1 && (s1 || s2) && n > 0 && s > 0 && c > 0 && (dt == CN_F32 || dt == CN_BF16), "nc_reduce: bad args");
     hipStream_t st = (hipStream_t)stream;
     if (flags & 16) {
@@ -543,11 +557,24 @@ extern "C" int cn_nc_reduce(const void* x1, const void* x2, float* s1, float* s2
     CN_CHECK_ARG(period2 == 0 || (x2 && n % period2 == 0), "nc_reduce: bad x2 period %d for n = %d", period2, n);
     CN_DISPATCH_DT(dt, {
         const T* p1 = (const T*)x1; const T* p2 = (const T*)x2;
-        if (V == 4) hipLaunchKernelGGL((nc_reduce_kernel<4, T>), grid, block, 0, st, p1, p2, s1, s2, s, c, (int)rpb, flags & 255, slope, period2);
-        else hipLaunchKernelGGL((nc_reduce_kernel<1, T>), grid, block, 0, st, p1, p2, s1, s2, s, c, (int)rpb, flags & 255, slope, period2);
+        if (V == 4) hipLaunchKernelGGL((nc_reduce_kernel<4, T>), grid, block, 0, st, p1, p2, s1, s2, s, c, (int)rpb, flags & 255, slope, period2, (T*)dact_out, dact);
+        else hipLaunchKernelGGL((nc_reduce_kernel<1, T>), grid, block, 0, st, p1, p2, s1, s2, s, c, (int)rpb, flags & 255, slope, period2, (T*)dact_out, dact);
     });
     CN_LAUNCH_CHECK();
     return CN_OK;
+}
+
+extern "C" int cn_nc_reduce(const void* x1, const void* x2, float* s1, float* s2, int n, int s, int c, int flags,
+                            float slope, int dt, void* stream) {
+    return nc_reduce_launch(x1, x2, s1, s2, n, s, c, flags, slope, dt, stream, nullptr, 0);
+}
+
+// Activation backward fused with the bias gradient: gx = gy * act'(y) (y = the activation's output), gb[n][c] = sum_s gx --
+// one pass over gy and y instead of an act_bwd pass plus a reduction pass over its result.  flags: bit 4 (16) as cn_nc_reduce.
+extern "C" int cn_act_bwd_bias(const void* gy, const void* y, void* gx, float* gb, int n, int s, int c, int act, float slope,
+                               int flags, int dt, void* stream) {
+    CN_CHECK_ARG(gy && y && gx && gb, "act_bwd_bias: NULL");
+    return nc_reduce_launch(gy, y, gb, nullptr, n, s, c, flags & 16, slope, dt, stream, gx, act);
 }
 
 extern "C" int cn_nc_lin2(const void* x1, const float* a1, const void* x2, const float* a2, const float* bb,

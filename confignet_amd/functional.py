@@ -59,11 +59,15 @@ class ConvFn(Function):
     def backward(ctx, gy):
         x, w, y = ctx.saved_tensors
         gy = _cg(gy)
+        gb_fused = None
         if ctx.act != ACT_NONE:
             if torch.is_grad_enabled():
                 raise RuntimeError("double backward through a fused-activation conv is not supported; "
                                    "use conv(..., act=ACT_NONE) + lrelu()")
-            gy = ops.act_bwd(gy, y, ctx.act, ctx.slope)
+            if ctx.has_bias and ctx.needs_input_grad[2] and not _INPUT_GRADS_ONLY:
+                gy, gb_fused = ops.act_bwd_bias(gy, y, ctx.act, ctx.slope)      # one pass: activation gradient + its channel sums
+            else:
+                gy = ops.act_bwd(gy, y, ctx.act, ctx.slope)
         gx = gw = gb = None
         if ops.upfold_ok(ctx.g) and not torch.is_grad_enabled():
             # first-order backward of the collapsed form: data gradient straight at the stored extent (no upsampled gradient,
@@ -75,7 +79,7 @@ class ConvFn(Function):
                 if ctx.needs_input_grad[1]:
                     gw = ops.upfold_wgrad(ops.conv_wgrad(gy, x, g2, tuple(wd.shape)), ctx.g, tuple(w.shape))
                 if ctx.has_bias and ctx.needs_input_grad[2]:
-                    gb = ops.nc_reduce(gy.detach(), None, want_dot=False, per_channel=True)[0].reshape(-1)
+                    gb = gb_fused if gb_fused is not None else ops.nc_reduce(gy.detach(), None, want_dot=False, per_channel=True)[0].reshape(-1)
             return gx, gw, gb, None, None, None
         if ctx.needs_input_grad[0]:
             gx = ConvDgradFn.apply(gy, w, ctx.g)
@@ -83,7 +87,7 @@ class ConvFn(Function):
             if ctx.needs_input_grad[1]:
                 gw = ConvWgradFn.apply(x, gy, ctx.g, tuple(w.shape))
             if ctx.has_bias and ctx.needs_input_grad[2]:
-                gb = ops.nc_reduce(gy.detach(), None, want_dot=False, per_channel=True)[0].reshape(-1)
+                gb = gb_fused if gb_fused is not None else ops.nc_reduce(gy.detach(), None, want_dot=False, per_channel=True)[0].reshape(-1)
         return gx, gw, gb, None, None, None
 
 
@@ -217,12 +221,13 @@ class LinearActFn(Function):
         if torch.is_grad_enabled():
             raise RuntimeError("LinearActFn is first-order only; use linear() + lrelu()")
         x, w, y = ctx.saved_tensors
-        g = ops.act_bwd(_cg(gy), y, ctx.act, ctx.slope)
-        gx = ops.gemm(g, w, False, True) if ctx.needs_input_grad[0] else None
-        gw = ops.gemm(x, g, True, False) if ctx.needs_input_grad[1] else None
         gb = None
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            gb = ops.nc_reduce(g, None, want_dot=False, per_channel=True)[0].reshape(-1)
+            g, gb = ops.act_bwd_bias(_cg(gy), y, ctx.act, ctx.slope)
+        else:
+            g = ops.act_bwd(_cg(gy), y, ctx.act, ctx.slope)
+        gx = ops.gemm(g, w, False, True) if ctx.needs_input_grad[0] else None
+        gw = ops.gemm(x, g, True, False) if ctx.needs_input_grad[1] else None
         return gx, gw, gb, None, None
 
 

@@ -579,6 +579,22 @@ def act_bwd(gy, y, act, slope=0.0):
     return gx
 
 
+def act_bwd_bias(gy, y, act, slope=0.0):
+    """(gx, gb): act_bwd fused with the per-channel sum of its result (the bias gradient) -- one pass instead of two."""
+    gy, y = _unify(gy, y)
+    _, _, c = _nsc(gy)
+    rows = gy.numel() // c
+    rep = next(r for r in (16, 8, 4, 2, 1) if rows % r == 0) if rows >= 8192 else 1      # as nc_reduce(per_channel=True)
+    gx = torch.empty_like(gy)
+    gb = zero_pool_alloc((rep, c), gy.device)
+    flags = 16
+    if gb is None:
+        gb, flags = torch.empty((rep, c), device=gy.device, dtype=torch.float32), 0
+    check(lib.cn_act_bwd_bias(_ptr(gy), _ptr(y), _ptr(gx), _ptr(gb), rep, rows // rep, c, act, slope, flags, _dt(gy), _stream()),
+          "cn_act_bwd_bias")
+    return gx, (gb.sum(0) if rep > 1 else gb.reshape(-1))
+
+
 def axpby(x, y, a, b):
     x, y = _unify(x, y)
     out = torch.empty_like(x)

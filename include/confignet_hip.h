@@ -182,6 +182,11 @@ int cn_dual_tail_gx(const void* h, const void* ta, const void* tx, const void* x
 int cn_act_fwd(const void* x, void* y, size_t numel, int act, float slope, int dt, void* stream);
 /* gx = gy * act'(.) evaluated from the activation OUTPUT (lrelu/relu: sign of y; tanh: 1-y^2). */
 int cn_act_bwd(const void* gy, const void* y, void* gx, size_t numel, int act, float slope, int dt, void* stream);
+/* The same fused with the bias gradient that follows it in a convolution / dense backward (reference: the Keras layers'
+ * bias_add gradient after the activation gradient, building_blocks.py:37-44,73-80): gx = gy * act'(y) over (n, s, c) and
+ * gb[n][c] = sum_s gx in one pass.  flags: 16 = gb already cleared by the caller. */
+int cn_act_bwd_bias(const void* gy, const void* y, void* gx, float* gb, int n, int s, int c, int act, float slope, int flags,
+                    int dt, void* stream);
 int cn_axpby(const void* x, const void* y, void* out, size_t numel, float a, float b, int dt, void* stream);
 int cn_mul(const void* x, const void* y, void* out, size_t numel, int dt, void* stream);
 /* out[0] += scale * sum (a-b)^2  (perceptual_loss.py:74-80); out must be initialised by the caller */

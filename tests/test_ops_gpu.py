@@ -268,6 +268,15 @@ def test_elementwise_and_losses():
         xr = t64(x).requires_grad_(True)
         (f(xr) * t64(y)).sum().backward()
         close(ops.act_bwd(dev(y), out, act, 0.3), xr.grad, what="act_bwd")
+        gx, gb = ops.act_bwd_bias(dev(y), out, act, 0.3)              # fused with the channel sums (bias gradient)
+        close(gx, xr.grad, what="act_bwd_bias gx")
+        close(gb, xr.grad.reshape(-1, 5).sum(0), tol=1e-4, what="act_bwd_bias gb")
+    xl, yl = rng.normal(size=(2, 96, 96, 8)), rng.normal(size=(2, 96, 96, 8))      # >= 8192 rows: partial rows + final add
+    ol = ops.act_fwd(dev(xl), 1, 0.3)
+    gx, gb = ops.act_bwd_bias(dev(yl), ol, 1, 0.3)
+    ref = t64(yl) * torch.where(t64(xl) > 0, 1.0, 0.3)
+    close(gx, ref, what="act_bwd_bias gx (long)")
+    close(gb, ref.reshape(-1, 8).sum(0), tol=1e-4, what="act_bwd_bias gb (long)")
     close(ops.axpby(dev(x), dev(y), 2.0, -0.5), 2 * t64(x) - 0.5 * t64(y))
     close(ops.mul(dev(x), dev(y)), t64(x) * t64(y))
     close(ops.sqdiff_sum(dev(x), dev(y), 0.25), (0.25 * ((t64(x) - t64(y)) ** 2).sum()).reshape(1), tol=1e-4)
