@@ -70,8 +70,8 @@ class Adam:
         Also accepts the Keras form `apply_gradients(zip(gradients, variables))` (confignet_first_stage.py:472-474) when the
         variables are weights of confignet_amd networks: the gradients are copied into the owners' gradient arenas (weights
         of those networks that are not listed get a zero gradient, which Keras-Adam with zero moments leaves unchanged)."""
-        if not isinstance(nets, (list, tuple)) and not hasattr(nets, "arena"):
-            nets = list(nets)
+        if not isinstance(nets, (list, tuple)) and hasattr(nets, "__iter__") and not hasattr(nets, "arena"):
+            nets = list(nets)                   # zip(...) and other iterators
         if isinstance(nets, (list, tuple)) and nets and isinstance(nets[0], (list, tuple)):
             pairs, nets = nets, []
             for _, var in pairs:

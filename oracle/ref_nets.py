@@ -229,7 +229,7 @@ def vgg_features(w, x_pre, cfg, taps):
             x = O.maxpool(x, 2, 2)
         else:
             ck, cb = c.take(2)
-            x = torch.relu(O.conv_same(x, ck, cb))
+            x = O.relu(O.conv_same(x, ck, cb))
             if ci in taps:
                 feats.append(x)
             ci += 1
@@ -276,7 +276,7 @@ def _conv_bn(conv, bn, x, stride=1, relu=True, pad7=False):
     else:
         x = O.conv_same(x, ck, cb, stride=stride)
     x = O.bn_inference(x, g, b, m, v, BN_EPS)
-    return torch.relu(x) if relu else x
+    return O.relu(x) if relu else x
 
 
 def resnet50_layer_order():
@@ -322,7 +322,7 @@ def resnet50_features(w_cursor, x_pre):
             y = cb(n + "_1", x, stride=s)                                    # 1_conv 1x1 (f, stride)
             y = cb(n + "_2", y)                                              # 2_conv 3x3 same
             y = cb(n + "_3", y, relu=False)                                  # 3_conv 1x1 (4f)
-            x = torch.relu(sc + y)
+            x = O.relu(sc + y)
     return x.mean(dim=(1, 2))                                                # pooling="avg"
 
 
