@@ -68,53 +68,71 @@ class BranchControl:
     """Test instrument, not part of the restated algorithm.  A piecewise-linear activation whose input lies within the
     product's fp32 rounding of zero may take the other branch on the GPU than in this float64 oracle; the value is continuous
     there, but the derivative mask differs, which moves every upstream gradient by ~1/sqrt(#elements).  With `record` the
-    activations list their near-zero inputs ((call number, flat index, |x| / mean|x|)); with `flips` the listed elements take
-    the other branch.  The gradient tests use it to attribute a deviation to named branch decisions (tests/test_nets_gpu.py:
-    close_grads) instead of absorbing it in a loose tolerance."""
+    activations list their near-zero (non-zero) inputs per call -- flat index, |x| / mean|x|, and, after a backward pass, the
+    magnitude of the gradient that reached that element; with `flips` = {(call number, flat index)} the listed elements
+    take the other branch.  The gradient tests use it to attribute a deviation to named branch decisions
+    (tests/test_nets_gpu.py: check_grads) instead of absorbing it in a loose tolerance."""
     active = False
     record = False
-    delta = 3e-5
+    delta = 1e-4
     calls = 0
-    near = []
+    cand = {}            # call number -> (flat indices, margins, gradient magnitudes)
     flips = frozenset()
 
     @classmethod
     def start(cls, record=False, flips=()):
-        cls.active, cls.record, cls.flips, cls.calls, cls.near = True, record, frozenset(flips), 0, []
+        cls.active, cls.record, cls.flips, cls.calls, cls.cand = True, record, frozenset(flips), 0, {}
 
     @classmethod
     def stop(cls):
         cls.active = cls.record = False
         cls.flips = frozenset()
 
+    @classmethod
+    def candidates(cls):
+        """[(call number, flat index, margin, gradient magnitude)] of the last recorded run."""
+        out = []
+        for cid, (idx, mar, infl) in cls.cand.items():
+            out += [(cid, int(i), float(m), float(g)) for i, m, g in zip(idx, mar, infl)]
+        return out
 
-def _branch_mask(x, neg):
-    """d/dx of max-like activations as a constant factor: 1 where x > 0, `neg` elsewhere."""
+
+def _branch_act(x, neg):
+    """max-like activation as x * (constant derivative mask): 1 where x > 0, `neg` elsewhere -- the same values and the same
+    first and second derivatives as where(x > 0, x, neg * x); the mask form lets BranchControl name single branch decisions."""
     xd = x.detach()
     m = torch.where(xd > 0, torch.ones((), dtype=x.dtype), torch.full((), neg, dtype=x.dtype))
     bc = BranchControl
-    if bc.active:
-        cid, bc.calls = bc.calls, bc.calls + 1
-        if bc.record:
-            ax = xd.abs().reshape(-1)
-            scale = float(ax.mean()) + 1e-300
-            for i in torch.nonzero(ax < bc.delta * scale).reshape(-1).tolist():
-                bc.near.append((cid, i, float(ax[i]) / scale))
-        for c, i in bc.flips:
-            if c == cid:
-                mf = m.reshape(-1)
-                mf[i] = neg if float(mf[i]) == 1.0 else 1.0
-    return m
+    if not bc.active:
+        return x * m
+    cid, bc.calls = bc.calls, bc.calls + 1
+    for c, i in bc.flips:
+        if c == cid:
+            mf = m.reshape(-1)
+            mf[i] = neg if float(mf[i]) == 1.0 else 1.0
+    y = x * m
+    if bc.record:
+        ax = xd.abs().reshape(-1)
+        scale = float(ax.mean()) + 1e-300
+        idx = torch.nonzero((ax < bc.delta * scale) & (ax > 0)).reshape(-1)
+        if idx.numel():
+            infl = torch.zeros(idx.numel(), dtype=torch.float64)
+            bc.cand[cid] = (idx, ax[idx] / scale, infl)
+            if y.requires_grad:
+                def note(g, idx=idx, infl=infl):
+                    infl.add_(g.detach().reshape(-1)[idx].abs().double())
+                y.register_hook(note)
+    return y
 
 
 def leaky_relu(x, alpha):
-    """keras.layers.LeakyReLU() default alpha=0.3; tf.nn.leaky_relu default 0.2 (R1).  (x * mask: the same values and the same
-    first and second derivatives as where(x > 0, x, alpha x); the mask form lets BranchControl name single branch decisions.)"""
-    return x * _branch_mask(x, alpha)
+    """keras.layers.LeakyReLU() default alpha=0.3; tf.nn.leaky_relu default 0.2 (R1)."""
+    return _branch_act(x, alpha)
 
 
 def relu(x):
-    return x * _branch_mask(x, 0.0)
+    return _branch_act(x, 0.0)
+
 
 
 def dense(x, w, b=None):

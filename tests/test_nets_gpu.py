@@ -37,28 +37,93 @@ def close(got, ref, tol=1e-3, what="", rel=False):
     assert err <= tol * scale, "%s: max abs err %.3e vs scale %.3e" % (what, err, scale)
 
 
-def close_grads(net, ref_grads, what, tol=2e-2):
-    """Gradients are compared in relative L2 (plus a loose max-abs bound): a LeakyReLU/ReLU whose
-    pre-activation is within fp32 rounding of zero takes the other branch than the float64 oracle, which
-    moves single entries of small reductions (e.g. a bias gradient summed over 512 positions) by percents
-    -- torch-CPU fp32 shows the same 1e-3..1e-2 max-abs deviations against float64.  With f flipped
-    elements out of n the relative L2 error is ~sqrt(0.64 f/n): a handful of flips among 262144
-    projection-conv outputs already gives 3e-3..6e-3 on everything upstream (scripts/diag_gen.py shows
-    2e-5 through the flip-free 2-D tail of the generator).  The raw ops are pinned at 2e-4 in test_ops_gpu."""
-    for i, (p, g) in enumerate(zip(net.weights, ref_grads)):
-        if not p.requires_grad:
-            continue
-        if g is None:
-            g = torch.zeros(tuple(p.shape), dtype=torch.float64)
-        got = p.grad.detach().cpu().double()
-        assert torch.isfinite(got).all(), "%s grad[%d]: non-finite" % (what, i)
+def _grad_pairs(parts, ref_grads):
+    """[(label, product gradient, oracle gradient)] over the trainable weights of parts = [(net, what, slice into ref_grads)]."""
+    out = []
+    for net, what, sl in parts:
+        for i, (p, g) in enumerate(zip(net.weights, ref_grads[sl])):
+            if not p.requires_grad:
+                continue
+            if g is None:
+                g = torch.zeros(tuple(p.shape), dtype=torch.float64)
+            out.append(("%s grad[%d] %s" % (what, i, tuple(p.shape)), p.grad.detach().cpu().double(), g.detach()))
+    return out
+
+
+def _rel_errors(pairs):
+    errs = []
+    for label, got, g in pairs:
+        assert torch.isfinite(got).all(), label + ": non-finite"
         den = float(g.norm())
         if den == 0.0:
-            assert float(got.abs().max()) == 0.0, "%s grad[%d] should be exactly zero" % (what, i)
+            assert float(got.abs().max()) == 0.0, label + " should be exactly zero"
             continue
-        rel = float((got - g).norm()) / den
-        mx = float((got - g).abs().max()) / float(g.abs().max())
-        assert rel <= tol and mx <= 0.3, "%s grad[%d] %s: rel-L2 %.3e max %.3e" % (what, i, tuple(p.shape), rel, mx)
+        errs.append((float((got - g).norm()) / den, label))
+    return errs
+
+
+def check_grads(parts, recompute, tol=5e-3, max_flips=12):
+    """Gradient parity at `tol` relative L2 per tensor, with branch decisions accounted for by name.
+
+    A LeakyReLU / ReLU whose pre-activation is within fp32 rounding of zero takes the other branch on the GPU than in the
+    float64 oracle.  The forward value is continuous there, but the derivative mask differs in that element, which moves
+    every upstream gradient by ~1/sqrt(#elements) (3e-3..6e-2 measured, depending on depth) -- far above the kernels' own
+    error (2e-4 in test_ops_gpu).  Instead of a tolerance that absorbs it, the oracle lists its near-zero pre-activations
+    (oracle.ref_ops.BranchControl), each candidate is flipped in a separate oracle run, and the product gradient must equal
+    the oracle gradient plus the single-flip differences of a subset of them (gradients are linear in each mask element),
+    to `tol`.  recompute() reruns the oracle and returns its gradient list."""
+    O.BranchControl.start(record=True)
+    try:
+        base = recompute()
+        # near-zero pre-activations that a gradient actually reaches, closest to zero first
+        cands = sorted((c for c in O.BranchControl.candidates() if c[3] > 0.0), key=lambda t: t[2])[:max_flips]
+    finally:
+        O.BranchControl.stop()
+    pairs = _grad_pairs(parts, base)
+    errs = _rel_errors(pairs)
+    if all(e <= tol for e, _ in errs):
+        return
+    assert cands, "gradient mismatch with no near-zero pre-activation to attribute it to: %s" % sorted(errs, reverse=True)[:3]
+    # single-flip differences, every tensor scaled by its oracle norm so that each weighs the same in the fit
+    live = [(label, got, g, float(g.norm())) for label, got, g in pairs if float(g.norm()) > 0.0]
+    resid = torch.cat([((got - g) / den).reshape(-1) for _, got, g, den in live])
+    cols = []
+    for cid, idx, _, _ in cands:
+        O.BranchControl.start(flips=[(cid, idx)])
+        try:
+            flipped = _grad_pairs(parts, recompute())
+        finally:
+            O.BranchControl.stop()
+        fl = {label: g for label, _, g in flipped}
+        cols.append(torch.cat([((fl[label] - g) / den).reshape(-1) for label, _, g, den in live]))
+    # a flip is taken or not: greedy selection of the single-flip differences (coefficient exactly 1) that reduce the residual
+    fit, chosen = torch.zeros_like(resid), []
+    while True:
+        cur = float((resid - fit).norm())
+        gains = [(cur - float((resid - fit - c).norm()), k) for k, c in enumerate(cols) if k not in chosen]
+        if not gains or max(gains)[0] <= 1e-3 * cur:
+            break
+        k = max(gains)[1]
+        chosen.append(k)
+        fit = fit + cols[k]
+    coef = [1 if k in chosen else 0 for k in range(len(cols))]
+    o = 0
+    for label, got, g, den in live:
+        n = g.numel()
+        rel = float((resid[o:o + n] - fit[o:o + n]).norm())
+        assert rel <= tol, "%s: rel-L2 %.3e with %d of the %d nearest branch decisions flipped %s" % (
+            label, rel, len(chosen), len(cands), coef)
+        o += n
+
+
+def close_grads(net, ref_grads, what, tol=5e-3, recompute=None):
+    """One network's gradients against the oracle's at `tol` relative L2 per tensor.  recompute (a callable returning the
+    oracle gradient list again) enables the branch-flip accounting of check_grads()."""
+    if recompute is not None:
+        return check_grads([(net, what, slice(None))], recompute, tol)
+    errs = _rel_errors(_grad_pairs([(net, what, slice(None))], list(ref_grads)))
+    for e, label in errs:
+        assert e <= tol, "%s: rel-L2 %.3e" % (label, e)
 
 
 def randomize(net, seed, scale=0.1):
@@ -92,7 +157,8 @@ def test_generator_forward_backward(res, n):
     torch.autograd.backward((img * torch.tensor(cot, device="cuda", dtype=torch.float32)).sum(),
                             inputs=g.trainable_weights + [rot_t])
     grads = torch.autograd.grad((ref * t64(cot)).sum(), wr + [rot_r], allow_unused=True)
-    close_grads(g, grads[:-1], "generator")
+    close_grads(g, None, "generator", recompute=lambda: torch.autograd.grad(
+        (R.generator_forward(wr, t64(z), rot_r, res) * t64(cot)).sum(), wr, allow_unused=True))
     close(rot_t.grad, grads[-1], tol=2e-2, what="d/d rotation", rel=True)
     # predict() == eager call, numpy out; learned_input kernel gradient is identically zero
     # (fp32 atomics in the statistics kernels: the last bits are run-dependent)
@@ -122,7 +188,8 @@ def test_discriminator_loss_with_r1_double_backward():
     assert list(losses.keys()) == list(ref_losses.keys())
     for k in losses:
         close(losses[k], ref_losses[k], what=k)
-    close_grads(d, S.grads_of(ref_losses["loss_sum"], wr), "discriminator (R1)")
+    close_grads(d, None, "discriminator (R1)",
+                recompute=lambda: S.grads_of(S.discriminator_loss(wr, t64(real), t64(fake))["loss_sum"], wr))
     # the literal reverse-over-reverse formulation (second-order tape on composite ops) agrees as well
     g_jvp = [p.grad.detach().clone() for p in d.weights]
     d.zero_grad()
@@ -149,7 +216,8 @@ def test_latent_regressor_and_latent_discriminator():
     close(out, ref, what="latent regressor")
     lr.zero_grad()
     torch.autograd.backward((out ** 2).sum(), inputs=lr.trainable_weights)
-    close_grads(lr, S.grads_of((ref ** 2).sum(), wr), "latent regressor")
+    close_grads(lr, None, "latent regressor",
+                recompute=lambda: S.grads_of((R.latent_regressor_forward(wr, t64(img)) ** 2).sum(), wr))
 
     ld = MLPSimple(4, 43, 43, 1, rng=rng)
     randomize(ld, 4)
@@ -161,7 +229,8 @@ def test_latent_regressor_and_latent_discriminator():
     ref_losses = S.latent_discriminator_loss(wr, t64(a), t64(b))
     for k in losses:
         close(losses[k], ref_losses[k], what="latent D " + k)
-    close_grads(ld, S.grads_of(ref_losses["loss_sum"], wr), "latent discriminator (R1)")
+    close_grads(ld, None, "latent discriminator (R1)",
+                recompute=lambda: S.grads_of(S.latent_discriminator_loss(wr, t64(a), t64(b))["loss_sum"], wr))
 
 
 @pytest.mark.parametrize("model_type", ["imagenet", "VGGFace"])
@@ -196,8 +265,10 @@ def test_real_encoder():
     close(rot, rot_r, what="encoder rotation")
     enc.zero_grad()
     torch.autograd.backward((emb ** 2).sum() + (rot ** 2).sum() * 10, inputs=enc.trainable_weights)
-    grads = torch.autograd.grad((emb_r ** 2).sum() + (rot_r ** 2).sum() * 10, wr, allow_unused=True)
-    close_grads(enc, grads, "real encoder")
+    def ref_grads():
+        e, r = R.real_encoder_forward(wr, t64(img))
+        return torch.autograd.grad((e ** 2).sum() + (r ** 2).sum() * 10, wr, allow_unused=True)
+    close_grads(enc, None, "real encoder", recompute=ref_grads)
     e2, r2 = enc.predict(img.astype(np.float32))
     np.testing.assert_allclose(e2, emb.detach().cpu().numpy(), rtol=1e-4, atol=1e-4)
 
@@ -259,9 +330,13 @@ def test_first_stage_generator_step_and_adam():
     allw = W["generator"] + W["latent_regressor"] + W["synthetic_encoder"]
     grads = S.grads_of(ref["loss_sum"], allw)
     ng, nl = len(W["generator"]), len(W["latent_regressor"])
-    close_grads(m.generator, grads[:ng], "G step: generator")
-    close_grads(m.latent_regressor, grads[ng:ng + nl], "G step: latent regressor")
-    close_grads(m.synthetic_encoder, grads[ng + nl:], "G step: synthetic encoder")
+
+    def ref_grads():
+        r, _ = S.first_stage_generator_loss(W, m.config, [t64(p) for p in params], t64(rot[:ns]), t64(imgs[:ns]),
+                                            torch.as_tensor(masks), t64(z_real), t64(rot[ns:]), vgg_w)
+        return S.grads_of(r["loss_sum"], allw)
+    check_grads([(m.generator, "G step: generator", slice(0, ng)), (m.latent_regressor, "G step: latent regressor", slice(ng, ng + nl)),
+                 (m.synthetic_encoder, "G step: synthetic encoder", slice(ng + nl, None))], ref_grads)
     # Keras Adam (shared counter) + EMA on the arenas vs the oracle
     # With beta_1 = 0 the first Keras-Adam step is lr*sign(g): entries whose gradient is at noise level may
     # take the other sign than the float64 oracle, so the update is compared where |g| is significant.
@@ -313,12 +388,18 @@ def test_second_stage_generator_step():
     for k in losses:
         close(losses[k], ref[k], what="stage-2 G step " + k)
     allw = W["generator"] + W["latent_regressor"] + W["synthetic_encoder"] + W["real_encoder"]
-    grads = torch.autograd.grad(ref["loss_sum"], allw, allow_unused=True)
     ng, nl, ne = len(W["generator"]), len(W["latent_regressor"]), len(W["synthetic_encoder"])
-    close_grads(m.generator, grads[:ng], "stage-2: generator", tol=4e-2)
-    close_grads(m.latent_regressor, grads[ng:ng + nl], "stage-2: latent regressor", tol=5e-2)
-    close_grads(m.synthetic_encoder, grads[ng + nl:ng + nl + ne], "stage-2: synthetic encoder", tol=8e-2)
-    close_grads(m.encoder, grads[ng + nl + ne:], "stage-2: real encoder", tol=4e-2)
+
+    def ref_grads():
+        r, _ = S.second_stage_generator_loss(W, m.config, [t64(p) for p in params], t64(rot[:ns]), t64(imgs[:ns]),
+                                             torch.as_tensor(masks), t64(imgs[ns:]), vgg_w)
+        return torch.autograd.grad(r["loss_sum"], allw, allow_unused=True)
+    check_grads([(m.generator, "stage-2: generator", slice(0, ng)), (m.latent_regressor, "stage-2: latent regressor", slice(ng, ng + nl)),
+                 (m.synthetic_encoder, "stage-2: synthetic encoder", slice(ng + nl, ng + nl + ne)),
+                 (m.encoder, "stage-2: real encoder", slice(ng + nl + ne, None))], ref_grads, tol=2e-2)
+    # (the deepest chain of the suite -- generator + VGG-19 + ResNet-50 + six discriminator heads, millions of ReLU /
+    # LeakyReLU / max-pool decisions: the 12 nearest-to-zero candidates explain the deviation down to 1.2e-2 (two of them
+    # are taken: 4e-2..8e-2 before); every further candidate costs one more oracle pass of ~10 s)
 
 
 def test_full_iteration_runs_and_api(tmp_path):
@@ -385,7 +466,8 @@ def test_latent_gan_step():
     ref = latent_discriminator_loss(wr, t64(real), t64(fake))
     for k in losses:
         close(losses[k], ref[k], what="LatentGAN D " + k)
-    close_grads(gan.discriminator, grads_of(ref["loss_sum"], wr), "LatentGAN D")
+    close_grads(gan.discriminator, None, "LatentGAN D",
+                recompute=lambda: grads_of(latent_discriminator_loss(wr, t64(real), t64(fake))["loss_sum"], wr))
     for _ in range(2):
         d = gan.discriminator_training_step(emb, opt)
         g = gan.generator_training_step(opt)
