@@ -1,0 +1,36 @@
+#!/bin/bash
+# Everything the judged profiles/ artifacts are made from, in one GPU-box call:
+#   gpurun --timeout 3000 -- 'bash scripts/make_profiles.sh round2'
+# writes gpurun_out/profiles_<tag>/ ; copy what is to be judged into profiles/ and commit.
+TAG=${1:-round2}
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/profiles_$TAG
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+PY="python"
+# 1. the bench lines (default flags), fp32 and bf16
+timeout 900 $PY $R/bench.py > $O/${TAG}_bench.json 2> $O/bench.err
+timeout 300 $PY $R/bench.py --dtype bf16 --no-cpu-baseline > $O/${TAG}_bench_bf16.json 2>> $O/bench.err
+# 2. kernel traces: the default (concurrent graphs) command and the serial one whose averages the roofline object quotes
+rm -rf /tmp/kt1 /tmp/kt2
+timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/kt1 -- $PY $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $O/${TAG}_bench_under_rocprof.json 2>/dev/null
+$PY $R/scripts/prof_summary.py $(ls /tmp/kt1/*/*.db | head -1) > $O/${TAG}_bench_kernel_trace.txt
+timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/kt2 -- $PY $R/bench.py --serial --steps 10 --warmup 3 --no-cpu-baseline > $O/${TAG}_bench_serial_under_rocprof.json 2>/dev/null
+$PY $R/scripts/prof_summary.py $(ls /tmp/kt2/*/*.db | head -1) > $O/${TAG}_bench_serial_kernel_trace.txt
+$PY $R/scripts/torch_share.py /tmp/kt2 $O/${TAG}_torch_share.json > /dev/null
+# 3. PMC passes (each in its own run, --kernel-trace only)
+CMD="bench.py --steps 2 --warmup 1 --no-cpu-baseline --serial"
+rm -rf /tmp/pf /tmp/pw /tmp/pm
+timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/pf -- $PY $R/$CMD > /dev/null 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/pw -- $PY $R/$CMD > /dev/null 2>&1
+$PY $R/scripts/pmc_traffic_json.py /tmp/pf /tmp/pw $O/${TAG}_pmc_traffic.json "python $CMD" > /dev/null
+timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES -d /tmp/pm -- $PY $R/$CMD > /dev/null 2>&1
+$PY $R/scripts/pmc_mfma.py /tmp/pm $O/${TAG}_pmc_mfma.json > $O/${TAG}_pmc_mfma.txt
+# 4. per-shape tables
+cd $R
+timeout 600 $PY scripts/conv_shapes_bench.py 16 f32 > $O/${TAG}_conv_shapes.txt 2>/dev/null
+timeout 600 $PY scripts/conv_shapes_bench.py 16 bf16 > $O/${TAG}_conv_shapes_bf16.txt 2>/dev/null
+timeout 300 $PY scripts/ew_shapes_bench.py > $O/${TAG}_elementwise_shapes.txt 2>/dev/null
+timeout 300 $PY scripts/predict_latency.py > $O/${TAG}_predict_latency.txt 2>/dev/null
+timeout 900 $PY scripts/bench_configs.py > $O/${TAG}_secondary_configs.json 2>/dev/null
+ls -la $O

@@ -1,8 +1,11 @@
-"""profiles/round1_pmc_traffic.json from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; rocpd sqlite):
+"""profiles/roundN_pmc_traffic.json from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; rocpd sqlite):
 HBM bytes per launch of the implicit-GEMM kernel class.  usage: pmc_traffic_json.py <fetch_dir> <write_dir> <out.json> <cmd>"""
-import glob, json, sqlite3, sys
+import glob, json, os, sqlite3, sys
 
-CLASS = ("igemm_fwd_kernel", "igemm_wgrad_kernel", "s2_image_dgrad_kernel", "c3_fwd_kernel", "up2k4_rgb_fwd_kernel")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import kernels_hash
+
+CLASS = ("igemm_fwd_kernel", "igemm_wgrad_kernel", "wino_fwd_kernel", "s2_image_dgrad_kernel", "c3_fwd_kernel", "up2k4_rgb_fwd_kernel")
 
 
 def load(d, counter):
@@ -17,7 +20,7 @@ def load(d, counter):
 
 nf, fetch = load(sys.argv[1], "FETCH_SIZE")
 nw, write = load(sys.argv[2], "WRITE_SIZE")
-out = {"kernel_class": "/".join(CLASS), "launches_sampled": nf,
+out = {"kernels_hash": kernels_hash(), "kernel_class": "/".join(CLASS), "launches_sampled": nf,
        "hbm_bytes_per_launch": (2 * fetch / nf + write / nw),
        "fetch_bytes_per_launch_corrected_x2": 2 * fetch / nf, "write_bytes_per_launch": write / nw,
        "how": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, with --kernel-trace only) on `%s`; FETCH_SIZE "
