@@ -49,6 +49,7 @@ class ConvFn(Function):
             # UpSampling + Conv collapsed per output-parity class: 8/27 (3-D k3) or 6.25/16 (2-D k4) of the multiply-adds
             wf, _, gd, _ = ops.upfold_prepare(w, g)
             y = ops.conv_fwd(x, wf, bias, gd, act, slope)
+            ops.prof_note_saved(ops.upfold_saved_flops(g))
         else:
             y = ops.conv_fwd(x, w, bias, g, act, slope)
         ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
@@ -75,9 +76,11 @@ class ConvFn(Function):
             _, wd, _, g2 = ops.upfold_prepare(w, ctx.g)
             if ctx.needs_input_grad[0]:
                 gx = ops.conv_fwd(gy, wd, None, g2)
+                ops.prof_note_saved(ops.upfold_saved_flops(ctx.g))
             if not _INPUT_GRADS_ONLY:
                 if ctx.needs_input_grad[1]:
                     gw = ops.upfold_wgrad(ops.conv_wgrad(gy, x, g2, tuple(wd.shape)), ctx.g, tuple(w.shape))
+                    ops.prof_note_saved(ops.upfold_saved_flops(ctx.g))
                 if ctx.has_bias and ctx.needs_input_grad[2]:
                     gb = gb_fused if gb_fused is not None else ops.nc_reduce(gy.detach(), None, want_dot=False, per_channel=True)[0].reshape(-1)
             return gx, gw, gb, None, None, None

@@ -289,6 +289,7 @@ def conv_fwd(x, w, bias, g, act=ACT_NONE, slope=0.0):
         y = torch.empty(geom_out_shape(g), device=x.device, dtype=torch.float32)
         check(lib.cn_conv_fwd_wino(g.n, g.in_h, g.in_w, g.cin, g.cout, _ptr(x), _ptr(_wino_filter(w, False)), _fptr(bias), _ptr(y),
                                    act, slope, _stream()), "cn_conv_fwd_wino")
+        prof_note_saved(wino_saved_flops(g))
         return y
     if _bf16_conv_ok(g):
         x = cast(x, torch.bfloat16)
@@ -325,6 +326,7 @@ def conv_dgrad(gy, w, g):
     if ACT_DTYPE == torch.float32 and _wino_ok(g, g.cout, g.cin):
         check(lib.cn_conv_fwd_wino(g.n, g.in_h, g.in_w, g.cout, g.cin, _ptr(gy), _ptr(_wino_filter(w, True)), None, _ptr(gu),
                                    ACT_NONE, 0.0, _stream()), "cn_conv_fwd_wino")
+        prof_note_saved(wino_saved_flops(g))
         return gu
     wt = _weight_cache(w, "_cn_tflip", weight_tflip)
     check(lib.cn_conv_dgrad(ctypes.byref(g), _ptr(gy), _fptr(wt), _ptr(gu), _stream()), "cn_conv_dgrad")
@@ -727,12 +729,44 @@ def to_uint8(x):
     return out
 
 
+_PROF = {"on": False, "saved_flops": 0.0}
+
+
 def prof_enable(on):
+    _PROF["on"] = bool(on)
     check(lib.cn_prof_enable(int(on)), "cn_prof_enable")
 
 
 def prof_reset():
+    _PROF["saved_flops"] = 0.0
     check(lib.cn_prof_reset(), "cn_prof_reset")
+
+
+def prof_note_saved(flops):
+    """Multiply-adds a direct convolution would have issued and the algorithm in use does not (Winograd, parity-class
+    collapse of upsample-folded layers): bench.py reports them next to the issued work, never inside `roofline.frac`."""
+    if _PROF["on"]:
+        _PROF["saved_flops"] += flops
+
+
+def prof_saved_flops():
+    return _PROF["saved_flops"]
+
+
+def wino_saved_flops(g):
+    """direct 3x3 count (border taps included: an upper bound) minus the 16 products per 2x2 tile issued"""
+    tiles = g.n * ((g.in_h + 1) // 2) * ((g.in_w + 1) // 2)
+    return 2.0 * g.cin * g.cout * (9.0 * g.n * g.in_h * g.in_w - 16.0 * tiles)
+
+
+def upfold_saved_flops(g):
+    """direct count of the conv on the x2-upsampled grid minus the parity-class form: (2/3)^nd of it for k3, (2.5/4)^nd for k4"""
+    ks = [k for k in (g.k_d, g.k_h, g.k_w)][3 - g.nd:]
+    ratio = 1.0
+    for k in ks:
+        ratio *= (2.0 / 3.0) if k == 3 else (2.5 / 4.0)
+    direct = 2.0 * g.n * g.out_d * g.out_h * g.out_w * g.k_d * g.k_h * g.k_w * g.cin * g.cout
+    return direct * (1.0 - ratio)
 
 
 def prof_collect():

@@ -113,6 +113,9 @@ def best_thread_count(res, candidates, probe_batch=2):
         seen[c] = round(sec, 2)
         if ips > best_ips:
             best, best_ips = c, ips
+        else:
+            break           # past the knee: on a 256-core host the 64-thread probe is 3x slower than the 16-thread one and
+                            # an all-cores iteration did not finish in 14 minutes -- never probe beyond a slowdown
     return best, seen
 
 
@@ -122,7 +125,7 @@ if __name__ == "__main__":
     b = int(sys.argv[1]) if len(sys.argv) > 1 else 2
     r = int(sys.argv[2]) if len(sys.argv) > 2 else 256
     host = os.cpu_count() or 1
-    cands = sorted({min(16, host), min(64, host), host})
+    cands = sorted({min(8, host), min(16, host), min(32, host), min(64, host)})
     threads, probe = best_thread_count(r, cands)
     v, sec, cores = time_second_stage_iteration(r, b, repeats=3, threads=threads, warmup=1)     # 1 warm-up + median of 3
     print(json.dumps({"value": v, "seconds": sec, "cores": cores, "host_cores": host, "thread_probe_seconds": probe}))

@@ -15,16 +15,16 @@ calls = OrderedDict()
 o_red, o_lin = ops.nc_reduce, ops.nc_lin2
 
 
-def nc_reduce(x1, x2=None, want_sum=True, want_dot=True, flags=0, slope=0.0, per_channel=False):
+def nc_reduce(x1, x2=None, want_sum=True, want_dot=True, flags=0, slope=0.0, per_channel=False, **kw):
     k = ("reduce", tuple(x1.shape), x2 is not None, want_sum, want_dot, flags, per_channel)
     calls[k] = calls.get(k, 0) + 1
-    return o_red(x1, x2, want_sum, want_dot, flags, slope, per_channel)
+    return o_red(x1, x2, want_sum, want_dot, flags, slope, per_channel, **kw)
 
 
-def nc_lin2(shape, x1=None, a1=None, x2=None, a2=None, b=None, flags=0, slope=0.0, per_channel=False, a3=None, b3=None):
+def nc_lin2(shape, x1=None, a1=None, x2=None, a2=None, b=None, flags=0, slope=0.0, per_channel=False, a3=None, b3=None, **kw):
     k = ("lin2", tuple(shape), x1 is not None, x2 is not None, b is not None, flags, per_channel, a3 is not None)
     calls[k] = calls.get(k, 0) + 1
-    return o_lin(shape, x1, a1, x2, a2, b, flags, slope, per_channel, a3, b3)
+    return o_lin(shape, x1, a1, x2, a2, b, flags, slope, per_channel, a3, b3, **kw)
 
 
 ops.nc_reduce, ops.nc_lin2 = nc_reduce, nc_lin2
