@@ -66,6 +66,7 @@ SIGNATURES = {
     "cn_masked_diff": [_p, _p, _p, _p, _z, _i, _p],
     "cn_maxpool_fwd": [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "cn_maxpool_bwd": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
+    "cn_avgpool3_same": [_p, _p, _i, _i, _i, _i, _i, _p],
     "cn_chan_affine3_fwd": [_p, _p, _z, ctypes.POINTER(_i), _f, ctypes.POINTER(_f), _p],
     "cn_chan_affine3_bwd": [_p, _p, _z, ctypes.POINTER(_i), _f, _p],
     "cn_gan_loss_fwd": [_p, _p, _i, _f, _p],

@@ -534,6 +534,9 @@ class ConfigNetFirstStage:
             losses["GAN_loss_synth_" + str(i)] = GAN_G_loss(o)
         if side is not main:
             main.wait_stream(side)
+            if not torch.cuda.is_current_stream_capturing():    # (see ConfigNet._generator_loss: allocator hand-off in eager mode)
+                for t in [generator_output_real] + gan_real:
+                    t.record_stream(main)
         for i, l in enumerate(gan_real):
             losses["GAN_loss_real_" + str(i)] = l
         latent_discriminator_output = self.latent_discriminator(synth_latents)
@@ -583,12 +586,94 @@ class ConfigNetFirstStage:
             return losses
         return self._run_step("g", (real_training_set, synth_training_set), optimizer, device)
 
+    n_checkpoint_rotations = 6       # confignet_first_stage.py:111-112
+    n_checkpoint_samples = 10
+
     def setup_training(self, log_dir, synth_training_set, n_samples_for_metrics, real_training_set=None):
+        """confignet_first_stage.py:562-595, same order of np.random draws: the FID/KID reference sample, the metric and
+        checkpoint-visualisation generator inputs, the synthetic checkpoint batch.  config["run_metrics"] = False skips the
+        InceptionV3 extractor (and only that)."""
+        if real_training_set is None:
+            real_training_set = synth_training_set
+        if log_dir is not None:
+            os.makedirs(log_dir, exist_ok=True)
+        self._inception_metric_object = None
+        if self.config.get("run_metrics", True):
+            from .metrics import InceptionMetrics
+            self._inception_metric_object = InceptionMetrics(self.config, real_training_set)
+        self._generator_input_for_metrics = {"latent": self.sample_latent_vector(n_samples_for_metrics),
+                                             "rotation": self.sample_rotations(n_samples_for_metrics)}
+        checkpoint_latent = np.vstack([self.sample_latent_vector(self.n_checkpoint_samples)] * self.n_checkpoint_rotations)
+        checkpoint_rotation = np.zeros((self.n_checkpoint_rotations, 3))
+        rr = self.config["rotation_ranges"][0]
+        checkpoint_rotation[:, 0] = np.pi * np.linspace(rr[0], rr[1], self.n_checkpoint_rotations) / 180
+        checkpoint_rotation = np.reshape(np.hstack([checkpoint_rotation] * self.n_checkpoint_samples), (-1, 3))
+        self._checkpoint_visualization_input = {"latent": checkpoint_latent, "rotation": checkpoint_rotation}
         self.facemodel_param_distributions = synth_training_set.metadata_input_distributions   # l.587
+        facemodel_params, _, gt_imgs, _ = self.sample_synthetic_dataset(synth_training_set, self.n_checkpoint_samples)
+        facemodel_params = [np.tile(np.asarray(p), (self.n_checkpoint_rotations, 1)) for p in facemodel_params]
+        self._checkpoint_visualization_input["facemodel_params"] = facemodel_params
+        self._checkpoint_visualization_input["gt_imgs"] = gt_imgs
+
+    # ---- checkpoint-related code (confignet_first_stage.py:289-386) ----------------------------------
+    def synth_data_image_checkpoint(self, output_dir):
+        vis = self._checkpoint_visualization_input
+        generated = self.generate_images_from_facemodel(vis["facemodel_params"], vis["rotation"])
+        gt = vis["gt_imgs"]
+        if torch.is_tensor(gt):
+            gt = gt.detach().cpu().numpy()
+        gt = np.asarray(gt)
+        if gt.dtype != np.uint8:                               # the device pipeline hands out [-1, 1] floats
+            gt = np.clip((gt + 1.0) * 127.5, 0, 255).astype(np.uint8)
+        grid = confignet_utils.build_image_matrix(np.vstack((gt, generated)), self.n_checkpoint_rotations + 1, self.n_checkpoint_samples)
+        img_dir = os.path.join(output_dir, "output_imgs")
+        os.makedirs(img_dir, exist_ok=True)
+        confignet_utils.write_image(os.path.join(img_dir, str(self.get_training_step_number()).zfill(6) + "_synth.jpg"), grid)
+
+    def image_checkpoint(self, output_dir):
+        vis = self._checkpoint_visualization_input
+        grid = confignet_utils.build_image_matrix(self.generate_images(vis["latent"], vis["rotation"]),
+                                                  self.n_checkpoint_rotations, self.n_checkpoint_samples)
+        img_dir = os.path.join(output_dir, "output_imgs")
+        os.makedirs(img_dir, exist_ok=True)
+        confignet_utils.write_image(os.path.join(img_dir, str(self.get_training_step_number()).zfill(6) + ".png"), grid)
+        self.synth_data_image_checkpoint(output_dir)
+
+    def generate_output_for_metrics(self):
+        return self.generate_images(self._generator_input_for_metrics["latent"], self._generator_input_for_metrics["rotation"])
+
+    def calculate_metrics(self, output_dir, aml_run=None):
+        """l.378-386: KID / FID of n_samples_for_metrics generated images against the training-set sample."""
+        if self._inception_metric_object is None:
+            return
+        generated_images = self.generate_output_for_metrics()
+        self.metrics.setdefault("training_step_number", []).append(self.get_training_step_number())
+        self._inception_metric_object.update_and_log_metrics(generated_images, self.metrics, output_dir, aml_run, None)
+
+    def run_checkpoints(self, output_dir, iteration_time, aml_run=None, checkpoint_start=None):
+        """l.334-376: every image_checkpoint_period steps loss logs + image grids, every metrics_checkpoint_period steps
+        metrics + save (step 0 included).  Rank 0 only under data parallelism."""
+        if output_dir is None or parallel.rank() != 0:
+            return
+        checkpoint_start = time.perf_counter()
+        step_number = self.get_training_step_number()
+        if step_number % self.config["image_checkpoint_period"] == 0:
+            confignet_utils.log_loss_vals(self.synth_d_losses, output_dir, step_number, "synth_discriminator_", aml_run=aml_run)
+            confignet_utils.log_loss_vals(self.latent_d_losses, output_dir, step_number, "latent_discriminator_", aml_run=aml_run)
+        if step_number % self.config["metrics_checkpoint_period"] == 0:
+            print("Running metrics")
+            self.calculate_metrics(output_dir, aml_run=aml_run)
+            self.save(os.path.join(output_dir, "checkpoints"), str(step_number).zfill(6))
+        if step_number % self.config["image_checkpoint_period"] == 0:
+            self.image_checkpoint(output_dir)
+            confignet_utils.log_loss_vals(self.g_losses, output_dir, step_number, "generator_", aml_run=aml_run)
+            confignet_utils.log_loss_vals(self.d_losses, output_dir, step_number, "discriminator_", aml_run=aml_run)
+            print("Training iteration time: %f" % iteration_time)
+            print("Checkpoint time: %f" % (time.perf_counter() - checkpoint_start))
 
     def train(self, real_training_set, synth_training_set, output_dir, log_dir, n_steps=100000,
               n_samples_for_metrics=1000, aml_run=None):
-        """confignet_first_stage.py:597-626 (checkpoint images / metrics are out of scope)."""
+        """confignet_first_stage.py:597-626."""
         self.setup_training(log_dir, synth_training_set, n_samples_for_metrics, real_training_set=real_training_set)
         parallel.broadcast_weights(self.all_networks())       # data-parallel replicas start from rank 0's weights
         start_step = self.get_training_step_number()
@@ -622,9 +707,7 @@ class ConfigNetFirstStage:
             confignet_utils.update_loss_dict(self.d_losses, d_loss)
             confignet_utils.update_loss_dict(self.synth_d_losses, synth_d_loss)
             confignet_utils.update_loss_dict(self.latent_d_losses, latent_d_loss)
-            step = self.get_training_step_number()
-            if output_dir is not None and step % self.config["metrics_checkpoint_period"] == 0 and parallel.rank() == 0:
-                self.save(os.path.join(output_dir, "checkpoints"), str(step).zfill(6))     # (l.349-355; incl. step 0)
+            self.run_checkpoints(output_dir, self.last_iteration_time, aml_run=aml_run)
 
     # ---- evaluation code ----------------------------------------------------------------------------
     use_inference_graphs = True      # generate_images: one replayed HIP graph per (generator, batch) instead of ~60 eager launches

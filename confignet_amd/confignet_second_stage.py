@@ -141,6 +141,12 @@ class ConfigNet(ConfigNetFirstStage):
         out_synth = self.latent_discriminator(synth_latents)
         if side is not main:
             main.wait_stream(side)                            # join: everything below needs both branches
+            if not torch.cuda.is_current_stream_capturing():
+                # eager dispatch: blocks allocated on the side stream are consumed on the main stream from here on -- tell the
+                # caching allocator, which otherwise hands them back to the side stream's pool on free (wait_stream orders the
+                # kernels, not the allocator).  Captured graphs allocate from their private pool.
+                for t in [real_latents, real_rotations, generator_output_real, image_loss_real, out_real] + gan_real:
+                    t.record_stream(main)
         losses["image_loss_real"] = image_loss_real
         for i, l in enumerate(gan_real):
             losses["GAN_loss_real_" + str(i)] = l
@@ -196,11 +202,40 @@ class ConfigNet(ConfigNetFirstStage):
 
     def setup_training(self, log_dir, synth_training_set, n_samples_for_metrics, attribute_classifier=None,
                        real_training_set=None, validation_set=None):
+        """confignet_second_stage.py:255-266 (ControllabilityMetrics: out of scope)."""
         super(ConfigNet, self).setup_training(log_dir, synth_training_set, n_samples_for_metrics, real_training_set)
+        if validation_set is None:
+            validation_set = real_training_set if real_training_set is not None else synth_training_set
+        imgs = validation_set.imgs
+        sample_idxs = np.random.randint(0, imgs.shape[0], self.n_checkpoint_samples)
+        self._checkpoint_visualization_input["input_images"] = self._host_images(imgs, sample_idxs)
+        sample_idxs = np.random.randint(0, imgs.shape[0], n_samples_for_metrics)
+        self._generator_input_for_metrics["input_images"] = self._host_images(imgs, sample_idxs)
+
+    @staticmethod
+    def _host_images(imgs, idxs):
+        """imgs[idxs] as float32 in [-1, 1] on the host (the dataset pool may live in HBM as a uint8 tensor)."""
+        sel = imgs[torch.as_tensor(idxs, device=imgs.device)].cpu().numpy() if torch.is_tensor(imgs) else np.asarray(imgs)[idxs]
+        return sel.astype(np.float32) / 127.5 - 1.0
+
+    def calculate_metrics(self, output_dir, aml_run=None):
+        """confignet_second_stage.py:220-253: FID/KID (first stage) + the perceptual reconstruction metric of the metric
+        images through encoder -> smoothed generator; the controllability metrics are out of scope."""
+        super(ConfigNet, self).calculate_metrics(output_dir, aml_run)
+        inp = self._generator_input_for_metrics["input_images"]
+        latents, rotations = self.encode_images(inp)
+        generated = self.generator_smoothed.predict(self.generator_smoothed.build_input_dict(latents, rotations))
+        vals = []
+        with torch.no_grad():
+            for s in range(0, len(inp), 16):                               # metric_batch_size 16 (l.231)
+                vals.append(float(self.perceptual_loss.loss(inp[s:s + 16], generated[s:s + 16])))
+        self.metrics.setdefault("perceptual_loss", []).append(float(np.mean(vals)))
+        os.makedirs(output_dir, exist_ok=True)
+        np.savetxt(os.path.join(output_dir, "image_metrics.txt"), self.metrics["perceptual_loss"])
 
     def train(self, real_training_set, synth_training_set, validation_set, attribute_classifier, output_dir, log_dir,
               n_steps=100000, n_samples_for_metrics=1000, aml_run=None):
-        """confignet_second_stage.py:268-299 (metrics / image checkpoints are out of scope)."""
+        """confignet_second_stage.py:268-299."""
         self.setup_training(log_dir, synth_training_set, n_samples_for_metrics, attribute_classifier,
                             real_training_set=real_training_set, validation_set=validation_set)
         parallel.broadcast_weights(self.all_networks())       # data-parallel replicas start from rank 0's weights
@@ -223,9 +258,7 @@ class ConfigNet(ConfigNetFirstStage):
             confignet_utils.update_loss_dict(self.d_losses, d_loss)
             confignet_utils.update_loss_dict(self.synth_d_losses, synth_d_loss)
             confignet_utils.update_loss_dict(self.latent_d_losses, latent_d_loss)
-            step = self.get_training_step_number()
-            if output_dir is not None and step % self.config["metrics_checkpoint_period"] == 0 and parallel.rank() == 0:
-                self.save(os.path.join(output_dir, "checkpoints"), str(step).zfill(6))     # (first_stage l.349-355; incl. step 0)
+            self.run_checkpoints(output_dir, self.last_iteration_time, aml_run=aml_run)
 
     # ---- inference ----------------------------------------------------------------------------------
     def encode_images(self, input_images):

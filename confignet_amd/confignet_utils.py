@@ -53,6 +53,28 @@ def update_loss_dict(main_loss_dict, new_loss_dict):
         main_loss_dict.setdefault(key, []).append(val)
 
 
+def log_loss_vals(loss_dict, output_dir, step_number, prefix, aml_run=None, tb_log_writer=None):
+    """confignet_utils.py:214-241 without the matplotlib / TensorBoard sinks: <prefix>losses.txt, one column per loss."""
+    import os
+    os.makedirs(output_dir, exist_ok=True)
+    loss_names, loss_vals = list(loss_dict.keys()), list(loss_dict.values())
+    if not loss_vals:
+        return
+    if aml_run is not None:
+        from . import azure_ml_utils
+        azure_ml_utils.log_losses(aml_run, loss_names, [x[-1] for x in loss_vals], prefix)
+    np.savetxt(os.path.join(output_dir, prefix + "losses.txt"), np.stack(loss_vals, axis=1), header="\t".join(loss_names))
+
+
+def write_image(path, bgr_image):
+    """cv2.imwrite stand-in (OpenCV is not a dependency here): PNG / JPEG through Pillow when it is installed, else .npy."""
+    try:
+        from PIL import Image
+        Image.fromarray(np.ascontiguousarray(bgr_image[..., ::-1])).save(path)
+    except ImportError:
+        np.save(path + ".npy", bgr_image)
+
+
 def build_image_matrix(images, n_rows, n_cols):
     """confignet_utils.py:182-190: tiles images[j * n_cols + i] into an (n_rows*H, n_cols*W, 3) uint8 canvas."""
     h, w = images.shape[1:3]

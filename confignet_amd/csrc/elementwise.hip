@@ -390,6 +390,43 @@ __global__ void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, i
     }
 }
 
+// AveragePooling2D((3, 3), strides 1, padding "same") [TF-2.1]: the mean over the window cells INSIDE the image (tf.nn.avg_pool
+// does not count padding), float4 over channels.  InceptionV3's pool branches (metrics path).
+template <int V, typename T>
+__global__ void avgpool3_same_kernel(const T* __restrict__ x, T* __restrict__ y, int n, int h, int w, int c) {
+    const int CG = c / V;
+    const long total = (long)n * h * w * CG;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int cg = (int)(i % CG);
+        long t = i / CG;
+        const int ox = (int)(t % w);
+        t /= w;
+        const int oy = (int)(t % h);
+        const int b = (int)(t / h);
+        float acc[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) acc[e] = 0.f;
+        int cnt = 0;
+        for (int dy = -1; dy <= 1; ++dy)
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int iy = oy + dy, ix = ox + dx;
+                if (iy < 0 || iy >= h || ix < 0 || ix >= w) continue;
+                const T* p = x + (((long)b * h + iy) * w + ix) * c + (long)cg * V;
+                if (V == 4) {
+                    const float4 v = ld4<T>(p);
+                    acc[0] += v.x; acc[1 % V] += v.y; acc[2 % V] += v.z; acc[3 % V] += v.w;
+                } else {
+                    acc[0] += ldf<T>(p);
+                }
+                ++cnt;
+            }
+        const float r = 1.f / (float)cnt;
+        T* q = y + (((long)b * h + oy) * w + ox) * c + (long)cg * V;
+        if (V == 4) st4<T>(q, make_float4(acc[0] * r, acc[1 % V] * r, acc[2 % V] * r, acc[3 % V] * r));
+        else stf<T>(q, acc[0] * r);
+    }
+}
+
 // Gradient goes to the first maximum of each window in row-major window order (a zero-padding cell that wins takes it
 // nowhere).  Written as a GATHER over input elements -- every element re-evaluates the (at most ceil(k/s)^2) windows
 // that contain it -- so there are no atomics: deterministic, and gx may be stored in bf16.
@@ -704,6 +741,17 @@ extern "C" int cn_maxpool_fwd(const void* x, void* y, int n, int h, int w, int c
     const int oh = (h + 2 * pad - k) / s + 1, ow = (w + 2 * pad - k) / s + 1;
     const size_t total = (size_t)n * oh * ow * c;
     CN_DISPATCH_DT(dt, hipLaunchKernelGGL((maxpool_fwd_kernel<T>), dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (T*)y, n, h, w, c, oh, ow, k, s, pad));
+    CN_LAUNCH_CHECK();
+    return CN_OK;
+}
+extern "C" int cn_avgpool3_same(const void* x, void* y, int n, int h, int w, int c, int dt, void* stream) {
+    CN_CHECK_ARG(x && y && n > 0 && h > 0 && w > 0 && c > 0 && (dt == CN_F32 || dt == CN_BF16), "avgpool3_same: bad args");
+    const bool v4 = c % 4 == 0 && alv(x, dt) && alv(y, dt);
+    const size_t total = (size_t)n * h * w * (v4 ? c / 4 : c);
+    CN_DISPATCH_DT(dt, {
+        if (v4) hipLaunchKernelGGL((avgpool3_same_kernel<4, T>), dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (T*)y, n, h, w, c);
+        else hipLaunchKernelGGL((avgpool3_same_kernel<1, T>), dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (T*)y, n, h, w, c);
+    });
     CN_LAUNCH_CHECK();
     return CN_OK;
 }

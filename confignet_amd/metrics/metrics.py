@@ -1,0 +1,49 @@
+"""InceptionMetrics (reference: confignet/metrics/metrics.py:201-264): KID / FID of generated images against the inception
+features of a fixed sample of the training set, logged per metrics checkpoint."""
+import os
+
+import numpy as np
+
+from .inception_distance import InceptionFeatureExtractor, compute_FID, compute_KID
+
+
+class InceptionMetrics:
+    def __init__(self, confignet_config, dataset, n_samples_for_metrics=1000, weights_path=None):
+        self.n_samples_for_metrics = n_samples_for_metrics
+        self.inception_feature_extractor = InceptionFeatureExtractor(
+            confignet_config["output_shape"], weights_path or confignet_config.get("inception_weights_path"))
+        metric_sample_idxs = np.random.randint(0, dataset.imgs.shape[0], n_samples_for_metrics)          # metrics.py:206
+        feats = getattr(dataset, "inception_features", None)
+        if feats is None:
+            # the reference's dataset files carry precomputed features (neural_renderer_dataset.py:323-325); a dataset
+            # without them gets the features of the sampled images computed here, with this extractor
+            feats_sample = self.inception_feature_extractor.get_features(np.asarray(dataset.imgs)[metric_sample_idxs])
+        else:
+            feats_sample = np.asarray(feats)[metric_sample_idxs]
+        self.gt_inception_features = feats_sample
+
+    def get_metrics(self, generated_images):
+        generated_inception_features = self.inception_feature_extractor.get_features(generated_images)
+        kid = compute_KID(generated_inception_features, self.gt_inception_features)
+        fid = compute_FID(generated_inception_features, self.gt_inception_features)
+        return kid, fid
+
+    def update_and_log_metrics(self, images, metrics_dict, output_dir, aml_run=None, tb_log_writer=None):
+        """metrics.py:216-264 without the matplotlib / TensorBoard / AzureML sinks: appends to metrics_dict["kid" | "fid"]
+        and rewrites <output_dir>/inception_metrics.txt (step_number, kid, fid per row, the reference's header)."""
+        os.makedirs(output_dir, exist_ok=True)
+        kid, fid = self.get_metrics(images)
+        metrics_dict.setdefault("kid", []).append(kid)
+        metrics_dict.setdefault("fid", []).append(fid)
+        assert len(metrics_dict["kid"]) == len(metrics_dict["fid"])
+        if "training_step_number" in metrics_dict:
+            steps = metrics_dict["training_step_number"]
+            assert len(steps) == len(metrics_dict["kid"])
+        else:
+            steps = range(len(metrics_dict["kid"]))
+        if aml_run is not None:
+            aml_run.log("Kernel Inception Distance", kid)
+            aml_run.log("Frechet Inception Distance", fid)
+        rows = np.stack((list(steps), metrics_dict["kid"], metrics_dict["fid"]), axis=1)
+        np.savetxt(os.path.join(output_dir, "inception_metrics.txt"), rows, delimiter="\t", header="\t".join(["step_number", "kid", "fid"]))
+        return kid, fid

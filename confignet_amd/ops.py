@@ -647,6 +647,15 @@ def maxpool_fwd(x, k, s, pad):
     return y
 
 
+def avgpool3_same(x):
+    """AveragePooling2D((3, 3), strides 1, padding "same"); padding cells are not counted."""
+    n, h, w, c = x.shape
+    x = _c(x)
+    y = torch.empty_like(x)
+    check(lib.cn_avgpool3_same(_ptr(x), _ptr(y), n, h, w, c, _dt(x), _stream()), "cn_avgpool3_same")
+    return y
+
+
 def maxpool_bwd(x, gy, k, s, pad):
     n, h, w, c = x.shape
     x, gy = _unify(x, gy)

@@ -201,6 +201,9 @@ int cn_masked_diff(const float* a, const float* b, const uint8_t* mask, float* o
  * first maximum in row-major window order (computed as a gather: no atomics) */
 int cn_maxpool_fwd(const void* x, void* y, int n, int h, int w, int c, int k, int s, int pad, int dt, void* stream);
 int cn_maxpool_bwd(const void* x, const void* gy, void* gx, int n, int h, int w, int c, int k, int s, int pad, int dt, void* stream);
+/* AveragePooling2D((3,3), strides 1, padding "same") of keras.applications InceptionV3's pool branches (reference:
+ * metrics/inception_distance.py:12, the FID/KID feature extractor); window cells outside the image are not counted [TF-2.1]. */
+int cn_avgpool3_same(const void* x, void* y, int n, int h, int w, int c, int dt, void* stream);
 /* y[...,j] = scale * x[...,perm[j]] + off[j] on 3-channel images: (x+1)*127.5 + "caffe"/VGGFace
  * preprocessing (perceptual_loss.py:52-61 ; real_encoder.py:24-25); bwd scatters back. */
 int cn_chan_affine3_fwd(const float* x, float* y, size_t pixels, const int* perm, float scale, const float* off, void* stream);

@@ -98,7 +98,10 @@ def test_fine_tune_on_img_matches_oracle_golden(graphs):
                           for a, b in zip(m.generator_fine_tuned.get_weights(), W["generator_smoothed"])])
     ref = GOLD_FT["gen_delta_norms"]
     sel = ref > 0
-    assert np.all(np.abs(got_norms[sel] - ref[sel]) <= 0.05 * ref[sel] + 1e-6), (got_norms, ref)
+    # (measured over 20 runs: typically 1-3 %, one run in ~10 above 5 % on a 64-entry bias -- the atomics' summation order decides
+    # the sign of noise-level gradient entries, and a sign step moves such an entry by 2 lr; a wrong lr_t / moment moves every
+    # norm by 100 %)
+    assert np.all(np.abs(got_norms[sel] - ref[sel]) <= 0.10 * ref[sel] + 1e-6), (got_norms, ref)
     assert float(got_norms[0]) == 0.0 and ref[0] == 0.0             # learned_input kernel: zero gradient, never moves
     # generate_images now decodes with the fine-tuned copy (confignet_second_stage.py:310-319)
     out = m.generate_images(emb, rot)
