@@ -5,7 +5,7 @@ Run on ANY machine with TensorFlow 2.x and a checkout of microsoft/ConfigNet imp
 own dependencies cv2 / azureml are NOT needed: only confignet/dnn_models and confignet/confignet_utils.py are imported, by
 file path).  It builds, with seeded weights, one Conv2dAdaIn, one Conv3dAdaIn, one DiscrBlock, transform_3d_grid_tf,
 one shared-optimizer Keras-Adam trace, one InstanceNormalization, the SAME-padding cases, and records the weight NAMES and
-shapes of keras.applications ResNet50 / VGG19 / VGG16 in get_weights() order, and writes
+shapes of keras.applications ResNet50 / VGG19 / VGG16 / InceptionV3 in get_weights() order (+ one seeded InceptionV3 forward), and writes
 
     tests/golden/tf_pins.npz
 
@@ -146,7 +146,9 @@ def main():
     if not args.no_applications:
         for name, ctor in (("resnet50", lambda: keras.applications.ResNet50(weights=None, include_top=False, input_shape=(224, 224, 3), pooling="avg")),
                            ("vgg19", lambda: keras.applications.VGG19(weights=None, include_top=False, input_shape=(224, 224, 3))),
-                           ("vgg16", lambda: keras.applications.VGG16(weights=None, include_top=False, input_shape=(224, 224, 3)))):
+                           ("vgg16", lambda: keras.applications.VGG16(weights=None, include_top=False, input_shape=(224, 224, 3))),
+                           # the FID / KID feature extractor (confignet/metrics/inception_distance.py:12)
+                           ("inception_v3", lambda: keras.applications.InceptionV3(weights=None, include_top=False, input_shape=(256, 256, 3), pooling="avg"))):
             m = ctor()
             out[name + "_weight_names"] = np.array([w.name for w in m.weights])
             out[name + "_weight_shapes"] = np.array([str(tuple(w.shape)) for w in m.weights])
@@ -154,6 +156,17 @@ def main():
         # BatchNormalization epsilon of ResNet50 and the preprocess_input constants
         out["resnet50_bn_eps"] = np.array([l.epsilon for l in keras.applications.ResNet50(weights=None, include_top=False, input_shape=(64, 64, 3)).layers
                                            if isinstance(l, keras.layers.BatchNormalization)][:1])
+        # one seeded forward of InceptionV3 (weights = the seeded arrays written next to it, in get_weights() order)
+        inc = keras.applications.InceptionV3(weights=None, include_top=False, input_shape=(139, 107, 3), pooling="avg")
+        rs = np.random.RandomState(7)
+        ws = [(rs.uniform(0.5, 1.5, size=w.shape) if "moving_variance" in v.name else rs.normal(size=w.shape) * (0.05 if w.ndim == 4 else 0.1)).astype(np.float32)
+              for w, v in zip(inc.get_weights(), inc.weights)]
+        inc.set_weights(ws)
+        xin = rs.uniform(-1, 1, size=(2, 139, 107, 3)).astype(np.float32)
+        out["inception_v3_probe_input"] = xin
+        out["inception_v3_probe_seed"] = np.array(7)
+        out["inception_v3_probe_features"] = inc.predict(xin)
+        out["inception_preprocess_probe"] = keras.applications.inception_v3.preprocess_input(np.array([[0.0, 127.5, 255.0]], np.float32))
         probe = np.zeros((1, 2, 2, 3), np.float32)
         probe[..., 0], probe[..., 1], probe[..., 2] = 10.0, 20.0, 30.0
         out["caffe_preprocess_probe"] = keras.applications.resnet50.preprocess_input(probe.copy())

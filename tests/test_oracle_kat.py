@@ -236,6 +236,20 @@ def _check_pins(P):
         assert [eval(s) for s in P["resnet50_weight_shapes"]] == [tuple(s) for s in R.resnet50_weight_shapes()]
         assert abs(float(P["resnet50_bn_eps"][0]) - R.BN_EPS) < 1e-12
         assert np.allclose(P["caffe_preprocess_probe"][0, 0, 0], [30.0 - 103.939, 20.0 - 116.779, 10.0 - 123.68])
+    if "inception_v3_weight_shapes" in files:
+        from oracle import ref_metrics as M
+        assert [eval(s) for s in P["inception_v3_weight_shapes"]] == M.inception_weight_shapes(), \
+            "keras InceptionV3 get_weights() order differs from oracle/ref_metrics.py"
+        if "inception_v3_probe_features" in files:             # the seeded forward: same RandomState draws as the dump script
+            rs = np.random.RandomState(int(P["inception_v3_probe_seed"]))
+            names = [str(n) for n in P["inception_v3_weight_names"]]
+            ws = [(rs.uniform(0.5, 1.5, size=s_) if "moving_variance" in n else rs.normal(size=s_) * (0.05 if len(s_) == 4 else 0.1)).astype(np.float32)
+                  for s_, n in zip(M.inception_weight_shapes(), names)]
+            xin = rs.uniform(-1, 1, size=(2, 139, 107, 3)).astype(np.float32)
+            assert np.array_equal(xin, P["inception_v3_probe_input"])
+            got = M.inception_features([t(w) for w in ws], t(xin)).numpy()
+            assert np.abs(got - P["inception_v3_probe_features"]).max() <= 1e-3 * np.abs(got).max()
+            assert np.allclose(P["inception_preprocess_probe"], [[-1.0, 0.0, 1.0]])
 
 
 def test_pin_checker_runs_on_a_self_made_file():
