@@ -212,8 +212,9 @@ class InceptionFeatureExtractor:
         if weights_path is not None:
             self.model.load_keras_weights(weights_path)
         else:
+            import sys
             print("InceptionFeatureExtractor: no imagenet weights file given -- seeded random weights; FID / KID values "
-                  "are only comparable between runs of this code")
+                  "are only comparable between runs of this code", file=sys.stderr)
 
     def get_features(self, images, max_chunk_size=1000, batch_size=32):
         n_imgs = images.shape[0]

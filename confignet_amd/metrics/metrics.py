@@ -10,17 +10,38 @@ from .inception_distance import InceptionFeatureExtractor, compute_FID, compute_
 class InceptionMetrics:
     def __init__(self, confignet_config, dataset, n_samples_for_metrics=1000, weights_path=None):
         self.n_samples_for_metrics = n_samples_for_metrics
-        self.inception_feature_extractor = InceptionFeatureExtractor(
-            confignet_config["output_shape"], weights_path or confignet_config.get("inception_weights_path"))
-        metric_sample_idxs = np.random.randint(0, dataset.imgs.shape[0], n_samples_for_metrics)          # metrics.py:206
-        feats = getattr(dataset, "inception_features", None)
-        if feats is None:
-            # the reference's dataset files carry precomputed features (neural_renderer_dataset.py:323-325); a dataset
-            # without them gets the features of the sampled images computed here, with this extractor
-            feats_sample = self.inception_feature_extractor.get_features(np.asarray(dataset.imgs)[metric_sample_idxs])
-        else:
-            feats_sample = np.asarray(feats)[metric_sample_idxs]
-        self.gt_inception_features = feats_sample
+        self._config, self._dataset = confignet_config, dataset
+        self._weights_path = weights_path or confignet_config.get("inception_weights_path")
+        self._metric_sample_idxs = np.random.randint(0, dataset.imgs.shape[0], n_samples_for_metrics)    # metrics.py:206
+        # The reference builds the extractor and slices dataset.inception_features here; both are deferred to the first
+        # metrics checkpoint (same values; a run that never reaches one -- benchmarks, step tests -- does not pay for an
+        # InceptionV3 and 1000 feature vectors).  The np.random draw above stays where the reference has it.
+        self._extractor = None
+        self._gt_features = None
+
+    @property
+    def inception_feature_extractor(self):
+        if self._extractor is None:
+            self._extractor = InceptionFeatureExtractor(self._config["output_shape"], self._weights_path)
+        return self._extractor
+
+    @property
+    def gt_inception_features(self):
+        if self._gt_features is None:
+            feats = getattr(self._dataset, "inception_features", None)
+            if feats is None:
+                # the reference's dataset files carry precomputed features (neural_renderer_dataset.py:323-325); a dataset
+                # without them gets the features of the sampled images computed here, with this extractor
+                imgs = self._dataset.imgs
+                import torch
+                if torch.is_tensor(imgs):
+                    sel = imgs[torch.as_tensor(self._metric_sample_idxs, device=imgs.device)].cpu().numpy()
+                else:
+                    sel = np.asarray(imgs)[self._metric_sample_idxs]
+                self._gt_features = self.inception_feature_extractor.get_features(sel)
+            else:
+                self._gt_features = np.asarray(feats)[self._metric_sample_idxs]
+        return self._gt_features
 
     def get_metrics(self, generated_images):
         generated_inception_features = self.inception_feature_extractor.get_features(generated_images)

@@ -333,11 +333,28 @@ def conv_dgrad(gy, w, g):
     return cast(gu, _act_out_dtype(g.cin))
 
 
+C3_WGRAD = os.environ.get("CN_NO_C3_WGRAD") is None
+_C3_PARTS = []
+
+
+def _c3_partials():
+    if not _C3_PARTS:
+        _C3_PARTS.append(int(lib.cn_conv_wgrad_c3_partials()))
+    return _C3_PARTS[0]
+
+
 def conv_wgrad(x, gy, g, w_shape):
     gw = zero_pool_alloc(w_shape, x.device)
     pre = gw is not None
     if not pre:
         gw = torch.empty(w_shape, device=x.device, dtype=torch.float32)
+    if C3_WGRAD and g.nd == 2 and g.cin == 3 and g.k_h == 3 and g.k_w == 3 and g.s_h == g.s_w and g.s_h in (1, 2) \
+            and g.dl_h == 1 and g.dl_w == 1 and g.up == 0 and g.cout <= 64 and g.cout % 4 == 0 and gy.dtype in (torch.float32, torch.bfloat16):
+        # K = 27 first layers: staged-tile kernel without atomics (the generic split-over-rows kernel runs them at 10 TFLOP/s)
+        x, gy = _c(f32(x)), _c(gy)
+        scratch = torch.empty(_c3_partials() * 27 * g.cout, device=x.device, dtype=torch.float32)
+        check(lib.cn_conv_wgrad_c3(ctypes.byref(g), _ptr(x), _ptr(gy), _dt(gy), _ptr(scratch), _fptr(gw), 0, _stream()), "cn_conv_wgrad_c3")
+        return gw
     if _bf16_conv_ok(g):
         x, gy = cast(x, torch.bfloat16), cast(gy, torch.bfloat16)
         check(lib.cn_conv_wgrad_bf16(ctypes.byref(g), _ptr(x), _ptr(gy), _fptr(gw), int(pre), _stream()), "cn_conv_wgrad_bf16")

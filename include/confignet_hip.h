@@ -80,6 +80,12 @@ int cn_conv_wgrad(const CnConvGeom* g, const float* x, const float* gy, float* g
  * of the data-gradient convolution [16][cout][cin] (dgrad = 1: flipped taps, channels swapped), made once per weight update.
  * cn_conv_fwd_wino: x (n,h,w,cin) -> y (n,h,w,cout) with fused bias + activation; CN_EUNSUPPORTED (nothing launched)
  * unless cin % 8 == 0 and cout % 64 == 0. */
+/* Filter gradient of a 3x3 convolution of a 3-channel fp32 image (from-RGB block of the discriminators, building_blocks.py:91;
+ * VGG conv1_1): stride 1 or 2, cout <= 64, gy in fp32 or bf16 (gy_dt).  No atomics: scratch holds
+ * cn_conv_wgrad_c3_partials() partial filters of 27 * cout floats.  Returns CN_EUNSUPPORTED without launching otherwise. */
+int cn_conv_wgrad_c3_partials(void);
+int cn_conv_wgrad_c3(const CnConvGeom* g, const float* x, const void* gy, int gy_dt, float* scratch, float* gw, int accumulate,
+                     void* stream);
 int cn_conv_wino_filter(const float* w, float* u, int cin, int cout, int dgrad, void* stream);
 int cn_conv_fwd_wino(int n, int h, int w, int cin, int cout, const float* x, const float* u, const float* bias, float* y,
                      int act, float slope, void* stream);

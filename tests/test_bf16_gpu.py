@@ -106,6 +106,22 @@ def test_bf16_conv_fwd_dgrad_wgrad(case):
     assert float((gw.double().cpu() - wr.grad).abs().max()) <= 2e-4 * max(1.0, float(wr.grad.abs().max()))
 
 
+@pytest.mark.parametrize("xs,cout,stride", [((2, 64, 64, 3), 48, 2), ((1, 9, 150, 3), 64, 1), ((1, 11, 301, 3), 20, 2)])
+def test_first_layer_filter_gradient_with_a_bf16_output_gradient(xs, cout, stride):
+    """K = 27 filter gradient (cn_conv_wgrad_c3): the 3-channel image stays fp32, the output gradient arrives in bf16."""
+    from confignet_amd import ops
+    rng = np.random.default_rng(cout + stride)
+    x = rng.normal(size=xs)
+    g = ops.ConvSpec((3, 3), stride=stride).geom(xs, cout)
+    wr = torch.zeros(3, 3, 3, cout, dtype=torch.float64, requires_grad=True)
+    y = O.conv_same(t64(x.astype(np.float32)), wr, None, stride=stride)
+    gy = rng.normal(size=tuple(y.shape))
+    (y * bf16_round(gy)).sum().backward()
+    gw = ops.conv_wgrad(dev(x), dev_bf16(gy), g, (3, 3, 3, cout))
+    assert gw.dtype == torch.float32
+    assert float((gw.double().cpu() - wr.grad).abs().max()) <= 2e-4 * max(1.0, float(wr.grad.abs().max()))
+
+
 def test_bf16_elementwise_family_matches_fp32_math_on_the_same_bits():
     """Statistics / affine / activation / pooling kernels in bf16 storage: identical arithmetic to the fp32 kernels applied to
     the bf16 values (fp32 accumulate), outputs rounded once."""

@@ -40,6 +40,8 @@ CONV_CASES = [
     ((2, 32, 32, 48), (3, 3), 96, 2, 0, None, 0, 0.0),        # D block 1
     ((2, 17, 13, 48), (3, 3), 96, 2, 0, None, 0, 0.0),        # ragged odd extents
     ((2, 32, 32, 3), (3, 3), 64, 1, 0, None, 2, 0.0),         # VGG conv1_1 + relu
+    ((1, 9, 150, 3), (3, 3), 64, 1, 0, None, 0, 0.0),         # K = 27 filter gradient: three 64-pixel tiles per row, the last ragged
+    ((1, 11, 301, 3), (3, 3), 20, 2, 0, None, 0, 0.0),        # ... stride 2, 151 outputs per row, cout below one column block
     ((1, 64, 64, 3), (7, 7), 64, 2, 0, 3, 0, 0.0),            # ResNet conv1 (pad 3, valid)
     ((2, 32, 32, 32), (4, 4), 3, 1, 1, None, 3, 0.0),         # map_final: thin cout + tanh + upsample
     ((1, 20, 13, 32), (4, 4), 3, 1, 1, None, 3, 0.0),         # map_final, extents that do not fill the 8x16 tiles
