@@ -44,6 +44,8 @@ SIGNATURES = {
     "cn_conv_dgrad": [_G, _p, _p, _p, _p],
     "cn_conv_wgrad": [_G, _p, _p, _p, _i, _p],
     "cn_conv_tune": [_i, _i, ctypes.c_long],
+    "cn_conv_fwd_dt": [_p, _p, _i, _p, _p, _p, _i, _i, _f, _p],
+    "cn_conv_dgrad_dt": [_p, _p, _i, _p, _p, _i, _p],
     "cn_conv_wgrad_c3_partials": [],
     "cn_conv_wgrad_c3": [_p, _p, _p, _i, _p, _p, _i, _p],
     "cn_conv_wino_filter": [_p, _p, _i, _i, _i, _p],

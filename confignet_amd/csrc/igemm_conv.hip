@@ -715,8 +715,8 @@ __global__ void sumpool2_kernel(const T* __restrict__ GU, T* __restrict__ GX, in
 // and each output pixel is the sum of the <= 4 entries of P that land on it (col2im).  One workgroup: (TH+1) x (TW+1)
 // input pixels (one halo row/column, on the side the padding fixes) -> P in LDS -> its 2TH x 2TW output pixels.
 // No atomics, gy is read once (+ halo), K order is permuted so that a lane's A operand is one float4 load.
-template <int NG>   // C = 8 * NG
-__global__ __launch_bounds__(256) void s2_image_dgrad_kernel(CnConvGeom g, const float* __restrict__ GY,
+template <int NG, typename TI = float>   // C = 8 * NG; TI: storage type of gy (fp32 / bf16)
+__global__ __launch_bounds__(256) void s2_image_dgrad_kernel(CnConvGeom g, const TI* __restrict__ GY,
                                                              const float* __restrict__ WT, float* __restrict__ Y) {
     constexpr int TH = 8, TW = 32, RW = TW + 1, R = (TH + 1) * RW, MT = (R + 31) / 32, PS = 28, C = 8 * NG;
     __shared__ float P[MT * 32][PS];
@@ -747,11 +747,11 @@ __global__ __launch_bounds__(256) void s2_image_dgrad_kernel(CnConvGeom g, const
         const bool inb = r < R && ii >= 0 && ii < g.in_h && jj >= 0 && jj < g.in_w;
         // lane (row, half) holds channels 8 jg + 4 half + {0..3}: MFMA step (jg, q) contracts channel pair
         // {8 jg + q, 8 jg + 4 + q} -- any K order is fine as long as A and B agree
-        const float* src = GY + (((long)n * g.in_h + ii) * g.in_w + jj) * C + 4 * half;
+        const TI* src = GY + (((long)n * g.in_h + ii) * g.in_w + jj) * C + 4 * half;
         float4 a[NG];
 #pragma unroll
         for (int jg = 0; jg < NG; ++jg)
-            a[jg] = inb ? *reinterpret_cast<const float4*>(src + 8 * jg) : make_float4(0.f, 0.f, 0.f, 0.f);
+            a[jg] = inb ? ld4<TI>(src + 8 * jg) : make_float4(0.f, 0.f, 0.f, 0.f);
         f32x16 acc;
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc[q] = 0.f;
@@ -807,9 +807,9 @@ __global__ __launch_bounds__(256) void s2_image_dgrad_kernel(CnConvGeom g, const
 // (A matching filter-gradient kernel -- rows = the 27 filter rows, K' = pixels -- was tried and dropped: with a
 // 27 x cout output every workgroup ends in the same 1296 atomics, and ~75 ns per same-address atomic put it at
 // 70-90 us against the generic kernel's 65.)
-template <int S, int NB>
+template <int S, int NB, typename TO = float>   // TO: storage type of the output (fp32 / bf16)
 __global__ __launch_bounds__(256) void c3_fwd_kernel(CnConvGeom g, const float* __restrict__ X, const float* __restrict__ W,
-                                                     const float* __restrict__ bias, float* __restrict__ Y, int act, float slope) {
+                                                     const float* __restrict__ bias, TO* __restrict__ Y, int act, float slope) {
     constexpr int TH = 8, TW = 32, PR = (TH - 1) * S + 3, PC = ((TW - 1) * S + 3) * 3, PCP = PC + 1;
     __shared__ float patch[PR * PCP];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, half = lane >> 5;
@@ -865,7 +865,7 @@ __global__ __launch_bounds__(256) void c3_fwd_kernel(CnConvGeom g, const float* 
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 const int ox = ox0 + 4 * half + (q & 3) + 8 * (q >> 2);
-                if (ox < g.out_w) Y[(((long)n * g.out_h + oy) * g.out_w + ox) * g.cout + col] = cn_apply_act(acc[nb][q] + bv, act, slope);
+                if (ox < g.out_w) stf<TO>(Y + (((long)n * g.out_h + oy) * g.out_w + ox) * g.cout + col, cn_apply_act(acc[nb][q] + bv, act, slope));
             }
         }
     }
@@ -1177,6 +1177,58 @@ extern "C" int cn_conv_weight_tflip(const float* w, float* wt, int taps, int cin
     hipLaunchKernelGGL(weight_tflip_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, wt, taps, cin, cout);
     CN_LAUNCH_CHECK();
     return CN_OK;
+}
+
+// First / last layers with mixed storage types (the bf16 path keeps 3-channel images in fp32, everything wider in bf16):
+//   * 3x3 convolution of a 3-channel fp32 image written in bf16 (c3_fwd_kernel), and
+//   * the data gradient of the stride-2 one INTO the fp32 image from a bf16 output gradient (s2_image_dgrad_kernel, the
+//     geometry cn_conv_dgrad_dt builds),
+// without a conversion pass over the 48 / 64-channel tensor.  Everything else: CN_EUNSUPPORTED, nothing launched.
+extern "C" int cn_conv_fwd_dt(const CnConvGeom* gp, const void* x, int x_dt, const float* w, const float* bias, void* y, int y_dt,
+                              int act, float slope, void* stream) {
+    if (int e = check_geom(gp)) return e;
+    CN_CHECK_ARG(x && w && y, "NULL tensor");
+    const CnConvGeom g = *gp;
+    hipStream_t s = (hipStream_t)stream;
+    if (x_dt == CN_F32 && y_dt == CN_BF16 && g.nd == 2 && g.cin == 3 && g.k_h == 3 && g.k_w == 3 && g.s_h == g.s_w &&
+        (g.s_h == 1 || g.s_h == 2) && g.dl_h == 1 && g.dl_w == 1 && !g.up && g.cout > 4 && g.cout <= 64) {
+        dim3 grid((unsigned)(g.n * cn_cdiv(g.out_h, 8) * cn_cdiv(g.out_w, 32)));
+        cn_prof_begin(s, conv_flops(g));
+#define C3F(S_, NB_) hipLaunchKernelGGL((c3_fwd_kernel<S_, NB_, bf16_t>), grid, dim3(256), 0, s, g, (const float*)x, w, bias, (bf16_t*)y, act, slope)
+        if (g.s_h == 1) { if (g.cout <= 32) C3F(1, 1); else C3F(1, 2); }
+        else { if (g.cout <= 32) C3F(2, 1); else C3F(2, 2); }
+#undef C3F
+        cn_prof_end(s);
+        CN_LAUNCH_CHECK();
+        return CN_OK;
+    }
+    if (x_dt == CN_BF16 && y_dt == CN_F32 && g.nd == 2 && g.k_h == 3 && g.k_w == 3 && g.dl_h == 2 && g.dl_w == 2 && g.s_h == 1 &&
+        g.s_w == 1 && !g.up && g.cout == 3 && g.cin == 48 && !bias && act == CN_ACT_NONE && g.p_h >= 0 && g.p_h <= 2 && g.p_w >= 0 &&
+        g.p_w <= 2 && g.out_h <= 2 * g.in_h && g.out_w <= 2 * g.in_w) {
+        dim3 grid((unsigned)(g.n * cn_cdiv(g.in_h, 8) * cn_cdiv(g.in_w, 32)));
+        cn_prof_begin(s, conv_flops(g));
+        hipLaunchKernelGGL((s2_image_dgrad_kernel<6, bf16_t>), grid, dim3(256), 0, s, g, (const bf16_t*)x, w, (float*)y);
+        cn_prof_end(s);
+        CN_LAUNCH_CHECK();
+        return CN_OK;
+    }
+    return CN_EUNSUPPORTED;
+}
+
+extern "C" int cn_conv_dgrad_dt(const CnConvGeom* gp, const void* gy, int gy_dt, const float* w_tflip, void* gu, int gu_dt,
+                                void* stream) {
+    if (int e = check_geom(gp)) return e;
+    if (gp->dl_d != 1 || gp->dl_h != 1 || gp->dl_w != 1) return CN_EUNSUPPORTED;
+    CnConvGeom d = *gp;
+    d.in_d = gp->out_d; d.in_h = gp->out_h; d.in_w = gp->out_w; d.cin = gp->cout;
+    d.out_d = gp->in_d << gp->up; d.out_h = gp->in_h << gp->up; d.out_w = gp->in_w << gp->up;
+    if (gp->nd == 2) d.out_d = 1;
+    d.cout = gp->cin;
+    d.s_d = d.s_h = d.s_w = 1;
+    d.dl_d = gp->s_d; d.dl_h = gp->s_h; d.dl_w = gp->s_w;
+    d.p_d = gp->k_d - 1 - gp->p_d; d.p_h = gp->k_h - 1 - gp->p_h; d.p_w = gp->k_w - 1 - gp->p_w;
+    d.up = 0;
+    return cn_conv_fwd_dt(&d, gy, gy_dt, w_tflip, nullptr, gu, gu_dt, CN_ACT_NONE, 0.f, stream);
 }
 
 extern "C" int cn_conv_dgrad(const CnConvGeom* gp, const float* gy, const float* w_tflip, float* gu, void* stream) {

@@ -298,6 +298,14 @@ def conv_fwd(x, w, bias, g, act=ACT_NONE, slope=0.0):
         check(lib.cn_conv_fwd_bf16(ctypes.byref(g), _ptr(x), _ptr(wf), _fptr(bias), _ptr(y), act, slope, _stream()), "cn_conv_fwd_bf16")
         return y
     x = f32(x)                                  # 3-channel image layers (and everything in fp32 mode): fp32 MFMA family
+    if out_dtype == torch.bfloat16 and MIXED_FIRST_LAYERS and g.cin == 3:
+        # first layer of the bf16 path: fp32 image in, bf16 out of the same kernel (no conversion pass over the wide tensor)
+        y = torch.empty(geom_out_shape(g), device=x.device, dtype=torch.bfloat16)
+        rc = lib.cn_conv_fwd_dt(ctypes.byref(g), _ptr(x), CN_F32, _fptr(w), _fptr(bias), _ptr(y), CN_BF16, act, slope, _stream())
+        if rc == 0:
+            return y
+        if rc != CN_EUNSUPPORTED:
+            check(rc, "cn_conv_fwd_dt")
     y = torch.empty(geom_out_shape(g), device=x.device, dtype=torch.float32)
     check(lib.cn_conv_fwd(ctypes.byref(g), _ptr(x), _fptr(w), _fptr(bias), _ptr(y), act, slope, _stream()), "cn_conv_fwd")
     return cast(y, out_dtype)
@@ -321,6 +329,15 @@ def conv_dgrad(gy, w, g):
         _, wd = weight_prep_bf16(w)
         check(lib.cn_conv_dgrad_bf16(ctypes.byref(g), _ptr(gy), _ptr(wd), _ptr(gu), _stream()), "cn_conv_dgrad_bf16")
         return gu
+    if gy.dtype == torch.bfloat16 and MIXED_FIRST_LAYERS and g.cin == 3:
+        # data gradient into the fp32 image straight from the bf16 output gradient
+        gu = torch.empty(shape, device=gy.device, dtype=torch.float32)
+        wt = _weight_cache(w, "_cn_tflip", weight_tflip)
+        rc = lib.cn_conv_dgrad_dt(ctypes.byref(g), _ptr(_c(gy)), CN_BF16, _fptr(wt), _ptr(gu), CN_F32, _stream())
+        if rc == 0:
+            return cast(gu, _act_out_dtype(g.cin))
+        if rc != CN_EUNSUPPORTED:
+            check(rc, "cn_conv_dgrad_dt")
     gy = f32(gy)
     gu = torch.empty(shape, device=gy.device, dtype=torch.float32)
     if ACT_DTYPE == torch.float32 and _wino_ok(g, g.cout, g.cin):
@@ -334,6 +351,7 @@ def conv_dgrad(gy, w, g):
 
 
 C3_WGRAD = os.environ.get("CN_NO_C3_WGRAD") is None
+MIXED_FIRST_LAYERS = os.environ.get("CN_NO_MIXED_FIRST") is None      # bf16 path: first-layer kernels that read / write both storage types
 _C3_PARTS = []
 
 

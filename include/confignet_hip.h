@@ -80,6 +80,13 @@ int cn_conv_wgrad(const CnConvGeom* g, const float* x, const float* gy, float* g
  * of the data-gradient convolution [16][cout][cin] (dgrad = 1: flipped taps, channels swapped), made once per weight update.
  * cn_conv_fwd_wino: x (n,h,w,cin) -> y (n,h,w,cout) with fused bias + activation; CN_EUNSUPPORTED (nothing launched)
  * unless cin % 8 == 0 and cout % 64 == 0. */
+/* First / last layers of the bf16 path with mixed storage types (3-channel images stay fp32): the 3x3 convolution of an fp32
+ * image written in bf16 (x_dt = CN_F32, y_dt = CN_BF16) and the data gradient of the stride-2 one into the fp32 image from a
+ * bf16 output gradient (cn_conv_dgrad_dt with gy_dt = CN_BF16, gu_dt = CN_F32) without a conversion pass.  Same geometry /
+ * filter conventions as cn_conv_fwd / cn_conv_dgrad; any other combination returns CN_EUNSUPPORTED without launching. */
+int cn_conv_fwd_dt(const CnConvGeom* g, const void* x, int x_dt, const float* w, const float* bias, void* y, int y_dt, int act,
+                   float slope, void* stream);
+int cn_conv_dgrad_dt(const CnConvGeom* g, const void* gy, int gy_dt, const float* w_tflip, void* gu, int gu_dt, void* stream);
 /* Filter gradient of a 3x3 convolution of a 3-channel fp32 image (from-RGB block of the discriminators, building_blocks.py:91;
  * VGG conv1_1): stride 1 or 2, cout <= 64, gy in fp32 or bf16 (gy_dt).  No atomics: scratch holds
  * cn_conv_wgrad_c3_partials() partial filters of 27 * cout floats.  Returns CN_EUNSUPPORTED without launching otherwise. */

@@ -122,6 +122,33 @@ def test_first_layer_filter_gradient_with_a_bf16_output_gradient(xs, cout, strid
     assert float((gw.double().cpu() - wr.grad).abs().max()) <= 2e-4 * max(1.0, float(wr.grad.abs().max()))
 
 
+@pytest.mark.parametrize("xs,cout,stride", [((2, 64, 64, 3), 48, 2), ((2, 37, 45, 3), 48, 2), ((2, 32, 32, 3), 64, 1)])
+def test_first_layer_forward_and_image_gradient_with_mixed_storage(xs, cout, stride):
+    """bf16 path: the 3x3 convolution of the fp32 image writes bf16 directly (cn_conv_fwd_dt), and the data gradient into the
+    image reads the bf16 output gradient directly (cn_conv_dgrad_dt); both against the float64 oracle."""
+    from confignet_amd import ops
+    rng = np.random.default_rng(cout * stride)
+    x, w, b = rng.normal(size=xs), rng.normal(size=(3, 3, 3, cout)) / math.sqrt(27), rng.normal(size=cout)
+    g = ops.ConvSpec((3, 3), stride=stride).geom(xs, cout)
+    ops.set_activation_dtype("bf16")
+    try:
+        y = ops.conv_fwd(dev(x), dev(w), dev(b), g, 1, 0.3)
+        assert y.dtype == torch.bfloat16
+        xr = t64(x.astype(np.float32)).requires_grad_(True)
+        wr = t64(w.astype(np.float32))
+        yr = O.leaky_relu(O.conv_same(xr, wr, t64(b.astype(np.float32)), stride=stride), 0.3).detach()
+        err = (y.double().cpu() - yr).abs()
+        assert float((err - 2.0 ** -8 * yr.abs()).max()) <= 2e-4 * max(1.0, float(yr.abs().max())), float(err.max())
+        y0 = O.conv_same(xr, wr, None, stride=stride)
+        gy = rng.normal(size=tuple(y0.shape))
+        (y0 * bf16_round(gy)).sum().backward()
+        gx = ops.conv_dgrad(dev_bf16(gy), dev(w), g)
+        assert gx.dtype == torch.float32                       # 3-channel tensors stay fp32
+        assert float((gx.double().cpu() - xr.grad).abs().max()) <= 2e-4 * max(1.0, float(xr.grad.abs().max()))
+    finally:
+        ops.set_activation_dtype("f32")
+
+
 def test_bf16_elementwise_family_matches_fp32_math_on_the_same_bits():
     """Statistics / affine / activation / pooling kernels in bf16 storage: identical arithmetic to the fp32 kernels applied to
     the bf16 values (fp32 accumulate), outputs rounded once."""
