@@ -14,6 +14,7 @@
 // The filter gradient needs BOTH operands with the position index contiguous; they arrive channel-contiguous, so the
 // LDS store transposes (two positions packed per ds_write_b32).
 #include "common.h"
+#include <stdlib.h>
 
 #include "conv_geom.h"
 #include "typed.h"
@@ -26,10 +27,22 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int KS = 32;          // bf16 elements of the reduction axis per LDS stage
 constexpr int LDK = KS + 8;     // LDS row pitch in elements (80 bytes)
 
+typedef short s16x4 __attribute__((ext_vector_type(4)));
 union Frag {
     uint4 u;
     bf16x8 v;
+    s16x4 h[2];
 };
+
+// smallest row pitch (elements) >= w whose byte length is a multiple of 16 and 64 or 192 (mod 256)
+constexpr int tr_pitch(int w) {
+    int p = (w + 7) / 8 * 8;
+    while ((p * 2) % 256 != 64 && (p * 2) % 256 != 192) p += 8;
+    return p;
+}
+__device__ __forceinline__ s16x4 tr_read(const bf16_t* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
+}
 
 __global__ void wprep_bf16_kernel(const float* __restrict__ W, bf16_t* __restrict__ Wf, bf16_t* __restrict__ Wd, int T, int cin,
                                   int cout) {
@@ -383,6 +396,180 @@ __global__ __launch_bounds__(256) void igemm_bf16_wgrad_kernel(CnConvGeom g, con
 }
 
 template <int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(256) void igemm_bf16_wgrad_tr_kernel(CnConvGeom g, const bf16_t* __restrict__ X,
+                                                               const bf16_t* __restrict__ GY, float* __restrict__ GW,
+                                                               int rows_per_split) {
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+    constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
+    constexpr int IPA = BM / 8, IPB = BN / 8;              // 8-channel pieces per position in each tile
+    constexpr int AT = (IPA * 16 + 255) / 256, BT = (IPB * 16 + 255) / 256;   // (piece, position pair) tasks per thread
+    // Row-major [reduction row][channel] images exactly as they sit in memory (16-byte stores, no transposition); the MFMA
+    // operands -- 8 consecutive reduction rows of ONE channel per lane -- come out of ds_read_b64_tr_b16: the 16 lanes of a
+    // group address a [4 rows][16 channels] block (lane s: row s / 4, channels 4 (s % 4) ..) and lane i receives column i.
+    // Row pitch = 64 or 192 (mod 256) bytes: the 4 rows x 64 bytes that 32 lanes read then fall on distinct banks.
+    constexpr int PA = tr_pitch(BM), PB = tr_pitch(BN);
+    __shared__ __attribute__((aligned(16))) bf16_t As[2][KS][PA];
+    __shared__ __attribute__((aligned(16))) bf16_t Bs[2][KS][PB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN, half = lane >> 5, l31 = lane & 31;
+    const int M = g.n * g.out_d * g.out_h * g.out_w;
+    const int T = g.k_d * g.k_h * g.k_w;
+    const int Ktot = T * g.cin;
+    const int i0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int mbeg = blockIdx.z * rows_per_split;
+    const int mend = min(M, mbeg + rows_per_split);
+    if (mbeg >= mend) return;
+
+    // A tasks: piece ip (8 consecutive (tap, ci) rows: one tap, cin % 8 == 0) x position pair mp; fixed per thread
+    int a_ip[AT], a_mp[AT], a_ci[AT], a_kd[AT], a_kh[AT], a_kw[AT];
+    bool a_on[AT];
+    int p_n[AT][2], p_d[AT][2], p_h[AT][2], p_w[AT][2], p_m[AT][2];
+#pragma unroll
+    for (int t = 0; t < AT; ++t) {
+        const int task = tid + 256 * t;
+        a_ip[t] = task % IPA;
+        a_mp[t] = task / IPA;
+        const int i = i0 + a_ip[t] * 8;
+        a_on[t] = a_mp[t] < 16 && i < Ktot;
+        const int tap = a_on[t] ? i / g.cin : 0;
+        a_ci[t] = a_on[t] ? i - tap * g.cin : 0;
+        tap_decode(g, tap, a_kd[t], a_kh[t], a_kw[t]);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            int m = mbeg + 2 * a_mp[t] + e;
+            p_m[t][e] = m;
+            p_w[t][e] = m % g.out_w; m /= g.out_w;
+            p_h[t][e] = m % g.out_h; m /= g.out_h;
+            p_d[t][e] = m % g.out_d;
+            p_n[t][e] = m / g.out_d;
+        }
+    }
+    int b_ip[BT], b_mp[BT];
+#pragma unroll
+    for (int t = 0; t < BT; ++t) {
+        const int task = tid + 256 * t;
+        b_ip[t] = task % IPB;
+        b_mp[t] = task / IPB;
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    uint4 ra[AT][2], rb[BT][2];
+    const int nks = (mend - mbeg + KS - 1) / KS;
+
+    auto load_tiles = [&](int ks) {      // called with ks = 0, 1, 2, ... in order (the row coordinates advance by carries)
+#pragma unroll
+        for (int t = 0; t < AT; ++t) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                RowInfo r;
+                r.ok = a_on[t] && p_m[t][e] < mend;
+                r.nbase = p_n[t][e] * g.in_d;
+                r.vd = p_d[t][e] * g.s_d - g.p_d;
+                r.vh = p_h[t][e] * g.s_h - g.p_h;
+                r.vw = p_w[t][e] * g.s_w - g.p_w;
+                p_m[t][e] += KS;
+                p_w[t][e] += KS;
+                while (p_w[t][e] >= g.out_w) {
+                    p_w[t][e] -= g.out_w;
+                    if (++p_h[t][e] == g.out_h) {
+                        p_h[t][e] = 0;
+                        if (++p_d[t][e] == g.out_d) {
+                            p_d[t][e] = 0;
+                            ++p_n[t][e];
+                        }
+                    }
+                }
+                const int off = src_off(g, r, a_kd[t], a_kh[t], a_kw[t]);
+                ra[t][e] = off >= 0 ? *reinterpret_cast<const uint4*>(X + off + a_ci[t]) : make_uint4(0, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < BT; ++t) {
+            const int col = n0 + b_ip[t] * 8;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int m = mbeg + ks * KS + 2 * b_mp[t] + e;
+                rb[t][e] = (b_mp[t] < 16 && m < mend && col < g.cout) ? *reinterpret_cast<const uint4*>(GY + (long)m * g.cout + col)
+                                                                       : make_uint4(0, 0, 0, 0);
+            }
+        }
+    };
+    auto store_tiles = [&](int buf) {
+#pragma unroll
+        for (int t = 0; t < AT; ++t) {
+            if (a_mp[t] >= 16) continue;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) *reinterpret_cast<uint4*>(&As[buf][2 * a_mp[t] + e][a_ip[t] * 8]) = ra[t][e];
+        }
+#pragma unroll
+        for (int t = 0; t < BT; ++t) {
+            if (b_mp[t] >= 16) continue;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) *reinterpret_cast<uint4*>(&Bs[buf][2 * b_mp[t] + e][b_ip[t] * 8]) = rb[t][e];
+        }
+    };
+
+    load_tiles(0);
+    store_tiles(0);
+    __syncthreads();
+    const int a_col0 = wm * 32 * TM, b_col0 = wn * 32 * TN;
+    for (int ks = 0; ks < nks; ++ks) {
+        const int buf = ks & 1;
+        if (ks + 1 < nks) load_tiles(ks + 1);
+        Frag a[2][TM], b[2][TN];
+        {
+            // this lane's part of its 16-lane group's block: row (lane & 15) >> 2, channels 16 * ((lane >> 4) & 1) + 4 * (lane & 3) ..
+            const int trow = (lane & 15) >> 2, tcol = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int k0 = 16 * s + 8 * half + trow;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    a[s][i].h[0] = tr_read(&As[buf][k0][a_col0 + 32 * i + tcol]);
+                    a[s][i].h[1] = tr_read(&As[buf][k0 + 4][a_col0 + 32 * i + tcol]);
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    b[s][j].h[0] = tr_read(&Bs[buf][k0][b_col0 + 32 * j + tcol]);
+                    b[s][j].h[1] = tr_read(&Bs[buf][k0 + 4][b_col0 + 32 * j + tcol]);
+                }
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s][i].v, b[s][j].v, acc[i][j], 0, 0, 0);
+        if (ks + 1 < nks) store_tiles(buf ^ 1);
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = n0 + wn * 32 * TN + 32 * j + l31;
+        if (col >= g.cout) continue;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int rbase = i0 + wm * 32 * TM + 32 * i + 4 * half;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = rbase + (r & 3) + 8 * (r >> 2);
+                if (row < Ktot) unsafeAtomicAdd(&GW[(long)row * g.cout + col], acc[i][j][r]);
+            }
+        }
+    }
+}
+
+template <int WM, int WN, int TM, int TN>
 int launch_bf16(const CnConvGeom& g, int par, int flip, const bf16_t* x, const bf16_t* wb, const float* bias, bf16_t* y,
                 int act, float slope, hipStream_t s) {
     const long M = (long)g.n * g.out_d * g.out_h * g.out_w;
@@ -432,7 +619,9 @@ int launch_bf16_wgrad(const CnConvGeom& g, const bf16_t* x, const bf16_t* gy, fl
     rows = (rows + KS - 1) / KS * KS;
     splits = (M + rows - 1) / rows;
     dim3 grid(cn_cdiv(Ktot, BMt), cn_cdiv(g.cout, BNt), (unsigned)splits);
-    hipLaunchKernelGGL((igemm_bf16_wgrad_kernel<WM, WN, TM, TN>), grid, dim3(256), 0, s, g, x, gy, gw, (int)rows);
+    static const bool old = getenv("CN_BF16_WGRAD_OLD") != nullptr;
+    if (old) hipLaunchKernelGGL((igemm_bf16_wgrad_kernel<WM, WN, TM, TN>), grid, dim3(256), 0, s, g, x, gy, gw, (int)rows);
+    else hipLaunchKernelGGL((igemm_bf16_wgrad_tr_kernel<WM, WN, TM, TN>), grid, dim3(256), 0, s, g, x, gy, gw, (int)rows);
     CN_LAUNCH_CHECK();
     return CN_OK;
 }
