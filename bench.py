@@ -88,6 +88,8 @@ def main():
         args.no_graphs = True
         model.fork_generator_step = False
     model.use_graphs = not args.no_graphs
+    # real half of the next iteration's discriminator steps under the generator tail
+    model.overlap_discriminators = model.use_graphs and os.environ.get("CN_NO_D_OVERLAP") is None
     # graph mode needs three untimed iterations whatever W says: eager call, capture, first replay (which still pays the
     # graph's one-off upload); the JSON reports the number actually run.  A capture that fails next to the process group is
     # FATAL (no silent eager fallback: an eager multi-GPU number would not be the configuration this benchmark names);
@@ -165,6 +167,7 @@ def main():
                        "parallelism": "dp%d" % world, "losses_finite": bool(finite),
                        "dispatch": ("eager, one stream" if args.serial else "eager" if args.no_graphs else
                                     "hip-graph replay per step function, D-type steps concurrent, G step forked over 2 streams" +
+                                    (", real half of the next iteration's discriminator steps under the generator tail" if model.overlap_discriminators else "") +
                                     ("" if not parallel.active() else " (fwd+bwd), eager RCCL all-reduce + Adam"))},
             "step_functions_ms": step_ms,
             "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",

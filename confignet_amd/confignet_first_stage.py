@@ -18,7 +18,7 @@ from .dnn_models.hologan_discriminator import HologanDiscriminator, HologanLaten
 from .dnn_models.hologan_generator import HologanGenerator
 from .dnn_models.synthetic_encoder import SyntheticDataEncoder
 from .losses import (GAN_G_loss, compute_discriminator_loss, compute_latent_discriminator_loss,
-                     compute_latent_regression_loss, eye_loss)
+                     compute_latent_regression_loss, discriminator_loss_fake, discriminator_loss_real, eye_loss)
 from .neural_renderer_dataset import dump_pickle, load_pickle
 from .nn import backward_into_arenas, require_gpu
 from .perceptual_loss import PerceptualLoss
@@ -97,6 +97,7 @@ class ConfigNetFirstStage:
         self._bufs = StaticBuffers(self.device)
         self._graphs = {}
         self._deferred = None
+        self._prestaged, self._stagers = {}, {}      # cross-iteration overlap of the discriminator steps (see overlap_discriminators)
         self.fork_generator_step = os.environ.get("CN_NO_FORK") is None   # second stage: real / synthetic branches of the generator step on two streams
         self._work_streams = []
         self.use_graphs = False       # capture each step's device half into a HIP graph (single-GPU runs)
@@ -361,6 +362,12 @@ class ConfigNetFirstStage:
         pool = self._pool(dataset)
         return params, rot, ops.gather_images_u8(pool["imgs"], idx, None), pool["eye_masks"][idx].contiguous()
 
+    def _graph_key(self, name, datasets, optimizer):
+        return (name, tuple(id(d) for d in datasets), id(optimizer), self._bufs.generation)
+
+    def _graph_of(self, name, datasets, optimizer):
+        return self._graphs.get(self._graph_key(name, datasets, optimizer))
+
     def _run_step(self, name, datasets, optimizer, device_fn):
         """optimizer.advance() on the host, then the device half -- eagerly, or as a captured HIP graph."""
         optimizer.advance(name)
@@ -376,17 +383,25 @@ class ConfigNetFirstStage:
                 ops.zero_pool_end()
         if not self.use_graphs:
             return device_fn()
-        key = (name, tuple(id(d) for d in datasets), id(optimizer), self._bufs.generation)
+        key = self._graph_key(name, datasets, optimizer)
         g = self._graphs.get(key)
         if g is None:
             from .graphs import StepGraph
             self._graphs = {k: v for k, v in self._graphs.items() if k[3] == self._bufs.generation}
             g = self._graphs[key] = StepGraph(device_fn, stream=self._work_stream(name))
+            g.name = name
         if self._deferred is not None:
             if g.graph is not None:
                 self._deferred.append(g)       # replayed together with its independent sibling steps
                 return g.result()              # (filled by g.finish() right after the replay)
             self._flush_deferred()             # not captured yet: everything collected before it runs first, in order
+        if getattr(g, "prelaunched", False):   # called on its own while its real half is already in flight: wait for it, run the rest
+            g.prelaunched = False
+            torch.cuda.current_stream().wait_stream(g.stream)
+            res = g.result()
+            g.replay(g.early_cut)
+            g.finish()
+            return res
         return g()
 
     def run_concurrently(self, step_calls, then=None):
@@ -426,7 +441,11 @@ class ConfigNetFirstStage:
         for g in pending:
             g.stream.wait_stream(cur)
             with torch.cuda.stream(g.stream):
-                g.replay()
+                if getattr(g, "prelaunched", False):       # its real half ran next to the previous iteration's generator tail
+                    g.replay(g.early_cut)
+                    g.prelaunched = False
+                else:
+                    g.replay()
                 g.finish()
         if follower is not None and self.early_generator_forward:
             follower.replay(0, follower.early_cut)
@@ -435,10 +454,47 @@ class ConfigNetFirstStage:
         if follower is not None:
             follower.replay(follower.early_cut if self.early_generator_forward else 0)
             follower.finish()
+            if self.overlap_discriminators:
+                # next iteration's image-discriminator steps: host half (np.random draws in the reference's order: after the
+                # generator step's, discriminator before synthetic discriminator; staging copies on the step's own stream,
+                # behind the work it has just finished) and the real half of the graph -- they run under the generator tail
+                for g in pending:
+                    st = self._stagers.get(getattr(g, "name", None))
+                    if st is None or not g.early_cut:
+                        continue
+                    stage, training_set, optimizer = st
+                    with torch.cuda.stream(g.stream):
+                        stage(training_set)
+                        g.replay(0, g.early_cut)
+                    g.prelaunched = True
+                    net = self.discriminator if g.name == "d" else self.synth_discriminator
+                    self._prestaged[g.name] = (id(training_set), id(optimizer), net.epoch, self._bufs.generation)
 
     early_generator_forward = os.environ.get("CN_NO_EARLY_G") is None
 
+    # Cross-iteration overlap (graph dispatch, steady training loops: bench.py and train() switch it on).  The REAL half of
+    # an image-discriminator step -- forward on real images, the R1 sweep and tangent pass, their backward: more than half of
+    # the step -- reads only that discriminator's own weights, which are final when the discriminator phase of the previous
+    # iteration ends.  With this flag the step's graph is cut between its halves, and the real half of iteration t+1 is
+    # replayed on the step's stream NEXT TO the generator tail of iteration t (the host half of the step -- its np.random
+    # draws and the staging copies -- moves with it: the draws still happen in the reference's order, generator step of t,
+    # then discriminator steps of t+1).  The fake half and the Adam update follow the generator update as before.  Same
+    # arithmetic; the two halves' gradients are added in the arena instead of inside one backward pass.
+    overlap_discriminators = False
+
     def _discriminator_update(self, net, real_imgs, fake_imgs, optimizer, slot="default"):
+        """real_imgs / fake_imgs: tensors, or (with overlap_discriminators) callables that produce them."""
+        if callable(real_imgs):
+            from .graphs import segment_break
+            real, gp = discriminator_loss_real(net, real_imgs())
+            backward_into_arenas(sum(real.values()) + sum(gp.values()), [net])
+            segment_break(early=True)          # nothing above reads a generator / encoder weight
+            fake = discriminator_loss_fake(net, fake_imgs())
+            backward_into_arenas(sum(fake.values()), [net], accumulate=True)
+            optimizer.apply_gradients(net, advance=False, slot=slot)
+            losses = {**real, **fake, **gp}    # the reference's key order (losses.py:20-47)
+            losses["loss_sum"] = sum(losses.values())
+            return losses
         losses = compute_discriminator_loss(net, real_imgs, fake_imgs)
         backward_into_arenas(losses["loss_sum"], [net])
         optimizer.apply_gradients(net, advance=False, slot=slot)
@@ -455,37 +511,50 @@ class ConfigNetFirstStage:
         self._stage("d/z", self.sample_latent_vector(n))
         self._stage("d/rot", self.sample_rotations(n))
 
-    def _d_batch(self, training_set):
-        real_imgs = self._real_imgs("d", training_set)
+    def _d_fake(self, training_set):
         with torch.no_grad():
-            fake_imgs = self.generator([self._bufs["d/z"], self._bufs["d/rot"]])
-        return real_imgs, fake_imgs
+            return self.generator([self._bufs["d/z"], self._bufs["d/rot"]])
+
+    def _d_batch(self, training_set):
+        return self._real_imgs("d", training_set), self._d_fake(training_set)
+
+    def _image_discriminator_step(self, name, net, training_set, optimizer, stage, real, fake):
+        """Host half + device half of the discriminator / synthetic-discriminator step (l.466-516)."""
+        pre = self._prestaged.pop(name, None)
+        if pre != (id(training_set), id(optimizer), net.epoch, self._bufs.generation):
+            # no real half in flight for exactly this call (first iteration, other arguments, weights replaced since): the
+            # step starts from its host half; a half that was pre-replayed for something else is simply redone
+            for g in self._graphs.values():
+                if getattr(g, "name", None) == name:
+                    g.prelaunched = False
+            stage(training_set)
+        self._stagers[name] = (stage, training_set, optimizer)
+        if self.overlap_discriminators and self.use_graphs:
+            device = lambda: self._discriminator_update(net, lambda: real(training_set), lambda: fake(training_set), optimizer, name)
+        else:
+            device = lambda: self._discriminator_update(net, real(training_set), fake(training_set), optimizer, name)
+        return self._run_step(name, (training_set,), optimizer, device)
 
     def discriminator_training_step(self, training_set, optimizer):
-        self._stage_d_batch(training_set)
-        return self._run_step("d", (training_set,), optimizer, lambda: self._discriminator_update(
-            self.discriminator, *self._d_batch(training_set), optimizer, "d"))
-
-    def get_synth_discriminator_batch(self, training_set):
-        self._stage_sd_batch(training_set)
-        return self._sd_batch(training_set)
+        return self._image_discriminator_step("d", self.discriminator, training_set, optimizer, self._stage_d_batch,
+                                              lambda ts: self._real_imgs("d", ts), self._d_fake)
 
     def _stage_sd_batch(self, training_set):
         n = self.get_batch_size()
         self._stage_real("sd", training_set, n)
         self._stage_synth("sd", training_set, n)
 
-    def _sd_batch(self, training_set):
-        real_imgs = self._real_imgs("sd", training_set)
+    def _sd_fake(self, training_set):
         params, rotations, _, _ = self._synth_batch("sd", training_set, imgs=False)
         with torch.no_grad():
-            fake_imgs = self.generator([self.synthetic_encoder(params), rotations])
-        return real_imgs, fake_imgs
+            return self.generator([self.synthetic_encoder(params), rotations])
+
+    def _sd_batch(self, training_set):
+        return self._real_imgs("sd", training_set), self._sd_fake(training_set)
 
     def synth_discriminator_training_step(self, synth_training_set, optimizer):
-        self._stage_sd_batch(synth_training_set)
-        return self._run_step("sd", (synth_training_set,), optimizer, lambda: self._discriminator_update(
-            self.synth_discriminator, *self._sd_batch(synth_training_set), optimizer, "sd"))
+        return self._image_discriminator_step("sd", self.synth_discriminator, synth_training_set, optimizer, self._stage_sd_batch,
+                                              lambda ts: self._real_imgs("sd", ts), self._sd_fake)
 
     def _latent_discriminator_update(self, real_latents, fake_latents, optimizer):
         net = self.latent_discriminator
@@ -683,6 +752,7 @@ class ConfigNetFirstStage:
         # the step functions stay eager by default: in graph mode the returned loss scalars are the graph's static
         # outputs, overwritten by the next replay)
         self.use_graphs = bool(self.config.get("use_hip_graphs", True))
+        self.overlap_discriminators = self.use_graphs and bool(self.config.get("overlap_discriminators", True))
         for _ in range(start_step, n_steps):
             t0 = time.perf_counter()
             with self._main_line():

@@ -77,14 +77,12 @@ class ConfigNet(ConfigNetFirstStage):
         self._stage_real("d", training_set, n)
         self._stage("d/enc_idx", np.random.randint(0, training_set.imgs.shape[0], n), torch.int64)
 
-    def _d_batch(self, training_set):
+    def _d_fake(self, training_set):
         """confignet_second_stage.py:119-130: fakes are generated from encoded (unflipped) real images."""
-        real_imgs = self._real_imgs("d", training_set)
         with torch.no_grad():
             input_imgs = ops.gather_images_u8(self._pool(training_set)["imgs"], self._bufs["d/enc_idx"], None)
             latent_vector, rotation = self.encoder(input_imgs)
-            fake_imgs = self.generator([latent_vector, rotation])
-        return real_imgs, fake_imgs
+            return self.generator([latent_vector, rotation])
 
     def latent_discriminator_training_step(self, real_training_set, synth_training_set, optimizer):
         n = self.get_batch_size()
@@ -246,6 +244,7 @@ class ConfigNet(ConfigNetFirstStage):
         # the step functions stay eager by default: in graph mode the returned loss scalars are the graph's static
         # outputs, overwritten by the next replay)
         self.use_graphs = bool(self.config.get("use_hip_graphs", True))
+        self.overlap_discriminators = self.use_graphs and bool(self.config.get("overlap_discriminators", True))
         for _ in range(start_step, n_steps):
             t0 = time.perf_counter()
             d_loss, synth_d_loss, latent_d_loss, g_loss = self.training_iteration(

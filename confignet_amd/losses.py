@@ -81,6 +81,32 @@ def compute_discriminator_loss(discriminator, real_imgs, fake_imgs, second_order
     return losses
 
 
+def discriminator_loss_real(discriminator, real_imgs):
+    """The terms of compute_discriminator_loss that depend on the real images only: GAN_loss_real_i and gp_loss_i."""
+    real_imgs = real_imgs.detach().requires_grad_(True)
+    inter = []
+    out_real = discriminator(real_imgs, intermediates=inter)
+    real, gp = {}, {}
+    for i, o in enumerate(out_real.values()):
+        real["GAN_loss_real_" + str(i)] = GAN_D_loss(1.0, o)
+    if BATCHED_R1 and hasattr(discriminator, "input_gradients"):
+        gs = discriminator.input_gradients(inter)
+    else:
+        with F.input_grads_only():
+            gs = [torch.autograd.grad(o, real_imgs, grad_outputs=torch.ones_like(o), retain_graph=True)[0]
+                  for o in out_real.values()]
+    for i, g in enumerate(gs):
+        g = g.detach()
+        jvp = discriminator.tangent(g, inter, i).reshape(-1)
+        gp["gp_loss_" + str(i)] = 10 * 0.5 * (2.0 * jvp - F.row_sumsq(g)).mean()
+    return real, gp
+
+
+def discriminator_loss_fake(discriminator, fake_imgs):
+    out_fake = discriminator(fake_imgs.detach())
+    return {"GAN_loss_fake_" + str(i): GAN_D_loss(0.0, o) for i, o in enumerate(out_fake.values())}
+
+
 def _compute_discriminator_loss_tape(discriminator, real_imgs, fake_imgs):
     real_imgs = real_imgs.detach().requires_grad_(True)
     out_real = discriminator(real_imgs, twice_differentiable=True)

@@ -138,7 +138,7 @@ class Net:
         raise NotImplementedError
 
 
-def backward_into_arenas(loss, nets, extra=(), grad_outputs=None):
+def backward_into_arenas(loss, nets, extra=(), grad_outputs=None, accumulate=False):
     """tape.gradient(loss, trainable_weights) written into the networks' gradient arenas.
     Uses autograd.grad + one multi-tensor copy instead of .backward(): AccumulateGrad nodes are bound to the
     stream they were created on, which breaks HIP-graph capture of a step on a capture stream.
@@ -147,7 +147,8 @@ def backward_into_arenas(loss, nets, extra=(), grad_outputs=None):
     gradient: Keras-Adam on a zero gradient with zero moments leaves them unchanged.
     `extra`: further tensors of the tape whose gradients are returned (a list, None where unused) -- with `grad_outputs` and
     `loss` a list of such tensors a later call continues the backward pass from them (two-part backward, see
-    ConfigNetFirstStage._generator_update)."""
+    ConfigNetFirstStage._generator_update).  accumulate: ADD to the arenas (second part of a loss whose first part was
+    written by an earlier call: the discriminator steps' real / fake halves)."""
     every = [p for n in nets for p in n.trainable_weights]
     params = [p for p in every if p.requires_grad]
     extra = list(extra)
@@ -157,11 +158,15 @@ def backward_into_arenas(loss, nets, extra=(), grad_outputs=None):
     dst = [p.grad for p, g in zip(params, grads) if g is not None]
     src = [g.reshape(p.shape) for p, g in zip(params, grads) if g is not None]
     if dst:
-        torch._foreach_copy_(dst, src)
-    for p, g in zip(params, grads):
-        if g is None:
-            p.grad.zero_()
-    for p in every:
-        if not p.requires_grad:
-            p.grad.zero_()
+        if accumulate:
+            torch._foreach_add_(dst, src)
+        else:
+            torch._foreach_copy_(dst, src)
+    if not accumulate:
+        for p, g in zip(params, grads):
+            if g is None:
+                p.grad.zero_()
+        for p in every:
+            if not p.requires_grad:
+                p.grad.zero_()
     return extra_grads

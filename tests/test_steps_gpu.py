@@ -539,3 +539,66 @@ def test_loss_dicts_survive_the_next_replay_and_keras_style_apply_gradients():
     o2.apply_gradients(b)
     assert o1.iterations == o2.iterations == 1 and torch.equal(a.arena, b.arena)
     assert float((a.arena - MLPSimple(3, 8, 12, 4, rng=np.random.default_rng(5)).arena).abs().max()) > 5e-4
+
+
+def test_cross_iteration_overlap_of_the_discriminator_steps():
+    """overlap_discriminators (bench.py / train() switch it on): the real half of the next iteration's discriminator and
+    synthetic-discriminator steps is replayed next to the generator tail.  Same np.random draws in the same order, same
+    first iteration, and -- as far as the chaotic lr*sign(g) steps of a fresh GAN allow a comparison -- the same trajectory:
+    the terms that depend only on the discriminator's own weights and the real batch (GAN_loss_real_i, gp_loss_i) stay
+    together, the fake terms spread like two runs of the SAME configuration do (atomics order)."""
+    from confignet_amd import ConfigNet, SyntheticFaceDataset, optim
+    from confignet_amd.confignet_first_stage import DEFAULT_CONFIG
+    from confignet_amd.confignet_utils import merge_configs
+    runs = {}
+    for flag in (False, True):
+        np.random.seed(0)
+        ds = SyntheticFaceDataset(64, 128, seed=1)
+        cfg = merge_configs(DEFAULT_CONFIG, {"batch_size": 4, "output_shape": (128, 128, 3)})
+        ds.process_metadata(cfg, True)
+        m = ConfigNet(cfg, seed=0)
+        m.setup_training(None, ds, 0, real_training_set=ds)
+        m.use_graphs, m.overlap_discriminators = True, flag
+        dopt, gopt = optim.Adam(**cfg["optimizer"]), optim.Adam(**cfg["optimizer"])
+        draws, orig = [], m._stage_real
+
+        def logged(key, dataset, n, orig=orig, draws=draws):
+            st = np.random.get_state()
+            draws.append((key, tuple(np.random.randint(0, dataset.imgs.shape[0], n).tolist())))
+            np.random.set_state(st)
+            return orig(key, dataset, n)
+        m._stage_real = logged
+        hist = []
+        for _ in range(5):
+            hist.append([{k: float(v) for k, v in d.items()} for d in m.training_iteration(ds, ds, dopt, gopt)])
+        torch.cuda.synchronize()
+        segs = {k[0]: (len(g.segments), g.early_cut) for k, g in m._graphs.items()}
+        runs[flag] = (hist, draws, segs, m, ds, dopt, gopt)
+    (h0, d0, s0, _, _, _, _), (h1, d1, s1, m, ds, dopt, gopt) = runs[False], runs[True]
+    assert s0["d"] == (1, 0) and s1["d"] == (2, 1) and s1["sd"] == (2, 1) and s1["g"] == s0["g"]
+    # the overlapped run has drawn the NEXT iteration's two discriminator batches already, nothing else differs
+    assert d1[:len(d0)] == d0 and [k for k, _ in d1[len(d0):]] == ["d", "sd"]
+    assert set(m._prestaged) == {"d", "sd"}
+    for a, b in zip(h0[0], h1[0]):                                   # first iteration: the split update against the single one
+        for k in a:
+            assert abs(a[k] - b[k]) <= 1e-3 * max(1.0, abs(a[k])), (k, a[k], b[k])
+    for it in range(1, 5):
+        for step in (0, 1):                                          # discriminator, synthetic discriminator
+            for k, v in h0[it][step].items():
+                # (two runs of the SAME configuration are 1e-5 apart here at iteration 1 and percents apart by iteration 3)
+                if it <= 2 and (k.startswith("GAN_loss_real_") or k.startswith("gp_loss_")):
+                    assert abs(v - h1[it][step][k]) <= 2e-2 * max(1.0, abs(v)), (it, step, k, v, h1[it][step][k])
+        assert all(np.isfinite(v) for d in h1[it] for v in d.values())
+    # a step called on its own while its real half is in flight completes that iteration's step ...
+    before = m.discriminator.get_weights()[2].copy()
+    out = m.discriminator_training_step(ds, dopt)
+    assert np.isfinite(float(out["loss_sum"])) and "d" not in m._prestaged
+    assert np.abs(m.discriminator.get_weights()[2] - before).max() > 0
+    # ... and one called with other arguments does not use the half that was prepared for these
+    from confignet_amd import SyntheticFaceDataset as SFD
+    other = SFD(32, 128, seed=7)
+    other.process_metadata(m.config, True)
+    m.training_iteration(ds, ds, dopt, gopt)
+    assert "sd" in m._prestaged
+    out = m.synth_discriminator_training_step(other, dopt)
+    assert np.isfinite(float(out["loss_sum"])) and "sd" not in m._prestaged
