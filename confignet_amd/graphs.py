@@ -119,6 +119,13 @@ class StepGraph:
                 self.finish()
                 return out
             torch.cuda.synchronize()
+            # The cyclic garbage collector must not run inside a capture: if it frees an old graph / tensor of another pool
+            # there, the runtime aborts the process (seen as "Fatal Python error: Aborted ... Garbage-collecting" in the
+            # middle of a step's capture).  Collect now, keep it off until the capture has ended.
+            import gc
+            gc.collect()
+            gc_was_on = gc.isenabled()
+            gc.disable()
             ops.prof_enable(False)                 # no event records inside a capture
             WEIGHTS_EPOCH[0] += 1                  # derived caches must be rebuilt INSIDE this graph
             self.stream.wait_stream(cur)
@@ -132,6 +139,8 @@ class StepGraph:
                 finally:
                     _recording = None
                     self._cur.capture_end()
+                    if gc_was_on:
+                        gc.enable()
                 self.segments.append((self._cur, None))
             cur.wait_stream(self.stream)
             self.graph = self._cur
@@ -161,12 +170,18 @@ class InferenceGraph:
             self.graph = torch.cuda.CUDAGraph()
             mode = "thread_local" if parallel.active() else "global"
             ops._keepalive = self.derived = []                  # the graph reads these copies: they live as long as it does
+            import gc
+            gc.collect()                                        # (no garbage collection inside a capture: see StepGraph)
+            gc_was_on = gc.isenabled()
+            gc.disable()
             try:
                 self.graph.capture_begin(capture_error_mode=mode)
                 self.out = fn(**self.inputs)
                 self.graph.capture_end()
             finally:
                 ops._keepalive = None
+                if gc_was_on:
+                    gc.enable()
         cur.wait_stream(stream)
 
     def __call__(self, **inputs):

@@ -9,7 +9,7 @@ np.random.seed(0)
 ds = SyntheticFaceDataset(512, 256, seed=1)
 cfg = merge_configs(DEFAULT_CONFIG, {"batch_size": 16, "output_shape": (256, 256, 3)})
 ds.process_metadata(cfg, True)
-m = ConfigNet(cfg, seed=0); m.use_graphs = True
+m = ConfigNet(cfg, seed=0); m.use_graphs = True; m.overlap_discriminators = os.environ.get('CN_NO_D_OVERLAP') is None
 m.setup_training(None, ds, 0, real_training_set=ds)
 dopt, gopt = optim.Adam(**cfg["optimizer"]), optim.Adam(**cfg["optimizer"])
 for _ in range(5):
@@ -29,7 +29,11 @@ def flush(self):
     for g in pending:
         g.stream.wait_stream(cur)
         with torch.cuda.stream(g.stream):
-            g.replay(); g.finish()
+            if getattr(g, "prelaunched", False):
+                g.replay(g.early_cut); g.prelaunched = False
+            else:
+                g.replay()
+            g.finish()
     if follower is not None and self.early_generator_forward:
         follower.replay(0, follower.early_cut)
     for g in pending:
@@ -38,6 +42,18 @@ def flush(self):
     if follower is not None:
         follower.replay(follower.early_cut if self.early_generator_forward else 0)
         follower.finish()
+        if self.overlap_discriminators:
+            for g in pending:
+                st = self._stagers.get(getattr(g, "name", None))
+                if st is None or not g.early_cut:
+                    continue
+                stage, training_set, optimizer = st
+                with torch.cuda.stream(g.stream):
+                    stage(training_set)
+                    g.replay(0, g.early_cut)
+                g.prelaunched = True
+                net = self.discriminator if g.name == "d" else self.synth_discriminator
+                self._prestaged[g.name] = (id(training_set), id(optimizer), net.epoch, self._bufs.generation)
     c = ev()
     marks.append([a, b, c])
 ConfigNetFirstStage._flush_deferred = flush
