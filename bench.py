@@ -165,6 +165,10 @@ def main():
                                                                           "fp32" if args.dtype == "f32" else "bf16 compute / fp32 master weights"),
                        "global_batch": args.batch * world, "resolution": args.res, "latent_dim": cfg_latent(model),
                        "parallelism": "dp%d" % world, "losses_finite": bool(finite),
+                       "pipelining": ("steady state across iterations: the real half of the discriminator steps of iteration k+1 runs under "
+                                      "the generator tail of iteration k, so the timed window holds the halves of iterations 2..K+1 instead "
+                                      "of 1..K -- K iterations' worth of every kernel either way; CN_NO_D_OVERLAP=1 times the unpipelined loop"
+                                      if model.overlap_discriminators else "none (every iteration starts after the previous one has finished)"),
                        "dispatch": ("eager, one stream" if args.serial else "eager" if args.no_graphs else
                                     "hip-graph replay per step function, D-type steps concurrent, G step forked over 2 streams" +
                                     (", real half of the next iteration's discriminator steps under the generator tail" if model.overlap_discriminators else "") +
