@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--serial", action="store_true",
                     help="one stream, eager dispatch: no kernel overlaps another (the form to trace for per-kernel durations)")
     ap.add_argument("--cpu-batch", type=int, default=16)
+    ap.add_argument("--no-parity", action="store_true", help="skip the loss-parity iteration (loss_parity_vs_cpu)")
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="f32: the reference's arithmetic (BASELINE.json configs[1], the headline).  bf16: configs[2]'s compute type "
                          "(bf16 activations / filter copies on bf16 MFMA, fp32 accumulate, fp32 master weights) -- a separate line")
@@ -50,9 +51,7 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from confignet_amd import ConfigNet, SyntheticFaceDataset, ops, optim, parallel
-    from confignet_amd.confignet_first_stage import DEFAULT_CONFIG
-    from confignet_amd.confignet_utils import merge_configs
+    from confignet_amd import ops, parallel
 
     ops.set_activation_dtype(args.dtype)
     world = parallel.init_from_env()
@@ -63,17 +62,7 @@ def main():
     if world == 1:
         torch.cuda.set_device(0)
 
-    np.random.seed(1234 + rank)                       # per-rank batch sampling stream
-    real_set = SyntheticFaceDataset(args.pool, args.res, seed=1)
-    synth_set = SyntheticFaceDataset(args.pool, args.res, seed=2)
-    cfg = merge_configs(DEFAULT_CONFIG, {"batch_size": args.batch, "output_shape": (args.res, args.res, 3)})
-    synth_set.process_metadata(cfg, True)
-    cfg["image_loss_weight"] *= 10                    # second stage (train_confignet.py:67)
-    model = ConfigNet(cfg, seed=0)                    # identical seeded weights on every rank
-    parallel.broadcast_weights(model.all_networks())
-    model.setup_training(None, synth_set, 0, real_training_set=real_set)
-    d_opt, g_opt = optim.Adam(**cfg["optimizer"]), optim.Adam(**cfg["optimizer"])
-    model._pool(real_set), model._pool(synth_set)     # uint8 pools -> HBM before timing
+    model, real_set, synth_set, d_opt, g_opt, cfg = setup(args.batch, args.res, args.pool, rank)
 
     def sync():
         torch.cuda.synchronize()
@@ -106,6 +95,13 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     finite = all(np.isfinite(float(l["loss_sum"].detach())) for l in losses)
+
+    # Loss parity of THE DISPATCH JUST TIMED against the CPU oracle at this very size (rank 0, N = 1): one more iteration of the
+    # same loop (replayed graphs, its real halves already in flight from the previous iteration) on fresh Adam moments; its
+    # weights and batches go to the oracle subprocess of the cpu_baseline leg, which runs the same iteration first.
+    parity_state = None
+    if world == 1 and not args.no_cpu_baseline and not args.no_parity:
+        parity_state = dump_parity_state(model, real_set, synth_set, d_opt, g_opt)
 
     # Per-step-function times: each function of the iteration on its own, in the dispatch mode
     # of the timed region, 5 calls each; "d_phase" is the three discriminator-type steps as the iteration runs them.
@@ -197,11 +193,37 @@ def main():
             "torch_kernel_time_share": torch_kernel_share(),
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args)
+            out["cpu_baseline"], ref_losses = cpu_baseline(args, parity_state["path"] if parity_state else None)
+            if parity_state is not None:
+                out["loss_parity_vs_cpu"] = compare_losses(parity_state["losses"], ref_losses, parity_state["dispatch"])
+                try:
+                    os.remove(parity_state["path"])
+                except OSError:
+                    pass
         print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
+
+
+def setup(batch, res, pool, rank=0):
+    """The benchmark's model, datasets and optimizers (BASELINE.json configs[1] at batch 16, res 256): seeded synthetic
+    FFHQ-shaped uint8 pools resident in HBM, identical seeded weights on every rank."""
+    from confignet_amd import ConfigNet, SyntheticFaceDataset, optim, parallel
+    from confignet_amd.confignet_first_stage import DEFAULT_CONFIG
+    from confignet_amd.confignet_utils import merge_configs
+    np.random.seed(1234 + rank)                       # per-rank batch sampling stream
+    real_set = SyntheticFaceDataset(pool, res, seed=1)
+    synth_set = SyntheticFaceDataset(pool, res, seed=2)
+    cfg = merge_configs(DEFAULT_CONFIG, {"batch_size": batch, "output_shape": (res, res, 3)})
+    synth_set.process_metadata(cfg, True)
+    cfg["image_loss_weight"] *= 10                    # second stage (train_confignet.py:67)
+    model = ConfigNet(cfg, seed=0)                    # identical seeded weights on every rank
+    parallel.broadcast_weights(model.all_networks())
+    model.setup_training(None, synth_set, 0, real_training_set=real_set)
+    d_opt, g_opt = optim.Adam(**cfg["optimizer"]), optim.Adam(**cfg["optimizer"])
+    model._pool(real_set), model._pool(synth_set)     # uint8 pools -> HBM before timing
+    return model, real_set, synth_set, d_opt, g_opt, cfg
 
 
 def kernels_hash():
@@ -249,22 +271,109 @@ def torch_kernel_share():
     return None if v is None else round(v, 4)
 
 
-def cpu_baseline(args):
+def cpu_baseline(args, state_path=None):
     """The oracle's restatement of one whole second-stage iteration, timed on the host cores in a subprocess with a hard
-    time limit: thread count = the fastest of {8, 16, 32, 64} in a one-iteration probe at batch 2 (stopping at the first slowdown), then 1 warm-up + the median
-    of 3 iterations at the benchmark's batch."""
+    time limit: thread count = the fastest of {8, 16, 32, 64} in a one-iteration probe at batch 2 (stopping at the first
+    slowdown: NOT the box's best -- a batch-2 iteration cannot feed many threads), then 1 warm-up + the median of 3
+    iterations at the benchmark's batch.  state_path: a dump_parity_state() file -- the warm-up iteration then runs on the
+    HIP path's own weights and batch and its loss dicts come back as the second return value."""
     import subprocess
-    cmd = [sys.executable, "-m", "oracle.cpu_baseline", str(args.cpu_batch), str(args.res)]
+    cmd = [sys.executable, "-m", "oracle.cpu_baseline", str(args.cpu_batch), str(args.res)] + ([state_path] if state_path else [])
     try:
-        p = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=420)
+        p = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=480)
         r = json.loads(p.stdout.strip().splitlines()[-1])
         return {"value": round(r["value"], 4), "unit": "images/sec", "cores": r["cores"], "kind": "port",
-                "sample": "second-stage iteration at %dx%d, batch %d: 1 warm-up + median of 3 (%.1f s each) on %d of %d host cores "
-                          "(fastest of an {8, 16, 32, 64}-thread probe, stopped at the first slowdown: %s s per batch-2 iteration); torch-CPU fp32 restatement of the "
+                "sample": "second-stage iteration at %dx%d, batch %d: 1 warm-up + median of 3 (%.1f s each) on %d threads of the %d host cores "
+                          "(thread count from a probe AT BATCH 2 over {8, 16, 32, 64}, stopped at the first slowdown: %s s per batch-2 iteration -- "
+                          "not claimed to be the box's best); torch-CPU fp32 restatement of the "
                           "reference (oracle/) -- TensorFlow 2.1 itself cannot be installed here"
-                          % (args.res, args.res, args.cpu_batch, r["seconds"], r["cores"], r["host_cores"], r["thread_probe_seconds"])}
+                          % (args.res, args.res, args.cpu_batch, r["seconds"], r["cores"], r["host_cores"], r["thread_probe_seconds"])}, \
+            r.get("parity_losses")
     except Exception as e:   # timeout / crash: report it, never block the GPU result
-        return {"value": None, "unit": "images/sec", "cores": None, "kind": "port", "sample": "failed: %r" % (e,)}
+        return {"value": None, "unit": "images/sec", "cores": None, "kind": "port", "sample": "failed: %r" % (e,)}, None
+
+
+PARITY_NETS = ("generator", "generator_smoothed", "discriminator", "synth_discriminator", "latent_discriminator",
+               "latent_regressor", "synthetic_encoder", "real_encoder")
+
+
+def dump_parity_state(model, real_set, synth_set, d_opt, g_opt, path=None):
+    """Runs ONE MORE iteration in the dispatch the caller has set up and writes what the CPU oracle needs to run the same
+    iteration (oracle/cpu_baseline.py:load_state): every network's weights before it, the batches (uint8 images gathered ON
+    THE HOST from the dataset arrays by the staged indices, flip flags, face-model parameters, rotations), and the three
+    discriminators' weights after it.  Adam moments / step counters are reset first (the oracle starts from fresh moments);
+    weights are NOT touched, so with the cross-iteration overlap the real halves that the previous iteration pre-replayed for
+    this one are consumed as they are -- this is the pipelined dispatch, not a restart.  Returns path / losses / dispatch."""
+    import tempfile
+
+    import torch
+    nets = dict(zip(PARITY_NETS, (model.generator, model.generator_smoothed, model.discriminator, model.synth_discriminator,
+                                  model.latent_discriminator, model.latent_regressor, model.synthetic_encoder, model.encoder)))
+    model._bufs.log = {}
+    model.training_iteration(real_set, synth_set, d_opt, g_opt)           # (its tail stages the discriminator batches of the next one)
+    torch.cuda.synchronize()
+    pipelined = bool(model.use_graphs and model.overlap_discriminators and
+                     all(getattr(g, "prelaunched", False) for g in model._graphs.values() if g.name in ("d", "sd")))
+    for o in (d_opt, g_opt):
+        o.iterations = 0
+        for mom, var in o._state.values():
+            mom.zero_()
+            var.zero_()
+    z = {}
+    for name, net in nets.items():
+        ws = net.get_weights()
+        z["n/" + name] = np.int64(len(ws))
+        for i, w in enumerate(ws):
+            z["%s/%d" % (name, i)] = w
+    vgg = model.perceptual_loss._pretrained_dnn_activations.get_weights()
+    z["n/vgg"] = np.int64(len(vgg))
+    for i, w in enumerate(vgg):
+        z["vgg/%d" % i] = w
+    mark = {k: len(v) for k, v in model._bufs.log.items()}
+    out = model.training_iteration(real_set, synth_set, d_opt, g_opt)
+    losses = [{k: float(v) for k, v in d.items()} for d in out]
+    log, model._bufs.log = model._bufs.log, None
+    # this iteration's batch per key: what it staged itself (first entry after `mark`), except the image-discriminator steps
+    # of the pipelined loop, whose batch was staged by the PREVIOUS iteration's tail (last entry before `mark`)
+    B = {k: v[mark[k] - 1 if (pipelined and k.startswith(("d/", "sd/"))) else mark[k]] for k, v in log.items()}
+    assert len(log["g/rot"]) == mark["g/rot"] + 1 and len(log["d/real_idx"]) >= mark["d/real_idx"] + 1, "unexpected staging sequence"
+    for name in ("discriminator", "synth_discriminator", "latent_discriminator"):
+        for i, w in enumerate(nets[name].get_weights()):
+            z["post/%s/%d" % (name, i)] = w
+    R, Sy = np.asarray(real_set.imgs), np.asarray(synth_set.imgs)
+    z.update({"img/real_d": R[B["d/real_idx"]], "flip/real_d": B["d/real_flip"], "img/enc_in_d": R[B["d/enc_idx"]],
+              "img/real_sd": Sy[B["sd/real_idx"]], "flip/real_sd": B["sd/real_flip"], "sd/rot": B["sd/rot"],
+              "img/real_ld": R[B["ld/real_idx"]], "flip/real_ld": B["ld/real_flip"],
+              "g/rot": B["g/rot"], "img/synth_g": Sy[B["g/synth_idx"]], "eye_masks_g": np.asarray(synth_set.eye_masks)[B["g/synth_idx"]],
+              "img/real_g": R[B["g/real_idx"]], "flip/real_g": B["g/real_flip"]})
+    for k, v in B.items():
+        if "/p/" in k:
+            z[k] = v
+    if path is None:
+        fd, path = tempfile.mkstemp(prefix="cn_parity_", suffix=".npz")
+        os.close(fd)
+    np.savez(path, **z)
+    dispatch = ("hip-graph replay, real halves of this iteration's discriminator steps pre-replayed under the previous generator tail"
+                if pipelined else "hip-graph replay" if model.use_graphs else "eager")
+    return {"path": path, "losses": losses, "dispatch": dispatch}
+
+
+def compare_losses(got, ref, dispatch, tol=1e-3):
+    """max over every scalar of the four loss dicts of |hip - cpu| / max(1, |cpu|) (north_star: 1e-3 at fp32)."""
+    if ref is None:
+        return {"max_err": None, "tolerance": tol, "note": "the CPU oracle run failed"}
+    worst, n = (0.0, None), 0
+    for g, step in zip(got, ("d", "synth_d", "latent_d", "g")):
+        r = ref[step]
+        assert list(g.keys()) == list(r.keys()), (step, list(g.keys()), list(r.keys()))
+        for k, v in g.items():
+            e = abs(v - r[k]) / max(1.0, abs(r[k]))
+            n += 1
+            if not (e <= worst[0]):
+                worst = (e, "%s/%s: hip %.6g cpu %.6g" % (step, k, v, r[k]))
+    return {"max_err": float("%.3g" % worst[0]), "tolerance": tol, "ok": bool(worst[0] <= tol), "n_scalars": n, "worst": worst[1],
+            "what": "all loss scalars of one whole iteration at the benchmark's size, HIP (%s) vs the torch-CPU fp32 oracle on the "
+                    "same weights and batches; |hip - cpu| / max(1, |cpu|)" % dispatch}
 
 
 def cfg_latent(model):

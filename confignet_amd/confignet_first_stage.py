@@ -1,8 +1,9 @@
 """ConfigNetFirstStage (reference: confignet/confignet_first_stage.py): same config dict, attributes,
 step functions, persistence format and inference API, with every network on HIP kernels.
 
-Out of scope here: FID/KID/controllability metrics, image-grid checkpoints,
-TensorBoard/AzureML logging.  `train()` keeps the reference's iteration structure and timing."""
+Out of scope here: the controllability metrics and the TensorBoard / AzureML sinks (FID / KID and
+the image-grid checkpoints are built: confignet_amd/metrics, run_checkpoints).  `train()` keeps the reference's iteration
+structure and timing."""
 import contextlib
 import json
 import os
@@ -258,6 +259,7 @@ class ConfigNetFirstStage:
         """w_bar = a*w_bar + (1-a)*w over the whole generator arena in one launch (l.393-400; the
         reference round-trips every weight through numpy)."""
         ops.ema_step(self.generator_smoothed.arena, self.generator.arena, smoother_alpha)
+        self.generator_smoothed.mark_updated()      # raw-pointer kernel: derived filter copies / inference graphs are keyed on the epoch
 
     def sample_rotations(self, n_samples, axes=[0, 1, 2]):
         r = np.zeros((n_samples, 3))

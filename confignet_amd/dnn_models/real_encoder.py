@@ -108,10 +108,16 @@ class RealEncoder(Net):
         return torch.split(a, sizes), torch.split(shift, sizes)
 
     def non_trainable_changed(self):
-        """set_weights / copy_weights_from / a data-parallel broadcast rewrote the moving mean / variance in place: drop
-        their concatenated copy.  (Not tied to mark_updated(): the optimizer calls that every step, and a copy re-made
-        inside one captured step graph must not be shared with another.)"""
-        self._stat_cache = None
+        """set_weights / copy_weights_from / a data-parallel broadcast rewrote the moving mean / variance in place: refill
+        their concatenated copy IN PLACE -- captured step graphs read it at its address, so it is never dropped once made.
+        (Not tied to mark_updated(): the optimizer calls that every step, and a copy re-made inside one captured step graph
+        must not be shared with another.)"""
+        cache = getattr(self, "_stat_cache", None)
+        if cache is not None:
+            bs = [b for _, b, _ in self._convs]
+            with torch.no_grad():
+                cache[0].copy_(torch.cat([self.weights[b + 2] for b in bs]))
+                cache[1].copy_(torch.cat([self.weights[b + 3] for b in bs]))
 
     def _conv_bn(self, ci, x, coef, res=None, relu=True):
         kidx, _, spec = self._convs[ci]

@@ -54,6 +54,7 @@ class StepGraph:
         self.packed, self._result = None, None      # all loss scalars of the step in one static tensor / this call's copy
         self.segments = []           # [(CUDAGraph, action run after it | None)]; self.graph is the last segment
         self.early_cut = 0           # segments[:early_cut] may run concurrently with the iteration's sibling steps
+        self.updated_nets = []       # networks whose Adam launches are nodes of this graph: every replay changes their weights
 
     def _run_fn(self):
         if not self.split:
@@ -69,6 +70,8 @@ class StepGraph:
         tensor handed to the caller for THIS execution (one small launch)."""
         if self.tail:
             optim.run_deferred(self.tail)
+        for net in self.updated_nets:      # graph-node Adam launches do not run Python: eager forwards between replays must not
+            net.mark_updated()             # find derived filter copies / inference graphs of the previous weights (nn.Net.epoch)
         if self._result is not None and self.packed is not None:
             self._result.copy_(self.packed)
             self._result = None
@@ -132,12 +135,14 @@ class StepGraph:
             with torch.cuda.stream(self.stream):
                 self._begin()
                 _recording = self
+                optim._touched = self.updated_nets = []
                 try:
                     self.out = self._run_fn()
                     if isinstance(self.out, dict) and self.out and all(torch.is_tensor(v) and v.numel() == 1 for v in self.out.values()):
                         self.packed = torch.stack([v.reshape(()).float() for v in self.out.values()])
                 finally:
                     _recording = None
+                    optim._touched = None
                     self._cur.capture_end()
                     if gc_was_on:
                         gc.enable()
@@ -258,6 +263,9 @@ class StaticBuffers:
     def __init__(self, device):
         self.device, self.bufs, self.generation = device, {}, 0
         self._pinned, self._events = {}, {}
+        self.log = None         # a dict key -> [host array of every stage() call, in order] while a checker records the batches
+                                # (tests / bench.py's loss parity: with the cross-iteration overlap the buffers of the
+                                # discriminator steps already hold the NEXT iteration's batch when an iteration returns)
 
     def stage(self, key, array, dtype=None):
         t = torch.as_tensor(array)
@@ -276,6 +284,8 @@ class StaticBuffers:
         else:
             ev = self._events[key] = torch.cuda.Event()
         self._pinned[key].copy_(t)
+        if self.log is not None:
+            self.log.setdefault(key, []).append(self._pinned[key].numpy().copy())
         b.copy_(self._pinned[key], non_blocking=True)
         ev.record()
         return b

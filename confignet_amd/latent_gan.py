@@ -120,6 +120,7 @@ class LatentGAN:
 
     def update_smoothed_weights(self, smoother_alpha=0.999):
         ops.ema_step(self.generator_smoothed.arena, self.generator.arena, smoother_alpha)
+        self.generator_smoothed.mark_updated()
 
     def extract_embeddings(self, confignet_model, training_set, max_chunk_size=1000):
         """latent_gan.py:218-232."""

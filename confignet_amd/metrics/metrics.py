@@ -29,6 +29,11 @@ class InceptionMetrics:
     def gt_inception_features(self):
         if self._gt_features is None:
             feats = getattr(self._dataset, "inception_features", None)
+            if feats is not None and self._weights_path is None:
+                # the dataset's precomputed features come from the imagenet InceptionV3; without its weights the extractor
+                # here is a seeded-random network, and FID / KID between features of two DIFFERENT networks mean nothing:
+                # recompute the ground-truth side with the extractor that sees the generated images
+                feats = None
             if feats is None:
                 # the reference's dataset files carry precomputed features (neural_renderer_dataset.py:323-325); a dataset
                 # without them gets the features of the sampled images computed here, with this extractor

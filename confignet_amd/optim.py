@@ -11,6 +11,7 @@ from . import parallel
 
 
 _deferred = None     # list of (optimizer, nets, slot) while a step is recorded with deferred updates
+_touched = None      # list that receives every network an Adam launch updates (graphs.StepGraph sets it while it captures a step)
 
 
 class deferred_updates:
@@ -69,7 +70,10 @@ class Adam:
         data-parallel gradient all-reduce first, then one fused Adam launch per arena.
         Also accepts the Keras form `apply_gradients(zip(gradients, variables))` (confignet_first_stage.py:472-474) when the
         variables are weights of confignet_amd networks: the gradients are copied into the owners' gradient arenas (weights
-        of those networks that are not listed get a zero gradient, which Keras-Adam with zero moments leaves unchanged)."""
+        of those networks that are not listed get a zero gradient, which Keras-Adam with zero moments leaves unchanged).
+        RESTRICTION of that form: Adam runs over the owners' WHOLE arenas, so an unlisted weight of a listed network whose
+        moments are already non-zero in THIS optimizer (it was listed in an earlier call) would keep moving, which Keras does
+        not do -- asserted below on the first-moment arena (the reference never mixes variable lists on one optimizer)."""
         if not isinstance(nets, (list, tuple)) and hasattr(nets, "__iter__") and not hasattr(nets, "arena"):
             nets = list(nets)                   # zip(...) and other iterators
         if isinstance(nets, (list, tuple)) and nets and isinstance(nets[0], (list, tuple)):
@@ -83,6 +87,16 @@ class Adam:
             for g, var in pairs:
                 if g is not None:
                     var.grad.copy_(g.reshape(var.shape))
+            listed = {id(var) for _, var in pairs}
+            for owner in nets:
+                st = self._state.get(id(owner))
+                if st is None or len(listed) >= len(owner.trainable_weights):
+                    continue
+                for w in owner.trainable_weights:
+                    if id(w) not in listed:
+                        off = (w.data_ptr() - owner.arena.data_ptr()) // 4
+                        assert float(st[1][off:off + w.numel()].abs().max()) == 0.0, \
+                            "apply_gradients(zip(grads, vars)): an unlisted weight of a listed network has optimizer state"
         if not isinstance(nets, (list, tuple)):
             nets = [nets]
         if _deferred is not None:
@@ -96,3 +110,5 @@ class Adam:
             m, v = self.state_for(net)
             ops.adam_step(net.arena, net.grad_arena, m, v, None, self._lr_dev[slot], self.beta_1, self.beta_2, self.epsilon)
             net.mark_updated()
+            if _touched is not None and all(net is not t for t in _touched):
+                _touched.append(net)

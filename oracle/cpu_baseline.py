@@ -81,8 +81,51 @@ def make_batch(res, b, rng, dtype=torch.float32):
             "eye_masks_g": torch.as_tensor(masks), "real_imgs_g": img(nr)}
 
 
-def time_second_stage_iteration(res=256, batch=2, repeats=1, threads=None, warmup=0):
-    """Returns (images_per_sec, median seconds per iteration, threads used)."""
+STATE_NETS = ("generator", "generator_smoothed", "discriminator", "synth_discriminator", "latent_discriminator",
+              "latent_regressor", "synthetic_encoder", "real_encoder")
+STATE_D_NETS = ("discriminator", "synth_discriminator", "latent_discriminator")
+
+
+def flip_subset(imgs, flags):
+    """flip_random_subset_of_images (confignet_utils.py:24-31): images with a set flag are mirrored left-right."""
+    out = np.array(imgs, copy=True)
+    for i, f in enumerate(flags):
+        if f:
+            out[i] = out[i, :, ::-1]
+    return out
+
+
+def load_state(path, dtype=torch.float32):
+    """The HIP path's own weights and batches of ONE iteration, written by bench.py:dump_parity_state (a flat .npz): the
+    iteration below is then the checker of that iteration's loss scalars (bench line: loss_parity_vs_cpu).
+    Returns (W, vgg, batch, post_d): post_d = the device path's discriminator weights after its discriminator phase,
+    handed over before the generator step exactly as tests/test_steps_gpu.py does (lr*sign(g) steps of noise-level
+    gradient entries differ between any two fp32 summation orders)."""
+    z = np.load(path)
+    t = lambda a, grad=False: torch.tensor(np.asarray(a), dtype=dtype, requires_grad=grad)
+    W = {}
+    for net in STATE_NETS:
+        n = int(z["n/" + net])
+        W[net] = [t(z["%s/%d" % (net, i)], net != "generator_smoothed") for i in range(n)]
+    for w, role in zip(W["real_encoder"], R.resnet50_weight_roles()):
+        if role in ("mean", "var"):
+            w.requires_grad_(False)
+    vgg = [t(z["vgg/%d" % i]) for i in range(int(z["n/vgg"]))]
+    post_d = {net: [t(z["post/%s/%d" % (net, i)]) for i in range(int(z["n/" + net]))] for net in STATE_D_NETS}
+    names = list(FACEMODEL_IO.keys())
+    img = lambda key, flip=None: t((flip_subset(z[key], z[flip]) if flip else z[key]).astype(np.float64) / 127.5 - 1.0)
+    batch = {"real_d": img("img/real_d", "flip/real_d"), "enc_in_d": img("img/enc_in_d"),
+             "real_sd": img("img/real_sd", "flip/real_sd"), "params_sd": [t(z["sd/p/" + n]) for n in names], "rot_sd": t(z["sd/rot"]),
+             "real_ld": img("img/real_ld", "flip/real_ld"), "params_ld": [t(z["ld/p/" + n]) for n in names],
+             "params_g": [t(z["g/p/" + n]) for n in names], "rot_g": t(z["g/rot"]), "synth_imgs_g": img("img/synth_g"),
+             "eye_masks_g": torch.as_tensor(z["eye_masks_g"]), "real_imgs_g": img("img/real_g", "flip/real_g")}
+    return W, vgg, batch, post_d
+
+
+def time_second_stage_iteration(res=256, batch=2, repeats=1, threads=None, warmup=0, state=None):
+    """Returns (images_per_sec, median seconds per iteration, threads used[, loss dicts of the state iteration]).
+    state: path of a bench.py parity dump -- its weights replace the seeded ones and its batch is the FIRST iteration run
+    (with fresh Adam moments, as the device path ran it); that iteration's four loss dicts are returned as floats."""
     threads = threads or min(os.cpu_count() or 1, 16)
     torch.set_num_threads(threads)
     rng = np.random.default_rng(0)
@@ -90,17 +133,34 @@ def time_second_stage_iteration(res=256, batch=2, repeats=1, threads=None, warmu
     cfg = {"output_shape": (res, res, 3), "rotation_ranges": ((-30, 30), (-10, 10), (0, 0)),
            "image_loss_weight": 5e-4, "eye_loss_weight": 5, "domain_adverserial_loss_weight": 5.0,
            "latent_regression_weight": 10.0, "latent_regressor_rot_weight": 5.0}
-    W, vgg = build_weights(res, latent_dim, rng)
+    parity = None
+    if state is None:
+        W, vgg = build_weights(res, latent_dim, rng)
+        first = post_d = None
+    else:
+        W, vgg, first, post_d = load_state(state)
+        batch = first["real_d"].shape[0]
+
+    def hand_over(Wd):
+        with torch.no_grad():
+            for net in STATE_D_NETS:
+                for w, a in zip(Wd[net], post_d[net]):
+                    w.copy_(a)
     d_opt = O.KerasAdam(lr=4e-4, beta_1=0.0, beta_2=0.9)
     g_opt = O.KerasAdam(lr=4e-4, beta_1=0.0, beta_2=0.9)
     times = []
     for i in range(warmup + repeats):
-        b = make_batch(res, batch, rng)
+        use_state = first is not None and i == 0
+        b = first if use_state else make_batch(res, batch, rng)
         t0 = time.perf_counter()
-        S.second_stage_iteration(W, cfg, b, d_opt, g_opt, vgg)
+        out = S.second_stage_iteration(W, cfg, b, d_opt, g_opt, vgg, after_discriminator_phase=hand_over if use_state else None)
         if i >= warmup:
             times.append(time.perf_counter() - t0)
-    sec = float(np.median(times))
+        if use_state:
+            parity = {step: {k: float(v.detach()) for k, v in d.items()} for step, d in out.items()}
+    sec = float(np.median(times)) if times else float("nan")
+    if state is not None:
+        return batch / sec, sec, threads, parity
     return batch / sec, sec, threads
 
 
@@ -122,10 +182,18 @@ def best_thread_count(res, candidates, probe_batch=2):
 if __name__ == "__main__":
     import json
     import sys
+    # usage: python -m oracle.cpu_baseline BATCH RES [STATE.npz [--parity-only]]
     b = int(sys.argv[1]) if len(sys.argv) > 1 else 2
     r = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+    state = sys.argv[3] if len(sys.argv) > 3 else None
     host = os.cpu_count() or 1
+    if "--parity-only" in sys.argv:                 # tests: the state iteration alone, no timing
+        _, _, cores, parity = time_second_stage_iteration(r, b, repeats=0, threads=min(16, host), warmup=1, state=state)
+        print(json.dumps({"cores": cores, "parity_losses": parity}))
+        sys.exit(0)
     cands = sorted({min(8, host), min(16, host), min(32, host), min(64, host)})
     threads, probe = best_thread_count(r, cands)
-    v, sec, cores = time_second_stage_iteration(r, b, repeats=3, threads=threads, warmup=1)     # 1 warm-up + median of 3
-    print(json.dumps({"value": v, "seconds": sec, "cores": cores, "host_cores": host, "thread_probe_seconds": probe}))
+    res_ = time_second_stage_iteration(r, b, repeats=3, threads=threads, warmup=1, state=state)     # 1 warm-up (= the parity iteration, if any) + median of 3
+    v, sec, cores = res_[:3]
+    print(json.dumps({"value": v, "seconds": sec, "cores": cores, "host_cores": host, "thread_probe_seconds": probe,
+                      "parity_losses": res_[3] if state is not None else None}))

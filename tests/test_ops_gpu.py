@@ -99,9 +99,11 @@ def test_conv_fwd_dgrad_wgrad(case):
     close(gw, wr.grad, tol=5e-4, what="wgrad")
 
 
-# The layer shapes of the 256x256, batch-16 iteration (BASELINE.json configs[1]) are too big for the float64 oracle; at
-# full size the three convolution kernels of a layer are checked against each other through the adjoint identities
-#   <conv(x, w), gy> == <x_up, dgrad(gy, w)> == <w, wgrad(x, gy)>      (exact in exact arithmetic, size-independent)
+# The layer shapes of the 256x256, batch-16 iteration (BASELINE.json configs[1]): the tile / split-K / XCD-order / Winograd
+# code paths are selected BY SIZE, so the small cases above never reach them.  Each layer is compared with the float64
+# oracle on the FULL tensors (forward, data gradient, filter gradient: seconds per layer on the host), and -- second line of
+# defence, size-independent -- the three kernels are checked against each other through the adjoint identities
+#   <conv(x, w), gy> == <x_up, dgrad(gy, w)> == <w, wgrad(x, gy)>
 # and through linearity in x, with the inner products accumulated in float64 on the device.
 FULL_SIZE_LAYERS = [
     # (x shape, kernel, cout, stride, up)
@@ -115,7 +117,90 @@ FULL_SIZE_LAYERS = [
     ((16, 256, 256, 64), (3, 3), 64, 1, 0),       # VGG block1_conv2
     ((16, 64, 64, 256), (3, 3), 256, 1, 0),       # VGG block3
     ((8, 16, 16, 1024), (1, 1), 512, 1, 0),       # generator projection conv / ResNet 1x1
+    ((16, 128, 128, 128), (3, 3), 128, 1, 0),     # VGG block2_conv2 (Winograd)
+    ((8, 32, 32, 512), (3, 3), 512, 1, 0),        # VGG block4_conv2 (Winograd, cin = 512)
+    ((16, 32, 32, 192), (3, 3), 384, 2, 0),       # DiscrBlock 3: 64 x 64 tiles, few rows
+    ((96, 16, 16, 384), (3, 3), 768, 2, 0),       # DiscrBlock 4 under the batched R1 sweep (6 heads x 16 samples)
+    ((8, 16, 16, 16, 256), (3, 3, 3), 128, 1, 1),  # generator Conv3D 16^3 -> 32^3 with folded upsample
+    ((8, 32, 32, 256), (4, 4), 64, 1, 1),         # generator k4 + upsample to 64^2
 ]
+
+
+def _full_size_oracle(xs, k, cout, stride, up, x, w, gy):
+    """float64 forward / data gradient (at the upsampled extent) / filter gradient of one layer on the host."""
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    xr, wr = x.detach().cpu().double().requires_grad_(True), w.detach().cpu().double().requires_grad_(True)
+    xu = O.upsample2(xr) if up else xr
+    xu.retain_grad()
+    yr = O.conv_same(xu, wr, None, stride=stride)
+    (yr * gy.detach().cpu().double()).sum().backward()
+    return yr.detach(), xu.grad, wr.grad
+
+
+@pytest.mark.parametrize("case", FULL_SIZE_LAYERS, ids=[str(i) for i in range(len(FULL_SIZE_LAYERS))])
+def test_conv_full_size_vs_oracle(case):
+    """building_blocks.py:29,65,91, perceptual_loss.py:19-26 at the sizes of configs[1]: every output element of the three
+    kernels against the float64 oracle (a shifted SAME padding, a mis-ordered parity class or a wrong tile-boundary row
+    passes the adjoint identities below as long as it is consistent; it does not pass this)."""
+    from confignet_amd import ops
+    xs, k, cout, stride, up = case
+    gen = torch.Generator(device="cuda").manual_seed(sum(xs) + 7 * cout)
+    rnd = lambda *shape: torch.randn(*shape, device="cuda", generator=gen)
+    cin = xs[-1]
+    x = rnd(*xs)
+    w = rnd(*k, cin, cout) / math.sqrt(np.prod(k) * cin)
+    g = ops.ConvSpec(k, stride=stride, up=up).geom(xs, cout)
+    y = ops.conv_fwd(x, w, None, g, 0, 0.0)
+    gy = rnd(*y.shape)
+    gu = ops.conv_dgrad(gy, w, g)
+    gw = ops.conv_wgrad(x, gy, g, tuple(w.shape))
+    yr, gur, gwr = _full_size_oracle(xs, k, cout, stride, up, x, w, gy)
+    close(y, yr, what="fwd")
+    close(gu, gur, what="dgrad")
+    close(gw, gwr, tol=5e-4, what="wgrad")
+
+
+SWEEP_LAYERS = [
+    # (x shape, kernel, cout, stride): every tile configuration / split-K factor the heuristic can pick, forced one by one
+    ((4, 64, 64, 96), (3, 3), 192, 2),
+    ((4, 32, 32, 128), (3, 3), 128, 1),
+]
+
+
+@pytest.mark.parametrize("case", SWEEP_LAYERS, ids=[str(i) for i in range(len(SWEEP_LAYERS))])
+def test_conv_forced_tile_and_split_configurations_vs_oracle(case, monkeypatch):
+    """cn_conv_tune sweep: tiles 128x128 / 128x64 / 64x64 / 128x32 / 128x96, split-K 1 / 3 / 8, forward and parity-ordered
+    data gradient, filter-gradient workgroup targets -- each against the float64 oracle (Winograd off: the direct kernels are
+    what is being configured)."""
+    from confignet_amd import ops
+    from confignet_amd._lib import lib
+    monkeypatch.setattr(ops, "WINOGRAD", False)
+    xs, k, cout, stride = case
+    gen = torch.Generator(device="cuda").manual_seed(11 + cout)
+    rnd = lambda *shape: torch.randn(*shape, device="cuda", generator=gen)
+    x = rnd(*xs)
+    w = rnd(*k, xs[-1], cout) / math.sqrt(np.prod(k) * xs[-1])
+    g = ops.ConvSpec(k, stride=stride).geom(xs, cout)
+    y0 = ops.conv_fwd(x, w, None, g, 0, 0.0)
+    gy = rnd(*y0.shape)
+    yr, gur, gwr = _full_size_oracle(xs, k, cout, stride, 0, x, w, gy)
+    try:
+        for cfg in (0, 1, 2, 3, 4):
+            if cfg == 4 and cout % 96:
+                continue
+            for splits in (1, 3, 8):
+                ops.check(lib.cn_conv_tune(cfg, splits, 0), "cn_conv_tune")
+                close(ops.conv_fwd(x, w, None, g, 0, 0.0), yr, what="fwd cfg %d splits %d" % (cfg, splits))
+                if cfg != 4 or xs[-1] % 96 == 0:
+                    wt = ops.weight_tflip(w)
+                    gu = torch.empty_like(x)
+                    ops.check(lib.cn_conv_dgrad(__import__("ctypes").byref(g), ops._ptr(gy), ops._ptr(wt), ops._ptr(gu), ops._stream()), "cn_conv_dgrad")
+                    close(gu, gur, what="dgrad cfg %d splits %d" % (cfg, splits))
+        for wg_blocks in (256, 1024, 4096):
+            ops.check(lib.cn_conv_tune(-1, 0, wg_blocks), "cn_conv_tune")
+            close(ops.conv_wgrad(x, gy, g, tuple(w.shape)), gwr, tol=5e-4, what="wgrad wg_blocks %d" % wg_blocks)
+    finally:
+        ops.check(lib.cn_conv_tune(-1, 0, 0), "cn_conv_tune")
 
 
 @pytest.mark.parametrize("case", FULL_SIZE_LAYERS, ids=[str(i) for i in range(len(FULL_SIZE_LAYERS))])
