@@ -226,7 +226,7 @@ def test_whole_second_stage_iteration_under_graph_dispatch_matches_oracle(overla
     nets = m.all_networks()
     by_name = _nets_by_name(m)
     start = [n.get_weights() for n in nets]
-    for _ in range(3):                                         # eager warm-up, capture, first replay
+    for _ in range(4 if overlap else 3):                       # eager warm-ups, capture (+ first replay), first concurrent replay
         m.training_iteration(real_set, synth_set, d_opt, g_opt)
     torch.cuda.synchronize()
     assert len(m._graphs) == 4 and all(g.graph is not None for g in m._graphs.values())
@@ -343,7 +343,7 @@ def test_full_size_iteration_in_the_benchmarked_dispatch_matches_cpu_oracle():
     model, real_set, synth_set, d_opt, g_opt, _ = bench.setup(16, 256, 64)
     model.use_graphs = True
     model.overlap_discriminators = True
-    for _ in range(3):
+    for _ in range(4):                                         # eager warm-ups, capture, first concurrent replay (+ prestage)
         model.training_iteration(real_set, synth_set, d_opt, g_opt)
     torch.cuda.synchronize()
     st = bench.dump_parity_state(model, real_set, synth_set, d_opt, g_opt)
