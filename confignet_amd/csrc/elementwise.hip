@@ -614,6 +614,12 @@ extern "C" int cn_act_bwd_bias(const void* gy, const void* y, void* gx, float* g
     return nc_reduce_launch(gy, y, gb, nullptr, n, s, c, flags & 16, slope, dt, stream, gx, act);
 }
 
+extern "C" int cn_nc_reduce_dact(const void* x1, const void* x2, float* s1, float* s2, void* dact_out, int n, int s, int c,
+                                 int flags, float slope, int act, int dt, void* stream) {
+    CN_CHECK_ARG(x1 && x2 && s1 && dact_out, "nc_reduce_dact: NULL");
+    return nc_reduce_launch(x1, x2, s1, s2, n, s, c, flags, slope, dt, stream, dact_out, act);
+}
+
 extern "C" int cn_nc_lin2(const void* x1, const float* a1, const void* x2, const float* a2, const float* bb,
                           const float* a3, const float* b3, void* y, int n, int s, int c, int cstride, int flags,
                           float slope, int dt, void* stream) {

@@ -139,22 +139,28 @@ __global__ void dual_coef_fwd_kernel(const float* __restrict__ T1, const float* 
                                      const float* __restrict__ mean, const float* __restrict__ qv,
                                      const float* __restrict__ sm, const float* __restrict__ ssd,
                                      const float* __restrict__ gamma, float* __restrict__ C1, float* __restrict__ C2,
-                                     float* __restrict__ C0, float* __restrict__ tstyle, int N, int C, float invS, float eps) {
+                                     float* __restrict__ C0, float* __restrict__ tstyle, int N, int C, float invS, float eps,
+                                     int n_style, int period) {
+    // rows [0, n_style): style branch (U*, tstyle indexed by the row); rows [n_style, N): instance-norm branch (T*, C* indexed
+    // by row - n_style); the primal statistics hold `period` samples and row r of either branch reads sample r % period
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N * C) return;
     const int n = i / C, c = i - n * C;
-    if (C1) {
-        const float mu = mean[i], q = qv[i], g = gamma[c];
+    if (n >= n_style) {
+        if (!C1) return;
+        const int r = n - n_style;
+        const int j = r * C + c, p = (r % period) * C + c;
+        const float mu = mean[p], q = qv[p], g = gamma[c];
         const float sigma = fmaxf(1.f / q - eps, 1e-20f);
-        const float tmu = T1[i] * invS;
-        const float P = T2[i] * invS - mu * tmu;
+        const float tmu = T1[j] * invS;
+        const float P = T2[j] * invS - mu * tmu;
         const float tq = -q * q * P / sigma;
-        C1[i] = g * q;
-        C2[i] = g * tq;
-        C0[i] = -g * q * tmu - g * tq * mu;
-    }
-    if (tstyle) {
-        const float m = sm[i], sd = ssd[i];
+        C1[j] = g * q;
+        C2[j] = g * tq;
+        C0[j] = -g * q * tmu - g * tq * mu;
+    } else if (tstyle) {
+        const int p = (n % period) * C + c;
+        const float m = sm[p], sd = ssd[p];
         const float tm = U1[i] * invS;
         tstyle[n * 2 * C + c] = tm;
         tstyle[n * 2 * C + C + c] = (U2[i] * invS - m * tm) / sd;
@@ -171,12 +177,18 @@ __global__ void dual_coef_bwd_kernel(const float* __restrict__ H1, const float* 
                                      const float* __restrict__ U1, const float* __restrict__ U2,
                                      const float* __restrict__ mean, const float* __restrict__ qv,
                                      const float* __restrict__ sm, const float* __restrict__ ssd,
-                                     const float* __restrict__ gamma, DualBwdOut o, int N, int C, float invS, float eps) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+                                     const float* __restrict__ gamma, DualBwdOut o, int N, int C, float invS, float eps,
+                                     int n_style, int period) {
+    // row layout as in dual_coef_fwd_kernel
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N * C) return;
     const int n = i / C, c = i - n * C;
-    if (H1) {
-        const float mu = mean[i], q = qv[i], g = gamma[c];
+    if (n >= n_style) {
+        if (!H1) return;
+        const int r = n - n_style;
+        i = r * C + c;
+        const int p = (r % period) * C + c;
+        const float mu = mean[p], q = qv[p], g = gamma[c];
         const float sigma = fmaxf(1.f / q - eps, 1e-20f);
         const float tmu = T1[i] * invS;
         const float P = T2[i] * invS - mu * tmu;
@@ -195,9 +207,9 @@ __global__ void dual_coef_bwd_kernel(const float* __restrict__ H1, const float* 
         o.ka[i] = ka;
         o.kc[i] = k0 - ka * mu;
         unsafeAtomicAdd(&o.ggamma[c], q * e - q * tmu * h1 + tq * h2);
-    }
-    if (u) {
-        const float m = sm[i], sd = ssd[i];
+    } else if (u) {
+        const int p = (n % period) * C + c;
+        const float m = sm[p], sd = ssd[p];
         const float um = u[n * 2 * C + c], usd = u[n * 2 * C + C + c];
         const float tm = U1[i] * invS;
         const float Q = U2[i] * invS - m * tm;
@@ -217,8 +229,11 @@ __global__ void dual_gx_kernel(const T* __restrict__ h, const T* __restrict__ ta
                                const T* __restrict__ x, const float* __restrict__ kh, const float* __restrict__ kt,
                                const float* __restrict__ ka, const float* __restrict__ kc, const float* __restrict__ et,
                                const float* __restrict__ ex, const float* __restrict__ e0, T* __restrict__ out,
-                               long total4, int S, int C, float slope) {
+                               long total4, int S, int C, float slope, int nrep) {
+    // total4 = N*S*C/4 elements of x / out; h, ta and their coefficients hold nrep*N samples (the heads of a batched tangent
+    // pass that share this primal activation): their contributions are summed here, in head order
     const int C4 = C / 4;
+    const long NC = (total4 / S / C4) * (long)C;         // N * C: coefficient rows per head
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
         const int cg = (int)(i % C4);
         const int n = (int)((i / C4) / S);
@@ -227,13 +242,16 @@ __global__ void dual_gx_kernel(const T* __restrict__ h, const T* __restrict__ ta
         const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
         float r[4] = {0.f, 0.f, 0.f, 0.f};
         if (kh) {
-            const float4 hv = ld4<T>(h + 4 * i);
-            const float4 tv = ld4<T>(ta + 4 * i);
-            const float hs[4] = {hv.x, hv.y, hv.z, hv.w}, ts[4] = {tv.x, tv.y, tv.z, tv.w};
+            for (int j = 0; j < nrep; ++j) {
+                const float4 hv = ld4<T>(h + 4 * (i + j * total4));
+                const float4 tv = ld4<T>(ta + 4 * (i + j * total4));
+                const float hs[4] = {hv.x, hv.y, hv.z, hv.w}, ts[4] = {tv.x, tv.y, tv.z, tv.w};
+                const long cj = ci + j * NC;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float mk = xs[e] > 0.f ? 1.f : slope;
-                r[e] = mk * (kh[ci + e] * hs[e] + kt[ci + e] * ts[e] + ka[ci + e] * xs[e] * mk + kc[ci + e]);
+                for (int e = 0; e < 4; ++e) {
+                    const float mk = xs[e] > 0.f ? 1.f : slope;
+                    r[e] += mk * (kh[cj + e] * hs[e] + kt[cj + e] * ts[e] + ka[cj + e] * xs[e] * mk + kc[cj + e]);
+                }
             }
         }
         if (et) {
@@ -250,12 +268,14 @@ __global__ void dual_gx_kernel(const T* __restrict__ h, const T* __restrict__ ta
 
 extern "C" int cn_dual_tail_coef_fwd(const float* T1, const float* T2, const float* U1, const float* U2, const float* mean,
                                      const float* q, const float* sm, const float* ssd, const float* gamma, float* C1,
-                                     float* C2, float* C0, float* tstyle, int n, int c, int S, float eps, void* stream) {
-    CN_CHECK_ARG(n > 0 && c > 0 && S > 0 && (C1 || tstyle), "dual_tail_coef_fwd: bad args");
+                                     float* C2, float* C0, float* tstyle, int n, int c, int S, float eps, int n_style, int period,
+                                     void* stream) {
+    CN_CHECK_ARG(n > 0 && c > 0 && S > 0 && (C1 || tstyle) && n_style >= 0 && n_style <= n && period > 0, "dual_tail_coef_fwd: bad args");
+    CN_CHECK_ARG((n_style == 0 || tstyle) && (n_style == n || C1), "dual_tail_coef_fwd: a row range without its output tensors");
     CN_CHECK_ARG(!C1 || (T1 && T2 && mean && q && gamma && C2 && C0), "dual_tail_coef_fwd: missing instance-norm tensors");
     CN_CHECK_ARG(!tstyle || (U1 && U2 && sm && ssd), "dual_tail_coef_fwd: missing style tensors");
     hipLaunchKernelGGL(dual_coef_fwd_kernel, dim3(cn_cdiv((long)n * c, 256)), dim3(256), 0, (hipStream_t)stream, T1, T2, U1, U2,
-                       mean, q, sm, ssd, gamma, C1, C2, C0, tstyle, n, c, 1.f / (float)S, eps);
+                       mean, q, sm, ssd, gamma, C1, C2, C0, tstyle, n, c, 1.f / (float)S, eps, n_style, period);
     CN_LAUNCH_CHECK();
     return CN_OK;
 }
@@ -263,8 +283,9 @@ extern "C" int cn_dual_tail_coef_fwd(const float* T1, const float* T2, const flo
 extern "C" int cn_dual_tail_coef_bwd(const float* H1, const float* H2p, const float* E, const float* u, const float* T1,
                                      const float* T2, const float* U1, const float* U2, const float* mean, const float* q,
                                      const float* sm, const float* ssd, const float* gamma, float* const* out13, int n, int c,
-                                     int S, float eps, void* stream) {
-    CN_CHECK_ARG(n > 0 && c > 0 && S > 0 && out13 && (H1 || u), "dual_tail_coef_bwd: bad args");
+                                     int S, float eps, int n_style, int period, void* stream) {
+    CN_CHECK_ARG(n > 0 && c > 0 && S > 0 && out13 && (H1 || u) && n_style >= 0 && n_style <= n && period > 0, "dual_tail_coef_bwd: bad args");
+    CN_CHECK_ARG((n_style == 0 || u) && (n_style == n || H1), "dual_tail_coef_bwd: a row range without its input tensors");
     DualBwdOut o;
     o.K1 = out13[0]; o.K2 = out13[1]; o.K0 = out13[2]; o.D2 = out13[3]; o.D0 = out13[4];
     o.kh = out13[5]; o.kt = out13[6]; o.ka = out13[7]; o.kc = out13[8];
@@ -277,22 +298,22 @@ extern "C" int cn_dual_tail_coef_bwd(const float* H1, const float* H2p, const fl
         if (int ez__ = cn_zero_async(o.ggamma, sizeof(float) * c, s)) return ez__;
     }
     hipLaunchKernelGGL(dual_coef_bwd_kernel, dim3(cn_cdiv((long)n * c, 256)), dim3(256), 0, s, H1, H2p, E, u, T1, T2, U1, U2, mean,
-                       q, sm, ssd, gamma, o, n, c, 1.f / (float)S, eps);
+                       q, sm, ssd, gamma, o, n, c, 1.f / (float)S, eps, n_style, period);
     CN_LAUNCH_CHECK();
     return CN_OK;
 }
 
 extern "C" int cn_dual_tail_gx(const void* h, const void* ta, const void* tx, const void* x, const float* kh,
                                const float* kt, const float* ka, const float* kc, const float* et, const float* ex,
-                               const float* e0, void* out, int n, int s, int c, float slope, int dt, void* stream) {
-    CN_CHECK_ARG(x && out && n > 0 && s > 0 && c > 0 && c % 4 == 0 && (kh || et) && (dt == CN_F32 || dt == CN_BF16), "dual_tail_gx: bad args");
+                               const float* e0, void* out, int n, int s, int c, float slope, int nrep, int dt, void* stream) {
+    CN_CHECK_ARG(x && out && n > 0 && s > 0 && c > 0 && c % 4 == 0 && (kh || et) && nrep >= 1 && (dt == CN_F32 || dt == CN_BF16), "dual_tail_gx: bad args");
     CN_CHECK_ARG(!kh || (h && ta && kt && ka && kc), "dual_tail_gx: missing instance-norm tensors");
     CN_CHECK_ARG(!et || (tx && ex && e0), "dual_tail_gx: missing style tensors");
     const long total4 = (long)n * s * (c / 4);
     long blocks = (total4 + 255) / 256;
     if (blocks > 8192) blocks = 8192;
     CN_DISPATCH_DT(dt, hipLaunchKernelGGL((dual_gx_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const T*)h,
-                                          (const T*)ta, (const T*)tx, (const T*)x, kh, kt, ka, kc, et, ex, e0, (T*)out, total4, s, c, slope));
+                                          (const T*)ta, (const T*)tx, (const T*)x, kh, kt, ka, kc, et, ex, e0, (T*)out, total4, s, c, slope, nrep));
     CN_LAUNCH_CHECK();
     return CN_OK;
 }

@@ -60,7 +60,7 @@ class HologanDiscriminator(Net):
         out["discr_final"] = F.linear(x, w[-2], w[-1])
         return out
 
-    def input_gradients(self, intermediates):
+    def input_gradients(self, intermediates, stacked=False):
         """[d sum_n out_i / d image for every head i] -- what losses.py:75-82 asks the inner tape for, head by head
         (`tape.gradient(out_i, real_imgs)`) -- computed for ALL heads in ONE backward sweep without a tape: the cotangents of
         the heads still "above" a block are stacked along the batch axis (head b joins at block b through its style
@@ -97,7 +97,31 @@ class HologanDiscriminator(Net):
                 in_shape = (out.shape[0],) + tuple(it["in_shape"][1:])
                 G = ops.conv_dgrad(out, k.detach(), DISCR_CONV.geom(in_shape, c))
             g_img = ops.conv_dgrad(G, w[0].detach(), C1.geom(tuple(G.shape), 3))     # from-RGB 1x1 convolution
+        if stacked:
+            return g_img                           # (6 N, H, W, 3), head-major: style heads 0..n-1, then the final head
         return [g_img[i * n:(i + 1) * n] for i in range(nr + 1)]
+
+    def tangent_all(self, v, intermediates):
+        """The JVPs of ALL heads in one tangent pass (round 3): v = the stacked input gradients (input_gradients(..., stacked=True):
+        (heads * N, H, W, 3), head-major), each head's tangent pushed in ITS OWN direction.  At block k the stack holds heads
+        k..n: head k leaves through the block's style statistics, the others go on -- one convolution per block on the stack
+        (M grows up to 6x: the 1024..4096-row layers of the deep blocks fill the chip without split-K) and, in the backward pass,
+        one data gradient and one filter gradient per block instead of one per head.  Returns [jvp_0 .. jvp_n], each (N, 1);
+        same arithmetic as `tangent` head by head (kept as the cross-check)."""
+        from .building_blocks import DISCR_CONV, KERAS_LRELU
+        w, nr = self.weights, self.num_resample
+        heads = 2 + 4 * nr
+        n = intermediates[0]["x"].shape[0]
+        assert v.shape[0] == (nr + 1) * n
+        out = []
+        t = F.conv(v, w[0], None, C1)
+        for k in range(nr):
+            tx = F.conv(t, w[2 + 4 * k], None, DISCR_CONV)
+            it = intermediates[k]
+            t, tstyle = F.DualTailBatchedFn.apply(tx, it["x"], w[4 + 4 * k], it["mean"], it["q"], it["smean"], it["ssd"], KERAS_LRELU)
+            out.append(F.linear(tstyle, w[heads + 2 * k], None))
+        out.append(F.linear(t.reshape(t.shape[0], -1), w[-2], None))
+        return out
 
     def tangent(self, v, intermediates, head):
         """JVP of output `head` (0..n-1 style heads, n = final head) w.r.t. the input image in direction v,

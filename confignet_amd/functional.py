@@ -509,6 +509,55 @@ class DualTailFn(Function):
         return g_tx, g_x, g_gamma, None, None, None, None, None, None, None
 
 
+class DualTailBatchedFn(Function):
+    """DualTailFn for the tangents of SEVERAL heads at once (round 3): tx holds h*N samples, head-major -- the first N are the
+    head that leaves the trunk here through this block's style statistics, the other (h-1)*N go on through LeakyReLU + instance
+    norm -- against ONE copy of the primal pre-activation x (N samples, read through a sample period).  Returns
+    (ty ((h-1)*N samples), tstyle (N, 2C)).  Same arithmetic as h calls of DualTailFn; the heads' second-order terms w.r.t. x
+    are summed inside cn_dual_tail_gx.  With it the tangent pass of the R1 penalty (losses.py:75-82) is ONE convolution per
+    block on the stacked tangents (and one data / filter gradient per block in its backward) instead of one per head."""
+
+    @staticmethod
+    def forward(ctx, tx, x, gamma, mean, q, smean, ssd, slope):
+        ctx.set_materialize_grads(False)
+        tx, x = _cg(tx), _cg(x)
+        n = x.shape[0]
+        assert tx.shape[0] % n == 0 and tx.shape[0] >= 2 * n and tx.shape[1:] == x.shape[1:]
+        sp = _spatial(x)
+        tx_s, tx_r = tx[:n], tx[n:]
+        ta, T1, T2 = ops.nc_reduce_dact(tx_r, x, ACT_LRELU, slope, x2_period=n, flags=2)     # ta = lrelu'(x) tx; sum ta, sum ta*lrelu(x)
+        U = ops.nc_reduce(tx_s, x)                                                            # sum tx, sum tx*x
+        C1, C2, C0, tstyle = ops.dual_tail_coef_fwd((T1, T2), U, mean, q, smean, ssd, gamma, sp)
+        ty = ops.nc_lin2(tuple(tx_r.shape), ta, C1, x, C2, C0, flags=2, slope=slope, x2_period=n)
+        ctx.save_for_backward(tx, x, gamma, mean, q, smean, ssd, ta, T1, T2, U[0], U[1])
+        ctx.slope = slope
+        return ty, tstyle
+
+    @staticmethod
+    def backward(ctx, h, u):
+        if torch.is_grad_enabled():
+            raise RuntimeError("DualTailBatchedFn is first-order only")
+        tx, x, gamma, mean, q, smean, ssd, ta, T1, T2, U1, U2 = ctx.saved_tensors
+        slope = ctx.slope
+        n = x.shape[0]
+        sp = _spatial(x)
+        if h is None and u is None:
+            return torch.zeros_like(tx), torch.zeros_like(x), torch.zeros_like(gamma), None, None, None, None, None
+        if h is None:
+            h = torch.zeros_like(ta)
+        if u is None:
+            u = torch.zeros((n, 2 * x.shape[-1]), device=x.device, dtype=torch.float32)
+        h = _cg(h)
+        H = ops.nc_reduce(h, x, flags=2, slope=slope, x2_period=n)          # sum h, sum h*lrelu(x)
+        E = ops.nc_reduce(h, ta, want_sum=False)[1]                          # sum h*ta
+        co = ops.dual_tail_coef_bwd(H, E, _cg(u), (T1, T2), (U1, U2), mean, q, smean, ssd, gamma, sp)
+        g_tx = torch.empty_like(tx)
+        ops.nc_lin2(tuple(ta.shape), h, co["K1"], x, co["K2"], co["K0"], flags=2 | 4, slope=slope, x2_period=n, out=g_tx[n:])
+        ops.nc_lin2(tuple(x.shape), x, co["D2"], b=co["D0"], out=g_tx[:n])
+        g_x = ops.dual_tail_gx(h, ta, tx, x, co, slope)
+        return g_tx, g_x, co["ggamma"], None, None, None, None, None
+
+
 def instance_norm(x, gamma, beta, eps=1e-3):
     """InstanceNormalization (instance_normalization.py:108-131): (x-mean)/(std+eps)*gamma+beta."""
     inv = 1.0 / _spatial(x)

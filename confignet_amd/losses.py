@@ -7,6 +7,30 @@ import torch
 from . import functional as F
 
 BATCHED_R1 = os.environ.get("CN_NO_BATCHED_R1") is None
+BATCHED_TANGENT = os.environ.get("CN_NO_BATCHED_TANGENT") is None     # the six heads' tangent passes as one stacked pass
+
+
+def _r1_penalties(discriminator, out_real, real_imgs, inter):
+    """{gp_loss_i} of losses.py:75-82 for every head, without a second-order tape (see compute_discriminator_loss)."""
+    from . import ops
+    if BATCHED_R1 and BATCHED_TANGENT and hasattr(discriminator, "tangent_all"):
+        g_img = discriminator.input_gradients(inter, stacked=True).detach()      # all heads in one tape-free backward sweep
+        jvps = discriminator.tangent_all(g_img, inter)                           # ... and one stacked tangent pass
+        n = real_imgs.shape[0]
+        sq = ops.row_sumsq(g_img.reshape(g_img.shape[0], -1))                    # |g_i,n|^2 (constant of the tape)
+        return {"gp_loss_" + str(i): 10 * 0.5 * (2.0 * jvp.reshape(-1) - sq[i * n:(i + 1) * n]).mean() for i, jvp in enumerate(jvps)}
+    if BATCHED_R1 and hasattr(discriminator, "input_gradients"):
+        gs = discriminator.input_gradients(inter)              # all six heads in one tape-free backward sweep
+    else:
+        with F.input_grads_only():
+            gs = [torch.autograd.grad(o, real_imgs, grad_outputs=torch.ones_like(o), retain_graph=True)[0]
+                  for o in out_real.values()]
+    gp = {}
+    for i, g in enumerate(gs):
+        g = g.detach()
+        jvp = discriminator.tangent(g, inter, i).reshape(-1)          # == |g_n|^2, carries d/dtheta
+        gp["gp_loss_" + str(i)] = 10 * 0.5 * (2.0 * jvp - F.row_sumsq(g)).mean()
+    return gp
 
 
 def GAN_G_loss(scores):
@@ -67,16 +91,7 @@ def compute_discriminator_loss(discriminator, real_imgs, fake_imgs, second_order
         losses["GAN_loss_real_" + str(i)] = GAN_D_loss(1.0, o)
     for i, o in enumerate(out_fake.values()):
         losses["GAN_loss_fake_" + str(i)] = GAN_D_loss(0.0, o)
-    if BATCHED_R1 and hasattr(discriminator, "input_gradients"):
-        gs = discriminator.input_gradients(inter)              # all six heads in one tape-free backward sweep
-    else:
-        with F.input_grads_only():
-            gs = [torch.autograd.grad(o, real_imgs, grad_outputs=torch.ones_like(o), retain_graph=True)[0]
-                  for o in out_real.values()]
-    for i, g in enumerate(gs):
-        g = g.detach()
-        jvp = discriminator.tangent(g, inter, i).reshape(-1)          # == |g_n|^2, carries d/dtheta
-        losses["gp_loss_" + str(i)] = 10 * 0.5 * (2.0 * jvp - F.row_sumsq(g)).mean()
+    losses.update(_r1_penalties(discriminator, out_real, real_imgs, inter))
     losses["loss_sum"] = sum(losses.values())
     return losses
 
@@ -86,20 +101,10 @@ def discriminator_loss_real(discriminator, real_imgs):
     real_imgs = real_imgs.detach().requires_grad_(True)
     inter = []
     out_real = discriminator(real_imgs, intermediates=inter)
-    real, gp = {}, {}
+    real = {}
     for i, o in enumerate(out_real.values()):
         real["GAN_loss_real_" + str(i)] = GAN_D_loss(1.0, o)
-    if BATCHED_R1 and hasattr(discriminator, "input_gradients"):
-        gs = discriminator.input_gradients(inter)
-    else:
-        with F.input_grads_only():
-            gs = [torch.autograd.grad(o, real_imgs, grad_outputs=torch.ones_like(o), retain_graph=True)[0]
-                  for o in out_real.values()]
-    for i, g in enumerate(gs):
-        g = g.detach()
-        jvp = discriminator.tangent(g, inter, i).reshape(-1)
-        gp["gp_loss_" + str(i)] = 10 * 0.5 * (2.0 * jvp - F.row_sumsq(g)).mean()
-    return real, gp
+    return real, _r1_penalties(discriminator, out_real, real_imgs, inter)
 
 
 def discriminator_loss_fake(discriminator, fake_imgs):

@@ -552,55 +552,85 @@ def norm_coef_bwd(mode, t1, t2, mean, r, p1, spatial, eps):
 
 
 def dual_tail_coef_fwd(T, U, mean, q, sm, ssd, gamma, spatial, eps=1e-3):
-    """T = (T1, T2) or None (no ty wanted); U = (U1, U2) or None (no tstyle wanted)."""
+    """T = (T1, T2) or None (no ty wanted); U = (U1, U2) or None (no tstyle wanted).  One head at a time: the rows of T / U
+    are the samples of the primal statistics.  Batched (both given): U holds the N samples of the head that leaves through the
+    style statistics, T the (heads - 1) * N samples that go on, against N samples of primal statistics."""
     ref = mean if mean is not None else sm
-    n, c = ref.shape
+    period, c = ref.shape
     mk = lambda *sh: torch.empty(sh, device=ref.device, dtype=torch.float32)
     C1 = C2 = C0 = ts = None
+    n_inst = n_style = 0
     if T is not None:
-        C1, C2, C0 = mk(n, c), mk(n, c), mk(n, c)
+        n_inst = T[0].shape[0]
+        C1, C2, C0 = mk(n_inst, c), mk(n_inst, c), mk(n_inst, c)
     if U is not None:
-        ts = mk(n, 2 * c)
+        n_style = U[0].shape[0]
+        ts = mk(n_style, 2 * c)
     T1, T2 = T if T is not None else (None, None)
     U1, U2 = U if U is not None else (None, None)
     check(lib.cn_dual_tail_coef_fwd(_ptr(T1), _ptr(T2), _ptr(U1), _ptr(U2), _ptr(mean), _ptr(q), _ptr(sm), _ptr(ssd),
-                                    _ptr(gamma), _ptr(C1), _ptr(C2), _ptr(C0), _ptr(ts), n, c, spatial, eps, _stream()),
+                                    _ptr(gamma), _ptr(C1), _ptr(C2), _ptr(C0), _ptr(ts), n_inst + n_style, c, spatial, eps,
+                                    n_style, period, _stream()),
           "cn_dual_tail_coef_fwd")
     return C1, C2, C0, ts
 
 
 def dual_tail_coef_bwd(H, E, u, T, U, mean, q, sm, ssd, gamma, spatial, eps=1e-3):
-    """Returns dict of coefficient tensors (see include/confignet_hip.h)."""
+    """Returns dict of coefficient tensors (see include/confignet_hip.h).  Row counts as in dual_tail_coef_fwd: the
+    instance-norm group follows H (sum h ...), the style group follows u."""
     ref = mean if mean is not None else sm
-    n, c = ref.shape
+    period, c = ref.shape
     names = ["K1", "K2", "K0", "D2", "D0", "kh", "kt", "ka", "kc", "et", "ex", "e0", "ggamma"]
     out = {k: None for k in names}
     mk = lambda *sh: torch.empty(sh, device=ref.device, dtype=torch.float32)
+    n_inst = n_style = 0
     if H is not None:
+        n_inst = H[0].shape[0]
         for k in ("K1", "K2", "K0", "kh", "kt", "ka", "kc"):
-            out[k] = mk(n, c)
+            out[k] = mk(n_inst, c)
         out["ggamma"] = mk(c)
     if u is not None:
+        n_style = u.shape[0]
         for k in ("D2", "D0", "et", "ex", "e0"):
-            out[k] = mk(n, c)
+            out[k] = mk(n_style, c)
     arr = (ctypes.c_void_p * 13)(*[(out[k].data_ptr() if out[k] is not None else None) for k in names])
     H1, H2p = H if H is not None else (None, None)
     T1, T2 = T if T is not None else (None, None)
     U1, U2 = U if U is not None else (None, None)
     check(lib.cn_dual_tail_coef_bwd(_ptr(H1), _ptr(H2p), _ptr(E), _ptr(u), _ptr(T1), _ptr(T2), _ptr(U1), _ptr(U2),
-                                    _ptr(mean), _ptr(q), _ptr(sm), _ptr(ssd), _ptr(gamma), arr, n, c, spatial, eps, _stream()),
+                                    _ptr(mean), _ptr(q), _ptr(sm), _ptr(ssd), _ptr(gamma), arr, n_inst + n_style, c, spatial, eps,
+                                    n_style, period, _stream()),
           "cn_dual_tail_coef_bwd")
     return out
 
 
 def dual_tail_gx(h, ta, tx, x, co, slope):
+    """h / ta may hold a multiple of x's samples (batched tangent pass: the heads that share this activation, summed here)."""
     h, ta, tx, x = _unify(h, ta, tx, x)
     n, s, c = _nsc(x)
+    nrep = 1 if h is None else h.shape[0] // n
+    assert h is None or (h.shape[0] == nrep * n and ta.shape[0] == nrep * n)
     out = torch.empty_like(x)
     check(lib.cn_dual_tail_gx(_ptr(h), _ptr(ta), _ptr(tx), _ptr(x), _ptr(co["kh"]), _ptr(co["kt"]), _ptr(co["ka"]),
                               _ptr(co["kc"]), _ptr(co["et"]), _ptr(co["ex"]), _ptr(co["e0"]), _ptr(out), n, s, c, slope,
-                              _dt(x), _stream()), "cn_dual_tail_gx")
+                              nrep, _dt(x), _stream()), "cn_dual_tail_gx")
     return out
+
+
+def nc_reduce_dact(x1, x2, act, slope, x2_period=0, flags=0, want_dot=True):
+    """(a, sum_s a, sum_s a * f2(x2)) with a = x1 * act'(x2): cn_nc_reduce_dact (one pass instead of act_bwd + nc_reduce)."""
+    x1, x2 = _unify(x1, x2)
+    n, s, c = _nsc(x1)
+    a = torch.empty_like(x1)
+    flags |= x2_period << 8
+    s12 = zero_pool_alloc((2, n, c), x1.device)
+    if s12 is not None:
+        flags |= 16
+    else:
+        s12 = torch.empty((2, n, c), device=x1.device, dtype=torch.float32)
+    check(lib.cn_nc_reduce_dact(_ptr(x1), _ptr(x2), _ptr(s12[0]), _ptr(s12[1]) if want_dot else None, _ptr(a), n, s, c, flags, slope,
+                                act, _dt(x1), _stream()), "cn_nc_reduce_dact")
+    return a, s12[0], (s12[1] if want_dot else None)
 
 
 def act_fwd(x, act, slope=0.0):

@@ -148,6 +148,11 @@ int cn_gemm(int trans_a, int trans_b, int m, int n, int k, const float* a, int l
  *   Outputs are overwritten. */
 int cn_nc_reduce(const void* x1, const void* x2, float* sum1, float* sum2, int n, int s, int c,
                  int flags, float slope, int dt, void* stream);
+/* a = x1 * act'(f2(x2)) (the activation derivative taken from the sign / value of x2 as in cn_act_bwd), written to dact_out,
+ * with sum1[n,c] = sum_s a and (if sum2 != NULL) sum2[n,c] = sum_s a*f2(x2) in the same pass: the tangent of LeakyReLU and its
+ * two statistics (cn_dual_tail_*: ta, T1, T2) without a separate cn_act_bwd pass.  flags as cn_nc_reduce (bit1, bit4, period). */
+int cn_nc_reduce_dact(const void* x1, const void* x2, float* sum1, float* sum2, void* dact_out, int n, int s, int c,
+                      int flags, float slope, int act, int dt, void* stream);
 /* y = A1*f1(x1) + A2*f2(x2) + B, coefficient tensors indexed [n*cstride + c] (cstride = c, or 0 for
  * per-channel coefficients).  flags: bit0/bit1 as above, bit2: multiply the result by lrelu'(x2),
  * bit3: relu on the result, bits 8..: x2 sample period as in cn_nc_reduce.  x1, x2 and B are each optional (NULL); a NULL coefficient of a present
@@ -179,17 +184,25 @@ int cn_norm_coef_bwd(int mode, const float* t1, const float* t2, const float* sa
  * U1 = sum tx, U2 = sum tx*x; mean/q and sm/ssd are the primal instance-norm / style statistics.
  * fwd: ty = C1*ta + C2*a + C0 and tstyle (N,2C).  bwd (H1 = sum h, H2p = sum h*a, E = sum h*ta, u = d tstyle):
  *   out13 = {K1,K2,K0,D2,D0, kh,kt,ka,kc, et,ex,e0, dgamma}: g_tx = lrelu'(x)(K1 h + K2 a + K0) + D2 x + D0,
- *   g_x = lrelu'(x)(kh h + kt ta + ka a + kc) + et tx + ex x + e0 (cn_dual_tail_gx).  Either half optional. */
+ *   g_x = lrelu'(x)(kh h + kt ta + ka a + kc) + et tx + ex x + e0 (cn_dual_tail_gx).  Either half optional.
+ * Batched tangent pass (the six heads' tangents stacked along the sample axis against ONE copy of the primal activations,
+ * round 3): the coefficient kernels take `n` stacked samples of which rows [0, n_style) are the head that LEAVES through this
+ * block's style statistics (U1/U2/u/tstyle/D2/D0/et/ex/e0: n_style rows) and rows [n_style, n) the heads that go on through
+ * LeakyReLU + instance norm (T1/T2/H1/H2p/E and C1/C2/C0/K1/K2/K0/kh/kt/ka/kc: n - n_style rows, indexed from 0); the primal
+ * statistics mean/q/sm/ssd hold `period` samples and a row reads sample (row % period).  One head at a time: n_style = 0 or n,
+ * period = n.  cn_dual_tail_gx: x / out / tx and et/ex/e0 hold n samples, h / ta and kh/kt/ka/kc hold nrep*n (head-major);
+ * the heads' second-order terms are summed into out. */
 int cn_dual_tail_coef_fwd(const float* T1, const float* T2, const float* U1, const float* U2, const float* mean,
                           const float* q, const float* sm, const float* ssd, const float* gamma, float* C1,
-                          float* C2, float* C0, float* tstyle, int n, int c, int S, float eps, void* stream);
+                          float* C2, float* C0, float* tstyle, int n, int c, int S, float eps, int n_style, int period,
+                          void* stream);
 int cn_dual_tail_coef_bwd(const float* H1, const float* H2p, const float* E, const float* u, const float* T1,
                           const float* T2, const float* U1, const float* U2, const float* mean, const float* q,
                           const float* sm, const float* ssd, const float* gamma, float* const* out13, int n, int c,
-                          int S, float eps, void* stream);
+                          int S, float eps, int n_style, int period, void* stream);
 int cn_dual_tail_gx(const void* h, const void* ta, const void* tx, const void* x, const float* kh,
                     const float* kt, const float* ka, const float* kc, const float* et, const float* ex,
-                    const float* e0, void* out, int n, int s, int c, float slope, int dt, void* stream);
+                    const float* e0, void* out, int n, int s, int c, float slope, int nrep, int dt, void* stream);
 
 /* ---- elementwise / small ops ------------------------------------------------------------------*/
 int cn_act_fwd(const void* x, void* y, size_t numel, int act, float slope, int dt, void* stream);

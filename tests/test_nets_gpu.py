@@ -200,6 +200,21 @@ def test_discriminator_loss_with_r1_double_backward():
     for a, p in zip(g_jvp, d.weights):
         rel = float((a - p.grad).norm() / (p.grad.norm() + 1e-30))
         assert rel < 2e-2, "JVP-R1 vs tape-R1 gradient: rel-L2 %.3e" % rel
+    # the stacked tangent pass (all heads at once, HologanDiscriminator.tangent_all: the default above) against the six
+    # head-by-head passes: the same arithmetic up to summation order
+    from confignet_amd import losses as L
+    d.zero_grad()
+    prev, L.BATCHED_TANGENT = L.BATCHED_TANGENT, False
+    try:
+        losses_h = compute_discriminator_loss(d, d.to_device(real), d.to_device(fake))
+    finally:
+        L.BATCHED_TANGENT = prev
+    torch.autograd.backward(losses_h["loss_sum"], inputs=d.trainable_weights)
+    for k in losses:
+        close(losses_h[k], losses[k].detach().cpu().double(), tol=1e-5, what="head-by-head " + k)
+    for i, (a, p) in enumerate(zip(g_jvp, d.weights)):
+        rel = float((a - p.grad).norm() / (p.grad.norm() + 1e-30))
+        assert rel < 1e-4, "stacked vs head-by-head tangent pass, weight %d: rel-L2 %.3e" % (i, rel)
 
 
 def test_latent_regressor_and_latent_discriminator():
