@@ -614,6 +614,24 @@ extern "C" int cn_act_bwd_bias(const void* gy, const void* y, void* gx, float* g
     return nc_reduce_launch(gy, y, gb, nullptr, n, s, c, flags & 16, slope, dt, stream, gx, act);
 }
 
+namespace {
+// dst[c] (+)= sum_r src[r][c]: the partial rows of a per-channel reduction, added in row order (no atomics)
+__global__ void sum_rows_into_kernel(const float* __restrict__ src, float* __restrict__ dst, int rows, int cols, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= cols) return;
+    float t = 0.f;
+    for (int r = 0; r < rows; ++r) t += src[(long)r * cols + c];
+    dst[c] = accumulate ? dst[c] + t : t;
+}
+}  // namespace
+
+extern "C" int cn_sum_rows_into(const float* src, float* dst, int rows, int cols, int accumulate, void* stream) {
+    CN_CHECK_ARG(src && dst && rows > 0 && cols > 0, "sum_rows_into: bad args");
+    hipLaunchKernelGGL(sum_rows_into_kernel, dim3(cn_cdiv(cols, 256)), dim3(256), 0, (hipStream_t)stream, src, dst, rows, cols, accumulate);
+    CN_LAUNCH_CHECK();
+    return CN_OK;
+}
+
 extern "C" int cn_nc_reduce_dact(const void* x1, const void* x2, float* s1, float* s2, void* dact_out, int n, int s, int c,
                                  int flags, float slope, int act, int dt, void* stream) {
     CN_CHECK_ARG(x1 && x2 && s1 && dact_out, "nc_reduce_dact: NULL");

@@ -135,12 +135,12 @@ __global__ void zero_rows_kernel(float* C, int M, int N, int ldc) {
 
 }  // namespace
 
-extern "C" int cn_gemm(int ta, int tb, int m, int n, int k, const float* a, int lda, const float* b, int ldb, float* c,
-                       int ldc, const float* bias, int act, float slope, void* stream) {
+static int gemm_launch(int ta, int tb, int m, int n, int k, const float* a, int lda, const float* b, int ldb, float* c,
+                       int ldc, const float* bias, int act, float slope, int accumulate, void* stream) {
     CN_CHECK_ARG(m > 0 && n > 0 && k > 0 && a && b && c, "gemm: bad args m=%d n=%d k=%d", m, n, k);
     CN_CHECK_ARG(lda >= (ta ? m : k) && ldb >= (tb ? k : n) && ldc >= n, "gemm: leading dimension too small");
     hipStream_t s = (hipStream_t)stream;
-    if (!ta && !tb && n <= 4 && m <= 256 && k >= 128) {
+    if (!accumulate && !ta && !tb && n <= 4 && m <= 256 && k >= 128) {
         int slices = 1;
         if (act == CN_ACT_NONE && k >= 8192) slices = k / 4096;
         const int kps = (k + slices - 1) / slices;
@@ -163,12 +163,25 @@ extern "C" int cn_gemm(int ta, int tb, int m, int n, int k, const float* a, int 
     int kps = (k + splitk - 1) / splitk;
     kps = (kps + BK - 1) / BK * BK;
     splitk = (k + kps - 1) / kps;
-    if (splitk > 1) {
+    if (splitk > 1 && !accumulate) {
         hipLaunchKernelGGL(zero_rows_kernel, dim3(cn_cdiv((long)m * n, 256)), dim3(256), 0, s, c, m, n, ldc);
         CN_LAUNCH_CHECK();
     }
     dim3 grid(cn_cdiv(m, 64), cn_cdiv(n, 64), splitk);
-    hipLaunchKernelGGL(gemm_kernel, grid, dim3(256), 0, s, ta, tb, m, n, k, a, lda, b, ldb, c, ldc, bias, act, slope, kps, splitk);
+    // (the kernel adds with atomics whenever its last argument is > 1: split-K, or accumulation into the caller's C)
+    hipLaunchKernelGGL(gemm_kernel, grid, dim3(256), 0, s, ta, tb, m, n, k, a, lda, b, ldb, c, ldc, bias, act, slope, kps,
+                       accumulate ? 2 : splitk);
     CN_LAUNCH_CHECK();
     return CN_OK;
+}
+
+extern "C" int cn_gemm(int ta, int tb, int m, int n, int k, const float* a, int lda, const float* b, int ldb, float* c,
+                       int ldc, const float* bias, int act, float slope, void* stream) {
+    return gemm_launch(ta, tb, m, n, k, a, lda, b, ldb, c, ldc, bias, act, slope, 0, stream);
+}
+
+// C += op(A) op(B): the weight gradient of a Dense layer added straight into its slot of the network's gradient arena
+extern "C" int cn_gemm_acc(int ta, int tb, int m, int n, int k, const float* a, int lda, const float* b, int ldb, float* c,
+                           int ldc, void* stream) {
+    return gemm_launch(ta, tb, m, n, k, a, lda, b, ldb, c, ldc, nullptr, CN_ACT_NONE, 0.f, 1, stream);
 }

@@ -92,6 +92,31 @@ __global__ void zero_kernel(float* __restrict__ p, size_t n) {
 }
 }  // namespace
 
+namespace {
+__global__ void zero4_kernel(float4* __restrict__ p, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x)
+        p[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+}  // namespace
+
+// Clears a buffer (bytes % 4 == 0) with a kernel: a whole gradient arena at the start of a backward pass.
+extern "C" int cn_zero(void* p, size_t bytes, void* stream) {
+    if (!bytes) return CN_OK;
+    CN_CHECK_ARG(p && bytes % 4 == 0, "cn_zero: bad buffer");
+    hipStream_t s = (hipStream_t)stream;
+    if (((uintptr_t)p & 15) == 0 && bytes >= 65536) {
+        const size_t n4 = bytes / 16;
+        size_t blocks = (n4 + 255) / 256;
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(zero4_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (float4*)p, n4);
+        CN_LAUNCH_CHECK();
+        p = (char*)p + n4 * 16;
+        bytes -= n4 * 16;
+        if (!bytes) return CN_OK;
+    }
+    return cn_zero_async(p, bytes, s);
+}
+
 int cn_zero_async(void* p, size_t bytes, hipStream_t s) {
     if (!bytes) return CN_OK;
     CN_CHECK_ARG(p && bytes % 4 == 0, "cn_zero_async: bad buffer");

@@ -54,6 +54,7 @@ class ConvFn(Function):
             y = ops.conv_fwd(x, w, bias, g, act, slope)
         ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
         ctx.g, ctx.act, ctx.slope, ctx.has_bias = g, act, slope, bias is not None
+        ctx.bias_ref = bias if (bias is not None and bias.requires_grad) else None     # (only its identity: gradient-sink lookup)
         return y
 
     @staticmethod
@@ -61,36 +62,47 @@ class ConvFn(Function):
         x, w, y = ctx.saved_tensors
         gy = _cg(gy)
         gb_fused = None
+        first_order = not torch.is_grad_enabled()
+        want_w = ctx.needs_input_grad[1] and not _INPUT_GRADS_ONLY
+        want_b = ctx.has_bias and ctx.needs_input_grad[2] and not _INPUT_GRADS_ONLY
+        # inside nn.backward_into_arenas: filter / bias gradients are added straight into their gradient-arena slots by the
+        # kernels, on the sink's side stream (ops.grad_sink); autograd then sees None for them
+        w_slot = ops.sink_for(w) if (first_order and want_w) else None
+        b_slot = ops.sink_for(ctx.bias_ref) if (first_order and want_b and ctx.bias_ref is not None) else None
         if ctx.act != ACT_NONE:
-            if torch.is_grad_enabled():
+            if not first_order:
                 raise RuntimeError("double backward through a fused-activation conv is not supported; "
                                    "use conv(..., act=ACT_NONE) + lrelu()")
-            if ctx.has_bias and ctx.needs_input_grad[2] and not _INPUT_GRADS_ONLY:
-                gy, gb_fused = ops.act_bwd_bias(gy, y, ctx.act, ctx.slope)      # one pass: activation gradient + its channel sums
+            if want_b:
+                gy, gb_fused = ops.act_bwd_bias(gy, y, ctx.act, ctx.slope, sink=b_slot)   # one pass: activation gradient + its channel sums
             else:
                 gy = ops.act_bwd(gy, y, ctx.act, ctx.slope)
+        elif want_b and b_slot is not None:
+            ops.bias_grad(gy.detach(), sink=b_slot)
         gx = gw = gb = None
-        if ops.upfold_ok(ctx.g) and not torch.is_grad_enabled():
+        if want_b and b_slot is None:
+            gb = gb_fused if gb_fused is not None else ops.bias_grad(gy.detach())
+        if ops.upfold_ok(ctx.g) and first_order:
             # first-order backward of the collapsed form: data gradient straight at the stored extent (no upsampled gradient,
             # no sum-pool pass), filter gradient of the class filters scattered back to the k taps
             _, wd, _, g2 = ops.upfold_prepare(w, ctx.g)
             if ctx.needs_input_grad[0]:
                 gx = ops.conv_fwd(gy, wd, None, g2)
                 ops.prof_note_saved(ops.upfold_saved_flops(ctx.g))
-            if not _INPUT_GRADS_ONLY:
-                if ctx.needs_input_grad[1]:
+            if want_w:
+                if w_slot is not None:
+                    ops.sink_upfold_wgrad(gy, x, g2, tuple(wd.shape), ctx.g, tuple(w.shape), w_slot)
+                else:
                     gw = ops.upfold_wgrad(ops.conv_wgrad(gy, x, g2, tuple(wd.shape)), ctx.g, tuple(w.shape))
-                    ops.prof_note_saved(ops.upfold_saved_flops(ctx.g))
-                if ctx.has_bias and ctx.needs_input_grad[2]:
-                    gb = gb_fused if gb_fused is not None else ops.nc_reduce(gy.detach(), None, want_dot=False, per_channel=True)[0].reshape(-1)
+                ops.prof_note_saved(ops.upfold_saved_flops(ctx.g))
             return gx, gw, gb, None, None, None
         if ctx.needs_input_grad[0]:
             gx = ConvDgradFn.apply(gy, w, ctx.g)
-        if not _INPUT_GRADS_ONLY:
-            if ctx.needs_input_grad[1]:
+        if want_w:
+            if w_slot is not None:
+                ops.sink_conv_wgrad(x, gy, ctx.g, tuple(w.shape), w_slot)
+            else:
                 gw = ConvWgradFn.apply(x, gy, ctx.g, tuple(w.shape))
-            if ctx.has_bias and ctx.needs_input_grad[2]:
-                gb = gb_fused if gb_fused is not None else ops.nc_reduce(gy.detach(), None, want_dot=False, per_channel=True)[0].reshape(-1)
         return gx, gw, gb, None, None, None
 
 
@@ -191,6 +203,7 @@ class LinearFn(Function):
         x, w = _cg(x), _cg(w)
         ctx.save_for_backward(x, w)
         ctx.has_bias = b is not None
+        ctx.bias_ref = b if (b is not None and b.requires_grad) else None
         return ops.gemm(x, w, False, False, b)
 
     @staticmethod
@@ -198,13 +211,19 @@ class LinearFn(Function):
         x, w = ctx.saved_tensors
         gy = _cg(gy)
         gx = gw = gb = None
+        first_order = not torch.is_grad_enabled()
         if ctx.needs_input_grad[0]:
             gx = MatmulFn.apply(gy, w, False, True)
         if not _INPUT_GRADS_ONLY:
             if ctx.needs_input_grad[1]:
-                gw = MatmulFn.apply(x, gy, True, False)
+                slot = ops.sink_for(w) if first_order else None
+                if slot is not None:
+                    ops.sink_gemm(x, gy, slot, True, False)
+                else:
+                    gw = MatmulFn.apply(x, gy, True, False)
             if ctx.has_bias and ctx.needs_input_grad[2]:
-                gb = ops.nc_reduce(gy.detach(), None, want_dot=False, per_channel=True)[0].reshape(-1)
+                slot = ops.sink_for(ctx.bias_ref) if (first_order and ctx.bias_ref is not None) else None
+                gb = ops.bias_grad(gy.detach(), sink=slot)
         return gx, gw, gb
 
 
@@ -217,6 +236,7 @@ class LinearActFn(Function):
         y = ops.gemm(x, w, False, False, b, act, slope)
         ctx.save_for_backward(x, w, y)
         ctx.act, ctx.slope, ctx.has_bias = act, slope, b is not None
+        ctx.bias_ref = b if (b is not None and b.requires_grad) else None
         return y
 
     @staticmethod
@@ -224,13 +244,18 @@ class LinearActFn(Function):
         if torch.is_grad_enabled():
             raise RuntimeError("LinearActFn is first-order only; use linear() + lrelu()")
         x, w, y = ctx.saved_tensors
-        gb = None
+        gb = gw = None
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            g, gb = ops.act_bwd_bias(_cg(gy), y, ctx.act, ctx.slope)
+            g, gb = ops.act_bwd_bias(_cg(gy), y, ctx.act, ctx.slope, sink=ops.sink_for(ctx.bias_ref))
         else:
             g = ops.act_bwd(_cg(gy), y, ctx.act, ctx.slope)
         gx = ops.gemm(g, w, False, True) if ctx.needs_input_grad[0] else None
-        gw = ops.gemm(x, g, True, False) if ctx.needs_input_grad[1] else None
+        if ctx.needs_input_grad[1]:
+            slot = ops.sink_for(w)
+            if slot is not None:
+                ops.sink_gemm(x, g, slot, True, False)
+            else:
+                gw = ops.gemm(x, g, True, False)
         return gx, gw, gb, None, None
 
 

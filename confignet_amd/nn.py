@@ -142,6 +142,9 @@ def backward_into_arenas(loss, nets, extra=(), grad_outputs=None, accumulate=Fal
     """tape.gradient(loss, trainable_weights) written into the networks' gradient arenas.
     Uses autograd.grad + one multi-tensor copy instead of .backward(): AccumulateGrad nodes are bound to the
     stream they were created on, which breaks HIP-graph capture of a step on a capture stream.
+    Round 3: the arenas are cleared by one launch each and every gradient is ADDED -- the convolution / dense weight and bias
+    gradients by their own kernels, on a side stream off the backward chain (ops.grad_sink), the rest (norm parameters, free
+    variables) by one multi-tensor add of what autograd returns.
     Weights switched off with requires_grad_(False) (a variable the caller leaves out of the reference's
     trainable list, e.g. the expression slice of fine_tune_on_img(force_neutral_expression=True)) get a zero
     gradient: Keras-Adam on a zero gradient with zero moments leaves them unchanged.
@@ -149,24 +152,19 @@ def backward_into_arenas(loss, nets, extra=(), grad_outputs=None, accumulate=Fal
     `loss` a list of such tensors a later call continues the backward pass from them (two-part backward, see
     ConfigNetFirstStage._generator_update).  accumulate: ADD to the arenas (second part of a loss whose first part was
     written by an earlier call: the discriminator steps' real / fake halves)."""
+    from . import ops
     every = [p for n in nets for p in n.trainable_weights]
     params = [p for p in every if p.requires_grad]
     extra = list(extra)
-    grads = torch.autograd.grad(loss, params + extra, grad_outputs=grad_outputs, allow_unused=True)
+    if not accumulate:
+        for n in nets:                      # everything below ADDS into the arenas (kernels with an accumulate mode, then one
+            ops.zero_(n.grad_arena)         # multi-tensor add for what autograd returns)
+    with ops.grad_sink(params):             # filter / dense / bias gradients go straight into their arena slots (ops.grad_sink)
+        grads = torch.autograd.grad(loss, params + extra, grad_outputs=grad_outputs, allow_unused=True)
     extra_grads = list(grads[len(params):])
     grads = grads[:len(params)]
     dst = [p.grad for p, g in zip(params, grads) if g is not None]
     src = [g.reshape(p.shape) for p, g in zip(params, grads) if g is not None]
     if dst:
-        if accumulate:
-            torch._foreach_add_(dst, src)
-        else:
-            torch._foreach_copy_(dst, src)
-    if not accumulate:
-        for p, g in zip(params, grads):
-            if g is None:
-                p.grad.zero_()
-        for p in every:
-            if not p.requires_grad:
-                p.grad.zero_()
+        torch._foreach_add_(dst, src)
     return extra_grads

@@ -1,5 +1,6 @@
 """Raw (non-differentiable) wrappers: torch CUDA tensors in, C-ABI call on the current HIP
 stream, torch tensors out.  torch only allocates memory and provides the stream here."""
+import contextlib
 import ctypes
 import math
 import os
@@ -240,12 +241,12 @@ def upfold_prepare(w, g):
     return wf.view(taps + (g.cin, g.cout)), wd.view(taps + (g.cout, g.cin)), gd, g2
 
 
-def upfold_wgrad(gw2, g, w_shape):
-    """gw[kk][ci][co] from the conv2 filter gradient gw2[a][co][ci]."""
-    gw = torch.empty(w_shape, device=gw2.device, dtype=torch.float32)
+def upfold_wgrad(gw2, g, w_shape, out=None):
+    """gw[kk][ci][co] from the conv2 filter gradient gw2[a][co][ci]; out: add to this tensor instead."""
+    gw = out if out is not None else torch.empty(w_shape, device=gw2.device, dtype=torch.float32)
     k3 = (ctypes.c_int * 3)(g.k_d, g.k_h, g.k_w)
     p3 = (ctypes.c_int * 3)(g.p_d, g.p_h, g.p_w)
-    check(lib.cn_upfold_wgrad(_fptr(_c(gw2)), _ptr(gw), g.nd, k3, p3, g.cin, g.cout, 0, _stream()), "cn_upfold_wgrad")
+    check(lib.cn_upfold_wgrad(_fptr(_c(gw2)), _ptr(gw), g.nd, k3, p3, g.cin, g.cout, int(out is not None), _stream()), "cn_upfold_wgrad")
     return gw
 
 
@@ -361,8 +362,14 @@ def _c3_partials():
     return _C3_PARTS[0]
 
 
-def conv_wgrad(x, gy, g, w_shape):
-    gw = zero_pool_alloc(w_shape, x.device)
+_EXP_NO_WGRAD = os.environ.get("CN_EXP_NO_WGRAD") is not None       # timing experiment only (wrong gradients): filter gradients not launched
+
+
+def conv_wgrad(x, gy, g, w_shape, out=None):
+    """out: ADD the filter gradient to this tensor (a slot of a gradient arena, see grad_sink) instead of returning a new one."""
+    if _EXP_NO_WGRAD:
+        return out if out is not None else torch.empty(w_shape, device=x.device, dtype=torch.float32)
+    gw = out if out is not None else zero_pool_alloc(w_shape, x.device)
     pre = gw is not None
     if not pre:
         gw = torch.empty(w_shape, device=x.device, dtype=torch.float32)
@@ -371,7 +378,8 @@ def conv_wgrad(x, gy, g, w_shape):
         # K = 27 first layers: staged-tile kernel without atomics (the generic split-over-rows kernel runs them at 10 TFLOP/s)
         x, gy = _c(f32(x)), _c(gy)
         scratch = torch.empty(_c3_partials() * 27 * g.cout, device=x.device, dtype=torch.float32)
-        check(lib.cn_conv_wgrad_c3(ctypes.byref(g), _ptr(x), _ptr(gy), _dt(gy), _ptr(scratch), _fptr(gw), 0, _stream()), "cn_conv_wgrad_c3")
+        check(lib.cn_conv_wgrad_c3(ctypes.byref(g), _ptr(x), _ptr(gy), _dt(gy), _ptr(scratch), _fptr(gw), int(out is not None), _stream()),
+              "cn_conv_wgrad_c3")
         return gw
     if _bf16_conv_ok(g):
         x, gy = cast(x, torch.bfloat16), cast(gy, torch.bfloat16)
@@ -380,6 +388,113 @@ def conv_wgrad(x, gy, g, w_shape):
     x, gy = f32(x), f32(gy)
     check(lib.cn_conv_wgrad(ctypes.byref(g), _ptr(x), _ptr(gy), _fptr(gw), int(pre), _stream()), "cn_conv_wgrad")
     return gw
+
+
+# ---------------------------------------------------------------------------------------------
+# gradient sink: while nn.backward_into_arenas runs a backward pass, the filter / dense-weight / bias gradients are ADDED by
+# their kernels straight into the weights' slots of the networks' gradient arenas (tf.GradientTape sums the contributions of
+# every use of a variable: here the wgrad kernels' own accumulate mode does, not autograd's add kernels and not a copy pass
+# afterwards).  CN_NO_GRAD_SINK=1: gradients through autograd as before.
+# Nothing downstream of a weight gradient is on the backward chain, so the sinks CAN run on a side stream that forks off the
+# chain (CN_WGRAD_FORK=1, one cross-stream edge per CN_WGRAD_GROUP launches, joined at the end of the pass; all sinks share
+# ONE side stream, so accumulations into one slot never race).  Measured and left OFF: with the filter gradients not
+# launched at all the iteration drops 49.8 -> 42.3 ms (the bound of the idea), but the forked graphs replay SLOWER than the
+# single chain -- 63.6 ms with an edge per 8 launches, 53.2 per 32, 52.3 with one fork at the end of the pass, against
+# 49.5 unforked: the four hardware queues already carry the iteration's four concurrent lines, a fifth branch takes a queue
+# from one of them (GPU_MAX_HW_QUEUES = 6 / 8 make every variant worse: 61 - 87 ms).
+# ---------------------------------------------------------------------------------------------
+GRAD_SINK = os.environ.get("CN_NO_GRAD_SINK") is None
+WGRAD_FORK = os.environ.get("CN_WGRAD_FORK") == "1"
+_SINK = None              # {"slots": {data_ptr: grad view}, "side": stream | None, "keep": [...], "used": bool}
+_SIDE_STREAMS = {}
+
+
+class grad_sink:
+    def __init__(self, params):
+        self.params = params
+
+    def __enter__(self):
+        global _SINK
+        assert _SINK is None, "nested gradient sinks"
+        if not GRAD_SINK or not self.params:
+            return self
+        dev = self.params[0].device
+        side = None
+        if WGRAD_FORK:
+            side = _SIDE_STREAMS.get(dev)
+            if side is None:
+                side = _SIDE_STREAMS[dev] = torch.cuda.Stream(device=dev)
+        _SINK = {"slots": {p.data_ptr(): p.grad for p in self.params if p.grad is not None}, "side": side, "keep": [], "used": False}
+        return self
+
+    def join(self):
+        """Order the calling stream after everything the sinks launched; drop the tensors kept alive for them."""
+        st = _SINK
+        _sink_flush()
+        if st is not None and st["side"] is not None and st["used"]:
+            torch.cuda.current_stream().wait_stream(st["side"])
+        if st is not None:
+            st["keep"].clear()
+            st["used"] = False
+
+    def __exit__(self, *exc):
+        global _SINK
+        self.join()
+        _SINK = None
+
+
+def sink_for(w):
+    """The gradient-arena slot of weight w if a sink is active for it (else None)."""
+    if _SINK is None or w is None:
+        return None
+    return _SINK["slots"].get(w.data_ptr())
+
+
+WGRAD_GROUP = int(os.environ.get("CN_WGRAD_GROUP", "8"))      # sink launches per fork off the backward chain
+
+
+def _sink_flush():
+    """Fork the side stream off the calling stream HERE and launch everything queued since the last fork on it."""
+    st = _SINK
+    if st is None or not st.get("queue"):
+        return
+    queue, st["queue"] = st["queue"], []
+    side = st["side"]
+    for s_ in st.pop("streams", ()):          # every stream a queued launch's operands were produced on (a forked step has two)
+        side.wait_stream(s_)
+    st["used"] = True
+    with torch.cuda.stream(side):
+        for fn in queue:
+            fn()
+
+
+def _sink_run(fn, keep):
+    """Run one sink launch: immediately on the calling stream (no fork), or queued for the side stream -- every WGRAD_GROUP
+    launches one cross-stream edge (an edge per layer made the captured graph a ladder that replayed 35 % slower than the
+    single chain: 49.3 -> 66.5 ms).  `keep`: the tensors the launch reads; they stay alive until the join."""
+    st = _SINK
+    if st is None or st["side"] is None:
+        fn()
+        return
+    st["keep"].extend(t for t in keep if t is not None)
+    st.setdefault("queue", []).append(fn)
+    cur = torch.cuda.current_stream()
+    if all(cur != s_ for s_ in st.setdefault("streams", [])):
+        st["streams"].append(cur)
+    if len(st["queue"]) >= WGRAD_GROUP:
+        _sink_flush()
+
+
+def sink_conv_wgrad(x, gy, g, w_shape, slot):
+    _sink_run(lambda: conv_wgrad(x, gy, g, w_shape, out=slot), (x, gy))
+
+
+def sink_upfold_wgrad(gy, x, g2, wd_shape, g, w_shape, slot):
+    _sink_run(lambda: upfold_wgrad(conv_wgrad(gy, x, g2, wd_shape), g, w_shape, out=slot), (x, gy))
+
+
+def sink_gemm(a, b, slot, trans_a=False, trans_b=False):
+    _sink_run(lambda: gemm_acc(a, b, slot, trans_a, trans_b), (a, b))
 
 
 # ---------------------------------------------------------------------------------------------
@@ -430,6 +545,12 @@ def zero_pool_alloc(shape, device):
     return out
 
 
+def zero_(t):
+    """Clear a contiguous fp32 tensor with the library's own kernel (a graph node that re-executes on replay)."""
+    check(lib.cn_zero(_fptr(t), t.numel() * 4, _stream()), "cn_zero")
+    return t
+
+
 def sumpool2(gu):
     nd = gu.dim() - 2
     sp = [s // 2 for s in gu.shape[1:-1]]
@@ -452,6 +573,18 @@ def gemm(a, b, trans_a=False, trans_b=False, bias=None, act=ACT_NONE, slope=0.0)
     check(lib.cn_gemm(int(trans_a), int(trans_b), m, n, k, _ptr(a), a.shape[1], _ptr(b), b.shape[1], _ptr(c), n,
                       _ptr(bias), act, slope, _stream()), "cn_gemm")
     return c
+
+
+def gemm_acc(a, b, out, trans_a=False, trans_b=False):
+    """out += op(a) @ op(b) (cn_gemm_acc)."""
+    m = a.shape[1] if trans_a else a.shape[0]
+    k = a.shape[0] if trans_a else a.shape[1]
+    n = b.shape[0] if trans_b else b.shape[1]
+    a, b = f32(a), f32(b)
+    assert tuple(out.shape) == (m, n) and out.is_contiguous()
+    check(lib.cn_gemm_acc(int(trans_a), int(trans_b), m, n, k, _ptr(a), a.shape[1], _ptr(b), b.shape[1], _fptr(out), n, _stream()),
+          "cn_gemm_acc")
+    return out
 
 
 def _nsc(x):
@@ -646,8 +779,9 @@ def act_bwd(gy, y, act, slope=0.0):
     return gx
 
 
-def act_bwd_bias(gy, y, act, slope=0.0):
-    """(gx, gb): act_bwd fused with the per-channel sum of its result (the bias gradient) -- one pass instead of two."""
+def act_bwd_bias(gy, y, act, slope=0.0, sink=None):
+    """(gx, gb): act_bwd fused with the per-channel sum of its result (the bias gradient) -- one pass instead of two.
+    sink: the bias's slot of a gradient arena (grad_sink) -- the sum is ADDED there and gb is returned as None."""
     gy, y = _unify(gy, y)
     _, _, c = _nsc(gy)
     rows = gy.numel() // c
@@ -659,7 +793,37 @@ def act_bwd_bias(gy, y, act, slope=0.0):
         gb, flags = torch.empty((rep, c), device=gy.device, dtype=torch.float32), 0
     check(lib.cn_act_bwd_bias(_ptr(gy), _ptr(y), _ptr(gx), _ptr(gb), rep, rows // rep, c, act, slope, flags, _dt(gy), _stream()),
           "cn_act_bwd_bias")
+    if sink is not None:
+        sum_rows_into(gb, sink)
+        return gx, None
     return gx, (gb.sum(0) if rep > 1 else gb.reshape(-1))
+
+
+def sum_rows_into(partial, dst, accumulate=True, side=True):
+    """dst[c] (+)= sum_r partial[r][c] (cn_sum_rows_into); under a grad_sink on its side stream (off the backward chain)."""
+    rows, c = partial.shape
+    fn = lambda: check(lib.cn_sum_rows_into(_fptr(partial), _fptr(dst), rows, c, int(accumulate), _stream()), "cn_sum_rows_into")
+    if side:
+        _sink_run(fn, (partial,))
+    else:
+        fn()
+
+
+def bias_grad(gy, sink=None):
+    """sum over every axis but the last of gy (the bias gradient of a linear / convolution layer without fused activation)."""
+    gy = _c(gy)
+    if sink is None:
+        return nc_reduce(gy, None, want_dot=False, per_channel=True)[0].reshape(-1)
+    c = gy.shape[-1]
+    rows = gy.numel() // c
+    rep = next(r for r in (16, 8, 4, 2, 1) if rows % r == 0) if rows >= 8192 else 1
+    part = zero_pool_alloc((rep, c), gy.device)
+    flags = 16
+    if part is None:
+        part, flags = torch.empty((rep, c), device=gy.device, dtype=torch.float32), 0
+    check(lib.cn_nc_reduce(_ptr(gy), None, _ptr(part), None, rep, rows // rep, c, flags, 0.0, _dt(gy), _stream()), "cn_nc_reduce")
+    sum_rows_into(part, sink)
+    return None
 
 
 def axpby(x, y, a, b):

@@ -137,6 +137,15 @@ int cn_gemm(int trans_a, int trans_b, int m, int n, int k, const float* a, int l
             const float* b, int ldb, float* c, int ldc, const float* bias, int act, float slope,
             void* stream);
 
+/* Clears `bytes` (a multiple of 4) at p with a kernel launch (a HIP-graph node that re-executes on replay). */
+int cn_zero(void* p, size_t bytes, void* stream);
+/* C += op(A) op(B) (fp32 atomics): a Dense layer's weight gradient added straight into its slot of the network's gradient
+ * arena (tf.GradientTape sums the contributions of every use of a variable; here the kernels do, not a separate add). */
+int cn_gemm_acc(int trans_a, int trans_b, int m, int n, int k, const float* a, int lda, const float* b, int ldb,
+                float* c, int ldc, void* stream);
+/* dst[c] (+)= sum_r src[r][c]: adds the partial rows of a per-channel reduction (bias gradients) in row order. */
+int cn_sum_rows_into(const float* src, float* dst, int rows, int cols, int accumulate, void* stream);
+
 /* ---- per-(sample,channel) statistics and affine maps on (N, S, C) tensors ------------------
  * Building blocks of LayerNormalization/AdaIn (building_blocks.py:132-144), InstanceNormalization
  * (instance_normalization.py:108-131), get_layer_style (confignet_utils.py:147-159), BN inference
