@@ -467,6 +467,45 @@ __global__ void maxpool_bwd_kernel(const T* __restrict__ x, const T* __restrict_
     }
 }
 
+// The VGG pools (2x2, stride 2, no padding, even extents, C % 4 == 0): one thread owns one window of one 4-channel group --
+// four 16-byte reads of x, one of gy, four 16-byte writes of gx, no index arithmetic per element (the generic kernel above
+// re-derives the windows of every element with 64-bit div/mod: 286 us on the 8 x 256 x 256 x 64 tensor, 302 MB of traffic).
+// Same tie rule: the first maximum in (dy, dx) scan order takes the gradient.
+template <typename T>
+__global__ void maxpool2_bwd_kernel(const T* __restrict__ x, const T* __restrict__ gy, T* __restrict__ gx, long windows4,
+                                    int oh, int ow, int c4) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < windows4; i += (long)gridDim.x * blockDim.x) {
+        const int cg = (int)(i % c4);
+        long t = i / c4;
+        const int ox = (int)(t % ow);
+        t /= ow;
+        const int oy = (int)(t % oh);
+        const long b = t / oh;
+        const long row = (long)ow * 2 * c4 * 4;                       // floats per input row
+        const T* px = x + ((b * oh * 2 + oy * 2) * (long)ow * 2 + ox * 2) * c4 * 4 + cg * 4;
+        T* pg = gx + (px - x);
+        const float4 v00 = ld4<T>(px), v01 = ld4<T>(px + c4 * 4), v10 = ld4<T>(px + row), v11 = ld4<T>(px + row + c4 * 4);
+        const float4 g = ld4<T>(gy + i * 4);
+        const float a[4][4] = {{v00.x, v01.x, v10.x, v11.x}, {v00.y, v01.y, v10.y, v11.y}, {v00.z, v01.z, v10.z, v11.z}, {v00.w, v01.w, v10.w, v11.w}};
+        const float gg[4] = {g.x, g.y, g.z, g.w};
+        float o[4][4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            int arg = 0;
+            float best = a[e][0];
+#pragma unroll
+            for (int j = 1; j < 4; ++j)
+                if (a[e][j] > best) { best = a[e][j]; arg = j; }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[e][j] = (j == arg && best > -INFINITY) ? gg[e] : 0.f;
+        }
+        st4<T>(pg, make_float4(o[0][0], o[1][0], o[2][0], o[3][0]));
+        st4<T>(pg + c4 * 4, make_float4(o[0][1], o[1][1], o[2][1], o[3][1]));
+        st4<T>(pg + row, make_float4(o[0][2], o[1][2], o[2][2], o[3][2]));
+        st4<T>(pg + row + c4 * 4, make_float4(o[0][3], o[1][3], o[2][3], o[3][3]));
+    }
+}
+
 __global__ void chan_affine3_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, size_t pixels, int p0, int p1,
                                         int p2, float scale, float o0, float o1, float o2) {
     for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < pixels; p += (size_t)gridDim.x * blockDim.x) {
@@ -783,6 +822,13 @@ extern "C" int cn_maxpool_bwd(const void* x, const void* gy, void* gx, int n, in
     CN_CHECK_ARG(x && gy && gx && n > 0 && h > 0 && w > 0 && c > 0 && k > 0 && s > 0 && pad >= 0 && (dt == CN_F32 || dt == CN_BF16), "maxpool_bwd: bad args");
     const int oh = (h + 2 * pad - k) / s + 1, ow = (w + 2 * pad - k) / s + 1;
     const size_t total = (size_t)n * h * w * c;
+    if (k == 2 && s == 2 && pad == 0 && h % 2 == 0 && w % 2 == 0 && c % 4 == 0 && alv(x, dt) && alv(gy, dt) && alv(gx, dt)) {
+        const long windows4 = (long)n * oh * ow * (c / 4);
+        CN_DISPATCH_DT(dt, hipLaunchKernelGGL((maxpool2_bwd_kernel<T>), dim3(ew_blocks((size_t)windows4)), dim3(256), 0, (hipStream_t)stream,
+                                              (const T*)x, (const T*)gy, (T*)gx, windows4, oh, ow, c / 4));
+        CN_LAUNCH_CHECK();
+        return CN_OK;
+    }
     CN_DISPATCH_DT(dt, hipLaunchKernelGGL((maxpool_bwd_kernel<T>), dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)gy, (T*)gx, n, h, w, c, oh, ow, k, s, pad));
     CN_LAUNCH_CHECK();
     return CN_OK;

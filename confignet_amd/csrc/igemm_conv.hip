@@ -28,7 +28,11 @@ template <int WM, int WN, int TM, int TN, bool VEC, bool BVEC = true, int KB = B
 __global__ __launch_bounds__(256) void igemm_fwd_kernel(CnConvGeom g, const float* __restrict__ X,
                                                         const float* __restrict__ W, const float* __restrict__ bias,
                                                         float* __restrict__ Y, int act, float slope, int par,
-                                                        int xcd_swizzle, int ntiles_m, int ntiles_n) {
+                                                        int xcd_swizzle, int ntiles_m, int ntiles_n, int bt = 0) {
+    // bt: W is the ORIGINAL filter [t][n = output channel here][k = reduction channel here] of the convolution whose data
+    // gradient this launch computes (tap order reversed, the two channel axes swapped): the B tile is then loaded like the
+    // gathered A tile (16-byte pieces along k, transposed on the way into LDS) -- no tap-flipped, channel-transposed copy of
+    // every trainable filter per step (cn_conv_weight_tflip: 80 launches per iteration)
     static_assert(WM * WN == 4, "4 waves per workgroup");
     constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN, LDA = BM + 4, LDB = BN + 4;
     constexpr int KQ = KB / 4;                          // float4 pieces per A row per K step
@@ -147,19 +151,30 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(CnConvGeom g, const floa
             for (int i = 0; i < AP; ++i)
                 ra[i] = aoff[i] >= 0 ? *reinterpret_cast<const float4*>(X + aoff[i] + c0 + kq * 4)
                                      : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (bt) {
 #pragma unroll
-            for (int j = 0; j < BP; ++j) {
-                const int idx = tid + 256 * j;
-                const int brow = idx / (BN / 4), col = n0 + (idx % (BN / 4)) * 4;
-                const long kg = (long)tap * g.cin + c0 + brow;
-                if (BVEC) {
-                    rb[j] = (col < g.cout && idx < KB * BN / 4) ? *reinterpret_cast<const float4*>(W + kg * g.cout + col)
-                                                                : make_float4(0.f, 0.f, 0.f, 0.f);
-                } else {   // thin cout (3-channel image gradients): guarded scalar filter loads
-                    float v[4];
+                for (int j = 0; j < BP; ++j) {
+                    const int idx = tid + 256 * j;
+                    const int nn = n0 + idx / KQ, kk = (idx % KQ) * 4;
+                    rb[j] = (nn < g.cout && idx < KB * BN / 4)
+                                ? *reinterpret_cast<const float4*>(W + ((long)(T - 1 - tap) * g.cout + nn) * g.cin + c0 + kk)
+                                : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            } else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = (col + e < g.cout && idx < KB * BN / 4) ? W[kg * g.cout + col + e] : 0.f;
-                    rb[j] = make_float4(v[0], v[1], v[2], v[3]);
+                for (int j = 0; j < BP; ++j) {
+                    const int idx = tid + 256 * j;
+                    const int brow = idx / (BN / 4), col = n0 + (idx % (BN / 4)) * 4;
+                    const long kg = (long)tap * g.cin + c0 + brow;
+                    if (BVEC) {
+                        rb[j] = (col < g.cout && idx < KB * BN / 4) ? *reinterpret_cast<const float4*>(W + kg * g.cout + col)
+                                                                    : make_float4(0.f, 0.f, 0.f, 0.f);
+                    } else {   // thin cout (3-channel image gradients): guarded scalar filter loads
+                        float v[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = (col + e < g.cout && idx < KB * BN / 4) ? W[kg * g.cout + col + e] : 0.f;
+                        rb[j] = make_float4(v[0], v[1], v[2], v[3]);
+                    }
                 }
             }
         } else {
@@ -199,6 +214,20 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(CnConvGeom g, const floa
             As[buf][kq * 4 + 1][r] = ra[i].y;
             As[buf][kq * 4 + 2][r] = ra[i].z;
             As[buf][kq * 4 + 3][r] = ra[i].w;
+        }
+        if (VEC && bt) {
+#pragma unroll
+            for (int j = 0; j < BP; ++j) {
+                const int idx = tid + 256 * j;
+                const int nn = idx / KQ, kk = (idx % KQ) * 4;
+                if (idx < KB * BN / 4) {
+                    Bs[buf][kk + 0][nn] = rb[j].x;
+                    Bs[buf][kk + 1][nn] = rb[j].y;
+                    Bs[buf][kk + 2][nn] = rb[j].z;
+                    Bs[buf][kk + 3][nn] = rb[j].w;
+                }
+            }
+            return;
         }
 #pragma unroll
         for (int j = 0; j < BP; ++j) {
@@ -974,7 +1003,7 @@ static int g_xcd = getenv("CN_NO_XCD") ? 0 : 1;
 
 template <int WM, int WN, int TM, int TN>
 int launch_fwd(const CnConvGeom& g, bool vec, int par, int splits, const float* x, const float* w, const float* bias,
-               float* y, int act, float slope, hipStream_t s) {
+               float* y, int act, float slope, hipStream_t s, int bt = 0) {
     const long M = (long)g.n * g.out_d * g.out_h * g.out_w;
     dim3 grid(cn_cdiv(M, 32 * WM * TM), cn_cdiv(g.cout, 32 * WN * TN), splits);
     int xcd = g_xcd;
@@ -996,9 +1025,9 @@ int launch_fwd(const CnConvGeom& g, bool vec, int par, int splits, const float* 
     if ((xcd & 4) && (taps < 2 || taps > 9 || !vec)) xcd &= ~4;         // (offset table: taps x AP x 1 KiB of LDS)
     const size_t dyn = (xcd & 4) ? sizeof(int) * taps * (32 * WM * TM / (256 / ((kb32 ? 32 : BK) / 4))) * 256 : 0;   // taps x AP x 256 threads
     if (kb32)
-        hipLaunchKernelGGL((igemm_fwd_kernel<WM, WN, TM, TN, true, true, 32>), grid, dim3(256), dyn, s, g, x, w, bias, y, act, slope, par, xcd, ntm, ntn);
+        hipLaunchKernelGGL((igemm_fwd_kernel<WM, WN, TM, TN, true, true, 32>), grid, dim3(256), dyn, s, g, x, w, bias, y, act, slope, par, xcd, ntm, ntn, bt);
     else if (vec)
-        hipLaunchKernelGGL((igemm_fwd_kernel<WM, WN, TM, TN, true>), grid, dim3(256), dyn, s, g, x, w, bias, y, act, slope, par, xcd, ntm, ntn);
+        hipLaunchKernelGGL((igemm_fwd_kernel<WM, WN, TM, TN, true>), grid, dim3(256), dyn, s, g, x, w, bias, y, act, slope, par, xcd, ntm, ntn, bt);
     else
         hipLaunchKernelGGL((igemm_fwd_kernel<WM, WN, TM, TN, false>), grid, dim3(256), 0, s, g, x, w, bias, y, act, slope, par, xcd, ntm, ntn);
     CN_LAUNCH_CHECK();
@@ -1031,13 +1060,16 @@ int launch_wgrad(const CnConvGeom& g, const float* x, const float* gy, float* gw
 
 }  // namespace
 
-extern "C" int cn_conv_fwd(const CnConvGeom* gp, const float* x, const float* w, const float* bias, float* y, int act,
-                           float slope, void* stream) {
+// bt = 1: w is the original filter of the convolution whose data gradient g describes (see igemm_fwd_kernel); only the
+// vectorised implicit-GEMM path takes it -- every other path answers CN_EUNSUPPORTED without launching.
+static int conv_fwd_impl(const CnConvGeom* gp, const float* x, const float* w, const float* bias, float* y, int act,
+                         float slope, void* stream, int bt) {
     if (int e = check_geom(gp)) return e;
     CN_CHECK_ARG(x && w && y, "NULL tensor");
     const CnConvGeom g = *gp;
     hipStream_t s = (hipStream_t)stream;
     const long M = (long)g.n * g.out_d * g.out_h * g.out_w;
+    if (bt && (g.cout <= 4 || g.cin % BK != 0 || g.cout % 4 != 0)) return CN_EUNSUPPORTED;
     if (g.cout <= 4) {
         const bool vec = g.cin % 4 == 0;
         const int par = parity_ordered(g);
@@ -1104,7 +1136,7 @@ extern "C" int cn_conv_fwd(const CnConvGeom* gp, const float* x, const float* w,
         return CN_OK;
     }
     static const int no_c3 = getenv("CN_NO_C3") ? 1 : 0;
-    if (!no_c3 && g.nd == 2 && g.cin == 3 && g.k_h == 3 && g.k_w == 3 && g.s_h == g.s_w && (g.s_h == 1 || g.s_h == 2) &&
+    if (!bt && !no_c3 && g.nd == 2 && g.cin == 3 && g.k_h == 3 && g.k_w == 3 && g.s_h == g.s_w && (g.s_h == 1 || g.s_h == 2) &&
         g.dl_h == 1 && g.dl_w == 1 && !g.up && g.cout > 4 && g.cout <= 64) {
         dim3 grid((unsigned)(g.n * cn_cdiv(g.out_h, 8) * cn_cdiv(g.out_w, 32)));
         cn_prof_begin(s, conv_flops(g));
@@ -1159,15 +1191,20 @@ extern "C" int cn_conv_fwd(const CnConvGeom* gp, const float* x, const float* w,
     cn_prof_begin(s, conv_flops(g));
     int e;
     switch (cfg) {
-        case 3: e = launch_fwd<4, 1, 1, 1>(g, vec, par, splits, x, w, bias, y, kact, slope, s); break;   // 128 x 32
-        case 4: e = launch_fwd<4, 1, 1, 3>(g, vec, par, splits, x, w, bias, y, kact, slope, s); break;   // 128 x 96
-        case 0: e = launch_fwd<2, 2, 2, 2>(g, vec, par, splits, x, w, bias, y, kact, slope, s); break;   // 128 x 128
-        case 1: e = launch_fwd<2, 2, 2, 1>(g, vec, par, splits, x, w, bias, y, kact, slope, s); break;   // 128 x 64
-        default: e = launch_fwd<2, 2, 1, 1>(g, vec, par, splits, x, w, bias, y, kact, slope, s); break;  // 64 x 64
+        case 3: e = launch_fwd<4, 1, 1, 1>(g, vec, par, splits, x, w, bias, y, kact, slope, s, bt); break;   // 128 x 32
+        case 4: e = launch_fwd<4, 1, 1, 3>(g, vec, par, splits, x, w, bias, y, kact, slope, s, bt); break;   // 128 x 96
+        case 0: e = launch_fwd<2, 2, 2, 2>(g, vec, par, splits, x, w, bias, y, kact, slope, s, bt); break;   // 128 x 128
+        case 1: e = launch_fwd<2, 2, 2, 1>(g, vec, par, splits, x, w, bias, y, kact, slope, s, bt); break;   // 128 x 64
+        default: e = launch_fwd<2, 2, 1, 1>(g, vec, par, splits, x, w, bias, y, kact, slope, s, bt); break;  // 64 x 64
     }
     cn_prof_end(s);
     if (e == CN_OK && splits > 1 && act != CN_ACT_NONE) e = cn_act_fwd(y, y, (size_t)M * g.cout, act, slope, CN_F32, stream);
     return e;
+}
+
+extern "C" int cn_conv_fwd(const CnConvGeom* gp, const float* x, const float* w, const float* bias, float* y, int act,
+                           float slope, void* stream) {
+    return conv_fwd_impl(gp, x, w, bias, y, act, slope, stream, 0);
 }
 
 extern "C" int cn_conv_weight_tflip(const float* w, float* wt, int taps, int cin, int cout, void* stream) {
@@ -1229,6 +1266,23 @@ extern "C" int cn_conv_dgrad_dt(const CnConvGeom* gp, const void* gy, int gy_dt,
     d.p_d = gp->k_d - 1 - gp->p_d; d.p_h = gp->k_h - 1 - gp->p_h; d.p_w = gp->k_w - 1 - gp->p_w;
     d.up = 0;
     return cn_conv_fwd_dt(&d, gy, gy_dt, w_tflip, nullptr, gu, gu_dt, CN_ACT_NONE, 0.f, stream);
+}
+
+// Data gradient straight from the ORIGINAL filter w [t][cin][cout] (no cn_conv_weight_tflip copy): CN_EUNSUPPORTED (nothing
+// launched) where the shape does not reach the vectorised implicit-GEMM kernel -- the caller then uses cn_conv_dgrad.
+extern "C" int cn_conv_dgrad_w(const CnConvGeom* gp, const float* gy, const float* w, float* gu, void* stream) {
+    if (int e = check_geom(gp)) return e;
+    if (gp->dl_d != 1 || gp->dl_h != 1 || gp->dl_w != 1) return CN_EUNSUPPORTED;
+    CnConvGeom d = *gp;
+    d.in_d = gp->out_d; d.in_h = gp->out_h; d.in_w = gp->out_w; d.cin = gp->cout;
+    d.out_d = gp->in_d << gp->up; d.out_h = gp->in_h << gp->up; d.out_w = gp->in_w << gp->up;
+    if (gp->nd == 2) d.out_d = 1;
+    d.cout = gp->cin;
+    d.s_d = d.s_h = d.s_w = 1;
+    d.dl_d = gp->s_d; d.dl_h = gp->s_h; d.dl_w = gp->s_w;
+    d.p_d = gp->k_d - 1 - gp->p_d; d.p_h = gp->k_h - 1 - gp->p_h; d.p_w = gp->k_w - 1 - gp->p_w;
+    d.up = 0;
+    return conv_fwd_impl(&d, gy, w, nullptr, gu, CN_ACT_NONE, 0.f, stream, 1);
 }
 
 extern "C" int cn_conv_dgrad(const CnConvGeom* gp, const float* gy, const float* w_tflip, float* gu, void* stream) {

@@ -346,11 +346,19 @@ def conv_dgrad(gy, w, g):
                                    ACT_NONE, 0.0, _stream()), "cn_conv_fwd_wino")
         prof_note_saved(wino_saved_flops(g))
         return gu
+    if DGRAD_FROM_W:
+        # the kernel transposes the filter tile on its way into LDS: no tap-flipped copy per trainable filter per step
+        rc = lib.cn_conv_dgrad_w(ctypes.byref(g), _ptr(gy), _fptr(_c(w)), _ptr(gu), _stream())
+        if rc == 0:
+            return cast(gu, _act_out_dtype(g.cin))
+        if rc != CN_EUNSUPPORTED:
+            check(rc, "cn_conv_dgrad_w")
     wt = _weight_cache(w, "_cn_tflip", weight_tflip)
     check(lib.cn_conv_dgrad(ctypes.byref(g), _ptr(gy), _fptr(wt), _ptr(gu), _stream()), "cn_conv_dgrad")
     return cast(gu, _act_out_dtype(g.cin))
 
 
+DGRAD_FROM_W = os.environ.get("CN_NO_DGRAD_FROM_W") is None
 C3_WGRAD = os.environ.get("CN_NO_C3_WGRAD") is None
 MIXED_FIRST_LAYERS = os.environ.get("CN_NO_MIXED_FIRST") is None      # bf16 path: first-layer kernels that read / write both storage types
 _C3_PARTS = []

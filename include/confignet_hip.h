@@ -70,6 +70,10 @@ int cn_conv_weight_tflip(const float* w, float* w_tflip, int taps, int cin, int 
  * (in << up).  Replaces the Conv*DBackpropInput ops tf.GradientTape issues
  * (confignet_first_stage.py:473,485,557 ; losses.py:76). */
 int cn_conv_dgrad(const CnConvGeom* g, const float* gy, const float* w_tflip, float* gu, void* stream);
+/* The same from the ORIGINAL filter w [taps][cin][cout] (round 3): the filter tile is transposed on its way into LDS instead
+ * of by a cn_conv_weight_tflip launch per trainable filter per step.  CN_EUNSUPPORTED (nothing launched) for shapes that do
+ * not reach the vectorised implicit-GEMM kernel (thin outputs, cout % 16 != 0): use cn_conv_dgrad there. */
+int cn_conv_dgrad_w(const CnConvGeom* g, const float* gy, const float* w, float* gu, void* stream);
 /* Filter gradient (Conv*DBackpropFilter): gw[(t,ci),co] (+)= sum_m x[src(m,t),ci]*gy[m,co]; gw is overwritten,
  * or accumulated into when `accumulate` != 0 (the caller guarantees its previous content, e.g. zeros). */
 int cn_conv_wgrad(const CnConvGeom* g, const float* x, const float* gy, float* gw, int accumulate, void* stream);
