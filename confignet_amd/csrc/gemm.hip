@@ -6,6 +6,7 @@
 // are split over K across workgroups and combined with fp32 atomics.
 #include "common.h"
 #include "mma_tile.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -128,6 +129,90 @@ __global__ __launch_bounds__(256) void thin_gemm_kernel(int M, int N, int K, con
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Small dense layers (round 3).  The path's Dense layers run at M = batch (8 / 16 rows): AdaIN MLPs 145 -> 128 -> 2C, the
+// synthetic encoder's 24 per-input layers, the latent discriminator, heads.  ~360 launches per training iteration went
+// through the 64 x 64 MFMA tile above, which walks K in 16-deep stages with one global round trip per stage: 10 us for a
+// 16 x 145 x 128 product whose arithmetic is nothing.  These kernels issue every load up front instead.
+//   row-skinny (M <= 32; C = A op(B)): the whole A block sits in LDS, a thread owns one output column and a quarter of K
+//     (M accumulators), the four K quarters are combined through LDS;
+//   depth-skinny (K <= 32; C (+)= A^T B, the weight gradient x^T gy of such a layer): a thread owns 4 rows x 1 column.
+// ---------------------------------------------------------------------------------------------
+template <int MT, bool TB>
+__global__ __launch_bounds__(256) void gemm_rows_kernel(int M, int N, int K, const float* __restrict__ A, int lda,
+                                                        const float* __restrict__ B, int ldb, float* __restrict__ C, int ldc,
+                                                        const float* __restrict__ bias, int act, float slope) {
+    extern __shared__ float sm[];                 // A block [MT][K] (rows >= M are zero), then the partial sums [3][MT][64]
+    float* As = sm;
+    float* red = sm + MT * K;
+    const int tid = threadIdx.x, c = tid & 63, q = tid >> 6;
+    for (int i = tid; i < MT * K; i += 256) {
+        const int m = i / K, k = i - m * K;
+        As[i] = m < M ? A[(long)m * lda + k] : 0.f;
+    }
+    __syncthreads();
+    const int n = blockIdx.x * 64 + c;
+    const int kq = (K + 3) / 4, kbeg = q * kq, kend = min(K, kbeg + kq);
+    float acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[m] = 0.f;
+    if (n < N) {
+#pragma unroll 4
+        for (int k = kbeg; k < kend; ++k) {
+            const float b = TB ? B[(long)n * ldb + k] : B[(long)k * ldb + n];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[m] += As[m * K + k] * b;
+        }
+    }
+    if (q > 0) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) red[((q - 1) * MT + m) * 64 + c] = acc[m];
+    }
+    __syncthreads();
+    if (q == 0 && n < N) {
+        const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const float v = acc[m] + red[(0 * MT + m) * 64 + c] + red[(1 * MT + m) * 64 + c] + red[(2 * MT + m) * 64 + c] + bv;
+            if (m < M) C[(long)m * ldc + n] = cn_apply_act(v, act, slope);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void gemm_depth_kernel(int M, int N, int K, const float* __restrict__ A, int lda,
+                                                         const float* __restrict__ B, int ldb, float* __restrict__ C, int ldc,
+                                                         int accumulate) {
+    // C[m][n] (+)= sum_k A[k][m] B[k][n], K <= 32.  Workgroup tile: 16 rows x 64 columns.
+    __shared__ float As[32][16];
+    __shared__ float Bs[32][64];
+    const int tid = threadIdx.x, c = tid & 63, r = tid >> 6;
+    const int m0 = blockIdx.x * 16, n0 = blockIdx.y * 64;
+    for (int i = tid; i < K * 16; i += 256) {
+        const int k = i >> 4, m = i & 15;
+        As[k][m] = (m0 + m < M) ? A[(long)k * lda + m0 + m] : 0.f;
+    }
+    for (int i = tid; i < K * 64; i += 256) {
+        const int k = i >> 6, nn = i & 63;
+        Bs[k][nn] = (n0 + nn < N) ? B[(long)k * ldb + n0 + nn] : 0.f;
+    }
+    __syncthreads();
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < K; ++k) {
+        const float b = Bs[k][c];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] += As[k][r * 4 + e] * b;
+    }
+    const int n = n0 + c;
+    if (n >= N) return;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int m = m0 + r * 4 + e;
+        if (m >= M) continue;
+        if (accumulate) unsafeAtomicAdd(&C[(long)m * ldc + n], acc[e]);
+        else C[(long)m * ldc + n] = acc[e];
+    }
+}
+
 __global__ void zero_rows_kernel(float* C, int M, int N, int ldc) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < (long)M * N) C[(i / N) * ldc + i % N] = 0.f;
@@ -140,6 +225,25 @@ static int gemm_launch(int ta, int tb, int m, int n, int k, const float* a, int 
     CN_CHECK_ARG(m > 0 && n > 0 && k > 0 && a && b && c, "gemm: bad args m=%d n=%d k=%d", m, n, k);
     CN_CHECK_ARG(lda >= (ta ? m : k) && ldb >= (tb ? k : n) && ldc >= n, "gemm: leading dimension too small");
     hipStream_t s = (hipStream_t)stream;
+    static const int no_small = getenv("CN_NO_SMALL_GEMM") ? 1 : 0;
+    if (!no_small && !accumulate && !ta && m <= 32 && n > 4 && (long)(m <= 8 ? 8 : m <= 16 ? 16 : 32) * k <= 8192) {
+        const int mt = m <= 8 ? 8 : m <= 16 ? 16 : 32;
+        const size_t lds = sizeof(float) * ((size_t)mt * k + 3 * mt * 64);
+        dim3 grid(cn_cdiv(n, 64));
+#define ROWS(MT_, TB_) hipLaunchKernelGGL((gemm_rows_kernel<MT_, TB_>), grid, dim3(256), lds, s, m, n, k, a, lda, b, ldb, c, ldc, bias, act, slope)
+        if (mt == 8) { if (tb) ROWS(8, true); else ROWS(8, false); }
+        else if (mt == 16) { if (tb) ROWS(16, true); else ROWS(16, false); }
+        else { if (tb) ROWS(32, true); else ROWS(32, false); }
+#undef ROWS
+        CN_LAUNCH_CHECK();
+        return CN_OK;
+    }
+    if (!no_small && ta && !tb && k <= 32 && !bias && act == CN_ACT_NONE) {
+        dim3 grid(cn_cdiv(m, 16), cn_cdiv(n, 64));
+        hipLaunchKernelGGL(gemm_depth_kernel, grid, dim3(256), 0, s, m, n, k, a, lda, b, ldb, c, ldc, accumulate);
+        CN_LAUNCH_CHECK();
+        return CN_OK;
+    }
     if (!accumulate && !ta && !tb && n <= 4 && m <= 256 && k >= 128) {
         int slices = 1;
         if (act == CN_ACT_NONE && k >= 8192) slices = k / 4096;

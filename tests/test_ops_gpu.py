@@ -232,7 +232,10 @@ def test_conv_adjoint_identities_full_size(case):
 
 @pytest.mark.parametrize("m,n,k,ta,tb", [(16, 148, 32768, 0, 0), (16, 1, 32768, 0, 0), (8, 145, 145, 0, 0), (4096, 217, 145, 0, 0),
                                          (16, 32768, 148, 0, 1), (32768, 148, 16, 1, 0), (7, 5, 3, 1, 1), (130, 70, 33, 0, 1),
-                                         (16, 3, 2048, 0, 0), (16, 1, 768, 0, 0), (5, 4, 129, 0, 0)])
+                                         (16, 3, 2048, 0, 0), (16, 1, 768, 0, 0), (5, 4, 129, 0, 0),
+                                         # the small-layer kernels (round 3): row-skinny NN / NT at M <= 32, depth-skinny TN at K <= 32
+                                         (16, 128, 145, 0, 0), (8, 512, 128, 0, 0), (16, 145, 128, 0, 1), (3, 70, 62, 0, 0), (32, 65, 256, 0, 1),
+                                         (9, 30, 53, 0, 1), (1, 145, 145, 0, 0), (145, 128, 16, 1, 0), (62, 30, 8, 1, 0), (128, 512, 3, 1, 0)])
 def test_gemm(m, n, k, ta, tb):
     from confignet_amd import ops
     rng = np.random.default_rng(m * 7 + n)
@@ -243,6 +246,11 @@ def test_gemm(m, n, k, ta, tb):
     close(ops.gemm(dev(a), dev(b), bool(ta), bool(tb), dev(bias)), ref, what="gemm")
     if k < 1000 or n <= 4:
         close(ops.gemm(dev(a), dev(b), bool(ta), bool(tb), dev(bias), act=1, slope=0.3), O.leaky_relu(ref, 0.3), what="gemm+lrelu")
+    # C += op(A) op(B) (cn_gemm_acc: a Dense layer's weight gradient added into its gradient-arena slot)
+    c0 = rng.normal(size=(m, n))
+    out = dev(c0)
+    ops.gemm_acc(dev(a), dev(b), out, bool(ta), bool(tb))
+    close(out, t64(c0) + ref - t64(bias), what="gemm_acc")
 
 
 @pytest.mark.parametrize("shape", [(2, 16, 16, 48), (3, 8, 8, 8, 128), (2, 128, 128, 32), (2, 5, 7, 3), (4, 1, 1, 2048),
