@@ -99,7 +99,9 @@ class ConfigNetFirstStage:
         self._graphs = {}
         self._deferred = None
         self._prestaged, self._stagers = {}, {}      # cross-iteration overlap of the discriminator steps (see overlap_discriminators)
-        self.fork_generator_step = os.environ.get("CN_NO_FORK") is None   # second stage: real / synthetic branches of the generator step on two streams
+        # second stage: real / synthetic branches of the generator step on two streams (not in deterministic mode: both
+        # branches add into the generator's gradient slots, and the order of those adds would depend on the race)
+        self.fork_generator_step = os.environ.get("CN_NO_FORK") is None and not ops.DETERMINISTIC
         self._work_streams = []
         self.use_graphs = False       # capture each step's device half into a HIP graph (single-GPU runs)
 
@@ -309,6 +311,13 @@ class ConfigNetFirstStage:
     _WORK_SLOTS = {"main": 0, "d": 1, "sd": 2, "ld": 3, "g": 1}
 
     def _work_stream(self, name):
+        if name == "g" and ops.DETERMINISTIC:
+            # deterministic mode: the library's per-stream workspaces (partial sums) are bound at capture time to the stream a
+            # graph is captured on; the generator step's graph replays NEXT TO the discriminator step whose stream it would
+            # otherwise share for its capture, so it gets a capture stream (and with it a workspace) of its own
+            if getattr(self, "_g_capture_stream", None) is None:
+                self._g_capture_stream = torch.cuda.Stream()
+            return self._g_capture_stream
         if not self._work_streams:
             from .graphs import independent_streams
             self._work_streams = independent_streams(4)

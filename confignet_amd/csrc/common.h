@@ -38,6 +38,14 @@ void cn_set_error(const char* fmt, ...);
 // accumulate-into buffer is cleared by a kernel node instead.
 int cn_zero_async(void* p, size_t bytes, hipStream_t s);
 
+// Deterministic mode (cn_set_deterministic, prof.hip): reductions in a fixed order instead of fp32 atomics.  Kernels that
+// need room for their partial results take it from a per-stream workspace (allocated when the mode is switched on).
+int cn_det();
+float* cn_det_ws(hipStream_t s, size_t need_floats);     // NULL (+ error string) if the request does not fit
+constexpr size_t CN_DET_WS_FLOATS = (size_t)16 << 20;     // 64 MiB per stream, up to 8 streams
+// dst[i] (+)= scale * sum_{p < parts} src[p * count + i], parts added in index order (one thread per i)
+int cn_sum_parts(const float* src, float* dst, int parts, long count, int accumulate, float scale, hipStream_t s);
+
 // profiling hooks (prof.hip): bracket one launch of the dominant kernel class
 void cn_prof_begin(hipStream_t s, double flops);
 void cn_prof_end(hipStream_t s);

@@ -91,8 +91,13 @@ __global__ __launch_bounds__(256) void nc_reduce_kernel(const T* __restrict__ x1
                 t2 += red[1][(y * TX + tx) * V + e];
             }
             const long o = (long)n * C + (long)cg * V + e;
-            if (s1) unsafeAtomicAdd(&s1[o], t1);
-            if (s2) unsafeAtomicAdd(&s2[o], t2);
+            if (gridDim.y == 1) {                  // the only workgroup of this (n, channel block): no atomics (deterministic mode)
+                if (s1) s1[o] = t1;
+                if (s2) s2[o] = t2;
+            } else {
+                if (s1) unsafeAtomicAdd(&s1[o], t1);
+                if (s2) unsafeAtomicAdd(&s2[o], t2);
+            }
         }
     }
 }
@@ -302,7 +307,8 @@ __device__ __forceinline__ float block_sum(float v) {
 
 template <typename T>
 __global__ __launch_bounds__(256) void sqdiff_sum_kernel(const T* __restrict__ a, const T* __restrict__ b,
-                                                         float* __restrict__ out, size_t n, float scale, int vec) {
+                                                         float* __restrict__ out, size_t n, float scale, int vec,
+                                                         float* __restrict__ parts) {
     float acc = 0.f;
     const size_t stride = (size_t)gridDim.x * blockDim.x, t0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (vec) {
@@ -322,12 +328,15 @@ __global__ __launch_bounds__(256) void sqdiff_sum_kernel(const T* __restrict__ a
         }
     }
     const float t = block_sum(acc);
-    if (threadIdx.x == 0) unsafeAtomicAdd(out, t * scale);
+    if (threadIdx.x == 0) {
+        if (parts) parts[blockIdx.x] = t;           // deterministic mode: the partials are added in block order afterwards
+        else unsafeAtomicAdd(out, t * scale);
+    }
 }
 
 // grid (blocks_per_row, n)
 __global__ __launch_bounds__(256) void row_sumsq_kernel(const float* __restrict__ x, float* __restrict__ out, size_t row,
-                                                        int vec) {
+                                                        int vec, float* __restrict__ parts) {
     const float* p = x + (size_t)blockIdx.y * row;
     float acc = 0.f;
     const size_t stride = (size_t)gridDim.x * blockDim.x, t0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -340,7 +349,10 @@ __global__ __launch_bounds__(256) void row_sumsq_kernel(const float* __restrict_
         for (size_t i = t0; i < row; i += stride) acc += p[i] * p[i];
     }
     const float t = block_sum(acc);
-    if (threadIdx.x == 0) unsafeAtomicAdd(&out[blockIdx.y], t);
+    if (threadIdx.x == 0) {
+        if (parts) parts[(size_t)blockIdx.x * gridDim.y + blockIdx.y] = t;      // [block][row]: summed over blocks in order afterwards
+        else unsafeAtomicAdd(&out[blockIdx.y], t);
+    }
 }
 
 template <typename T>
@@ -623,6 +635,7 @@ static int nc_reduce_launch(const void* x1, const void* x2, float* s1, float* s2
     // ~512 workgroups in total, at least 4*TY rows each
     static const long red_blocks = getenv("CN_RED_BLOCKS") ? atol(getenv("CN_RED_BLOCKS")) : 512;   // sweep: fewer, longer workgroups = shorter same-address atomic tails
     long want = red_blocks / ((long)cblk * n);
+    if (cn_det()) want = 1;         // deterministic mode: one workgroup per (n, channel block), rows summed in a fixed order
     if (want < 1) want = 1;
     if (want > 256) want = 256;     // same-address atomics serialise (~100 ns each): 2048 per address cost 200 us
     long rpb = (s + want - 1) / want;
@@ -771,17 +784,30 @@ extern "C" int cn_sqdiff_sum(const void* a, const void* b, float* out, size_t nu
     if (!numel) return CN_OK;
     const int vec = alv(a, dt) && alv(b, dt);
     const int blocks = ew_blocks(numel / (vec ? 4 : 1) + 1) > 512 ? 512 : ew_blocks(numel / (vec ? 4 : 1) + 1);   // one atomic each
-    CN_DISPATCH_DT(dt, hipLaunchKernelGGL((sqdiff_sum_kernel<T>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const T*)a, (const T*)b, out, numel, scale, vec));
+    float* parts = nullptr;
+    if (cn_det()) {
+        parts = cn_det_ws((hipStream_t)stream, (size_t)blocks);
+        if (!parts) return CN_EINVAL;
+    }
+    CN_DISPATCH_DT(dt, hipLaunchKernelGGL((sqdiff_sum_kernel<T>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const T*)a, (const T*)b, out, numel, scale, vec, parts));
     CN_LAUNCH_CHECK();
+    if (parts) return cn_sum_parts(parts, out, blocks, 1, 1, scale, (hipStream_t)stream);    // out += scale * sum (out is the caller's accumulator)
     return CN_OK;
 }
 extern "C" int cn_row_sumsq(const float* x, float* out, int n, size_t row, void* stream) {
     CN_CHECK_ARG(x && out && n > 0 && row > 0, "row_sumsq: bad args");
-    if (int ez__ = cn_zero_async(out, sizeof(float) * n, (hipStream_t)stream)) return ez__;
     const int vec = al16(x) && row % 4 == 0;
     int bpr = (int)((row + 256 * 32 - 1) / (256 * 32));
     if (bpr > 64) bpr = 64;
-    hipLaunchKernelGGL(row_sumsq_kernel, dim3(bpr, n), dim3(256), 0, (hipStream_t)stream, x, out, row, vec);
+    if (cn_det()) {
+        float* parts = cn_det_ws((hipStream_t)stream, (size_t)bpr * n);
+        if (!parts) return CN_EINVAL;
+        hipLaunchKernelGGL(row_sumsq_kernel, dim3(bpr, n), dim3(256), 0, (hipStream_t)stream, x, out, row, vec, parts);
+        CN_LAUNCH_CHECK();
+        return cn_sum_parts(parts, out, bpr, n, 0, 1.f, (hipStream_t)stream);
+    }
+    if (int ez__ = cn_zero_async(out, sizeof(float) * n, (hipStream_t)stream)) return ez__;
+    hipLaunchKernelGGL(row_sumsq_kernel, dim3(bpr, n), dim3(256), 0, (hipStream_t)stream, x, out, row, vec, (float*)nullptr);
     CN_LAUNCH_CHECK();
     return CN_OK;
 }

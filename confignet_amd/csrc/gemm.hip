@@ -246,7 +246,7 @@ static int gemm_launch(int ta, int tb, int m, int n, int k, const float* a, int 
     }
     if (!accumulate && !ta && !tb && n <= 4 && m <= 256 && k >= 128) {
         int slices = 1;
-        if (act == CN_ACT_NONE && k >= 8192) slices = k / 4096;
+        if (act == CN_ACT_NONE && k >= 8192 && !cn_det()) slices = k / 4096;      // (deterministic mode: no K slices, no atomics)
         const int kps = (k + slices - 1) / slices;
         slices = (k + kps - 1) / kps;
         if (slices > 1) {
@@ -259,7 +259,7 @@ static int gemm_launch(int ta, int tb, int m, int n, int k, const float* a, int 
     }
     const long tiles = (long)cn_cdiv(m, 64) * cn_cdiv(n, 64);
     int splitk = 1;
-    if (act == CN_ACT_NONE && tiles < 128 && k >= 1024) {
+    if (act == CN_ACT_NONE && tiles < 128 && k >= 1024 && !cn_det()) {
         splitk = (int)((256 + tiles - 1) / tiles);
         if (splitk > k / 256) splitk = k / 256;
         if (splitk < 1) splitk = 1;

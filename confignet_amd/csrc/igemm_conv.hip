@@ -287,7 +287,7 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(CnConvGeom g, const floa
 template <int WM, int WN, int TM, int TN, bool VEC, bool BVEC>
 __global__ __launch_bounds__(256) void igemm_wgrad_kernel(CnConvGeom g, const float* __restrict__ X,
                                                           const float* __restrict__ GY, float* __restrict__ GW,
-                                                          int rows_per_split) {
+                                                          int rows_per_split, float* __restrict__ parts = nullptr) {
     static_assert(WM * WN == 4, "4 waves per workgroup");
     constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN, LDA = BM + 4, LDB = BN + 4;
     constexpr int AP = BM / 64, BP = (BN + 63) / 64;
@@ -429,7 +429,10 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(CnConvGeom g, const fl
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = rbase + (r & 3) + 8 * (r >> 2);
-                if (row < Ktot) unsafeAtomicAdd(&GW[(long)row * g.cout + col], acc[i][j][r]);
+                if (row >= Ktot) continue;
+                // deterministic mode: this split's partial filter goes to its own slab, the slabs are added in split order
+                if (parts) parts[((long)blockIdx.z * Ktot + row) * g.cout + col] = acc[i][j][r];
+                else unsafeAtomicAdd(&GW[(long)row * g.cout + col], acc[i][j][r]);
             }
         }
     }
@@ -623,7 +626,7 @@ __global__ __launch_bounds__(256) void thin_conv_coop_kernel(CnConvGeom g, const
 
 // from-RGB conv (3 -> 3): four pixels = three float4 per tensor per trip
 __global__ __launch_bounds__(256) void tiny_wgrad_3x3_kernel(const float* __restrict__ X, const float* __restrict__ GY,
-                                                             float* __restrict__ GW, long M) {
+                                                             float* __restrict__ GW, long M, float* __restrict__ parts = nullptr) {
     float acc[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) acc[i] = 0.f;
@@ -655,13 +658,18 @@ __global__ __launch_bounds__(256) void tiny_wgrad_3x3_kernel(const float* __rest
         if (lane == 0) sh[w][i] = v;
     }
     __syncthreads();
-    if (threadIdx.x < 9) unsafeAtomicAdd(&GW[threadIdx.x], sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+    if (threadIdx.x < 9) {
+        const float v = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
+        if (parts) parts[blockIdx.x * 9 + threadIdx.x] = v;      // deterministic mode: added in block order afterwards
+        else unsafeAtomicAdd(&GW[threadIdx.x], v);
+    }
 }
 
 // filter gradient of a 1x1 convolution between thin tensors (cin, cout <= 4: the from-RGB conv,
 // hologan_discriminator.py:20): a plain HBM-bound reduction gw[ci][co] = sum_m x[m][ci] gy[m][co]
 __global__ __launch_bounds__(256) void tiny_wgrad_1x1_kernel(const float* __restrict__ X, const float* __restrict__ GY,
-                                                             float* __restrict__ GW, long M, int cin, int cout) {
+                                                             float* __restrict__ GW, long M, int cin, int cout,
+                                                             float* __restrict__ parts = nullptr) {
     float acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -690,8 +698,11 @@ __global__ __launch_bounds__(256) void tiny_wgrad_1x1_kernel(const float* __rest
     __syncthreads();
     if (threadIdx.x < 16) {
         const int i = threadIdx.x >> 2, j = threadIdx.x & 3;
-        if (i < cin && j < cout)
-            unsafeAtomicAdd(&GW[i * cout + j], sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+        if (i < cin && j < cout) {
+            const float v = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
+            if (parts) parts[blockIdx.x * (cin * cout) + i * cout + j] = v;
+            else unsafeAtomicAdd(&GW[i * cout + j], v);
+        }
     }
 }
 
@@ -1042,19 +1053,32 @@ int launch_wgrad(const CnConvGeom& g, const float* x, const float* gy, float* gw
     const long tiles = (long)cn_cdiv(Ktot, BMt) * cn_cdiv(g.cout, BNt);
     const long wg_blocks = g_tune_wg_blocks > 0 ? g_tune_wg_blocks : 2048;   // sweep 256..4096: flat from 1536 up
     long splits = (wg_blocks + tiles - 1) / tiles;
+    float* parts = nullptr;
+    if (cn_det()) {
+        // deterministic mode: per-split partial filters in the stream's workspace, added in split order by a second launch
+        // (every split of every tile writes its whole slab region: no clearing).  As many splits as the workspace holds.
+        const long cap = (long)(CN_DET_WS_FLOATS / ((size_t)Ktot * g.cout));
+        CN_CHECK_ARG(cap >= 1, "deterministic filter gradient: %ld x %d filter does not fit the workspace", Ktot, g.cout);
+        if (splits > cap) splits = cap;
+    }
     long rows = (M + splits - 1) / splits;
     if (rows < 256) rows = 256;
     rows = (rows + BK - 1) / BK * BK;
     splits = (M + rows - 1) / rows;
+    if (cn_det()) {
+        parts = cn_det_ws(s, (size_t)splits * Ktot * g.cout);
+        if (!parts) return CN_EINVAL;
+    }
     dim3 grid(cn_cdiv(Ktot, BMt), cn_cdiv(g.cout, BNt), (unsigned)splits);
     const bool avec = g.cin % 4 == 0, bvec = g.cout % 4 == 0;
-#define WG(A, B) hipLaunchKernelGGL((igemm_wgrad_kernel<WM, WN, TM, TN, A, B>), grid, dim3(256), 0, s, g, x, gy, gw, (int)rows)
+#define WG(A, B) hipLaunchKernelGGL((igemm_wgrad_kernel<WM, WN, TM, TN, A, B>), grid, dim3(256), 0, s, g, x, gy, gw, (int)rows, parts)
     if (avec && bvec) WG(true, true);
     else if (avec) WG(true, false);
     else if (bvec) WG(false, true);
     else WG(false, false);
 #undef WG
     CN_LAUNCH_CHECK();
+    if (parts) return cn_sum_parts(parts, gw, (int)splits, Ktot * g.cout, 1, 1.f, s);      // gw was cleared (or holds the sum so far)
     return CN_OK;
 }
 
@@ -1184,6 +1208,7 @@ static int conv_fwd_impl(const CnConvGeom* gp, const float* x, const float* w, c
     }
     if (g_tune_cfg >= 0) cfg = g_tune_cfg;                        // tuning overrides (cn_conv_tune; scripts/conv_sweep.py)
     if (g_tune_splits > 0) splits = g_tune_splits;
+    if (cn_det()) splits = 1;                                     // deterministic mode: no split-K atomics
     const int kact = splits > 1 ? CN_ACT_NONE : act;
     if (splits > 1) {
         if (int ez__ = cn_zero_async(y, sizeof(float) * M * g.cout, s)) return ez__;
@@ -1313,11 +1338,20 @@ extern "C" int cn_conv_wgrad(const CnConvGeom* gp, const float* x, const float* 
         g.p_h == 0 && g.p_w == 0 && g.p_d == 0) {
         const long M = (long)g.n * g.out_d * g.out_h * g.out_w;
         const int blocks = (int)(cn_cdiv(M, 256) > 1024 ? 1024 : cn_cdiv(M, 256));
-        if (g.cin == 3 && g.cout == 3 && (((uintptr_t)x | (uintptr_t)gy) & 15) == 0)
-            hipLaunchKernelGGL(tiny_wgrad_3x3_kernel, dim3(blocks > 512 ? 512 : blocks), dim3(256), 0, s, x, gy, gw, M);
-        else
-            hipLaunchKernelGGL(tiny_wgrad_1x1_kernel, dim3(blocks), dim3(256), 0, s, x, gy, gw, M, g.cin, g.cout);
+        float* parts = nullptr;
+        if (cn_det()) {                  // deterministic mode: per-workgroup partials, added in workgroup order
+            parts = cn_det_ws(s, (size_t)blocks * 16);
+            if (!parts) return CN_EINVAL;
+        }
+        int nb = blocks;
+        if (g.cin == 3 && g.cout == 3 && (((uintptr_t)x | (uintptr_t)gy) & 15) == 0) {
+            nb = blocks > 512 ? 512 : blocks;
+            hipLaunchKernelGGL(tiny_wgrad_3x3_kernel, dim3(nb), dim3(256), 0, s, x, gy, gw, M, parts);
+        } else {
+            hipLaunchKernelGGL(tiny_wgrad_1x1_kernel, dim3(blocks), dim3(256), 0, s, x, gy, gw, M, g.cin, g.cout, parts);
+        }
         CN_LAUNCH_CHECK();
+        if (parts) return cn_sum_parts(parts, gw, nb, (long)g.cin * g.cout, 1, 1.f, s);
         return CN_OK;
     }
     cn_prof_begin(s, conv_flops(g));

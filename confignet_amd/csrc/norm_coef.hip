@@ -168,7 +168,7 @@ __global__ void dual_coef_fwd_kernel(const float* __restrict__ T1, const float* 
 }
 
 struct DualBwdOut {
-    float *K1, *K2, *K0, *D2, *D0, *kh, *kt, *ka, *kc, *et, *ex, *e0, *ggamma;
+    float *K1, *K2, *K0, *D2, *D0, *kh, *kt, *ka, *kc, *et, *ex, *e0, *ggamma, *ggamma_rows;
 };
 
 __global__ void dual_coef_bwd_kernel(const float* __restrict__ H1, const float* __restrict__ H2p,
@@ -206,7 +206,7 @@ __global__ void dual_coef_bwd_kernel(const float* __restrict__ H1, const float* 
         o.kt[i] = -g * h2 * q * q * invS / sigma;
         o.ka[i] = ka;
         o.kc[i] = k0 - ka * mu;
-        unsafeAtomicAdd(&o.ggamma[c], q * e - q * tmu * h1 + tq * h2);
+        o.ggamma_rows[i] = q * e - q * tmu * h1 + tq * h2;      // summed over the rows in row order afterwards (no atomics)
     } else if (u) {
         const int p = (n % period) * C + c;
         const float m = sm[p], sd = ssd[p];
@@ -284,22 +284,21 @@ extern "C" int cn_dual_tail_coef_bwd(const float* H1, const float* H2p, const fl
                                      const float* T2, const float* U1, const float* U2, const float* mean, const float* q,
                                      const float* sm, const float* ssd, const float* gamma, float* const* out13, int n, int c,
                                      int S, float eps, int n_style, int period, void* stream) {
+    // out13[13] (a 14th entry): scratch of (n - n_style) * c floats for the per-row dgamma terms
     CN_CHECK_ARG(n > 0 && c > 0 && S > 0 && out13 && (H1 || u) && n_style >= 0 && n_style <= n && period > 0, "dual_tail_coef_bwd: bad args");
     CN_CHECK_ARG((n_style == 0 || u) && (n_style == n || H1), "dual_tail_coef_bwd: a row range without its input tensors");
     DualBwdOut o;
     o.K1 = out13[0]; o.K2 = out13[1]; o.K0 = out13[2]; o.D2 = out13[3]; o.D0 = out13[4];
     o.kh = out13[5]; o.kt = out13[6]; o.ka = out13[7]; o.kc = out13[8];
-    o.et = out13[9]; o.ex = out13[10]; o.e0 = out13[11]; o.ggamma = out13[12];
-    CN_CHECK_ARG(!H1 || (H2p && E && T1 && T2 && mean && q && gamma && o.K1 && o.K2 && o.K0 && o.kh && o.kt && o.ka && o.kc && o.ggamma),
+    o.et = out13[9]; o.ex = out13[10]; o.e0 = out13[11]; o.ggamma = out13[12]; o.ggamma_rows = out13[13];
+    CN_CHECK_ARG(!H1 || (H2p && E && T1 && T2 && mean && q && gamma && o.K1 && o.K2 && o.K0 && o.kh && o.kt && o.ka && o.kc && o.ggamma && o.ggamma_rows),
                  "dual_tail_coef_bwd: missing instance-norm tensors");
     CN_CHECK_ARG(!u || (U1 && U2 && sm && ssd && o.D2 && o.D0 && o.et && o.ex && o.e0), "dual_tail_coef_bwd: missing style tensors");
     hipStream_t s = (hipStream_t)stream;
-    if (H1) {
-        if (int ez__ = cn_zero_async(o.ggamma, sizeof(float) * c, s)) return ez__;
-    }
     hipLaunchKernelGGL(dual_coef_bwd_kernel, dim3(cn_cdiv((long)n * c, 256)), dim3(256), 0, s, H1, H2p, E, u, T1, T2, U1, U2, mean,
                        q, sm, ssd, gamma, o, n, c, 1.f / (float)S, eps, n_style, period);
     CN_LAUNCH_CHECK();
+    if (H1) return cn_sum_parts(o.ggamma_rows, o.ggamma, n - n_style, c, 0, 1.f, s);
     return CN_OK;
 }
 

@@ -86,6 +86,60 @@ extern "C" int cn_prof_collect(int* launches, double* total_ms, double* total_fl
 }
 
 
+// ---- deterministic mode ------------------------------------------------------------------------------------------
+namespace {
+int g_det = 0;
+std::mutex g_det_mu;
+float* g_det_buf[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+hipStream_t g_det_stream[8];
+int g_det_used = 0;
+
+__global__ void sum_parts_kernel(const float* __restrict__ src, float* __restrict__ dst, int parts, long count, int accumulate,
+                                 float scale) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    float t = 0.f;
+    for (int p = 0; p < parts; ++p) t += src[(long)p * count + i];
+    t *= scale;
+    dst[i] = accumulate ? dst[i] + t : t;
+}
+}  // namespace
+
+extern "C" int cn_set_deterministic(int on) {
+    std::lock_guard<std::mutex> lk(g_det_mu);
+    if (on && !g_det_buf[0]) {
+        for (int i = 0; i < 8; ++i) CN_HIP(hipMalloc((void**)&g_det_buf[i], sizeof(float) * CN_DET_WS_FLOATS));
+    }
+    g_det = on ? 1 : 0;
+    return CN_OK;
+}
+
+extern "C" int cn_get_deterministic(void) { return g_det; }
+
+int cn_det() { return g_det; }
+
+float* cn_det_ws(hipStream_t s, size_t need_floats) {
+    std::lock_guard<std::mutex> lk(g_det_mu);
+    if (!g_det_buf[0] || need_floats > CN_DET_WS_FLOATS) {
+        cn_set_error("deterministic workspace: %zu floats requested, %zu available per stream", need_floats, g_det_buf[0] ? CN_DET_WS_FLOATS : (size_t)0);
+        return nullptr;
+    }
+    for (int i = 0; i < g_det_used; ++i)
+        if (g_det_stream[i] == s) return g_det_buf[i];
+    if (g_det_used == 8) {
+        cn_set_error("deterministic workspace: more than 8 streams");
+        return nullptr;
+    }
+    g_det_stream[g_det_used] = s;
+    return g_det_buf[g_det_used++];
+}
+
+int cn_sum_parts(const float* src, float* dst, int parts, long count, int accumulate, float scale, hipStream_t s) {
+    hipLaunchKernelGGL(sum_parts_kernel, dim3(cn_cdiv(count, 256)), dim3(256), 0, s, src, dst, parts, count, accumulate, scale);
+    CN_LAUNCH_CHECK();
+    return CN_OK;
+}
+
 namespace {
 __global__ void zero_kernel(float* __restrict__ p, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = 0.f;

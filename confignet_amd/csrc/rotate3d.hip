@@ -218,6 +218,93 @@ __global__ __launch_bounds__(256) void rotate3d_bwd_lds_kernel(const float* __re
     }
 }
 
+// Deterministic backward (cn_set_deterministic): ONE wave owns (sample n, 8 channels) and walks the output voxels in index
+// order; lane = (tap, channel) -- the eight taps of a voxel go to eight different addresses of the wave's LDS slab, except
+// where a clamped coordinate makes two taps coincide, and there the coinciding tap has weight exactly 0 (q clamped onto the
+// border => fractional part 0), so the order of those two adds cannot change the sum.  Contributions of different voxels to
+// one address are added in voxel order.  The rotation-matrix gradient goes to per-workgroup partials (added in order after).
+__global__ __launch_bounds__(64) void rotate3d_bwd_det_kernel(const float* __restrict__ grid, const float* __restrict__ rot,
+                                                              const float* __restrict__ gout, float* __restrict__ ggrid,
+                                                              float* __restrict__ grot_parts, int G, int C) {
+    __shared__ float slab[SLAB_FLOATS];                 // [voxel][8 channels]
+    const int n = blockIdx.y, c0 = blockIdx.x * 8;
+    const int P = G * G * G;
+    const int lane = threadIdx.x, tap = lane >> 3, ch = lane & 7;
+    const bool live = c0 + ch < C;
+    for (int i = lane; i < P * 8; i += 64) slab[i] = 0.f;
+    __syncthreads();
+    const float* R = rot + n * 9;
+    const float ctr = 0.5f * (float)(G - 1);
+    const float* gsrc = grid + (long)n * P * C;
+    float g9[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) g9[i] = 0.f;
+    constexpr int U = 4;                                // voxels per trip: their loads are in flight together
+    for (int p0 = 0; p0 < P; p0 += U) {
+        Taps t[U];
+        int o[U];
+        float w[U], gv[U], src[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int p = min(p0 + u, P - 1);
+            t[u] = make_taps(R, p, G);
+            const int xs = (tap & 1) ? t[u].x1 : t[u].x0, ys = (tap & 2) ? t[u].y1 : t[u].y0, zs = (tap & 4) ? t[u].z1 : t[u].z0;
+            w[u] = ((tap & 1) ? t[u].dx : 1.f - t[u].dx) * ((tap & 2) ? t[u].dy : 1.f - t[u].dy) * ((tap & 4) ? t[u].dz : 1.f - t[u].dz);
+            o[u] = (xs * G + ys) * G + zs;
+            gv[u] = (live && p0 + u < P) ? gout[((long)n * P + p) * C + c0 + ch] : 0.f;
+            src[u] = (live && grot_parts) ? gsrc[(long)o[u] * C + c0 + ch] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int p = p0 + u;
+            if (p >= P) break;
+            atomicAdd(&slab[o[u] * 8 + ch], gv[u] * w[u]);      // (LDS; distinct addresses within the wave but for zero-weight twins)
+            if (grot_parts) {
+                // d out / d q through the eight source values of this lane's channel: every lane needs all eight -> shuffles
+                float c8[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) c8[k] = __shfl(src[u], k * 8 + ch, 64);
+                if (tap == 0) {
+                    const Taps& tt = t[u];
+                    const float wx0 = 1.f - tt.dx, wy0 = 1.f - tt.dy, wz0 = 1.f - tt.dz;
+                    // tap bit 0 = x, bit 1 = y, bit 2 = z
+                    const float c000 = c8[0], c100 = c8[1], c010 = c8[2], c110 = c8[3], c001 = c8[4], c101 = c8[5], c011 = c8[6], c111 = c8[7];
+                    const float c00 = c000 * wx0 + c100 * tt.dx, c01 = c001 * wx0 + c101 * tt.dx;
+                    const float c10 = c010 * wx0 + c110 * tt.dx, c11 = c011 * wx0 + c111 * tt.dx;
+                    const float cc0 = c00 * wy0 + c10 * tt.dy, cc1 = c01 * wy0 + c11 * tt.dy;
+                    float gq2 = gv[u] * (cc1 - cc0);
+                    float gq1 = gv[u] * ((c10 - c00) * wz0 + (c11 - c01) * tt.dz);
+                    const float ex0 = (c100 - c000) * wy0 + (c110 - c010) * tt.dy;
+                    const float ex1 = (c101 - c001) * wy0 + (c111 - c011) * tt.dy;
+                    float gq0 = gv[u] * (ex0 * wz0 + ex1 * tt.dz);
+                    if (!tt.px) gq0 = 0.f;
+                    if (!tt.py) gq1 = 0.f;
+                    if (!tt.pz) gq2 = 0.f;
+                    const float pc0 = (float)(p / (G * G)) - ctr, pc1 = (float)((p / G) % G) - ctr, pc2 = (float)(p % G) - ctr;
+                    g9[0] += gq0 * pc0; g9[1] += gq0 * pc1; g9[2] += gq0 * pc2;
+                    g9[3] += gq1 * pc0; g9[4] += gq1 * pc1; g9[5] += gq1 * pc2;
+                    g9[6] += gq2 * pc0; g9[7] += gq2 * pc1; g9[8] += gq2 * pc2;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    float* dst = ggrid + (long)n * P * C + c0;
+    for (int i = lane; i < P * 8; i += 64) {
+        const int p = i >> 3, c = i & 7;
+        if (c0 + c < C) dst[(long)p * C + c] = slab[i];
+    }
+    if (grot_parts) {
+        // lanes 0..7 (tap 0) hold one channel each: add them in channel order
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            float v = 0.f;
+            for (int k = 0; k < 8; ++k) v += __shfl(g9[i], k, 64);
+            if (lane == 0) grot_parts[((long)blockIdx.x * gridDim.y + n) * 9 + i] = v;     // [channel block][n][9]
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int cn_rotate3d_fwd(const float* grid, const float* rot, float* out, int n, int g, int c, void* stream) {
@@ -233,6 +320,18 @@ extern "C" int cn_rotate3d_bwd(const float* grid, const float* rot, const float*
     CN_CHECK_ARG(grid && rot && gout && ggrid && n > 0 && g > 1 && c > 0 && c % 4 == 0, "rotate3d_bwd: bad args");
     hipStream_t s = (hipStream_t)stream;
     const long P = (long)g * g * g;
+    if (cn_det() && P * 8 <= SLAB_FLOATS) {
+        const int cblocks = cn_cdiv(c, 8);
+        float* parts = nullptr;
+        if (grot) {
+            parts = cn_det_ws(s, (size_t)cblocks * n * 9);
+            if (!parts) return CN_EINVAL;
+        }
+        hipLaunchKernelGGL(rotate3d_bwd_det_kernel, dim3(cblocks, n), dim3(64), 0, s, grid, rot, gout, ggrid, parts, g, c);
+        CN_LAUNCH_CHECK();
+        if (grot) return cn_sum_parts(parts, grot, cblocks, (long)n * 9, 0, 1.f, s);
+        return CN_OK;
+    }
     if (grot) {
         if (int ez__ = cn_zero_async(grot, sizeof(float) * n * 9, s)) return ez__;
     }

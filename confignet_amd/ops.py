@@ -32,6 +32,28 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+# Deterministic mode (CN_DETERMINISTIC=1 or set_deterministic(True); include/confignet_hip.h: cn_set_deterministic): every
+# reduction of the fp32 path in a fixed order instead of fp32 atomics -- two runs on the same inputs are bit-identical.  Also
+# switches off what reorders ADDS between streams: the generator step's fork (both branches add into the generator's slots).
+DETERMINISTIC = False
+
+
+def set_deterministic(on=True):
+    global DETERMINISTIC
+    check(lib.cn_set_deterministic(int(bool(on))), "cn_set_deterministic")
+    DETERMINISTIC = bool(on)
+
+
+def _partial_rows(rows):
+    """Partial rows of a per-channel reduction over `rows` rows: every workgroup ends in one atomic per channel, so a long
+    reduction is spread over partial rows (as if they were samples) that are added afterwards.  Deterministic mode has ONE
+    workgroup per partial row and channel block, so it takes many more of them to keep the chip busy."""
+    if rows < 8192:
+        return 1
+    cands = (256, 128, 64, 32, 16, 8, 4, 2, 1) if DETERMINISTIC else (16, 8, 4, 2, 1)
+    return next(r for r in cands if rows % r == 0)
+
+
 def _ptr(t):
     if t is None:
         return None
@@ -612,8 +634,7 @@ def nc_reduce(x1, x2=None, want_sum=True, want_dot=True, flags=0, slope=0.0, per
         # every workgroup ends in one atomic per channel: spread a long reduction over `rep` partial rows (as if
         # they were samples) so that no address takes more than ~128 of them, then add the partials
         rows = n * s
-        if rows >= 8192:
-            rep = next(r for r in (16, 8, 4, 2, 1) if rows % r == 0)
+        rep = _partial_rows(rows)
         n, s = rep, rows // rep
     if want_sum and want_dot:           # adjacent outputs: cleared by one launch (or by the step's zero pool)
         s12 = zero_pool_alloc((2, n, c), x1.device)
@@ -721,20 +742,20 @@ def dual_tail_coef_bwd(H, E, u, T, U, mean, q, sm, ssd, gamma, spatial, eps=1e-3
     instance-norm group follows H (sum h ...), the style group follows u."""
     ref = mean if mean is not None else sm
     period, c = ref.shape
-    names = ["K1", "K2", "K0", "D2", "D0", "kh", "kt", "ka", "kc", "et", "ex", "e0", "ggamma"]
+    names = ["K1", "K2", "K0", "D2", "D0", "kh", "kt", "ka", "kc", "et", "ex", "e0", "ggamma", "ggamma_rows"]
     out = {k: None for k in names}
     mk = lambda *sh: torch.empty(sh, device=ref.device, dtype=torch.float32)
     n_inst = n_style = 0
     if H is not None:
         n_inst = H[0].shape[0]
-        for k in ("K1", "K2", "K0", "kh", "kt", "ka", "kc"):
+        for k in ("K1", "K2", "K0", "kh", "kt", "ka", "kc", "ggamma_rows"):
             out[k] = mk(n_inst, c)
         out["ggamma"] = mk(c)
     if u is not None:
         n_style = u.shape[0]
         for k in ("D2", "D0", "et", "ex", "e0"):
             out[k] = mk(n_style, c)
-    arr = (ctypes.c_void_p * 13)(*[(out[k].data_ptr() if out[k] is not None else None) for k in names])
+    arr = (ctypes.c_void_p * 14)(*[(out[k].data_ptr() if out[k] is not None else None) for k in names])
     H1, H2p = H if H is not None else (None, None)
     T1, T2 = T if T is not None else (None, None)
     U1, U2 = U if U is not None else (None, None)
@@ -793,7 +814,7 @@ def act_bwd_bias(gy, y, act, slope=0.0, sink=None):
     gy, y = _unify(gy, y)
     _, _, c = _nsc(gy)
     rows = gy.numel() // c
-    rep = next(r for r in (16, 8, 4, 2, 1) if rows % r == 0) if rows >= 8192 else 1      # as nc_reduce(per_channel=True)
+    rep = _partial_rows(rows)                       # as nc_reduce(per_channel=True)
     gx = torch.empty_like(gy)
     gb = zero_pool_alloc((rep, c), gy.device)
     flags = 16
@@ -824,7 +845,7 @@ def bias_grad(gy, sink=None):
         return nc_reduce(gy, None, want_dot=False, per_channel=True)[0].reshape(-1)
     c = gy.shape[-1]
     rows = gy.numel() // c
-    rep = next(r for r in (16, 8, 4, 2, 1) if rows % r == 0) if rows >= 8192 else 1
+    rep = _partial_rows(rows)
     part = zero_pool_alloc((rep, c), gy.device)
     flags = 16
     if part is None:
@@ -1019,3 +1040,7 @@ def prof_collect():
     n, ms, fl = ctypes.c_int(0), ctypes.c_double(0), ctypes.c_double(0)
     check(lib.cn_prof_collect(ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl)), "cn_prof_collect")
     return n.value, ms.value, fl.value
+
+
+if os.environ.get("CN_DETERMINISTIC") == "1":
+    set_deterministic(True)

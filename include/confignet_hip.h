@@ -141,6 +141,13 @@ int cn_gemm(int trans_a, int trans_b, int m, int n, int k, const float* a, int l
             const float* b, int ldb, float* c, int ldc, const float* bias, int act, float slope,
             void* stream);
 
+/* Deterministic mode (process-wide; switch between steps, not inside a captured graph): with on != 0 every reduction of the
+ * fp32 path runs in a fixed order -- nc_reduce with one workgroup per (n, channel block), no split-K in cn_conv_fwd / cn_gemm,
+ * the filter gradients / loss reductions / the rotation's scatter through per-split partials that a second launch adds in
+ * index order -- so two runs on the same inputs give bit-identical results (at a cost: see DESIGN.md).  Allocates 8 per-stream
+ * workspaces of 64 MiB on first use.  The bf16 family is not covered. */
+int cn_set_deterministic(int on);
+int cn_get_deterministic(void);
 /* Clears `bytes` (a multiple of 4) at p with a kernel launch (a HIP-graph node that re-executes on replay). */
 int cn_zero(void* p, size_t bytes, void* stream);
 /* C += op(A) op(B) (fp32 atomics): a Dense layer's weight gradient added straight into its slot of the network's gradient
@@ -196,7 +203,7 @@ int cn_norm_coef_bwd(int mode, const float* t1, const float* t2, const float* sa
  * backward through a tangent forward pass.  T1 = sum ta, T2 = sum ta*a (ta = lrelu'(x) tx, a = lrelu(x)),
  * U1 = sum tx, U2 = sum tx*x; mean/q and sm/ssd are the primal instance-norm / style statistics.
  * fwd: ty = C1*ta + C2*a + C0 and tstyle (N,2C).  bwd (H1 = sum h, H2p = sum h*a, E = sum h*ta, u = d tstyle):
- *   out13 = {K1,K2,K0,D2,D0, kh,kt,ka,kc, et,ex,e0, dgamma}: g_tx = lrelu'(x)(K1 h + K2 a + K0) + D2 x + D0,
+ *   out13 = {K1,K2,K0,D2,D0, kh,kt,ka,kc, et,ex,e0, dgamma, dgamma_rows (scratch, one float per instance-norm row and channel)}: g_tx = lrelu'(x)(K1 h + K2 a + K0) + D2 x + D0,
  *   g_x = lrelu'(x)(kh h + kt ta + ka a + kc) + et tx + ex x + e0 (cn_dual_tail_gx).  Either half optional.
  * Batched tangent pass (the six heads' tangents stacked along the sample axis against ONE copy of the primal activations,
  * round 3): the coefficient kernels take `n` stacked samples of which rows [0, n_style) are the head that LEAVES through this

@@ -717,3 +717,48 @@ def test_eager_forwards_between_replays_and_after_ema_see_the_current_weights(mo
     assert np.abs(img1.astype(int) - img_ref.astype(int)).max() <= 1, np.abs(img1.astype(int) - img_ref.astype(int)).max()
     assert np.abs(emb1 - emb_ref).max() <= 1e-4 * max(1.0, np.abs(emb_ref).max()), np.abs(emb1 - emb_ref).max()
     assert np.abs(img1.astype(int) - img0.astype(int)).max() > 1 and np.abs(emb1 - emb0).max() > 1e-4     # (the weights did move)
+
+
+@pytest.mark.parametrize("graphs", [False, True])
+def test_deterministic_mode_is_bitwise_reproducible(graphs):
+    """cn_set_deterministic (CN_DETERMINISTIC=1): fixed-order reductions instead of fp32 atomics in the statistics passes,
+    split-K, the filter gradients, the loss reductions and the rotation's scatter -- two runs of two whole training
+    iterations from the same state end in BIT-IDENTICAL weights, Adam moments and loss scalars (the default mode does not:
+    the order of its atomics decides last bits, and through lr*sign(g) steps whole entries)."""
+    from confignet_amd import ops
+    ops.set_deterministic(True)
+    try:
+        m, real_set, synth_set, d_opt, g_opt = _small_second_stage()
+        assert not m.fork_generator_step
+        m.use_graphs = graphs
+        m.overlap_discriminators = graphs
+        nets = m.all_networks()
+        for _ in range(4 if graphs else 1):                   # (graphs: eager warm-ups, capture, first pipelined replay)
+            m.training_iteration(real_set, synth_set, d_opt, g_opt)
+        torch.cuda.synchronize()
+        start = [n.get_weights() for n in nets]
+
+        def run():
+            for n, w0 in zip(nets, start):
+                n.set_weights(w0)
+            for o in (d_opt, g_opt):
+                o.iterations = 0
+                for mom, var in o._state.values():
+                    mom.zero_(); var.zero_()
+            np.random.seed(123)
+            losses = []
+            for _ in range(2):
+                out = m.training_iteration(real_set, synth_set, d_opt, g_opt)
+                losses.append([{k: float(v) for k, v in d.items()} for d in out])
+            torch.cuda.synchronize()
+            state = [n.arena.detach().cpu().clone() for n in nets]
+            state += [t.detach().cpu().clone() for o in (d_opt, g_opt) for pair in o._state.values() for t in pair]
+            return losses, state
+
+        l1, s1 = run()
+        l2, s2 = run()
+        assert l1 == l2, [(a, b) for x, y in zip(l1, l2) for da, db in zip(x, y) for (_, a), (_, b) in zip(da.items(), db.items()) if a != b][:5]
+        for i, (a, b) in enumerate(zip(s1, s2)):
+            assert torch.equal(a, b), ("tensor %d differs" % i, float((a - b).abs().max()))
+    finally:
+        ops.set_deterministic(False)
