@@ -124,14 +124,25 @@ float* cn_det_ws(hipStream_t s, size_t need_floats) {
         cn_set_error("deterministic workspace: %zu floats requested, %zu available per stream", need_floats, g_det_buf[0] ? CN_DET_WS_FLOATS : (size_t)0);
         return nullptr;
     }
+    static unsigned long long tick = 0, last_use[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int i = 0; i < g_det_used; ++i)
-        if (g_det_stream[i] == s) return g_det_buf[i];
+        if (g_det_stream[i] == s) {
+            last_use[i] = ++tick;
+            return g_det_buf[i];
+        }
+    int slot = g_det_used;
     if (g_det_used == 8) {
-        cn_set_error("deterministic workspace: more than 8 streams");
-        return nullptr;
+        // more than 8 streams over the life of the process (models come and go): the least recently used binding is handed
+        // to the new stream.  Safe as long as no more than 8 streams run deterministic launches at the same time.
+        slot = 0;
+        for (int i = 1; i < 8; ++i)
+            if (last_use[i] < last_use[slot]) slot = i;
+    } else {
+        ++g_det_used;
     }
-    g_det_stream[g_det_used] = s;
-    return g_det_buf[g_det_used++];
+    g_det_stream[slot] = s;
+    last_use[slot] = ++tick;
+    return g_det_buf[slot];
 }
 
 int cn_sum_parts(const float* src, float* dst, int parts, long count, int accumulate, float scale, hipStream_t s) {
