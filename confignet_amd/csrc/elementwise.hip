@@ -26,7 +26,8 @@ template <int V, typename T>   // V = 4: 4-wide channel groups, V = 1: scalar ch
 __global__ __launch_bounds__(256) void nc_reduce_kernel(const T* __restrict__ x1, const T* __restrict__ x2,
                                                         float* __restrict__ s1, float* __restrict__ s2, int S, int C,
                                                         int rows_per_block, int flags, float slope, int period2,
-                                                        T* __restrict__ dact_out = nullptr, int dact = 0) {
+                                                        T* __restrict__ dact_out = nullptr, int dact = 0,
+                                                        float* __restrict__ parts = nullptr) {
     // dact_out: fused activation backward -- the reduced quantity is x1 * act'(x2) (x2 = the activation's OUTPUT), which is
     // also written to dact_out; only s1 (its sum) is produced.
     const int CG = C / V;                          // channel groups
@@ -91,7 +92,11 @@ __global__ __launch_bounds__(256) void nc_reduce_kernel(const T* __restrict__ x1
                 t2 += red[1][(y * TX + tx) * V + e];
             }
             const long o = (long)n * C + (long)cg * V + e;
-            if (gridDim.y == 1) {                  // the only workgroup of this (n, channel block): no atomics (deterministic mode)
+            if (parts) {                           // deterministic mode: per-row-block partials, added in block order afterwards
+                const long nc = (long)gridDim.z * C;
+                if (s1) parts[(long)blockIdx.y * nc + o] = t1;
+                if (s2) parts[((long)gridDim.y + blockIdx.y) * nc + o] = t2;
+            } else if (gridDim.y == 1) {           // the only workgroup of this (n, channel block): plain stores
                 if (s1) s1[o] = t1;
                 if (s2) s2[o] = t2;
             } else {
@@ -635,7 +640,10 @@ static int nc_reduce_launch(const void* x1, const void* x2, float* s1, float* s2
     // ~512 workgroups in total, at least 4*TY rows each
     static const long red_blocks = getenv("CN_RED_BLOCKS") ? atol(getenv("CN_RED_BLOCKS")) : 512;   // sweep: fewer, longer workgroups = shorter same-address atomic tails
     long want = red_blocks / ((long)cblk * n);
-    if (cn_det()) want = 1;         // deterministic mode: one workgroup per (n, channel block), rows summed in a fixed order
+    if (cn_det()) {                 // deterministic mode: as many row blocks as the per-stream workspace holds partials for
+        const long cap = (long)(CN_DET_WS_FLOATS / (2 * (size_t)n * c));
+        if (want > cap) want = cap;
+    }
     if (want < 1) want = 1;
     if (want > 256) want = 256;     // same-address atomics serialise (~100 ns each): 2048 per address cost 200 us
     long rpb = (s + want - 1) / want;
@@ -644,12 +652,21 @@ static int nc_reduce_launch(const void* x1, const void* x2, float* s1, float* s2
     dim3 grid(cblk, sblk, n), block(TX, TY);
     const int period2 = flags >> 8;                 // bits 8..: x2 holds `period2` samples, used for sample n as n % period2
     CN_CHECK_ARG(period2 == 0 || (x2 && n % period2 == 0), "nc_reduce: bad x2 period %d for n = %d", period2, n);
+    float* parts = nullptr;
+    if (cn_det() && sblk > 1) {
+        parts = cn_det_ws(st, 2 * (size_t)sblk * n * c);
+        if (!parts) return CN_EINVAL;
+    }
     CN_DISPATCH_DT(dt, {
         const T* p1 = (const T*)x1; const T* p2 = (const T*)x2;
-        if (V == 4) hipLaunchKernelGGL((nc_reduce_kernel<4, T>), grid, block, 0, st, p1, p2, s1, s2, s, c, (int)rpb, flags & 255, slope, period2, (T*)dact_out, dact);
-        else hipLaunchKernelGGL((nc_reduce_kernel<1, T>), grid, block, 0, st, p1, p2, s1, s2, s, c, (int)rpb, flags & 255, slope, period2, (T*)dact_out, dact);
+        if (V == 4) hipLaunchKernelGGL((nc_reduce_kernel<4, T>), grid, block, 0, st, p1, p2, s1, s2, s, c, (int)rpb, flags & 255, slope, period2, (T*)dact_out, dact, parts);
+        else hipLaunchKernelGGL((nc_reduce_kernel<1, T>), grid, block, 0, st, p1, p2, s1, s2, s, c, (int)rpb, flags & 255, slope, period2, (T*)dact_out, dact, parts);
     });
     CN_LAUNCH_CHECK();
+    if (parts) {
+        if (s1) { if (int e = cn_sum_parts(parts, s1, sblk, (long)n * c, 0, 1.f, st)) return e; }
+        if (s2) { if (int e = cn_sum_parts(parts + (size_t)sblk * n * c, s2, sblk, (long)n * c, 0, 1.f, st)) return e; }
+    }
     return CN_OK;
 }
 

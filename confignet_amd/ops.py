@@ -46,12 +46,10 @@ def set_deterministic(on=True):
 
 def _partial_rows(rows):
     """Partial rows of a per-channel reduction over `rows` rows: every workgroup ends in one atomic per channel, so a long
-    reduction is spread over partial rows (as if they were samples) that are added afterwards.  Deterministic mode has ONE
-    workgroup per partial row and channel block, so it takes many more of them to keep the chip busy."""
+    reduction is spread over partial rows (as if they were samples) that are added afterwards."""
     if rows < 8192:
         return 1
-    cands = (256, 128, 64, 32, 16, 8, 4, 2, 1) if DETERMINISTIC else (16, 8, 4, 2, 1)
-    return next(r for r in cands if rows % r == 0)
+    return next(r for r in (16, 8, 4, 2, 1) if rows % r == 0)
 
 
 def _ptr(t):
