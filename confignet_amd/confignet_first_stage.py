@@ -98,6 +98,7 @@ class ConfigNetFirstStage:
         self._bufs = StaticBuffers(self.device)
         self._graphs = {}
         self._deferred = None
+        self._deferred_terms = []                    # loss terms differentiated by hand in _generator_update (global batch statistics)
         self._prestaged, self._stagers = {}, {}      # cross-iteration overlap of the discriminator steps (see overlap_discriminators)
         # second stage: real / synthetic branches of the generator step on two streams (not in deterministic mode: both
         # branches add into the generator's gradient slots, and the order of those adds would depend on the race)
@@ -639,13 +640,20 @@ class ConfigNetFirstStage:
         is taken in two parts -- everything down to `tensors` first, whose gradient arenas (generator, latent regressor,
         synthetic encoder: 62 MB) then start their RCCL all-reduce while the second part (the ResNet-50 backward, the last
         and longest stretch of the tape) is still computing; only the encoder's arena is exchanged after it."""
+        roots, cots = losses["loss_sum"], None
+        terms, self._deferred_terms = self._deferred_terms, []
+        if terms:
+            # loss terms with global batch statistics: their (tensor, cotangent) pairs join the scalar as roots of the backward pass
+            pairs = [pc for t in terms for pc in t.cotangents()]
+            roots = [losses["loss_sum"]] + [t for t, _ in pairs]
+            cots = [torch.ones_like(losses["loss_sum"])] + [c for _, c in pairs]
         if cut is None or not parallel.active():
-            backward_into_arenas(losses["loss_sum"], nets)
+            backward_into_arenas(roots, nets, grad_outputs=cots)
         else:
             from .graphs import segment_break
             tensors, late = cut
             early = [n for n in nets if all(n is not m for m in late)]
-            cut_grads = backward_into_arenas(losses["loss_sum"], early, extra=tensors)
+            cut_grads = backward_into_arenas(roots, early, extra=tensors, grad_outputs=cots)
             segment_break(lambda: parallel.begin_allreduce(early))
             live = [(t, g) for t, g in zip(tensors, cut_grads) if g is not None]
             backward_into_arenas([t for t, _ in live], late, grad_outputs=[g for _, g in live])

@@ -10,7 +10,7 @@ from . import confignet_utils, ops, optim, parallel
 from .confignet_first_stage import DEFAULT_CONFIG, ConfigNetFirstStage, frozen
 from .dnn_models.hologan_generator import HologanGenerator
 from .dnn_models.real_encoder import RealEncoder
-from .losses import GAN_D_loss, GAN_G_loss, compute_latent_discriminator_loss, eye_loss, mean_squared_error
+from .losses import GAN_D_loss, GAN_G_loss, compute_latent_discriminator_loss, eye_loss, mean_squared_error, normalized_latent_regression
 from .nn import Net, backward_into_arenas
 from .perceptual_loss import PerceptualLoss
 
@@ -61,11 +61,14 @@ class ConfigNet(ConfigNetFirstStage):
         """confignet_second_stage.py:93-107.  The (N, L+3) batch statistics are latent-vector algebra
         (host-side plumbing); the latent regressor itself runs on HIP kernels."""
         out = self.latent_regressor(generator_outputs)
-        den = torch.sqrt(labels.var(dim=0, unbiased=False, keepdim=True) + 1e-3)
-        den = torch.cat((den[:, :-3], torch.ones((1, 3), device=den.device)), dim=1)
-        out = out.mean(dim=0) + (out - out.mean(dim=0)) / den
-        labels = labels.mean(dim=0) + (labels - labels.mean(dim=0)) / den
-        return mean_squared_error(labels, out) * self.config["latent_regression_weight"]
+        # config["dp_global_batch_statistics"] (default off): under data parallelism the batch statistics of the GLOBAL batch
+        # (one 2 x (L + 3)-float all-reduce forward and one backward per statistic) instead of the per-rank ones
+        if bool(self.config.get("dp_global_batch_statistics", False)) and parallel.active():
+            from .losses import DeferredGlobalStatsRegression
+            term = DeferredGlobalStatsRegression(out, labels, self.config["latent_regression_weight"])
+            self._deferred_terms.append(term)          # differentiated by _generator_update (its collectives run on this thread)
+            return term.value
+        return normalized_latent_regression(out, labels, self.config["latent_regression_weight"])
 
     def sample_random_batch_of_images(self, dataset, batch_size=None):
         """confignet_second_stage.py:109-117 (device gather of the staged indices/flips)."""

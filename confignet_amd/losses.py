@@ -141,6 +141,103 @@ def compute_latent_discriminator_loss(latent_discriminator, real_latents, fake_l
     return losses
 
 
+class GlobalBatchMoments(torch.autograd.Function):
+    """(mean, biased variance) over the GLOBAL batch of an (N_local, F) tensor under data parallelism: the per-feature sums
+    and sums of squares are added over the ranks (2 F floats), and in the backward pass the cotangents of the two statistics
+    are added over the ranks before they are pushed to the local rows -- each rank's loss depends on every rank's rows through
+    the statistics, and the data-parallel objective is the mean of the ranks' losses (option (i) of SURVEY.md section 8e for
+    confignet_second_stage.py:93-107; equal shards assumed, as everywhere in the data-parallel path)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        from . import parallel
+        n = x.shape[0] * parallel.world_size()
+        s = torch.cat((x.sum(dim=0), (x * x).sum(dim=0)))
+        parallel.allreduce_sum_inline(s)
+        f = x.shape[1]
+        mean = s[:f] / n
+        var = s[f:] / n - mean * mean
+        ctx.save_for_backward(x, mean)
+        ctx.n = n
+        return mean, var
+
+    @staticmethod
+    def backward(ctx, g_mean, g_var):
+        from . import parallel
+        x, mean = ctx.saved_tensors
+        f = x.shape[1]
+        g = torch.cat((g_mean if g_mean is not None else torch.zeros_like(mean), g_var if g_var is not None else torch.zeros_like(mean))).contiguous()
+        parallel.allreduce_sum_inline(g)
+        return (g[:f] + 2.0 * g[f:] * (x - mean)) / ctx.n
+
+
+class DeferredGlobalStatsRegression:
+    """normalized_latent_regression with GLOBAL batch statistics in a form whose collectives all run on the calling thread
+    (a captured step cuts its HIP graph at a collective, and a graph cannot be cut from autograd's worker thread, where a
+    Function's backward would run).  Forward: the three statistics come from one all-reduce of the local sums and enter the
+    loss as LEAVES.  `cotangents()` -- called by the step's update, before the main backward pass -- takes the loss's gradient
+    w.r.t. (labels, out, leaves) through the few nodes of the normalisation, adds the leaves' gradients over the ranks and folds
+    them back into the cotangents of labels / out; the main backward pass then continues from (labels, out) with those
+    cotangents next to the rest of the loss (`.loss` itself must stay OUT of the differentiated sum: use `.value`)."""
+
+    def __init__(self, out, labels, weight):
+        from . import parallel
+        self.out, self.labels = out, labels
+        f = labels.shape[1]
+        self.n = labels.shape[0] * parallel.world_size()
+        with torch.no_grad():
+            s = torch.cat((labels.sum(dim=0), (labels * labels).sum(dim=0), out.sum(dim=0))).contiguous()
+        parallel.allreduce_sum_inline(s)
+        with torch.no_grad():
+            l_mean = s[:f] / self.n
+            l_var = s[f:2 * f] / self.n - l_mean * l_mean
+            o_mean = s[2 * f:] / self.n
+        self.leaves = [t.clone().requires_grad_(True) for t in (l_mean, l_var, o_mean)]
+        lm, lv, om = (t.unsqueeze(0) for t in self.leaves)
+        den = torch.sqrt(lv + 1e-3)
+        den = torch.cat((den[:, :-3], torch.ones((1, 3), device=den.device, dtype=den.dtype)), dim=1)
+        self.loss = mean_squared_error(lm + (labels - lm) / den, om + (out - om) / den) * weight
+        self.value = self.loss.detach()
+
+    def cotangents(self):
+        """[(tensor, cotangent)] for labels and out: what the main backward pass continues from."""
+        from . import parallel
+        srcs = [t for t in (self.labels, self.out) if t.requires_grad]
+        grads = torch.autograd.grad(self.loss, srcs + self.leaves, allow_unused=True)
+        g_src = dict(zip([id(t) for t in srcs], grads[:len(srcs)]))
+        g = torch.cat([gi if gi is not None else torch.zeros_like(l) for gi, l in zip(grads[len(srcs):], self.leaves)]).contiguous()
+        parallel.allreduce_sum_inline(g)
+        f = self.labels.shape[1]
+        g_lm, g_lv, g_om = g[:f], g[f:2 * f], g[2 * f:]
+        out = []
+        if self.labels.requires_grad:
+            with torch.no_grad():
+                extra = (g_lm + 2.0 * g_lv * (self.labels - self.leaves[0])) / self.n
+            out.append((self.labels, g_src[id(self.labels)] + extra))
+        if self.out.requires_grad:
+            out.append((self.out, g_src[id(self.out)] + g_om / self.n))
+        return out
+
+
+def normalized_latent_regression(out, labels, weight, global_statistics=False):
+    """The arithmetic of ConfigNet.compute_normalized_latent_regression_loss (confignet_second_stage.py:96-107) on the
+    regressor's output: both sides are re-centred and the latent part is divided by the batch standard deviation of the labels.
+    global_statistics: the batch statistics are those of the GLOBAL batch of a data-parallel step (GlobalBatchMoments), so
+    that W ranks at batch B/W optimise exactly the single-process objective at batch B."""
+    if global_statistics:
+        l_mean, l_var = GlobalBatchMoments.apply(labels)
+        o_mean, _ = GlobalBatchMoments.apply(out)
+        l_mean, l_var, o_mean = l_mean.unsqueeze(0), l_var.unsqueeze(0), o_mean.unsqueeze(0)
+    else:
+        l_mean, l_var = labels.mean(dim=0, keepdim=True), labels.var(dim=0, unbiased=False, keepdim=True)
+        o_mean = out.mean(dim=0, keepdim=True)
+    den = torch.sqrt(l_var + 1e-3)
+    den = torch.cat((den[:, :-3], torch.ones((1, 3), device=den.device, dtype=den.dtype)), dim=1)
+    out = o_mean + (out - o_mean) / den
+    labels = l_mean + (labels - l_mean) / den
+    return mean_squared_error(labels, out) * weight
+
+
 def mean_squared_error(labels, outputs):
     """reduce_mean(tf.losses.mean_squared_error(a, b)) == global mean (R7).  Only ever applied to
     (N, latent_dim+3) tensors (<= a few thousand floats, gradients on BOTH sides through the encoders):

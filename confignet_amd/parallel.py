@@ -63,6 +63,17 @@ def allreduce_flat_(buffers):
             b.mul_(1.0 / ws)
 
 
+def allreduce_sum_inline(t):
+    """SUM over ranks of a small tensor IN THE MIDDLE of a step (global batch statistics of a loss): eager dispatch reduces on
+    the spot; under HIP-graph capture the step's graph is cut here and the collective runs between the two segments at every
+    replay (graphs.segment_break), on the tensor's fixed address in the graph's pool."""
+    if not active():
+        return t
+    from . import graphs
+    graphs.segment_break(lambda: dist.all_reduce(t, op=dist.ReduceOp.SUM))
+    return t
+
+
 _pending = {}        # id(net) -> async work handle of an all-reduce of its gradient arena that is in flight
 
 

@@ -98,7 +98,35 @@ def _worker(rank, world, port, out_dir):
     parallel.begin_allreduce([early])                             # ... the cut inside the step starts the early bucket ...
     optim.run_deferred(items)                                     # ... and StepGraph.finish() waits for it, reduces the rest, applies
     ok_adam = all(float((n.arena - w).abs().max()) < 1e-6 for n, w in zip((early, late), want)) and not parallel._pending
-    torch.save({"err": err, "bcast": ok_bcast, "adam": ok_adam, "theta": torch.cat([early.arena, late.arena])},
+    # Global batch statistics of the normalised latent regression (confignet_second_stage.py:93-107, option (i) of SURVEY.md 8e):
+    # with GlobalBatchMoments the rank-mean of the per-shard gradients equals the gradient of the single-process loss on the
+    # whole batch, although every rank's loss depends on every rank's rows through the batch mean / variance.
+    from confignet_amd.losses import normalized_latent_regression
+    gen = torch.Generator().manual_seed(5)
+    X, Y = torch.randn(8, 6, generator=gen, dtype=torch.float64), torch.randn(8, 6, generator=gen, dtype=torch.float64)
+    t1 = torch.randn(6, 7, generator=gen, dtype=torch.float64).requires_grad_(True)
+    t2 = torch.randn(6, 7, generator=gen, dtype=torch.float64).requires_grad_(True)
+    rows = slice(rank * 4, rank * 4 + 4)
+    l_loc = normalized_latent_regression(X[rows] @ t1, Y[rows] @ t2, 10.0, global_statistics=True)
+    g_loc = torch.cat([g.reshape(-1) for g in torch.autograd.grad(l_loc, [t1, t2])]).contiguous()
+    parallel.allreduce_flat_([g_loc])
+    l_all = normalized_latent_regression(X @ t1, Y @ t2, 10.0, global_statistics=False)
+    g_all = torch.cat([g.reshape(-1) for g in torch.autograd.grad(l_all, [t1, t2])])
+    l_mean = l_loc.detach().clone().reshape(1)
+    parallel.allreduce_flat_([l_mean])
+    err_stats = max(float((g_loc - g_all).abs().max() / g_all.abs().max()), abs(float(l_mean) - float(l_all)) / abs(float(l_all)))
+    # the form the captured steps use (collectives on the calling thread: DeferredGlobalStatsRegression) gives the same gradient
+    from confignet_amd.losses import DeferredGlobalStatsRegression
+    o_loc, y_loc = X[rows] @ t1, Y[rows] @ t2
+    term = DeferredGlobalStatsRegression(o_loc, y_loc, 10.0)
+    pairs = term.cotangents()
+    g_def = torch.cat([g.reshape(-1) for g in torch.autograd.grad([t for t, _ in pairs], [t1, t2], grad_outputs=[c for _, c in pairs])]).contiguous()
+    parallel.allreduce_flat_([g_def])
+    err_stats = max(err_stats, float((g_def - g_all).abs().max() / g_all.abs().max()), abs(float(term.value) - float(l_loc)))
+    # ... and per-rank statistics (option (ii), the default) are NOT that objective
+    l_ii = normalized_latent_regression(X[rows] @ t1, Y[rows] @ t2, 10.0, global_statistics=False)
+    differs = abs(float(l_ii) - float(l_loc)) > 1e-6
+    torch.save({"err": err, "bcast": ok_bcast, "adam": ok_adam, "err_stats": err_stats, "differs": differs, "theta": torch.cat([early.arena, late.arena])},
                os.path.join(out_dir, "r%d.pt" % rank))
     dist.barrier()
     dist.destroy_process_group()
@@ -111,5 +139,6 @@ def test_dp_gradient_identity_and_collectives_gloo(tmp_path):
         res = torch.load(os.path.join(str(tmp_path), "r%d.pt" % r))
         assert res["err"] < 1e-10, "DP-averaged gradient != global-batch gradient (%.3e)" % res["err"]
         assert res["bcast"] and res["adam"]
+        assert res["err_stats"] < 1e-10 and res["differs"], "global batch statistics: DP objective != global-batch objective (%.3e)" % res["err_stats"]
     a, b = (torch.load(os.path.join(str(tmp_path), "r%d.pt" % r))["theta"] for r in range(2))
     assert torch.equal(a, b), "replicated Adam must give bit-identical weights on every rank"

@@ -762,3 +762,41 @@ def test_deterministic_mode_is_bitwise_reproducible(graphs):
             assert torch.equal(a, b), ("tensor %d differs" % i, float((a - b).abs().max()))
     finally:
         ops.set_deterministic(False)
+
+
+def test_data_parallel_dispatch_with_overlap_matches_single_process(tmp_path):
+    """The multi-rank code path -- step graphs that end after the backward pass, RCCL all-reduce of the gradient arenas and
+    Adam issued eagerly after every replay (also for the split discriminator graphs of the cross-iteration overlap, whose real
+    half is pre-replayed under the previous generator tail and ACCUMULATES into the arena), the generator step's two-part
+    backward with the early all-reduce of the generator / regressor arenas, and the global batch statistics of the latent
+    regression (DeferredGlobalStatsRegression: two graph cuts with a collective each) -- on a 1-rank RCCL group
+    (CN_FORCE_DP=1), against the single-process dispatch of the same iterations.  Deterministic mode: without the statistics
+    flag the two must agree BIT FOR BIT (a 1-rank mean is the identity; the Adam kernel is the same launch inside or after
+    the graph)."""
+    import subprocess
+    helper = os.path.join(ROOT, "tests", "dp_run_helper.py")
+    dp_env = {"CN_FORCE_DP": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29547", "RANK": "0", "WORLD_SIZE": "1"}
+    outs = []
+    for tag, extra, flag in (("single", {}, 0), ("dp", dp_env, 0), ("dp_stats", dp_env, 1)):
+        env = {k: v for k, v in os.environ.items() if k not in ("CN_FORCE_DP",)}
+        env.update(extra)
+        path = str(tmp_path / (tag + ".npz"))
+        r = subprocess.run([sys.executable, helper, path, str(flag)], env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        outs.append(np.load(path))
+    a, b, c = outs
+    assert not bool(a["dp"][0]) and bool(b["dp"][0]) and bool(b["split"].all()) and not bool(a["split"].any())
+    assert np.array_equal(a["losses"], b["losses"]), np.abs(a["losses"] - b["losses"]).max()
+    for k in a.files:
+        if k[0] in "wmvf":
+            assert np.array_equal(a[k], b[k]), (k, float(np.abs(a[k] - b[k]).max()))
+    # global batch statistics (config["dp_global_batch_statistics"]): with ONE rank the global batch is the local one, so the
+    # objective is the same; the statistics are computed by another formula (E[x^2] - mean^2 of the reduced sums), hence not
+    # bit for bit: first-iteration loss scalars to 1e-4, first-iteration weight steps (lr*sign(g)) equal but for noise-level entries
+    l_a, l_c = a["losses"][0], c["losses"][0]
+    assert np.all(np.abs(l_a - l_c) <= 1e-4 * np.maximum(1.0, np.abs(l_a))), np.abs(l_a - l_c).max()
+    lr = 4e-4
+    for k in a.files:
+        if k[0] == "f":
+            wrong = float((np.abs(a[k] - c[k]) > 0.1 * lr).mean())
+            assert wrong < 0.02, (k, wrong)
