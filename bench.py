@@ -139,6 +139,14 @@ def main():
     ops.prof_enable(False)
     launches, kernel_ms, kernel_flops = ops.prof_collect()
     saved_flops = ops.prof_saved_flops()
+    families = ops.prof_collect_by_family()
+    nst = max(args.steps, 1)
+    by_kernel = {k: {"launches_per_step": round(v["launches"] / nst, 1), "us_per_launch": round(1e3 * v["ms"] / v["launches"], 1),
+                     "tflops": round(v["gflop"] / max(v["ms"], 1e-9), 2),
+                     "algorithmic_mb_per_launch": round(v["algorithmic_mb"] / v["launches"], 2),
+                     "algorithmic_gbps": round(v["algorithmic_mb"] / max(v["ms"], 1e-9), 1)}
+                 for k, v in sorted(families.items(), key=lambda kv: -kv[1]["ms"])}
+    alg_bytes_per_step = sum(v["algorithmic_mb"] for v in families.values()) * 1e6 / nst
 
     t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
     if world > 1:
@@ -171,8 +179,8 @@ def main():
                                     ("" if not parallel.active() else " (fwd+bwd), eager RCCL all-reduce + Adam"))},
             "step_functions_ms": step_ms,
             "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
-                         "frac": round(achieved / peak, 4), "traffic": pmc_traffic() if args.dtype == "f32" else None,
-                         "mfma_busy_pmc": pmc_mfma_busy() if args.dtype == "f32" else None,
+                         "frac": round(achieved / peak, 4), "traffic": pmc_traffic(args.dtype),
+                         "mfma_busy_pmc": pmc_mfma_busy(args.dtype),
                          "kernel": ("igemm_fwd/igemm_wgrad/wino_fwd (implicit-GEMM + Winograd F(2x2,3x3) convolutions, v_mfma_f32_32x32x2_f32)" if args.dtype == "f32" else
                                     "igemm_bf16/igemm_bf16_wgrad (implicit-GEMM conv, v_mfma_f32_32x32x16_bf16) + the fp32 kernels of the "
                                     "3-channel image layers"),
@@ -180,6 +188,11 @@ def main():
                          "kernel_ms_per_step": round(kernel_ms / max(args.steps, 1), 3),
                          "measured": "HIP events around every launch of the class, same K iterations run serially (eager, one stream)",
                          "algorithmic_gflop_per_step": round(kernel_flops / max(args.steps, 1) / 1e9, 2),
+                         "algorithmic_bytes_per_step": round(alg_bytes_per_step),
+                         "algorithmic_bytes_per_launch": round(alg_bytes_per_step * max(args.steps, 1) / max(launches, 1)),
+                         "traffic_over_algorithmic": (round(pmc_traffic(args.dtype) * launches / max(args.steps, 1) / alg_bytes_per_step, 2)
+                                                      if (pmc_traffic(args.dtype) and alg_bytes_per_step) else None),
+                         "by_kernel": by_kernel,
                          "work": "multiply-adds actually issued (Winograd: 16 per 2x2 tile, upsample-folded layers: the parity-class "
                                  "filters); `frac` is therefore comparable with mfma_busy_pmc",
                          "direct_equivalent": {
@@ -188,7 +201,7 @@ def main():
                              "note": "the same launches priced as direct convolutions (round 1's definition of the algorithmic work, "
                                      "border taps of the Winograd layers counted): an algorithmic saving, NOT a roofline fraction"},
                          "recorded": "traffic / mfma_busy_pmc come from committed rocprofv3 PMC passes and are quoted only when "
-                                     "profiles/round2_pmc_*.json carry this kernels_hash",
+                                     "profiles/round3_pmc_*.json carry this kernels_hash",
                          "kernels_hash": kernels_hash()},
             "torch_kernel_time_share": torch_kernel_share(),
         }
@@ -251,23 +264,23 @@ def _recorded(name, key):
         return None
 
 
-def pmc_traffic():
+def pmc_traffic(dtype="f32"):
     """HBM bytes per launch of the dominant kernel class (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE;
     scripts/pmc_summary.py, scripts/pmc_traffic_json.py)."""
-    v = _recorded("round2_pmc_traffic.json", "hbm_bytes_per_launch")
+    v = _recorded("round3_pmc_traffic%s.json" % ("" if dtype == "f32" else "_" + dtype), "hbm_bytes_per_launch")
     return None if v is None else round(v)
 
 
-def pmc_mfma_busy():
+def pmc_mfma_busy(dtype="f32"):
     """MFMA-pipe busy fraction of the class (SQ_VALU_MFMA_BUSY_CYCLES against GRBM_GUI_ACTIVE; scripts/pmc_mfma.py)."""
-    v = _recorded("round2_pmc_mfma.json", "mfma_busy_fraction")
+    v = _recorded("round3_pmc_mfma%s.json" % ("" if dtype == "f32" else "_" + dtype), "mfma_busy_fraction")
     return None if v is None else round(v, 4)
 
 
 def torch_kernel_share():
     """Share of the GPU time of one iteration spent in PyTorch's own kernels (autograd's gradient accumulation adds, cat,
     fills, small (N, L) algebra) from the committed kernel trace of this command -- north_star: torch is plumbing."""
-    v = _recorded("round2_torch_share.json", "torch_kernel_time_share")
+    v = _recorded("round3_torch_share.json", "torch_kernel_time_share")
     return None if v is None else round(v, 4)
 
 

@@ -99,6 +99,7 @@ SIGNATURES = {
     "cn_prof_enable": [_i],
     "cn_prof_reset": [],
     "cn_prof_collect": [ctypes.POINTER(_i), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)],
+    "cn_prof_collect_by_family": [ctypes.POINTER(_i), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)],
 }
 
 for _name, _args in SIGNATURES.items():

@@ -182,7 +182,9 @@ extern "C" int cn_conv_wgrad_c3(const CnConvGeom* gp, const float* x, const void
     size_t lds = sizeof(float) * 4 * (size_t)(3 * pw * 3 + C3W_TILE * gpitch);
     if (lds < sizeof(float) * 4 * 2 * 16 * 64) lds = sizeof(float) * 4 * 2 * 16 * 64;
     hipStream_t s = (hipStream_t)stream;
-    cn_prof_begin(s, 2.0 * 27.0 * g.cout * (double)g.n * g.out_h * g.out_w);
+    cn_prof_begin(s, 2.0 * 27.0 * g.cout * (double)g.n * g.out_h * g.out_w,
+                  4.0 * (double)g.n * g.in_h * g.in_w * 3 + (gy_dt == CN_BF16 ? 2.0 : 4.0) * g.n * g.out_h * g.out_w * g.cout + 4.0 * 27 * g.cout,
+                  CN_FAM_C3_WGRAD);
 #define C3W(S_, T_)                                                                                                              \
     do {                                                                                                                         \
         static bool attr_set = false;                                                                                            \

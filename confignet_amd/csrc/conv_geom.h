@@ -107,6 +107,12 @@ inline double conv_flops(const CnConvGeom& g) {
            valid_pairs_1d(g.out_w, g.k_w, g.s_w, g.dl_w, g.p_w, g.in_w, g.up) * g.cin * g.cout;
 }
 
+// algorithmic HBM bytes of one launch: input (stored extent) and filter read once, output written once; eb = bytes per element
+inline double conv_bytes(const CnConvGeom& g, double eb_in = 4.0, double eb_out = 4.0, double eb_w = 4.0) {
+    return eb_in * g.n * g.in_d * g.in_h * g.in_w * g.cin + eb_w * g.k_d * g.k_h * g.k_w * g.cin * g.cout +
+           eb_out * g.n * g.out_d * g.out_h * g.out_w * g.cout;
+}
+
 // parity-class row order applies to data-gradient geometries of strided convolutions
 inline bool parity_ordered(const CnConvGeom& g) {
     if (g.s_d != 1 || g.s_h != 1 || g.s_w != 1 || g.up) return false;

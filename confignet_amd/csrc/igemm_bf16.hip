@@ -594,7 +594,7 @@ int conv_bf16(const CnConvGeom& g, int flip, const bf16_t* x, const bf16_t* wb, 
     else if (t128x64 >= 512) cfg = 1;
     else cfg = 2;
     if (g.cout % 96 == 0 && g.cout % 128 != 0 && (long)cn_cdiv(M, 128) * (g.cout / 96) >= 256) cfg = 4;
-    cn_prof_begin(s, conv_flops(g));
+    cn_prof_begin(s, conv_flops(g), conv_bytes(g, 2.0, 2.0, 2.0), CN_FAM_BF16_FWD);
     int e;
     switch (cfg) {
         case 3: e = launch_bf16<4, 1, 1, 1>(g, par, flip, x, wb, bias, y, act, slope, s); break;   // 128 x 32
@@ -674,7 +674,7 @@ extern "C" int cn_conv_wgrad_bf16(const CnConvGeom* gp, const uint16_t* x, const
     if (!accumulate) {
         if (int ez__ = cn_zero_async(gw, sizeof(float) * Ktot * g.cout, s)) return ez__;
     }
-    cn_prof_begin(s, conv_flops(g));
+    cn_prof_begin(s, conv_flops(g), conv_bytes(g, 2.0, 2.0, 4.0), CN_FAM_BF16_WGRAD);
     int e;
     if (g.cout <= 32) e = launch_bf16_wgrad<4, 1, 1, 1>(g, x, gy, gw, s);                                     // 128 (tap,ci) x 32 co
     else if (Ktot >= 128 && g.cout % 96 == 0 && g.cout % 128 != 0) e = launch_bf16_wgrad<4, 1, 1, 3>(g, x, gy, gw, s);   // 128 x 96

@@ -1105,7 +1105,7 @@ static int conv_fwd_impl(const CnConvGeom* gp, const float* x, const float* w, c
             g.cout == 3 && g.cin == 32 && g.p_h == 1 && g.p_w == 1 && g.out_h <= 2 * g.in_h && g.out_w <= 2 * g.in_w &&
             !getenv("CN_NO_RGB")) {
             dim3 grid((unsigned)(g.n * cn_cdiv(g.in_h, 8) * cn_cdiv(g.in_w, 16)));
-            cn_prof_begin(s, conv_flops(g));
+            cn_prof_begin(s, conv_flops(g), conv_bytes(g), CN_FAM_THIN);
             hipLaunchKernelGGL((up2k4_rgb_fwd_kernel<4>), grid, dim3(256), 0, s, g, x, w, bias, y, act, slope);
             cn_prof_end(s);
             CN_LAUNCH_CHECK();
@@ -1115,7 +1115,7 @@ static int conv_fwd_impl(const CnConvGeom* gp, const float* x, const float* w, c
             g.cout == 3 && g.cin == 48 && !bias && act == CN_ACT_NONE && g.p_h >= 0 && g.p_h <= 2 && g.p_w >= 0 &&
             g.p_w <= 2 && g.out_h <= 2 * g.in_h && g.out_w <= 2 * g.in_w && !getenv("CN_NO_S2IMG")) {
             dim3 grid((unsigned)(g.n * cn_cdiv(g.in_h, 8) * cn_cdiv(g.in_w, 32)));
-            cn_prof_begin(s, conv_flops(g));
+            cn_prof_begin(s, conv_flops(g), conv_bytes(g), CN_FAM_S2_IMAGE_DGRAD);
             hipLaunchKernelGGL((s2_image_dgrad_kernel<6>), grid, dim3(256), 0, s, g, x, w, y);
             cn_prof_end(s);
             CN_LAUNCH_CHECK();
@@ -1125,7 +1125,7 @@ static int conv_fwd_impl(const CnConvGeom* gp, const float* x, const float* w, c
             // zero-stuffed data-gradient into a thin image: per pixel only ~taps/4 * cin MACs, the per-pixel
             // bookkeeping of a VALU kernel dominates; the 128x32 MFMA tile with dead-tap skipping is faster
             dim3 grid(cn_cdiv(M, 128), 1, 1);
-            cn_prof_begin(s, conv_flops(g));
+            cn_prof_begin(s, conv_flops(g), conv_bytes(g), CN_FAM_FWD_128x32);
             hipLaunchKernelGGL((igemm_fwd_kernel<4, 1, 1, 1, true, false>), grid, dim3(256), 0, s, g, x, w, bias, y, act, slope, 1, g_xcd, 0, 0);
             cn_prof_end(s);
             CN_LAUNCH_CHECK();
@@ -1163,7 +1163,7 @@ static int conv_fwd_impl(const CnConvGeom* gp, const float* x, const float* w, c
     if (!bt && !no_c3 && g.nd == 2 && g.cin == 3 && g.k_h == 3 && g.k_w == 3 && g.s_h == g.s_w && (g.s_h == 1 || g.s_h == 2) &&
         g.dl_h == 1 && g.dl_w == 1 && !g.up && g.cout > 4 && g.cout <= 64) {
         dim3 grid((unsigned)(g.n * cn_cdiv(g.out_h, 8) * cn_cdiv(g.out_w, 32)));
-        cn_prof_begin(s, conv_flops(g));
+        cn_prof_begin(s, conv_flops(g), conv_bytes(g), CN_FAM_C3_FWD);
 #define C3F(S_, NB_) hipLaunchKernelGGL((c3_fwd_kernel<S_, NB_>), grid, dim3(256), 0, s, g, x, w, bias, y, act, slope)
         if (g.s_h == 1) { if (g.cout <= 32) C3F(1, 1); else C3F(1, 2); }
         else { if (g.cout <= 32) C3F(2, 1); else C3F(2, 2); }
@@ -1213,7 +1213,7 @@ static int conv_fwd_impl(const CnConvGeom* gp, const float* x, const float* w, c
     if (splits > 1) {
         if (int ez__ = cn_zero_async(y, sizeof(float) * M * g.cout, s)) return ez__;
     }
-    cn_prof_begin(s, conv_flops(g));
+    cn_prof_begin(s, conv_flops(g), conv_bytes(g), cfg == 0 ? CN_FAM_FWD_128x128 : cfg == 1 ? CN_FAM_FWD_128x64 : cfg == 3 ? CN_FAM_FWD_128x32 : cfg == 4 ? CN_FAM_FWD_128x96 : CN_FAM_FWD_64x64);
     int e;
     switch (cfg) {
         case 3: e = launch_fwd<4, 1, 1, 1>(g, vec, par, splits, x, w, bias, y, kact, slope, s, bt); break;   // 128 x 32
@@ -1255,7 +1255,7 @@ extern "C" int cn_conv_fwd_dt(const CnConvGeom* gp, const void* x, int x_dt, con
     if (x_dt == CN_F32 && y_dt == CN_BF16 && g.nd == 2 && g.cin == 3 && g.k_h == 3 && g.k_w == 3 && g.s_h == g.s_w &&
         (g.s_h == 1 || g.s_h == 2) && g.dl_h == 1 && g.dl_w == 1 && !g.up && g.cout > 4 && g.cout <= 64) {
         dim3 grid((unsigned)(g.n * cn_cdiv(g.out_h, 8) * cn_cdiv(g.out_w, 32)));
-        cn_prof_begin(s, conv_flops(g));
+        cn_prof_begin(s, conv_flops(g), conv_bytes(g, 4.0, 2.0), CN_FAM_C3_FWD);
 #define C3F(S_, NB_) hipLaunchKernelGGL((c3_fwd_kernel<S_, NB_, bf16_t>), grid, dim3(256), 0, s, g, (const float*)x, w, bias, (bf16_t*)y, act, slope)
         if (g.s_h == 1) { if (g.cout <= 32) C3F(1, 1); else C3F(1, 2); }
         else { if (g.cout <= 32) C3F(2, 1); else C3F(2, 2); }
@@ -1268,7 +1268,7 @@ extern "C" int cn_conv_fwd_dt(const CnConvGeom* gp, const void* x, int x_dt, con
         g.s_w == 1 && !g.up && g.cout == 3 && g.cin == 48 && !bias && act == CN_ACT_NONE && g.p_h >= 0 && g.p_h <= 2 && g.p_w >= 0 &&
         g.p_w <= 2 && g.out_h <= 2 * g.in_h && g.out_w <= 2 * g.in_w) {
         dim3 grid((unsigned)(g.n * cn_cdiv(g.in_h, 8) * cn_cdiv(g.in_w, 32)));
-        cn_prof_begin(s, conv_flops(g));
+        cn_prof_begin(s, conv_flops(g), conv_bytes(g, 2.0, 4.0), CN_FAM_S2_IMAGE_DGRAD);
         hipLaunchKernelGGL((s2_image_dgrad_kernel<6, bf16_t>), grid, dim3(256), 0, s, g, (const bf16_t*)x, w, (float*)y);
         cn_prof_end(s);
         CN_LAUNCH_CHECK();
@@ -1354,9 +1354,9 @@ extern "C" int cn_conv_wgrad(const CnConvGeom* gp, const float* x, const float* 
         if (parts) return cn_sum_parts(parts, gw, nb, (long)g.cin * g.cout, 1, 1.f, s);
         return CN_OK;
     }
-    cn_prof_begin(s, conv_flops(g));
-    int e;
     static const int no_n96 = getenv("CN_NO_N96") ? 1 : 0;
+    cn_prof_begin(s, conv_flops(g), conv_bytes(g), g.cout <= 32 ? CN_FAM_WGRAD_128x32 : (!no_n96 && Ktot >= 128 && g.cout % 96 == 0 && g.cout % 128 != 0) ? CN_FAM_WGRAD_128x96 : (Ktot >= 128 && g.cout >= 128) ? CN_FAM_WGRAD_128x128 : CN_FAM_WGRAD_64x64);
+    int e;
     if (g.cout <= 32)
         e = launch_wgrad<4, 1, 1, 1>(g, x, gy, gw, s);       // 128 (tap,ci) x 32 co
     else if (!no_n96 && Ktot >= 128 && g.cout % 96 == 0 && g.cout % 128 != 0)

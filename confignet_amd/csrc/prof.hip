@@ -28,14 +28,14 @@ extern "C" int cn_spin(unsigned long long ticks, void* stream) {
 }
 
 namespace {
-struct Rec { hipEvent_t a, b; double flops; };
+struct Rec { hipEvent_t a, b; double flops, bytes; int family; };
 std::mutex g_mu;
 bool g_on = false;
 std::vector<Rec> g_pool;      // allocated event pairs
 size_t g_used = 0;            // pairs used since the last reset
 }  // namespace
 
-void cn_prof_begin(hipStream_t s, double flops) {
+void cn_prof_begin(hipStream_t s, double flops, double bytes, int family) {
     if (!g_on) return;
     std::lock_guard<std::mutex> lk(g_mu);
     if (g_used == g_pool.size()) {
@@ -45,6 +45,8 @@ void cn_prof_begin(hipStream_t s, double flops) {
         g_pool.push_back(r);
     }
     g_pool[g_used].flops = flops;
+    g_pool[g_used].bytes = bytes;
+    g_pool[g_used].family = family;
     (void)hipEventRecord(g_pool[g_used].a, s);
 }
 
@@ -85,6 +87,25 @@ extern "C" int cn_prof_collect(int* launches, double* total_ms, double* total_fl
     return CN_OK;
 }
 
+
+// Per kernel family (CN_FAM_* of common.h; slot 31 collects anything above): launches, summed ms, issued flops and ALGORITHMIC
+// bytes (every operand read once, the result written once) -- the byte model the PMC FETCH_SIZE / WRITE_SIZE of the same
+// kernels are compared with (profiles/round3_pmc_traffic_by_kernel.txt).  Arrays of 32 entries each.
+extern "C" int cn_prof_collect_by_family(int* launches, double* ms, double* flops, double* bytes) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (int f = 0; f < 32; ++f) { launches[f] = 0; ms[f] = flops[f] = bytes[f] = 0.0; }
+    for (size_t i = 0; i < g_used; ++i) {
+        CN_HIP(hipEventSynchronize(g_pool[i].b));
+        float t = 0;
+        CN_HIP(hipEventElapsedTime(&t, g_pool[i].a, g_pool[i].b));
+        const int f = g_pool[i].family < 0 || g_pool[i].family > 31 ? 31 : g_pool[i].family;
+        ++launches[f];
+        ms[f] += t;
+        flops[f] += g_pool[i].flops;
+        bytes[f] += g_pool[i].bytes;
+    }
+    return CN_OK;
+}
 
 // ---- deterministic mode ------------------------------------------------------------------------------------------
 namespace {

@@ -288,7 +288,8 @@ extern "C" int cn_conv_fwd_wino(int n, int h, int w, int cin, int cout, const fl
     }
     hipStream_t s = (hipStream_t)stream;
     // MFMA work that contributes to the result: 16 products per 2x2 output tile and (ci, co) pair
-    cn_prof_begin(s, 2.0 * 16.0 * (double)ntiles * cin * cout);
+    cn_prof_begin(s, 2.0 * 16.0 * (double)ntiles * cin * cout,
+                  4.0 * ((double)n * h * w * (cin + cout) + 16.0 * cin * cout), CN_FAM_WINO);
     hipLaunchKernelGGL(wino_fwd_kernel, dim3((unsigned)(nblk * (cout / 64))), dim3(512), lds, s, g, x, u, bias, y, act, slope);
     cn_prof_end(s);
     CN_LAUNCH_CHECK();

@@ -1034,6 +1034,24 @@ def upfold_saved_flops(g):
     return direct * (1.0 - ratio)
 
 
+PROF_FAMILIES = ["igemm_fwd<128x128>", "igemm_fwd<128x64>", "igemm_fwd<64x64>", "igemm_fwd<128x32>", "igemm_fwd<128x96>",
+                 "igemm_wgrad<128x128>", "igemm_wgrad<128x96>", "igemm_wgrad<64x64>", "igemm_wgrad<128x32>", "wino_fwd", "c3_fwd",
+                 "s2_image_dgrad", "thin / up2k4_rgb", "c3_wgrad", "igemm_bf16", "igemm_bf16_wgrad"]
+
+
+def prof_collect_by_family():
+    """{family: {"launches", "ms", "gflop", "algorithmic_mb"}} of the launches recorded since prof_reset()."""
+    n = (ctypes.c_int * 32)()
+    ms, fl, by = (ctypes.c_double * 32)(), (ctypes.c_double * 32)(), (ctypes.c_double * 32)()
+    check(lib.cn_prof_collect_by_family(n, ms, fl, by), "cn_prof_collect_by_family")
+    out = {}
+    for i in range(32):
+        if n[i]:
+            name = PROF_FAMILIES[i] if i < len(PROF_FAMILIES) else "other"
+            out[name] = {"launches": int(n[i]), "ms": ms[i], "gflop": fl[i] / 1e9, "algorithmic_mb": by[i] / 1e6}
+    return out
+
+
 def prof_collect():
     n, ms, fl = ctypes.c_int(0), ctypes.c_double(0), ctypes.c_double(0)
     check(lib.cn_prof_collect(ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl)), "cn_prof_collect")

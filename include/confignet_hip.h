@@ -286,6 +286,11 @@ int cn_prof_enable(int on);
 int cn_prof_reset(void);
 /* synchronises the recorded events; returns launches, summed kernel ms and algorithmic flops */
 int cn_prof_collect(int* launches, double* total_ms, double* total_flops);
+/* the same per kernel family (32 slots: 0-4 igemm_fwd tiles 128x128 / 128x64 / 64x64 / 128x32 / 128x96, 5-8 igemm_wgrad tiles
+ * 128x128 / 128x96 / 64x64 / 128x32, 9 wino_fwd, 10 c3_fwd, 11 s2_image_dgrad, 12 thin / rgb, 13 c3_wgrad, 14 / 15 the bf16
+ * forward / filter-gradient kernels) with the launches' ALGORITHMIC HBM bytes (every operand read once, the result written
+ * once): the byte model the PMC FETCH_SIZE / WRITE_SIZE of those kernels are compared with. */
+int cn_prof_collect_by_family(int* launches, double* ms, double* flops, double* bytes);
 
 /* ---- stream calibration: one wave busy-waits `ticks` of the 100 MHz wall clock on `stream`.  Two such launches on
  * streams that share a hardware queue run back to back, on independent queues side by side: graphs.py uses that to

@@ -1,8 +1,8 @@
 #!/bin/bash
 # Everything the judged profiles/ artifacts are made from, in one GPU-box call:
-#   gpurun --timeout 3000 -- 'bash scripts/make_profiles.sh round2'
+#   gpurun --timeout 3000 -- 'bash scripts/make_profiles.sh round3'
 # writes gpurun_out/profiles_<tag>/ ; copy what is to be judged into profiles/ and commit.
-TAG=${1:-round2}
+TAG=${1:-round3}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/profiles_$TAG
 mkdir -p $O
@@ -21,11 +21,21 @@ $PY $R/scripts/torch_share.py /tmp/kt2 $O/${TAG}_torch_share.json > /dev/null
 # 3. PMC passes (each in its own run, --kernel-trace only)
 CMD="bench.py --steps 2 --warmup 1 --no-cpu-baseline --serial"
 rm -rf /tmp/pf /tmp/pw /tmp/pm
-timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/pf -- $PY $R/$CMD > /dev/null 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/pf -- $PY $R/$CMD > /tmp/pf_line.json 2>/dev/null
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/pw -- $PY $R/$CMD > /dev/null 2>&1
 $PY $R/scripts/pmc_traffic_json.py /tmp/pf /tmp/pw $O/${TAG}_pmc_traffic.json "python $CMD" > /dev/null
+$PY $R/scripts/pmc_traffic_by_kernel.py /tmp/pf /tmp/pw /tmp/pf_line.json $O/${TAG}_pmc_traffic_by_kernel.txt $O/${TAG}_pmc_traffic_by_kernel.json > /dev/null
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES -d /tmp/pm -- $PY $R/$CMD > /dev/null 2>&1
 $PY $R/scripts/pmc_mfma.py /tmp/pm $O/${TAG}_pmc_mfma.json > $O/${TAG}_pmc_mfma.txt
+# 3b. the same counters for the bf16 path (configs[2]'s dtype)
+CMDB="bench.py --steps 2 --warmup 1 --no-cpu-baseline --serial --dtype bf16"
+rm -rf /tmp/pfb /tmp/pwb /tmp/pmb
+timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/pfb -- $PY $R/$CMDB > /tmp/pfb_line.json 2>/dev/null
+timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/pwb -- $PY $R/$CMDB > /dev/null 2>&1
+$PY $R/scripts/pmc_traffic_json.py /tmp/pfb /tmp/pwb $O/${TAG}_pmc_traffic_bf16.json "python $CMDB" > /dev/null
+$PY $R/scripts/pmc_traffic_by_kernel.py /tmp/pfb /tmp/pwb /tmp/pfb_line.json $O/${TAG}_pmc_traffic_by_kernel_bf16.txt > /dev/null
+timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES -d /tmp/pmb -- $PY $R/$CMDB > /dev/null 2>&1
+$PY $R/scripts/pmc_mfma.py /tmp/pmb $O/${TAG}_pmc_mfma_bf16.json > $O/${TAG}_pmc_mfma_bf16.txt
 # 4. per-shape tables
 cd $R
 timeout 600 $PY scripts/conv_shapes_bench.py 16 f32 > $O/${TAG}_conv_shapes.txt 2>/dev/null
