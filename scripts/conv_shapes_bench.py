@@ -35,9 +35,9 @@ def conv_dgrad(gy, wt, g):
     return orig["conv_dgrad"](gy, wt, g)
 
 
-def conv_wgrad(x, gy, g, ws):
+def conv_wgrad(x, gy, g, ws, out=None):
     rec("wgrad", g)
-    return orig["conv_wgrad"](x, gy, g, ws)
+    return orig["conv_wgrad"](x, gy, g, ws, out=out)
 
 
 ops.conv_fwd, ops.conv_dgrad, ops.conv_wgrad = conv_fwd, conv_dgrad, conv_wgrad
