@@ -156,7 +156,8 @@ __global__ __launch_bounds__(256) void c3_wgrad_reduce_kernel(const float* __res
         float t = 0.f;
 #pragma unroll
         for (int k = 0; k < 16; ++k) t += red[k][o];
-        gw[i] = accumulate ? gw[i] + t : t;
+        if (accumulate) unsafeAtomicAdd(&gw[i], t);      // (a slot of a gradient arena may be added to from two streams at once)
+        else gw[i] = t;
     }
 }
 

@@ -690,7 +690,8 @@ __global__ void sum_rows_into_kernel(const float* __restrict__ src, float* __res
     if (c >= cols) return;
     float t = 0.f;
     for (int r = 0; r < rows; ++r) t += src[(long)r * cols + c];
-    dst[c] = accumulate ? dst[c] + t : t;
+    if (accumulate) unsafeAtomicAdd(&dst[c], t);        // (two streams of a forked step may add into one slot at once)
+    else dst[c] = t;
 }
 }  // namespace
 

@@ -122,7 +122,8 @@ __global__ void sum_parts_kernel(const float* __restrict__ src, float* __restric
     float t = 0.f;
     for (int p = 0; p < parts; ++p) t += src[(long)p * count + i];
     t *= scale;
-    dst[i] = accumulate ? dst[i] + t : t;
+    if (accumulate) unsafeAtomicAdd(&dst[i], t);       // one writer per element and launch; concurrent launches may share dst
+    else dst[i] = t;
 }
 }  // namespace
 

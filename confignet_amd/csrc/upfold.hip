@@ -73,7 +73,9 @@ __global__ void upfold_wgrad_kernel(UpfoldTab t, const float* __restrict__ GW2, 
                     s += GW2[((long)((ad * t.k2[1] + ah) * t.k2[2] + aw) * cout + co) * cin + ci];
                 }
         float* dst = GW + ((long)kk * cin + ci) * cout + co;
-        *dst = accumulate ? *dst + s : s;
+        // (atomic: the two branches of a forked step add into one gradient-arena slot from two streams at once)
+        if (accumulate) unsafeAtomicAdd(dst, s);
+        else *dst = s;
     }
 }
 

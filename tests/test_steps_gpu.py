@@ -282,13 +282,16 @@ def test_whole_second_stage_iteration_under_graph_dispatch_matches_oracle(overla
             # fp32 LeakyReLU-branch flips against the float64 oracle move single gradient entries by up to ~30 % of the tensor's
             # largest one (tests/test_nets_gpu.py:close_grads): above that the step must agree entry by entry
             sig = g.abs() > 0.3 * g.abs().max()
-            tol = 0.02 if it == 0 else 0.05                    # (iteration 2: fp32 second moments of two gradients)
+            # iteration 2: the step is 1.38 lr * g2 / sqrt(0.9 g1^2 + g2^2) -- it inherits iteration 1's fp32-vs-float64 branch
+            # decisions through g1 (single entries of g1 differ by ~10 %: measured up to 0.10 lr on the learned input over runs);
+            # a wrong lr_t, a missing half of a split gradient or a stale moment moves EVERY significant entry by O(lr)
+            tol = 0.02 if it == 0 else 0.25
             assert float((step - step_ref)[sig].abs().max()) < tol * lr, (name, it, i, float((step - step_ref)[sig].abs().max()) / lr)
             if step_len is not None:
                 assert abs(float(step[sig].abs().mean()) - step_len * lr) < 0.01 * lr, (name, i, float(step[sig].abs().mean()) / lr, step_len)
             live = g.abs() > 1e-4 * g.abs().max()                # (entries with an exactly-zero true gradient step on fp32 noise)
-            wrong = ((step - step_ref)[live].abs() > 0.1 * lr * (1 if it == 0 else 2)).double().mean()
-            assert float(wrong) < 0.03, (name, it, i, float(wrong))   # ... and below it all but a few per cent do
+            wrong = ((step - step_ref)[live].abs() > 0.1 * lr * (1 if it == 0 else 3)).double().mean()
+            assert float(wrong) < (0.03 if it == 0 else 0.10), (name, it, i, float(wrong))   # ... and below it all but a few per cent do
 
     for it in range(n_iters):
         before = {k: [w.detach().clone() for w in v] for k, v in W.items()}
