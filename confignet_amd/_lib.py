@@ -6,7 +6,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libconfignet_hip.so")
+# (CN_LIB: another build of the same sources, for A/B measurements of kernel variants; tests and the benchmark use the default)
+LIB_PATH = os.environ.get("CN_LIB") or os.path.join(_HERE, "libconfignet_hip.so")
 
 
 class CnConvGeom(ctypes.Structure):
