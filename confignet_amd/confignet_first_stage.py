@@ -21,6 +21,7 @@ from .dnn_models.synthetic_encoder import SyntheticDataEncoder
 from .losses import (GAN_G_loss, compute_discriminator_loss, compute_latent_discriminator_loss,
                      compute_latent_regression_loss, discriminator_loss_fake, discriminator_loss_real, eye_loss)
 from .neural_renderer_dataset import dump_pickle, load_pickle
+from .losses import total as total_loss
 from .nn import backward_into_arenas, require_gpu
 from .perceptual_loss import PerceptualLoss
 
@@ -502,13 +503,13 @@ class ConfigNetFirstStage:
         if callable(real_imgs):
             from .graphs import segment_break
             real, gp = discriminator_loss_real(net, real_imgs())
-            backward_into_arenas(sum(real.values()) + sum(gp.values()), [net])
+            backward_into_arenas(total_loss(list(real.values()) + list(gp.values())), [net])
             segment_break(early=True)          # nothing above reads a generator / encoder weight
             fake = discriminator_loss_fake(net, fake_imgs())
-            backward_into_arenas(sum(fake.values()), [net], accumulate=True)
+            backward_into_arenas(total_loss(fake.values()), [net], accumulate=True)
             optimizer.apply_gradients(net, advance=False, slot=slot)
             losses = {**real, **fake, **gp}    # the reference's key order (losses.py:20-47)
-            losses["loss_sum"] = sum(losses.values())
+            losses["loss_sum"] = total_loss(losses.values())
             return losses
         losses = compute_discriminator_loss(net, real_imgs, fake_imgs)
         backward_into_arenas(losses["loss_sum"], [net])
@@ -631,7 +632,7 @@ class ConfigNetFirstStage:
         labels = torch.cat((stacked_latents, cfg["latent_regressor_rot_weight"] * stacked_rotations), dim=-1)
         reg = compute_latent_regression_loss(stacked_imgs, labels, self.latent_regressor)
         losses["latent_regression_loss"] = cfg["latent_regression_weight"] * reg
-        losses["loss_sum"] = sum(losses.values())
+        losses["loss_sum"] = total_loss(losses.values())
         return losses
 
     def _generator_update(self, losses, nets, optimizer, cut=None):

@@ -11,6 +11,7 @@ from .confignet_first_stage import DEFAULT_CONFIG, ConfigNetFirstStage, frozen
 from .dnn_models.hologan_generator import HologanGenerator
 from .dnn_models.real_encoder import RealEncoder
 from .losses import GAN_D_loss, GAN_G_loss, compute_latent_discriminator_loss, eye_loss, mean_squared_error, normalized_latent_regression
+from .losses import total as total_loss
 from .nn import Net, backward_into_arenas
 from .perceptual_loss import PerceptualLoss
 
@@ -160,7 +161,7 @@ class ConfigNet(ConfigNetFirstStage):
             stacked_rotations = torch.cat((synth_rotations, real_rotations), dim=0)
             labels = torch.cat((stacked_latents, cfg["latent_regressor_rot_weight"] * stacked_rotations), dim=-1)
             losses["latent_regression_loss"] = self.compute_normalized_latent_regression_loss(stacked_imgs, labels)
-        losses["loss_sum"] = sum(losses.values())
+        losses["loss_sum"] = total_loss(losses.values())
         return losses
 
     def generator_training_step(self, real_training_set, synth_training_set, optimizer):
@@ -323,7 +324,7 @@ class ConfigNet(ConfigNetFirstStage):
                 losses["latent_GAN_loss"] = w["domain_adverserial_loss_weight"] * latent_gan_loss
                 labels = torch.cat((embeddings, w["latent_regressor_rot_weight"] * rotations), dim=-1)
                 losses["latent_regression_loss"] = self.compute_normalized_latent_regression_loss(out, labels)
-                losses["loss_sum"] = sum(losses.values())
+                losses["loss_sum"] = total_loss(losses.values())
                 backward_into_arenas(losses["loss_sum"], [gen, var])
             # pre/post tiled BEFORE this step's update (what the reference returns after the last step, l.363-364,402)
             state["stale"] = torch.cat((pre_t, expr, post_t), dim=1).detach().clone()

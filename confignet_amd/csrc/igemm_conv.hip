@@ -287,10 +287,25 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(CnConvGeom g, const floa
 template <int WM, int WN, int TM, int TN, bool VEC, bool BVEC>
 __global__ __launch_bounds__(256) void igemm_wgrad_kernel(CnConvGeom g, const float* __restrict__ X,
                                                           const float* __restrict__ GY, float* __restrict__ GW,
-                                                          int rows_per_split, float* __restrict__ parts = nullptr) {
+                                                          int rows_per_split, float* __restrict__ parts = nullptr,
+                                                          int tiles_x = 0, int tiles_y = 0, int nsplits = 0) {
     static_assert(WM * WN == 4, "4 waves per workgroup");
     constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN, LDA = BM + 4, LDB = BN + 4;
     constexpr int AP = BM / 64, BP = (BN + 63) / 64;
+    // XCD-aware order (tiles_x != 0: 1-D launch).  Workgroup id runs on XCD id % 8 (observed dispatch order): every (tap, ci) /
+    // cout tile of ONE row slice goes to the same XCD, so the slice of X and GY that all of them read is fetched into that
+    // XCD's L2 once instead of once per tile on eight different XCDs (PMC: 4 - 5 x the algorithmic bytes at the fabric with the
+    // 3-D grid order).  Placement only affects speed.
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (tiles_x) {
+        const int T = tiles_x * tiles_y, id = blockIdx.x;
+        const int grp = id / (8 * T), r = id - grp * 8 * T;
+        bz = grp * 8 + (r & 7);
+        if (bz >= nsplits) return;
+        const int t = r >> 3;
+        by = t / tiles_x;
+        bx = t - by * tiles_x;
+    }
     __shared__ __attribute__((aligned(16))) float As[2][BK][LDA];
     __shared__ __attribute__((aligned(16))) float Bs[2][BK][LDB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -298,8 +313,8 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(CnConvGeom g, const fl
     const int M = g.n * g.out_d * g.out_h * g.out_w;
     const int T = g.k_d * g.k_h * g.k_w;
     const int Ktot = T * g.cin;
-    const int i0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-    const int mbeg = blockIdx.z * rows_per_split;
+    const int i0 = bx * BM, n0 = by * BN;
+    const int mbeg = bz * rows_per_split;
     const int mend = min(M, mbeg + rows_per_split);
     if (mbeg >= mend) return;
 
@@ -431,7 +446,7 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(CnConvGeom g, const fl
                 const int row = rbase + (r & 3) + 8 * (r >> 2);
                 if (row >= Ktot) continue;
                 // deterministic mode: this split's partial filter goes to its own slab, the slabs are added in split order
-                if (parts) parts[((long)blockIdx.z * Ktot + row) * g.cout + col] = acc[i][j][r];
+                if (parts) parts[((long)bz * Ktot + row) * g.cout + col] = acc[i][j][r];
                 else unsafeAtomicAdd(&GW[(long)row * g.cout + col], acc[i][j][r]);
             }
         }
@@ -1070,8 +1085,14 @@ int launch_wgrad(const CnConvGeom& g, const float* x, const float* gy, float* gw
         if (!parts) return CN_EINVAL;
     }
     dim3 grid(cn_cdiv(Ktot, BMt), cn_cdiv(g.cout, BNt), (unsigned)splits);
+    int tx = 0, ty = 0;
+    static const int wg_xcd = getenv("CN_NO_WGRAD_XCD") ? 0 : 1;
+    if (wg_xcd && grid.x * grid.y > 1 && splits >= 16) {
+        tx = (int)grid.x; ty = (int)grid.y;
+        grid = dim3((unsigned)(cn_cdiv(splits, 8) * 8 * tx * ty), 1, 1);
+    }
     const bool avec = g.cin % 4 == 0, bvec = g.cout % 4 == 0;
-#define WG(A, B) hipLaunchKernelGGL((igemm_wgrad_kernel<WM, WN, TM, TN, A, B>), grid, dim3(256), 0, s, g, x, gy, gw, (int)rows, parts)
+#define WG(A, B) hipLaunchKernelGGL((igemm_wgrad_kernel<WM, WN, TM, TN, A, B>), grid, dim3(256), 0, s, g, x, gy, gw, (int)rows, parts, tx, ty, (int)splits)
     if (avec && bvec) WG(true, true);
     else if (avec) WG(true, false);
     else if (bvec) WG(false, true);

@@ -9,6 +9,7 @@ from . import ops, optim
 from .confignet_utils import merge_configs
 from .dnn_models.building_blocks import MLPSimple
 from .losses import GAN_D_loss, GAN_G_loss, gradient_regularization
+from .losses import total as total_loss
 from .nn import backward_into_arenas
 
 DEFAULT_CONFIG = {
@@ -88,7 +89,7 @@ class LatentGAN:
         out_fake = self.discriminator(fake_embeddings.detach())
         losses = {"GAN_loss_real": GAN_D_loss(1.0, out_real), "GAN_loss_fake": GAN_D_loss(0.0, out_fake),
                   "gp_loss": gradient_regularization(out_real, real)}
-        losses["loss_sum"] = sum(losses.values())
+        losses["loss_sum"] = total_loss(losses.values())
         return losses
 
     def discriminator_training_step(self, gt_embeddings, optimizer):
@@ -111,7 +112,7 @@ class LatentGAN:
         self.discriminator.requires_grad_(False)
         try:
             losses = {"gan_loss": GAN_G_loss(self.discriminator(self.generator(latents)))}
-            losses["loss_sum"] = sum(losses.values())
+            losses["loss_sum"] = total_loss(losses.values())
             backward_into_arenas(losses["loss_sum"], [self.generator])
         finally:
             self.discriminator.requires_grad_(True)

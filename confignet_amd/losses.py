@@ -18,7 +18,9 @@ def _r1_penalties(discriminator, out_real, real_imgs, inter):
         jvps = discriminator.tangent_all(g_img, inter)                           # ... and one stacked tangent pass
         n = real_imgs.shape[0]
         sq = ops.row_sumsq(g_img.reshape(g_img.shape[0], -1))                    # |g_i,n|^2 (constant of the tape)
-        return {"gp_loss_" + str(i): 10 * 0.5 * (2.0 * jvp.reshape(-1) - sq[i * n:(i + 1) * n]).mean() for i, jvp in enumerate(jvps)}
+        # all heads at once: 10 * 0.5 * mean_n(2 jvp - |g|^2) per head (five small launches instead of five per head)
+        gp = (5.0 * (2.0 * torch.cat([j.reshape(1, n) for j in jvps], dim=0) - sq.reshape(len(jvps), n))).mean(dim=1)
+        return {"gp_loss_" + str(i): gp[i] for i in range(len(jvps))}
     if BATCHED_R1 and hasattr(discriminator, "input_gradients"):
         gs = discriminator.input_gradients(inter)              # all six heads in one tape-free backward sweep
     else:
@@ -31,6 +33,16 @@ def _r1_penalties(discriminator, out_real, real_imgs, inter):
         jvp = discriminator.tangent(g, inter, i).reshape(-1)          # == |g_n|^2, carries d/dtheta
         gp["gp_loss_" + str(i)] = 10 * 0.5 * (2.0 * jvp - F.row_sumsq(g)).mean()
     return gp
+
+
+def total(values):
+    """sum of the scalar loss terms (the reference's `sum(losses.values())`, losses.py:45, confignet_first_stage.py:552): one
+    stack + one reduction instead of a chain of ~20 two-operand adds (each a launch of its own, forward and backward)."""
+    vals = [v.reshape(()).float() if torch.is_tensor(v) else torch.as_tensor(float(v)) for v in values]
+    dev = next((v.device for v in vals if v.is_cuda), None)
+    if dev is not None:
+        vals = [v if v.is_cuda else v.to(dev) for v in vals]
+    return torch.stack(vals).sum() if len(vals) > 1 else vals[0]
 
 
 def GAN_G_loss(scores):
@@ -92,7 +104,7 @@ def compute_discriminator_loss(discriminator, real_imgs, fake_imgs, second_order
     for i, o in enumerate(out_fake.values()):
         losses["GAN_loss_fake_" + str(i)] = GAN_D_loss(0.0, o)
     losses.update(_r1_penalties(discriminator, out_real, real_imgs, inter))
-    losses["loss_sum"] = sum(losses.values())
+    losses["loss_sum"] = total(losses.values())
     return losses
 
 
@@ -123,7 +135,7 @@ def _compute_discriminator_loss_tape(discriminator, real_imgs, fake_imgs):
         losses["GAN_loss_fake_" + str(i)] = GAN_D_loss(0.0, o)
     for i, o in enumerate(out_real.values()):
         losses["gp_loss_" + str(i)] = gradient_regularization(o, real_imgs)
-    losses["loss_sum"] = sum(losses.values())
+    losses["loss_sum"] = total(losses.values())
     return losses
 
 
@@ -137,7 +149,7 @@ def compute_latent_discriminator_loss(latent_discriminator, real_latents, fake_l
         "GAN_loss_fake": GAN_D_loss(0.0, out_fake),
         "gp_loss": gradient_regularization(out_real, real_latents),
     }
-    losses["loss_sum"] = sum(losses.values())
+    losses["loss_sum"] = total(losses.values())
     return losses
 
 
