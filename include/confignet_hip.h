@@ -11,8 +11,13 @@
  * state are fp32 in either mode, and all arithmetic accumulates in fp32.
  * Every call enqueues on `stream` (a hipStream_t passed as void*) and returns 0 on success
  * or a negative CN_E* code; cn_last_error_string() describes the last failure of the
- * calling thread.  No exceptions cross the ABI.  No global state except a profiling event
- * pool (cn_prof_*).
+ * calling thread.  No exceptions cross the ABI.
+ * Process-wide state (everything else is per call): the profiling event pool (cn_prof_*); the deterministic-mode flag and
+ * its per-stream workspaces (cn_set_deterministic); the tuning overrides of cn_conv_tune (diagnostic: tile / split-K /
+ * filter-gradient workgroup target, default = the built-in heuristics); and diagnostic environment switches that are read
+ * ONCE at first use (CN_CFG, CN_SPLITS, CN_WG_BLOCKS, CN_NO_XCD, CN_NO_N96, CN_NO_C3, CN_KB32, CN_TAP_MINOR, CN_RED_BLOCKS,
+ * CN_NO_SMALL_GEMM, CN_NO_WGRAD_XCD: A/B switches of DESIGN.md section 7, never needed for correct results).  None of them
+ * changes WHAT a call computes, only which kernel variant computes it; a host that wants a re-entrant library leaves them unset.
  */
 #ifndef CONFIGNET_HIP_H
 #define CONFIGNET_HIP_H

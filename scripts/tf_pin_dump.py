@@ -142,6 +142,34 @@ def main():
     out["keras_leakyrelu_of_minus1"] = keras.layers.LeakyReLU()(tf.constant([-1.0])).numpy()
     out["tf_nn_leaky_relu_of_minus1"] = tf.nn.leaky_relu(tf.constant([-1.0])).numpy()
     out["layernorm_default_eps"] = np.array(keras.layers.LayerNormalization().epsilon)
+    # --- whole networks of the reference: get_weights() ORDER (shapes) and one seeded forward each (R11: Keras orders a subclassed
+    # model's weights by attribute-tracking order, which the checkpoint format model.npz relies on) ---------------------------------
+    try:
+        gen_mod = load_by_path("confignet.dnn_models.hologan_generator", os.path.join(args.reference, "confignet", "dnn_models", "hologan_generator.py"))
+        disc_mod = load_by_path("confignet.dnn_models.hologan_discriminator", os.path.join(args.reference, "confignet", "dnn_models", "hologan_discriminator.py"))
+        L = 9
+        gen = gen_mod.HologanGenerator(latent_dim=L, output_shape=(128, 128), n_adain_mlp_units=8, n_adain_mlp_layers=2, gen_output_activation="tanh")
+        z = rng.standard_normal((1, L)).astype(np.float32)
+        rot = np.array([[0.2, -0.1, 0.0]], np.float32)
+        inp = gen.build_input_dict(z, rot)
+        gen(inp)
+        ws = seeded(gen)
+        out["generator_weight_shapes"] = np.array([str(tuple(w.shape)) for w in ws])
+        out["generator_z"], out["generator_rot"], out["generator_img"] = z, rot, gen(inp).numpy()
+        pack("generator_w", ws)
+        d = disc_mod.HologanDiscriminator(img_shape=(64, 64), num_resample=5, disc_max_feature_maps=512, disc_kernel_size=3,
+                                          disc_expansion_factor=48, initial_from_rgb_layer_in_discr=True)
+        x = rng.uniform(-1, 1, (2, 64, 64, 3)).astype(np.float32)
+        d(x)
+        ws = seeded(d)
+        o = d(x)
+        out["discriminator_weight_shapes"] = np.array([str(tuple(w.shape)) for w in ws])
+        out["discriminator_x"] = x
+        out["discriminator_out_keys"] = np.array(list(o.keys()))
+        out["discriminator_out"] = np.concatenate([np.asarray(v).reshape(2, 1) for v in o.values()], axis=1)
+        pack("discriminator_w", ws)
+    except Exception as e:                                     # (an older / newer reference layout: keep the operator-level pins)
+        out["network_pins_error"] = np.array(repr(e))
     # --- keras.applications: get_weights() order (names + shapes) ------------------------------------------------------------------
     if not args.no_applications:
         for name, ctor in (("resnet50", lambda: keras.applications.ResNet50(weights=None, include_top=False, input_shape=(224, 224, 3), pooling="avg")),

@@ -226,6 +226,16 @@ def _check_pins(P):
         assert torch.equal(y, t(P["same_k%d_s%d_n%d" % (k_, s_, n_)])), (k_, s_, n_)
     assert abs(float(P["keras_leakyrelu_of_minus1"][0]) + 0.3) < 1e-7 and abs(float(P["tf_nn_leaky_relu_of_minus1"][0]) + 0.2) < 1e-7
     assert abs(float(P["layernorm_default_eps"]) - 1e-3) < 1e-12
+    if "generator_weight_shapes" in files:                    # whole networks: get_weights() order and a seeded forward (R11)
+        assert [eval(str(s_)) for s_ in P["generator_weight_shapes"]] == [tuple(s_) for s_ in R.generator_weight_shapes(9, 128, n_mlp_units=8)], \
+            "HologanGenerator.get_weights() order differs from oracle/ref_nets.py:generator_weight_shapes"
+        img = R.generator_forward(unpack("generator_w"), t(P["generator_z"]), t(P["generator_rot"]), 128)
+        assert float((img - t(P["generator_img"])).abs().max()) < 1e-3, "generator forward vs TensorFlow"
+        assert [eval(str(s_)) for s_ in P["discriminator_weight_shapes"]] == [tuple(s_) for s_ in R.discriminator_weight_shapes(64)]
+        o = R.discriminator_forward(unpack("discriminator_w"), t(P["discriminator_x"]))
+        assert [str(k_) for k_ in P["discriminator_out_keys"]] == list(o.keys())
+        got = torch.cat([v.reshape(2, 1) for v in o.values()], dim=1)
+        assert float((got - t(P["discriminator_out"])).abs().max()) < 1e-3 * max(1.0, float(t(P["discriminator_out"]).abs().max()))
     if "resnet50_weight_names" in files:
         names = [str(n) for n in P["resnet50_weight_names"]]
         want = []
@@ -308,4 +318,19 @@ def test_pin_checker_runs_on_a_self_made_file():
         x[0, 0, 0, 0], x[0, n_ - 1, n_ - 1, 0] = 1.0, 2.0
         P["same_k%d_s%d_n%d" % (k_, s_, n_)] = O.conv_same(x, torch.ones(k_, k_, 1, 1, dtype=torch.float64), None, stride=s_).numpy()
     P["keras_leakyrelu_of_minus1"], P["tf_nn_leaky_relu_of_minus1"], P["layernorm_default_eps"] = np.array([-0.3]), np.array([-0.2]), np.array(1e-3)
+    gshapes = R.generator_weight_shapes(9, 128, n_mlp_units=8)
+    gw = [rng.standard_normal(sh) * (0.3 if len(sh) > 1 else 0.1) for sh in gshapes]
+    z, rot = rng.standard_normal((1, 9)), np.array([[0.2, -0.1, 0.0]])
+    P["generator_weight_shapes"] = np.array([str(tuple(sh)) for sh in gshapes])
+    P["generator_z"], P["generator_rot"] = z, rot
+    P["generator_img"] = R.generator_forward([t(w) for w in gw], t(z), t(rot), 128).numpy()
+    pack("generator_w", gw)
+    dshapes = R.discriminator_weight_shapes(64)
+    dw = [rng.standard_normal(sh) * (0.3 if len(sh) > 1 else 0.1) for sh in dshapes]
+    x = rng.uniform(-1, 1, (2, 64, 64, 3))
+    o = R.discriminator_forward([t(w) for w in dw], t(x))
+    P["discriminator_weight_shapes"] = np.array([str(tuple(sh)) for sh in dshapes])
+    P["discriminator_x"], P["discriminator_out_keys"] = x, np.array(list(o.keys()))
+    P["discriminator_out"] = torch.cat([v.reshape(2, 1) for v in o.values()], dim=1).numpy()
+    pack("discriminator_w", dw)
     _check_pins(P)
