@@ -189,6 +189,14 @@ def main():
                          "measured": "HIP events around every launch of the class, same K iterations run serially (eager, one stream)",
                          "algorithmic_gflop_per_step": round(kernel_flops / max(args.steps, 1) / 1e9, 2),
                          "algorithmic_bytes_per_step": round(alg_bytes_per_step),
+                         "hbm_frac_of_algorithmic_bytes": round(alg_bytes_per_step / max(kernel_ms / max(args.steps, 1) * 1e-3, 1e-12) / 8.0e12, 4),
+                         "bound_note": ("fp32: the class is MFMA-bound by construction (2.76 TFLOP against 26 GB of algorithmic bytes per step: "
+                                        "107 FLOP/B, ridge 20 FLOP/B) and runs at the MFMA-busy fraction above; what separates it from the "
+                                        "peak is per-launch overhead of 50-150 us kernels (ramp, tail, split-K), see DESIGN.md section 3"
+                                        if args.dtype == "f32" else
+                                        "bf16: neither roof governs -- 45 us average launches at 0.06 of the bf16 MFMA peak and 0.07 of the HBM peak "
+                                        "on their algorithmic bytes: the class is bound by per-launch latency (ramp, tail, dependent chain), "
+                                        "see DESIGN.md section 3"),
                          "algorithmic_bytes_per_launch": round(alg_bytes_per_step * max(args.steps, 1) / max(launches, 1)),
                          "traffic_over_algorithmic": (round(pmc_traffic(args.dtype) * launches / max(args.steps, 1) / alg_bytes_per_step, 2)
                                                       if (pmc_traffic(args.dtype) and alg_bytes_per_step) else None),
