@@ -93,7 +93,8 @@ def test_fine_tune_on_img_matches_oracle_golden(graphs):
     # three Adam steps of ~1e-4 each: a wrong lr_t / moment / stale tile shifts EVERY entry at the 1e-4 level; a single entry whose
     # gradient changes sign near zero in a later step may take that one step the other way (<= 2e-4)
     err = np.abs(emb - GOLD_FT["emb"]).ravel()
-    assert np.quantile(err, 0.9) < 4e-5 and err.max() < 2.5e-4, (np.quantile(err, 0.9), err.max())
+    # (0.9-quantile: 2e-5 .. 3.5e-5 over runs of the default mode, 4.07e-5 -- every time -- in deterministic mode)
+    assert np.quantile(err, 0.9) < 5e-5 and err.max() < 2.5e-4, (np.quantile(err, 0.9), err.max())
     assert np.abs(rot - GOLD_FT["rot"]).max() < 1e-4, (rot, GOLD_FT["rot"])
     # the fine-tuned generator copy moved like the oracle's (per-tensor update norms; sign flips of noise-level
     # gradients move single entries by 2 lr)
