@@ -22,7 +22,7 @@ def family(name):
             t = name.split(k + "<")[1][:10]
             return "%s<%s>" % (k[:-7], TILES.get(t, t))
     for k, f in (("wino_fwd_kernel", "wino_fwd"), ("c3_fwd_kernel", "c3_fwd"), ("s2_image_dgrad_kernel", "s2_image_dgrad"),
-                 ("c3_wgrad_kernel", "c3_wgrad"), ("up2k4_rgb_fwd_kernel", "thin / up2k4_rgb"), ("igemm_bf16_wgrad_kernel", "igemm_bf16_wgrad"),
+                 ("c3_wgrad_kernel", "c3_wgrad"), ("up2k4_rgb_fwd_kernel", "thin / up2k4_rgb"), ("igemm_bf16_wgrad_tr_kernel", "igemm_bf16_wgrad"), ("igemm_bf16_wgrad_kernel", "igemm_bf16_wgrad"),
                  ("igemm_bf16_kernel", "igemm_bf16")):
         if k in name:
             return f
