@@ -13,7 +13,7 @@ namespace {
 __global__ __launch_bounds__(256) void gemm_kernel(int ta, int tb, int M, int N, int K, const float* __restrict__ A,
                                                    int lda, const float* __restrict__ B, int ldb, float* __restrict__ C,
                                                    int ldc, const float* __restrict__ bias, int act, float slope,
-                                                   int k_per_split, int splitk) {
+                                                   int k_per_split, int splitk, float* __restrict__ parts = nullptr) {
     constexpr int BM = 64, BN = 64, LDA = BM + 4, LDB = BN + 4;
     __shared__ float As[2][BK][LDA];
     __shared__ float Bs[2][BK][LDB];
@@ -92,7 +92,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(int ta, int tb, int M, int N,
         const int row = m0 + wm * 32 + 4 * half + (r & 3) + 8 * (r >> 2);
         if (row >= M) continue;
         const float v = acc[0][0][r] + bv;
-        if (splitk > 1) unsafeAtomicAdd(&C[(long)row * ldc + col], v);
+        if (parts) parts[((long)blockIdx.z * M + row) * N + col] = v;      // deterministic mode: per-split slabs, added in order afterwards
+        else if (splitk > 1) unsafeAtomicAdd(&C[(long)row * ldc + col], v);
         else C[(long)row * ldc + col] = cn_apply_act(v, act, slope);
     }
 }
@@ -259,7 +260,7 @@ static int gemm_launch(int ta, int tb, int m, int n, int k, const float* a, int 
     }
     const long tiles = (long)cn_cdiv(m, 64) * cn_cdiv(n, 64);
     int splitk = 1;
-    if (act == CN_ACT_NONE && tiles < 128 && k >= 1024 && !cn_det()) {
+    if (act == CN_ACT_NONE && tiles < 128 && k >= 1024 && !(cn_det() && (accumulate || ldc != n))) {
         splitk = (int)((256 + tiles - 1) / tiles);
         if (splitk > k / 256) splitk = k / 256;
         if (splitk < 1) splitk = 1;
@@ -267,15 +268,29 @@ static int gemm_launch(int ta, int tb, int m, int n, int k, const float* a, int 
     int kps = (k + splitk - 1) / splitk;
     kps = (kps + BK - 1) / BK * BK;
     splitk = (k + kps - 1) / kps;
-    if (splitk > 1 && !accumulate) {
+    float* parts = nullptr;
+    if (cn_det() && splitk > 1) {
+        // deterministic mode: K slices into per-split slabs of the stream's workspace, added in split order by a second launch
+        const long cap = (long)(CN_DET_WS_FLOATS / ((size_t)m * n));
+        if (splitk > cap) splitk = (int)(cap < 1 ? 1 : cap);
+        kps = (k + splitk - 1) / splitk;
+        kps = (kps + BK - 1) / BK * BK;
+        splitk = (k + kps - 1) / kps;
+        if (splitk > 1) {
+            parts = cn_det_ws(s, (size_t)splitk * m * n);
+            if (!parts) return CN_EINVAL;
+        }
+    }
+    if (splitk > 1 && !accumulate && !parts) {
         hipLaunchKernelGGL(zero_rows_kernel, dim3(cn_cdiv((long)m * n, 256)), dim3(256), 0, s, c, m, n, ldc);
         CN_LAUNCH_CHECK();
     }
     dim3 grid(cn_cdiv(m, 64), cn_cdiv(n, 64), splitk);
     // (the kernel adds with atomics whenever its last argument is > 1: split-K, or accumulation into the caller's C)
     hipLaunchKernelGGL(gemm_kernel, grid, dim3(256), 0, s, ta, tb, m, n, k, a, lda, b, ldb, c, ldc, bias, act, slope, kps,
-                       accumulate ? 2 : splitk);
+                       accumulate ? 2 : splitk, parts);
     CN_LAUNCH_CHECK();
+    if (parts) return cn_sum_parts(parts, c, splitk, (long)m * n, 0, 1.f, s);
     return CN_OK;
 }
 

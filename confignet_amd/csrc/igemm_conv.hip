@@ -28,7 +28,8 @@ template <int WM, int WN, int TM, int TN, bool VEC, bool BVEC = true, int KB = B
 __global__ __launch_bounds__(256) void igemm_fwd_kernel(CnConvGeom g, const float* __restrict__ X,
                                                         const float* __restrict__ W, const float* __restrict__ bias,
                                                         float* __restrict__ Y, int act, float slope, int par,
-                                                        int xcd_swizzle, int ntiles_m, int ntiles_n, int bt = 0) {
+                                                        int xcd_swizzle, int ntiles_m, int ntiles_n, int bt = 0,
+                                                        long part_stride = 0) {
     // bt: W is the ORIGINAL filter [t][n = output channel here][k = reduction channel here] of the convolution whose data
     // gradient this launch computes (tap order reversed, the two channel axes swapped): the B tile is then loaded like the
     // gathered A tile (16-byte pieces along k, transposed on the way into LDS) -- no tap-flipped, channel-transposed copy of
@@ -274,7 +275,9 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(CnConvGeom g, const floa
                 const int row = rowmap[rbase + (r & 3) + 8 * (r >> 2)];
                 if (row < 0) continue;
                 const float v = acc[i][j][r] + bv;
-                if (split) unsafeAtomicAdd(&Y[(long)row * g.cout + col], v);
+                // (deterministic mode: every K split stores its partial tile in its own slab; the slabs are added in order afterwards)
+                if (part_stride) Y[(long)blockIdx.z * part_stride + (long)row * g.cout + col] = v;
+                else if (split) unsafeAtomicAdd(&Y[(long)row * g.cout + col], v);
                 else Y[(long)row * g.cout + col] = cn_apply_act(v, act, slope);
             }
         }
@@ -1029,7 +1032,7 @@ static int g_xcd = getenv("CN_NO_XCD") ? 0 : 1;
 
 template <int WM, int WN, int TM, int TN>
 int launch_fwd(const CnConvGeom& g, bool vec, int par, int splits, const float* x, const float* w, const float* bias,
-               float* y, int act, float slope, hipStream_t s, int bt = 0) {
+               float* y, int act, float slope, hipStream_t s, int bt = 0, long part_stride = 0) {
     const long M = (long)g.n * g.out_d * g.out_h * g.out_w;
     dim3 grid(cn_cdiv(M, 32 * WM * TM), cn_cdiv(g.cout, 32 * WN * TN), splits);
     int xcd = g_xcd;
@@ -1051,9 +1054,9 @@ int launch_fwd(const CnConvGeom& g, bool vec, int par, int splits, const float* 
     if ((xcd & 4) && (taps < 2 || taps > 9 || !vec)) xcd &= ~4;         // (offset table: taps x AP x 1 KiB of LDS)
     const size_t dyn = (xcd & 4) ? sizeof(int) * taps * (32 * WM * TM / (256 / ((kb32 ? 32 : BK) / 4))) * 256 : 0;   // taps x AP x 256 threads
     if (kb32)
-        hipLaunchKernelGGL((igemm_fwd_kernel<WM, WN, TM, TN, true, true, 32>), grid, dim3(256), dyn, s, g, x, w, bias, y, act, slope, par, xcd, ntm, ntn, bt);
+        hipLaunchKernelGGL((igemm_fwd_kernel<WM, WN, TM, TN, true, true, 32>), grid, dim3(256), dyn, s, g, x, w, bias, y, act, slope, par, xcd, ntm, ntn, bt, part_stride);
     else if (vec)
-        hipLaunchKernelGGL((igemm_fwd_kernel<WM, WN, TM, TN, true>), grid, dim3(256), dyn, s, g, x, w, bias, y, act, slope, par, xcd, ntm, ntn, bt);
+        hipLaunchKernelGGL((igemm_fwd_kernel<WM, WN, TM, TN, true>), grid, dim3(256), dyn, s, g, x, w, bias, y, act, slope, par, xcd, ntm, ntn, bt, part_stride);
     else
         hipLaunchKernelGGL((igemm_fwd_kernel<WM, WN, TM, TN, false>), grid, dim3(256), 0, s, g, x, w, bias, y, act, slope, par, xcd, ntm, ntn);
     CN_LAUNCH_CHECK();
@@ -1229,21 +1232,38 @@ static int conv_fwd_impl(const CnConvGeom* gp, const float* x, const float* w, c
     }
     if (g_tune_cfg >= 0) cfg = g_tune_cfg;                        // tuning overrides (cn_conv_tune; scripts/conv_sweep.py)
     if (g_tune_splits > 0) splits = g_tune_splits;
-    if (cn_det()) splits = 1;                                     // deterministic mode: no split-K atomics
+    float* parts = nullptr;
+    if (cn_det() && splits > 1) {
+        // deterministic mode: the K splits write partial outputs into the stream's workspace (as many splits as it holds) and a
+        // second launch adds them in split order -- no atomics
+        const long cap = (long)(CN_DET_WS_FLOATS / ((size_t)M * g.cout));
+        if (splits > cap) splits = (int)cap;
+        if (splits > 1 && vec) {
+            parts = cn_det_ws(s, (size_t)splits * M * g.cout);
+            if (!parts) return CN_EINVAL;
+        } else {
+            splits = 1;
+        }
+    }
     const int kact = splits > 1 ? CN_ACT_NONE : act;
-    if (splits > 1) {
+    if (splits > 1 && !parts) {
         if (int ez__ = cn_zero_async(y, sizeof(float) * M * g.cout, s)) return ez__;
     }
+    float* const y_user = y;
+    const long part_stride = parts ? (long)M * g.cout : 0;
+    if (parts) y = parts;
     cn_prof_begin(s, conv_flops(g), conv_bytes(g), cfg == 0 ? CN_FAM_FWD_128x128 : cfg == 1 ? CN_FAM_FWD_128x64 : cfg == 3 ? CN_FAM_FWD_128x32 : cfg == 4 ? CN_FAM_FWD_128x96 : CN_FAM_FWD_64x64);
     int e;
     switch (cfg) {
-        case 3: e = launch_fwd<4, 1, 1, 1>(g, vec, par, splits, x, w, bias, y, kact, slope, s, bt); break;   // 128 x 32
-        case 4: e = launch_fwd<4, 1, 1, 3>(g, vec, par, splits, x, w, bias, y, kact, slope, s, bt); break;   // 128 x 96
-        case 0: e = launch_fwd<2, 2, 2, 2>(g, vec, par, splits, x, w, bias, y, kact, slope, s, bt); break;   // 128 x 128
-        case 1: e = launch_fwd<2, 2, 2, 1>(g, vec, par, splits, x, w, bias, y, kact, slope, s, bt); break;   // 128 x 64
-        default: e = launch_fwd<2, 2, 1, 1>(g, vec, par, splits, x, w, bias, y, kact, slope, s, bt); break;  // 64 x 64
+        case 3: e = launch_fwd<4, 1, 1, 1>(g, vec, par, splits, x, w, bias, y, kact, slope, s, bt, part_stride); break;   // 128 x 32
+        case 4: e = launch_fwd<4, 1, 1, 3>(g, vec, par, splits, x, w, bias, y, kact, slope, s, bt, part_stride); break;   // 128 x 96
+        case 0: e = launch_fwd<2, 2, 2, 2>(g, vec, par, splits, x, w, bias, y, kact, slope, s, bt, part_stride); break;   // 128 x 128
+        case 1: e = launch_fwd<2, 2, 2, 1>(g, vec, par, splits, x, w, bias, y, kact, slope, s, bt, part_stride); break;   // 128 x 64
+        default: e = launch_fwd<2, 2, 1, 1>(g, vec, par, splits, x, w, bias, y, kact, slope, s, bt, part_stride); break;  // 64 x 64
     }
     cn_prof_end(s);
+    if (e == CN_OK && parts) e = cn_sum_parts(parts, y_user, splits, (long)M * g.cout, 0, 1.f, s);
+    y = y_user;
     if (e == CN_OK && splits > 1 && act != CN_ACT_NONE) e = cn_act_fwd(y, y, (size_t)M * g.cout, act, slope, CN_F32, stream);
     return e;
 }

@@ -147,9 +147,9 @@ int cn_gemm(int trans_a, int trans_b, int m, int n, int k, const float* a, int l
             void* stream);
 
 /* Deterministic mode (process-wide; switch between steps, not inside a captured graph): with on != 0 every reduction of the
- * fp32 path runs in a fixed order -- nc_reduce with one workgroup per (n, channel block), no split-K in cn_conv_fwd / cn_gemm,
- * the filter gradients / loss reductions / the rotation's scatter through per-split partials that a second launch adds in
- * index order -- so two runs on the same inputs give bit-identical results (at a cost: see DESIGN.md).  Allocates 8 per-stream
+ * fp32 path runs in a fixed order -- statistics passes, split-K of cn_conv_fwd / cn_gemm, filter gradients and loss reductions
+ * through per-split partials that a second launch adds in index order, the rotation's scatter by one wave per (sample, 8
+ * channels) in voxel order -- so two runs on the same inputs give bit-identical results (at a cost: see DESIGN.md).  Allocates 8 per-stream
  * workspaces of 64 MiB on first use.  The bf16 family is not covered. */
 int cn_set_deterministic(int on);
 int cn_get_deterministic(void);
