@@ -167,7 +167,36 @@ float* cn_det_ws(hipStream_t s, size_t need_floats) {
     return g_det_buf[slot];
 }
 
+namespace {
+// many parts: 16 lanes per output element take every 16th part (independent loads instead of one chain of `parts` dependent
+// HBM latencies: 512 parts took 117 us that way), then the 16 sub-sums are added in lane order -- still a fixed order
+__global__ __launch_bounds__(256) void sum_parts_wide_kernel(const float* __restrict__ src, float* __restrict__ dst, int parts,
+                                                             long count, int accumulate, float scale) {
+    __shared__ float red[16][17];
+    const int o = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const long i = (long)blockIdx.x * 16 + o;
+    float t = 0.f;
+    if (i < count)
+        for (int p = grp; p < parts; p += 16) t += src[(long)p * count + i];
+    red[grp][o] = t;
+    __syncthreads();
+    if (grp == 0 && i < count) {
+        float u = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) u += red[k][o];
+        u *= scale;
+        if (accumulate) unsafeAtomicAdd(&dst[i], u);
+        else dst[i] = u;
+    }
+}
+}  // namespace
+
 int cn_sum_parts(const float* src, float* dst, int parts, long count, int accumulate, float scale, hipStream_t s) {
+    if (parts >= 64 && count * 16 <= (long)256 * 65536) {
+        hipLaunchKernelGGL(sum_parts_wide_kernel, dim3(cn_cdiv(count, 16)), dim3(256), 0, s, src, dst, parts, count, accumulate, scale);
+        CN_LAUNCH_CHECK();
+        return CN_OK;
+    }
     hipLaunchKernelGGL(sum_parts_kernel, dim3(cn_cdiv(count, 256)), dim3(256), 0, s, src, dst, parts, count, accumulate, scale);
     CN_LAUNCH_CHECK();
     return CN_OK;

@@ -379,6 +379,7 @@ def conv_dgrad(gy, w, g):
 
 
 DGRAD_FROM_W = os.environ.get("CN_NO_DGRAD_FROM_W") is None
+THIN_WGRAD = os.environ.get("CN_NO_THIN_WGRAD") is None
 C3_WGRAD = os.environ.get("CN_NO_C3_WGRAD") is None
 MIXED_FIRST_LAYERS = os.environ.get("CN_NO_MIXED_FIRST") is None      # bf16 path: first-layer kernels that read / write both storage types
 _C3_PARTS = []
@@ -409,6 +410,16 @@ def conv_wgrad(x, gy, g, w_shape, out=None):
         check(lib.cn_conv_wgrad_c3(ctypes.byref(g), _ptr(x), _ptr(gy), _dt(gy), _ptr(scratch), _fptr(gw), int(out is not None), _stream()),
               "cn_conv_wgrad_c3")
         return gw
+    if THIN_WGRAD and g.nd == 2 and g.cout <= 4 and 8 <= g.cin <= 64 and g.cin % 4 == 0 and g.s_h == 1 and g.s_w == 1:
+        # thin output (map_final): staged-tile VALU kernel with ordered partial sums (the implicit-GEMM kernel runs it at 6 TFLOP/s)
+        x32, gy32 = _c(f32(x)), _c(f32(gy))
+        taps = g.k_h * g.k_w
+        scratch = torch.empty(int(lib.cn_conv_wgrad_thin_partials()) * taps * g.cin * g.cout, device=x.device, dtype=torch.float32)
+        rc = lib.cn_conv_wgrad_thin(ctypes.byref(g), _ptr(x32), _ptr(gy32), _ptr(scratch), _fptr(gw), int(pre), _stream())
+        if rc == 0:
+            return gw
+        if rc != CN_EUNSUPPORTED:
+            check(rc, "cn_conv_wgrad_thin")
     if _bf16_conv_ok(g):
         x, gy = cast(x, torch.bfloat16), cast(gy, torch.bfloat16)
         check(lib.cn_conv_wgrad_bf16(ctypes.byref(g), _ptr(x), _ptr(gy), _fptr(gw), int(pre), _stream()), "cn_conv_wgrad_bf16")

@@ -102,6 +102,11 @@ int cn_conv_dgrad_dt(const CnConvGeom* g, const void* gy, int gy_dt, const float
 int cn_conv_wgrad_c3_partials(void);
 int cn_conv_wgrad_c3(const CnConvGeom* g, const float* x, const void* gy, int gy_dt, float* scratch, float* gw, int accumulate,
                      void* stream);
+/* Filter gradient of a 2-D stride-1 convolution with <= 4 output channels and 8 <= cin <= 64 (map_final, hologan_generator.py:101,
+ * behind the folded x2 upsample): LDS-staged tiles, VALU accumulation, per-workgroup partial filters in `scratch`
+ * (cn_conv_wgrad_thin_partials() * taps * cin * cout floats) added in order -- no atomics.  CN_EUNSUPPORTED otherwise. */
+int cn_conv_wgrad_thin_partials(void);
+int cn_conv_wgrad_thin(const CnConvGeom* g, const float* x, const float* gy, float* scratch, float* gw, int accumulate, void* stream);
 int cn_conv_wino_filter(const float* w, float* u, int cin, int cout, int dgrad, void* stream);
 int cn_conv_fwd_wino(int n, int h, int w, int cin, int cout, const float* x, const float* u, const float* bias, float* y,
                      int act, float slope, void* stream);
