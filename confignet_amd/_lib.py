@@ -68,6 +68,7 @@ SIGNATURES = {
     "cn_get_deterministic": [],
     "cn_gemm_acc": [_i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _p],
     "cn_sum_rows_into": [_p, _p, _i, _i, _i, _p],
+    "cn_bn_act_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "cn_nc_reduce_dact": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _i, _p],
     "cn_act_fwd": [_p, _p, _z, _i, _f, _i, _p],
     "cn_act_bwd": [_p, _p, _p, _z, _i, _f, _i, _p],
@@ -77,6 +78,7 @@ SIGNATURES = {
     "cn_sqdiff_sum": [_p, _p, _p, _z, _f, _i, _p],
     "cn_row_sumsq": [_p, _p, _i, _z, _p],
     "cn_row_scale": [_p, _p, _p, _i, _z, _f, _i, _p],
+    "cn_row_scale_diff": [_p, _p, _p, _p, _i, ctypes.c_size_t, _f, _i, _p],
     "cn_masked_diff": [_p, _p, _p, _p, _z, _i, _p],
     "cn_maxpool_fwd": [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "cn_maxpool_bwd": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],

@@ -27,9 +27,12 @@ __global__ __launch_bounds__(256) void nc_reduce_kernel(const T* __restrict__ x1
                                                         float* __restrict__ s1, float* __restrict__ s2, int S, int C,
                                                         int rows_per_block, int flags, float slope, int period2,
                                                         T* __restrict__ dact_out = nullptr, int dact = 0,
-                                                        float* __restrict__ parts = nullptr) {
-    // dact_out: fused activation backward -- the reduced quantity is x1 * act'(x2) (x2 = the activation's OUTPUT), which is
-    // also written to dact_out; only s1 (its sum) is produced.
+                                                        float* __restrict__ parts = nullptr, const T* __restrict__ x3 = nullptr,
+                                                        const float* __restrict__ coef = nullptr, T* __restrict__ scaled_out = nullptr,
+                                                        int dact_on = 0) {
+    // dact_on: fused activation backward -- a = x1 * act'(x2) (x2 = the activation's OUTPUT); a is written to dact_out (if given),
+    // coef[c] * a to scaled_out (if given: the input gradient of an inference-mode BatchNorm), s1 = sum a, s2 = sum a * (x3 if
+    // given, else f2(x2)): the whole backward of conv -> BN(inference) -> ReLU in one pass (cn_bn_act_bwd)
     const int CG = C / V;                          // channel groups
     const int tx = threadIdx.x, ty = threadIdx.y, TX = blockDim.x, TY = blockDim.y;
     const int cg = blockIdx.x * TX + tx;
@@ -52,10 +55,18 @@ __global__ __launch_bounds__(256) void nc_reduce_kernel(const T* __restrict__ x1
                     if (flags & 2) vb = lrelu4(vb, slope);
                     b[0] = vb.x; b[1 % V] = vb.y; b[2 % V] = vb.z; b[3 % V] = vb.w;
                 }
-                if (dact_out) {
+                if (dact_on) {
 #pragma unroll
                     for (int e = 0; e < V; ++e) a[e] *= act_deriv(b[e], dact, slope);
-                    st4<T>(dact_out + base + (long)s * C, make_float4(a[0], a[1 % V], a[2 % V], a[3 % V]));
+                    if (dact_out) st4<T>(dact_out + base + (long)s * C, make_float4(a[0], a[1 % V], a[2 % V], a[3 % V]));
+                    if (scaled_out) {
+                        const float4 k4 = *reinterpret_cast<const float4*>(coef + (long)cg * V);
+                        st4<T>(scaled_out + base + (long)s * C, make_float4(a[0] * k4.x, a[1 % V] * k4.y, a[2 % V] * k4.z, a[3 % V] * k4.w));
+                    }
+                    if (x3) {
+                        const float4 vc = ld4<T>(x3 + base + (long)s * C);
+                        b[0] = vc.x; b[1 % V] = vc.y; b[2 % V] = vc.z; b[3 % V] = vc.w;
+                    }
                 }
             } else {
                 a[0] = ldf<T>(x1 + base + (long)s * C);
@@ -64,9 +75,11 @@ __global__ __launch_bounds__(256) void nc_reduce_kernel(const T* __restrict__ x1
                     b[0] = ldf<T>(x2 + base2 + (long)s * C);
                     if (flags & 2) b[0] = lrelu(b[0], slope);
                 }
-                if (dact_out) {
+                if (dact_on) {
                     a[0] *= act_deriv(b[0], dact, slope);
-                    stf<T>(dact_out + base + (long)s * C, a[0]);
+                    if (dact_out) stf<T>(dact_out + base + (long)s * C, a[0]);
+                    if (scaled_out) stf<T>(scaled_out + base + (long)s * C, a[0] * coef[cg]);
+                    if (x3) b[0] = ldf<T>(x3 + base + (long)s * C);
                 }
             }
 #pragma unroll
@@ -362,17 +375,22 @@ __global__ __launch_bounds__(256) void row_sumsq_kernel(const float* __restrict_
 
 template <typename T>
 __global__ void row_scale_kernel(const T* __restrict__ x, const float* __restrict__ s, T* __restrict__ o,
-                                 size_t row, float k, int vec) {
+                                 size_t row, float k, int vec, const T* __restrict__ x2 = nullptr) {
+    // o = (x - x2) * s[row] * k (x2 optional): with x2 the backward of a squared-difference loss term in one pass
     const float f = s[blockIdx.y] * k;
     const size_t base = (size_t)blockIdx.y * row;
     const size_t stride = (size_t)gridDim.x * blockDim.x, t0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (vec) {
         for (size_t i = t0; i < row / 4; i += stride) {
-            const float4 u = ld4<T>(x + base + 4 * i);
+            float4 u = ld4<T>(x + base + 4 * i);
+            if (x2) {
+                const float4 w = ld4<T>(x2 + base + 4 * i);
+                u.x -= w.x; u.y -= w.y; u.z -= w.z; u.w -= w.w;
+            }
             st4<T>(o + base + 4 * i, make_float4(u.x * f, u.y * f, u.z * f, u.w * f));
         }
     } else {
-        for (size_t i = t0; i < row; i += stride) stf<T>(o + base + i, ldf<T>(x + base + i) * f);
+        for (size_t i = t0; i < row; i += stride) stf<T>(o + base + i, (ldf<T>(x + base + i) - (x2 ? ldf<T>(x2 + base + i) : 0.f)) * f);
     }
 }
 
@@ -616,7 +634,9 @@ inline int ew_blocks(size_t n) {
 }  // namespace
 
 static int nc_reduce_launch(const void* x1, const void* x2, float* s1, float* s2, int n, int s, int c, int flags,
-                            float slope, int dt, void* stream, void* dact_out, int dact) {
+                            float slope, int dt, void* stream, void* dact_out, int dact, const void* x3 = nullptr,
+                            const float* coef = nullptr, void* scaled_out = nullptr, int dact_on = -1) {
+    if (dact_on < 0) dact_on = dact_out != nullptr;
     CN_CHECK_ARG(x1 && (s1 || s2) && n > 0 && s > 0 && c > 0 && (dt == CN_F32 || dt == CN_BF16), "nc_reduce: bad args");
     hipStream_t st = (hipStream_t)stream;
     if (flags & 16) {
@@ -659,8 +679,8 @@ static int nc_reduce_launch(const void* x1, const void* x2, float* s1, float* s2
     }
     CN_DISPATCH_DT(dt, {
         const T* p1 = (const T*)x1; const T* p2 = (const T*)x2;
-        if (V == 4) hipLaunchKernelGGL((nc_reduce_kernel<4, T>), grid, block, 0, st, p1, p2, s1, s2, s, c, (int)rpb, flags & 255, slope, period2, (T*)dact_out, dact, parts);
-        else hipLaunchKernelGGL((nc_reduce_kernel<1, T>), grid, block, 0, st, p1, p2, s1, s2, s, c, (int)rpb, flags & 255, slope, period2, (T*)dact_out, dact, parts);
+        if (V == 4) hipLaunchKernelGGL((nc_reduce_kernel<4, T>), grid, block, 0, st, p1, p2, s1, s2, s, c, (int)rpb, flags & 255, slope, period2, (T*)dact_out, dact, parts, (const T*)x3, coef, (T*)scaled_out, dact_on);
+        else hipLaunchKernelGGL((nc_reduce_kernel<1, T>), grid, block, 0, st, p1, p2, s1, s2, s, c, (int)rpb, flags & 255, slope, period2, (T*)dact_out, dact, parts, (const T*)x3, coef, (T*)scaled_out, dact_on);
     });
     CN_LAUNCH_CHECK();
     if (parts) {
@@ -700,6 +720,16 @@ extern "C" int cn_sum_rows_into(const float* src, float* dst, int rows, int cols
     hipLaunchKernelGGL(sum_rows_into_kernel, dim3(cn_cdiv(cols, 256)), dim3(256), 0, (hipStream_t)stream, src, dst, rows, cols, accumulate);
     CN_LAUNCH_CHECK();
     return CN_OK;
+}
+
+// Backward of conv -> BatchNorm(inference: y0 = a[c] x + shift[c] (+ residual)) -> activation in ONE pass (keras ResNet50 blocks
+// of the real encoder, real_encoder.py:13-20): g = gy * act'(y) (y = the activation's output; act NONE: g = gy), gx = a[c] * g
+// written to gx, g itself to g_out if the residual branch needs it (else NULL), sum_g[r][c] = sum g (-> d shift),
+// sum_gx[r][c] = sum g * x (-> d a); n = partial rows the per-channel sums are spread over, s rows each.  flags: bit4 as cn_nc_reduce.
+extern "C" int cn_bn_act_bwd(const void* gy, const void* y, const void* x, const float* a, void* g_out, void* gx, float* sum_g,
+                             float* sum_gx, int n, int s, int c, int act, int flags, int dt, void* stream) {
+    CN_CHECK_ARG(gy && y && x && a && gx && sum_g && sum_gx, "bn_act_bwd: NULL");
+    return nc_reduce_launch(gy, y, sum_g, sum_gx, n, s, c, flags & 16, 0.f, dt, stream, g_out, act, x, a, gx, 1);
 }
 
 extern "C" int cn_nc_reduce_dact(const void* x1, const void* x2, float* s1, float* s2, void* dact_out, int n, int s, int c,
@@ -835,6 +865,15 @@ extern "C" int cn_row_scale(const void* x, const float* s, void* out, int n, siz
     int bpr = (int)((row + 256 * 16 - 1) / (256 * 16));
     if (bpr > 512) bpr = 512;
     CN_DISPATCH_DT(dt, hipLaunchKernelGGL((row_scale_kernel<T>), dim3(bpr, n), dim3(256), 0, (hipStream_t)stream, (const T*)x, s, (T*)out, row, k, vec));
+    CN_LAUNCH_CHECK();
+    return CN_OK;
+}
+extern "C" int cn_row_scale_diff(const void* x, const void* x2, const float* s, void* out, int n, size_t row, float k, int dt, void* stream) {
+    CN_CHECK_ARG(x && x2 && s && out && n > 0 && row > 0 && (dt == CN_F32 || dt == CN_BF16), "row_scale_diff: bad args");
+    const int vec = alv(x, dt) && alv(x2, dt) && alv(out, dt) && row % 4 == 0;
+    int bpr = (int)((row + 256 * 16 - 1) / (256 * 16));
+    if (bpr > 512) bpr = 512;
+    CN_DISPATCH_DT(dt, hipLaunchKernelGGL((row_scale_kernel<T>), dim3(bpr, n), dim3(256), 0, (hipStream_t)stream, (const T*)x, s, (T*)out, row, k, vec, (const T*)x2));
     CN_LAUNCH_CHECK();
     return CN_OK;
 }

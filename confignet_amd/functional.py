@@ -16,6 +16,8 @@ from . import ops
 from .ops import ACT_LRELU, ACT_NONE, ACT_RELU, ACT_TANH, ConvSpec  # noqa: F401
 
 _INPUT_GRADS_ONLY = False
+import os as _os
+BN_BWD_FUSED = _os.environ.get("CN_NO_BN_BWD_FUSED") is None      # conv -> BN(inference) -> ReLU backward as one pass (cn_bn_act_bwd)
 
 
 @contextlib.contextmanager
@@ -625,6 +627,10 @@ class ChannelAffineActFn(Function):
             raise RuntimeError("ChannelAffineActFn is first-order only")
         x, a, y = ctx.saved_tensors
         g = _cg(gy)
+        if ctx.needs_input_grad[0] and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]) and x.shape[-1] % 4 == 0 and BN_BWD_FUSED:
+            # one pass: ReLU backward, gx = a * g, sum g, sum g * x (and g itself for the residual branch)
+            gx, gres, gb, ga = ops.bn_act_bwd(g, y if ctx.relu else x, x, a, ACT_RELU if ctx.relu else ACT_NONE, ctx.has_res)
+            return gx, ga, gb, (gres if ctx.has_res else None), None
         if ctx.relu:
             g = ops.act_bwd(g, y, ACT_RELU)
         gx = ga = gb = None
@@ -725,8 +731,7 @@ class SqDiffSumFn(Function):
     @staticmethod
     def backward(ctx, g):
         a, b = ctx.saved_tensors
-        d = ops.axpby(a, b, 1.0, -1.0)
-        return ops.row_scale(d.reshape(1, -1), _cg(g.reshape(1)), 2.0 * ctx.scale).reshape(a.shape), None, None
+        return ops.row_scale_diff(a, b, _cg(g.reshape(1)), 2.0 * ctx.scale), None, None
 
 
 def mse_sum(a, b):

@@ -788,6 +788,28 @@ def dual_tail_gx(h, ta, tx, x, co, slope):
     return out
 
 
+def bn_act_bwd(gy, y, x, a, act, want_g):
+    """(gx, g | None, sum_c g, sum_c g*x): cn_bn_act_bwd -- activation backward, BatchNorm(inference) input gradient and the two
+    per-channel parameter sums in one pass over gy / y / x."""
+    gy, y, x = _unify(gy, y, x)
+    c = gy.shape[-1]
+    rows = gy.numel() // c
+    rep = _partial_rows(rows)
+    gx = torch.empty_like(gy)
+    g = torch.empty_like(gy) if want_g else None
+    s12 = zero_pool_alloc((2, rep, c), gy.device)
+    flags = 16
+    if s12 is None:
+        s12, flags = torch.empty((2, rep, c), device=gy.device, dtype=torch.float32), 0
+    check(lib.cn_bn_act_bwd(_ptr(gy), _ptr(y), _ptr(x), _fptr(_c(a)), _ptr(g), _ptr(gx), _ptr(s12[0]), _ptr(s12[1]), rep, rows // rep, c,
+                            act, flags, _dt(gy), _stream()), "cn_bn_act_bwd")
+    if rep > 1:
+        s12 = s12.sum(1)
+    else:
+        s12 = s12.reshape(2, c)
+    return gx, g, s12[0], s12[1]
+
+
 def nc_reduce_dact(x1, x2, act, slope, x2_period=0, flags=0, want_dot=True):
     """(a, sum_s a, sum_s a * f2(x2)) with a = x1 * act'(x2): cn_nc_reduce_dact (one pass instead of act_bwd + nc_reduce)."""
     x1, x2 = _unify(x1, x2)
@@ -896,6 +918,14 @@ def row_sumsq(x):
 def row_scale(x, s, k):
     out = torch.empty_like(x)
     check(lib.cn_row_scale(_ptr(x), _fptr(s), _ptr(out), x.shape[0], x.numel() // x.shape[0], k, _dt(x), _stream()), "cn_row_scale")
+    return out
+
+
+def row_scale_diff(a, b, s, k):
+    """(a - b) * s[row] * k in one pass (the backward of sqdiff_sum: s = the incoming scalar gradient, one row)."""
+    a, b = _unify(a, b)
+    out = torch.empty_like(a)
+    check(lib.cn_row_scale_diff(_ptr(a), _ptr(b), _fptr(s), _ptr(out), s.numel(), a.numel() // s.numel(), k, _dt(a), _stream()), "cn_row_scale_diff")
     return out
 
 

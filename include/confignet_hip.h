@@ -183,6 +183,11 @@ int cn_nc_reduce(const void* x1, const void* x2, float* sum1, float* sum2, int n
  * two statistics (cn_dual_tail_*: ta, T1, T2) without a separate cn_act_bwd pass.  flags as cn_nc_reduce (bit1, bit4, period). */
 int cn_nc_reduce_dact(const void* x1, const void* x2, float* sum1, float* sum2, void* dact_out, int n, int s, int c,
                       int flags, float slope, int act, int dt, void* stream);
+/* Backward of conv -> BatchNorm (inference mode: a[c] x + shift[c] (+ residual)) -> activation in one pass (keras ResNet50 blocks
+ * of the real encoder, real_encoder.py:13-20): g = gy * act'(y), gx = a[c] * g, g itself to g_out if the residual branch needs it
+ * (else NULL), sum_g[r][c] = sum g, sum_gx[r][c] = sum g * x over n partial rows of s rows each. */
+int cn_bn_act_bwd(const void* gy, const void* y, const void* x, const float* a, void* g_out, void* gx, float* sum_g,
+                  float* sum_gx, int n, int s, int c, int act, int flags, int dt, void* stream);
 /* y = A1*f1(x1) + A2*f2(x2) + B, coefficient tensors indexed [n*cstride + c] (cstride = c, or 0 for
  * per-channel coefficients).  flags: bit0/bit1 as above, bit2: multiply the result by lrelu'(x2),
  * bit3: relu on the result, bits 8..: x2 sample period as in cn_nc_reduce.  x1, x2 and B are each optional (NULL); a NULL coefficient of a present
@@ -251,6 +256,8 @@ int cn_sqdiff_sum(const void* a, const void* b, float* out, size_t numel, float 
 int cn_row_sumsq(const float* x, float* out, int n, size_t row, void* stream);
 /* out[n,:] = x[n,:] * s[n] * k */
 int cn_row_scale(const void* x, const float* s, void* out, int n, size_t row, float k, int dt, void* stream);
+/* out = (x - x2) * s[row] * k: the gradient of a squared-difference loss term (perceptual_loss.py:74-80) in one pass. */
+int cn_row_scale_diff(const void* x, const void* x2, const float* s, void* out, int n, size_t row, float k, int dt, void* stream);
 /* out = (a - b) * mask[n,h,w] broadcast over c (b optional) (losses.py:14) */
 int cn_masked_diff(const float* a, const float* b, const uint8_t* mask, float* out, size_t pixels, int c, void* stream);
 /* 2-D max pooling, zero padding (keras MaxPooling2D after ZeroPadding2D); bwd: the gradient of a window goes to its
