@@ -73,8 +73,10 @@ __global__ void upfold_wgrad_kernel(UpfoldTab t, const float* __restrict__ GW2, 
                     s += GW2[((long)((ad * t.k2[1] + ah) * t.k2[2] + aw) * cout + co) * cin + ci];
                 }
         float* dst = GW + ((long)kk * cin + ci) * cout + co;
-        // (atomic: the two branches of a forked step add into one gradient-arena slot from two streams at once)
-        if (accumulate) unsafeAtomicAdd(dst, s);
+        // accumulate = 1: atomic (the two branches of a forked step may add into one gradient-arena slot from two streams at
+        // once); accumulate = 2: plain read-modify-write (the caller guarantees a single writer: 4x faster on the 3.5 M-entry filters)
+        if (accumulate == 1) unsafeAtomicAdd(dst, s);
+        else if (accumulate) *dst += s;
         else *dst = s;
     }
 }

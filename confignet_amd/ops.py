@@ -261,12 +261,14 @@ def upfold_prepare(w, g):
     return wf.view(taps + (g.cin, g.cout)), wd.view(taps + (g.cout, g.cin)), gd, g2
 
 
-def upfold_wgrad(gw2, g, w_shape, out=None):
-    """gw[kk][ci][co] from the conv2 filter gradient gw2[a][co][ci]; out: add to this tensor instead."""
+def upfold_wgrad(gw2, g, w_shape, out=None, single_writer=False):
+    """gw[kk][ci][co] from the conv2 filter gradient gw2[a][co][ci]; out: add to this tensor instead (atomically, unless the
+    caller is the only one adding to it right now)."""
     gw = out if out is not None else torch.empty(w_shape, device=gw2.device, dtype=torch.float32)
     k3 = (ctypes.c_int * 3)(g.k_d, g.k_h, g.k_w)
     p3 = (ctypes.c_int * 3)(g.p_d, g.p_h, g.p_w)
-    check(lib.cn_upfold_wgrad(_fptr(_c(gw2)), _ptr(gw), g.nd, k3, p3, g.cin, g.cout, int(out is not None), _stream()), "cn_upfold_wgrad")
+    mode = 0 if out is None else (2 if single_writer else 1)
+    check(lib.cn_upfold_wgrad(_fptr(_c(gw2)), _ptr(gw), g.nd, k3, p3, g.cin, g.cout, mode, _stream()), "cn_upfold_wgrad")
     return gw
 
 
@@ -473,6 +475,13 @@ class grad_sink:
         if st is not None and st["side"] is not None and st["used"]:
             torch.cuda.current_stream().wait_stream(st["side"])
         if st is not None:
+            cur = torch.cuda.current_stream()
+            for s_ in st.pop("touched", []):            # every stream a sink launched on (a forked step has two) before anything
+                if s_ != cur:                           # below reads or adds to the arenas on the calling stream
+                    cur.wait_stream(s_)
+            for gw2, g, w_shape, slot in st.pop("upfold", {}).values():
+                upfold_wgrad(gw2, g, w_shape, out=slot, single_writer=True)
+        if st is not None:
             st["keep"].clear()
             st["used"] = False
 
@@ -512,6 +521,10 @@ def _sink_run(fn, keep):
     launches one cross-stream edge (an edge per layer made the captured graph a ladder that replayed 35 % slower than the
     single chain: 49.3 -> 66.5 ms).  `keep`: the tensors the launch reads; they stay alive until the join."""
     st = _SINK
+    if st is not None:
+        cur0 = torch.cuda.current_stream()
+        if all(cur0 != s_ for s_ in st.setdefault("touched", [])):
+            st["touched"].append(cur0)
     if st is None or st["side"] is None:
         fn()
         return
@@ -529,7 +542,19 @@ def sink_conv_wgrad(x, gy, g, w_shape, slot):
 
 
 def sink_upfold_wgrad(gy, x, g2, wd_shape, g, w_shape, slot):
-    _sink_run(lambda: upfold_wgrad(conv_wgrad(gy, x, g2, wd_shape), g, w_shape, out=slot), (x, gy))
+    """Upsample-folded layer: the class-filter gradient of EVERY use of the weight in this backward pass (the generator runs twice
+    in the generator step) is accumulated into one scratch by the filter-gradient kernel (atomics: any stream), and scattered
+    back to the k taps ONCE, at the join of the pass, by a single writer (10 atomic scatters of up to 172 us -> 5 plain ones)."""
+    st = _SINK
+    pend = st.setdefault("upfold", {})
+    ent = pend.get(slot.data_ptr())
+    if ent is None:
+        gw2 = zero_pool_alloc(wd_shape, x.device)
+        if gw2 is None:
+            gw2 = torch.zeros(wd_shape, device=x.device, dtype=torch.float32)
+        ent = pend[slot.data_ptr()] = (gw2, g, w_shape, slot)
+    gw2 = ent[0]
+    _sink_run(lambda: conv_wgrad(gy, x, g2, wd_shape, out=gw2), (x, gy))
 
 
 def sink_gemm(a, b, slot, trans_a=False, trans_b=False):

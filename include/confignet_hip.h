@@ -141,7 +141,7 @@ int cn_conv_wgrad_bf16(const CnConvGeom* g, const uint16_t* x, const uint16_t* g
 int cn_upfold_weights(const float* w, float* wf, float* wd, int nd, const int* k3, const int* pad_lo3, int cin, int cout,
                       int* k2_out3, int* pad2_out3, void* stream);
 int cn_upfold_wgrad(const float* gw2, float* gw, int nd, const int* k3, const int* pad_lo3, int cin, int cout,
-                    int accumulate, void* stream);
+                    int accumulate, void* stream);      /* accumulate: 0 store, 1 atomic add, 2 plain add (single writer) */
 /* dst = (dst_dt) src : storage-type conversion between fp32 and bf16 tensors */
 int cn_cast(const void* src, int src_dt, void* dst, int dst_dt, size_t numel, void* stream);
 
