@@ -857,6 +857,78 @@ __global__ __launch_bounds__(256) void s2_image_dgrad_kernel(CnConvGeom g, const
     }
 }
 
+// Data gradient of a 3x3 stride-1 convolution INTO a 3-channel image (VGG conv1_1 under the perceptual loss, twice per
+// generator step).  Same transposition as s2_image_dgrad_kernel: P[pixel][tap*3 + co] = sum_c gy[pixel][c] wt[tap][c][co]
+// for the (TH+2) x (TW+2) input pixels around a TH x TW output tile (one 32-column MFMA block per 32 pixels, gy read once
+// + halo), then every output pixel sums its 9 entries of P.
+template <int NG, typename TI = float>   // C = 8 * NG
+__global__ __launch_bounds__(256) void s1_image_dgrad_kernel(CnConvGeom g, const TI* __restrict__ GY,
+                                                             const float* __restrict__ WT, float* __restrict__ Y) {
+    constexpr int TH = 8, TW = 32, RW = TW + 2, R = (TH + 2) * RW, MT = (R + 31) / 32, PS = 29, C = 8 * NG;
+    __shared__ float P[MT * 32][PS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, half = lane >> 5;
+    const int tiles_w = (g.out_w + TW - 1) / TW, tiles_h = (g.out_h + TH - 1) / TH;
+    int b = blockIdx.x;
+    const int tj = b % tiles_w; b /= tiles_w;
+    const int ti = b % tiles_h;
+    const int n = b / tiles_h;
+    const int i0 = ti * TH - g.p_h, j0 = tj * TW - g.p_w;          // first input row / column of the patch
+
+    float breg[NG][4];
+#pragma unroll
+    for (int jg = 0; jg < NG; ++jg)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int k = 8 * jg + 4 * half + q;
+            breg[jg][q] = l31 < 27 ? WT[((l31 / 3) * C + k) * 3 + l31 % 3] : 0.f;
+        }
+
+    for (int mt = wave; mt < MT; mt += 4) {
+        const int r = mt * 32 + l31;
+        const int ri = r / RW, rj = r - ri * RW;
+        const int ii = i0 + ri, jj = j0 + rj;
+        const bool inb = r < R && ii >= 0 && ii < g.in_h && jj >= 0 && jj < g.in_w;
+        const TI* src = GY + (((long)n * g.in_h + ii) * g.in_w + jj) * C + 4 * half;
+        float4 a[NG];
+#pragma unroll
+        for (int jg = 0; jg < NG; ++jg)
+            a[jg] = inb ? ld4<TI>(src + 8 * jg) : make_float4(0.f, 0.f, 0.f, 0.f);
+        f32x16 acc;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+#pragma unroll
+        for (int jg = 0; jg < NG; ++jg) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[jg].x, breg[jg][0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[jg].y, breg[jg][1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[jg].z, breg[jg][2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[jg].w, breg[jg][3], acc, 0, 0, 0);
+        }
+        if (l31 < 27) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) P[mt * 32 + 4 * half + (q & 3) + 8 * (q >> 2)][l31] = acc[q];
+        }
+    }
+    __syncthreads();
+
+    const int ly = threadIdx.x / TW, lx = threadIdx.x - ly * TW;
+    const int y = ti * TH + ly, x = tj * TW + lx;
+    if (y >= g.out_h || x >= g.out_w) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const float* pr = &P[(ly + kh) * RW + lx + kw][(kh * 3 + kw) * 3];   // out-of-image pixels hold zeros
+            s0 += pr[0];
+            s1 += pr[1];
+            s2 += pr[2];
+        }
+    float* dst = Y + (((long)n * g.out_h + y) * g.out_w + x) * 3;
+    dst[0] = s0;
+    dst[1] = s1;
+    dst[2] = s2;
+}
+
 // ---------------------------------------------------------------------------------------------
 // First layers: 3x3 convolution of a 3-channel image (DiscrBlock 0 of both discriminators and the latent regressor,
 // VGG conv1_1): K = 27.  The generic kernel gathers those 27 values with per-element integer division (cin = 3 is not
@@ -1141,6 +1213,16 @@ static int conv_fwd_impl(const CnConvGeom* gp, const float* x, const float* w, c
             dim3 grid((unsigned)(g.n * cn_cdiv(g.in_h, 8) * cn_cdiv(g.in_w, 32)));
             cn_prof_begin(s, conv_flops(g), conv_bytes(g), CN_FAM_S2_IMAGE_DGRAD);
             hipLaunchKernelGGL((s2_image_dgrad_kernel<6>), grid, dim3(256), 0, s, g, x, w, y);
+            cn_prof_end(s);
+            CN_LAUNCH_CHECK();
+            return CN_OK;
+        }
+        if (g.nd == 2 && g.k_h == 3 && g.k_w == 3 && g.dl_h == 1 && g.dl_w == 1 && g.s_h == 1 && g.s_w == 1 && !g.up &&
+            g.cout == 3 && g.cin == 64 && !bias && act == CN_ACT_NONE && g.p_h >= 0 && g.p_h <= 2 && g.p_w >= 0 && g.p_w <= 2 &&
+            !getenv("CN_NO_S1IMG")) {
+            dim3 grid((unsigned)(g.n * cn_cdiv(g.out_h, 8) * cn_cdiv(g.out_w, 32)));
+            cn_prof_begin(s, conv_flops(g), conv_bytes(g), CN_FAM_S2_IMAGE_DGRAD);
+            hipLaunchKernelGGL((s1_image_dgrad_kernel<8>), grid, dim3(256), 0, s, g, x, w, y);
             cn_prof_end(s);
             CN_LAUNCH_CHECK();
             return CN_OK;

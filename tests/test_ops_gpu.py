@@ -123,6 +123,7 @@ FULL_SIZE_LAYERS = [
     ((96, 16, 16, 384), (3, 3), 768, 2, 0),       # DiscrBlock 4 under the batched R1 sweep (6 heads x 16 samples)
     ((8, 16, 16, 16, 256), (3, 3, 3), 128, 1, 1),  # generator Conv3D 16^3 -> 32^3 with folded upsample
     ((8, 32, 32, 256), (4, 4), 64, 1, 1),         # generator k4 + upsample to 64^2
+    ((8, 256, 256, 3), (3, 3), 64, 1, 0),         # VGG block1_conv1: c3_fwd, s1_image_dgrad, thin filter gradient
 ]
 
 
@@ -392,8 +393,8 @@ def test_elementwise_and_losses():
 def test_pools_preproc_uint8():
     from confignet_amd import ops
     rng = np.random.default_rng(6)
-    x = rng.normal(size=(2, 16, 16, 8))
-    for k, s, pad in [(2, 2, 0), (3, 2, 1)]:
+    for (k, s, pad), c in [((2, 2, 0), 8), ((3, 2, 1), 8), ((3, 2, 1), 6), ((2, 2, 0), 6)]:   # 4-channel-group and scalar kernels
+        x = rng.normal(size=(2, 16, 16, c))
         xr = t64(np.maximum(x, 0) if pad else x).requires_grad_(True)
         ref = O.maxpool(xr, k, s, pad)
         close(ops.maxpool_fwd(dev(xr.detach().numpy()), k, s, pad), ref, what="maxpool")
