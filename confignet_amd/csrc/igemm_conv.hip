@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(CnConvGeom g, const floa
     // Tap-minor (tap_minor != 0: all taps of a channel chunk, then the next chunk) recomputes them every step but keeps
     // the XCD's working set at (tiles in flight) x (rows) x KB channels, so the taps' shifted re-reads of a chunk hit
     // the 4 MiB L2 instead of going back to the fabric (stride-1 layers with many channels).
-    auto load_tiles = [&](int ks, float4 (&ra)[AP], float4 (&rb)[BP]) {
+    auto load_tiles = [&](int ks, float4 (&ra)[AP], float4 (&rb)[BP], unsigned& amask) {
         if (VEC) {
             int c0;
             if (tap_minor) {
@@ -148,28 +148,30 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(CnConvGeom g, const floa
                 }
             }
             const int tap = cur_tap;
+            // every load below is UNCONDITIONAL (dead rows / columns read a clamped, valid address and are zeroed on the way
+            // into LDS): a load inside a branch makes the compiler's waitcnt insertion assume the branch was skipped, and it
+            // then drains vmcnt to 0 before every LDS store -- the two-step lookahead of the register sets would be lost
+            amask = 0;
 #pragma unroll
-            for (int i = 0; i < AP; ++i)
-                ra[i] = aoff[i] >= 0 ? *reinterpret_cast<const float4*>(X + aoff[i] + c0 + kq * 4)
-                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int i = 0; i < AP; ++i) {
+                ra[i] = *reinterpret_cast<const float4*>(X + max(aoff[i], 0) + c0 + kq * 4);
+                amask |= (aoff[i] >= 0 ? 1u : 0u) << i;
+            }
             if (bt) {
 #pragma unroll
                 for (int j = 0; j < BP; ++j) {
-                    const int idx = tid + 256 * j;
-                    const int nn = n0 + idx / KQ, kk = (idx % KQ) * 4;
-                    rb[j] = (nn < g.cout && idx < KB * BN / 4)
-                                ? *reinterpret_cast<const float4*>(W + ((long)(T - 1 - tap) * g.cout + nn) * g.cin + c0 + kk)
-                                : make_float4(0.f, 0.f, 0.f, 0.f);
+                    const int idx = min(tid + 256 * j, KB * BN / 4 - 1);
+                    const int nn = min(n0 + idx / KQ, g.cout - 1), kk = (idx % KQ) * 4;
+                    rb[j] = *reinterpret_cast<const float4*>(W + ((long)(T - 1 - tap) * g.cout + nn) * g.cin + c0 + kk);
                 }
             } else {
 #pragma unroll
                 for (int j = 0; j < BP; ++j) {
-                    const int idx = tid + 256 * j;
+                    const int idx = BVEC ? min(tid + 256 * j, KB * BN / 4 - 1) : tid + 256 * j;
                     const int brow = idx / (BN / 4), col = n0 + (idx % (BN / 4)) * 4;
                     const long kg = (long)tap * g.cin + c0 + brow;
                     if (BVEC) {
-                        rb[j] = (col < g.cout && idx < KB * BN / 4) ? *reinterpret_cast<const float4*>(W + kg * g.cout + col)
-                                                                    : make_float4(0.f, 0.f, 0.f, 0.f);
+                        rb[j] = *reinterpret_cast<const float4*>(W + kg * g.cout + min(col, g.cout - 4));
                     } else {   // thin cout (3-channel image gradients): guarded scalar filter loads
                         float v[4];
 #pragma unroll
@@ -179,6 +181,7 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(CnConvGeom g, const floa
                 }
             }
         } else {
+            amask = ~0u;
 #pragma unroll
             for (int i = 0; i < AP; ++i) {
                 float v[4];
@@ -207,14 +210,15 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(CnConvGeom g, const floa
             }
         }
     };
-    auto store_tiles = [&](int buf, const float4 (&ra)[AP], const float4 (&rb)[BP]) {
+    auto store_tiles = [&](int buf, const float4 (&ra)[AP], const float4 (&rb)[BP], unsigned amask) {
 #pragma unroll
         for (int i = 0; i < AP; ++i) {
             const int r = arow + RPP * i;
-            As[buf][kq * 4 + 0][r] = ra[i].x;
-            As[buf][kq * 4 + 1][r] = ra[i].y;
-            As[buf][kq * 4 + 2][r] = ra[i].z;
-            As[buf][kq * 4 + 3][r] = ra[i].w;
+            const bool live = (amask >> i) & 1u;     // padding taps / rows past the end: zeros (the load read a clamped address)
+            As[buf][kq * 4 + 0][r] = live ? ra[i].x : 0.f;
+            As[buf][kq * 4 + 1][r] = live ? ra[i].y : 0.f;
+            As[buf][kq * 4 + 2][r] = live ? ra[i].z : 0.f;
+            As[buf][kq * 4 + 3][r] = live ? ra[i].w : 0.f;
         }
         if (VEC && bt) {
 #pragma unroll
@@ -239,26 +243,31 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(CnConvGeom g, const floa
     };
 
     const int a_col = wm * 32 * TM + l31, b_col = wn * 32 * TN + l31;
+    // The steps past the end re-load the last step (clamped index) and store it into the LDS buffer nobody reads again:
+    // no branch around a load or a store in the loop (see load_tiles).  Dead filter columns (>= cout) carry whatever the
+    // clamped address held: they only reach accumulator columns the epilogue never stores.
+    unsigned am0 = 0, am1 = 0;
     if (ks_beg < ks_end) {
-        load_tiles(ks_beg, ra0, rb0);
-        store_tiles(0, ra0, rb0);
-    }
-    if (ks_beg + 1 < ks_end) load_tiles(ks_beg + 1, ra1, rb1);
-    __syncthreads();
-    int ks = ks_beg;
-    for (; ks + 1 < ks_end; ks += 2) {
-        // even step: LDS buffer 0 holds step ks, set 1 holds step ks+1 (in flight), step ks+2 goes to set 0
-        if (ks + 2 < ks_end) load_tiles(ks + 2, ra0, rb0);
-        mma_step<TM, TN, LDA, LDB, KB>(As[0], Bs[0], acc, a_col, b_col, half);
-        store_tiles(1, ra1, rb1);
+        const int ks_last = ks_end - 1;
+        load_tiles(ks_beg, ra0, rb0, am0);
+        store_tiles(0, ra0, rb0, am0);
+        load_tiles(min(ks_beg + 1, ks_last), ra1, rb1, am1);
         __syncthreads();
-        // odd step: buffer 1 holds step ks+1, set 0 holds step ks+2, step ks+3 goes to set 1
-        if (ks + 3 < ks_end) load_tiles(ks + 3, ra1, rb1);
-        mma_step<TM, TN, LDA, LDB, KB>(As[1], Bs[1], acc, a_col, b_col, half);
-        if (ks + 2 < ks_end) store_tiles(0, ra0, rb0);
-        __syncthreads();
+        int ks = ks_beg;
+        for (; ks + 1 < ks_end; ks += 2) {
+            // even step: LDS buffer 0 holds step ks, set 1 holds step ks+1 (in flight), step ks+2 goes to set 0
+            load_tiles(min(ks + 2, ks_last), ra0, rb0, am0);
+            mma_step<TM, TN, LDA, LDB, KB>(As[0], Bs[0], acc, a_col, b_col, half);
+            store_tiles(1, ra1, rb1, am1);
+            __syncthreads();
+            // odd step: buffer 1 holds step ks+1, set 0 holds step ks+2, step ks+3 goes to set 1
+            load_tiles(min(ks + 3, ks_last), ra1, rb1, am1);
+            mma_step<TM, TN, LDA, LDB, KB>(As[1], Bs[1], acc, a_col, b_col, half);
+            store_tiles(0, ra0, rb0, am0);
+            __syncthreads();
+        }
+        if (ks < ks_end) mma_step<TM, TN, LDA, LDB, KB>(As[0], Bs[0], acc, a_col, b_col, half);   // odd number of steps: the last one
     }
-    if (ks < ks_end) mma_step<TM, TN, LDA, LDB, KB>(As[0], Bs[0], acc, a_col, b_col, half);   // odd number of steps: the last one
 
     // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     const bool split = gridDim.z > 1;

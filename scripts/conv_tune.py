@@ -5,9 +5,10 @@ import os, sys, subprocess, json
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 SHAPES = [  # (n, h, w, cin, cout, k, stride)
-    (8, 16, 16, 256, 256, 3, 1), (8, 32, 32, 128, 128, 3, 1), (8, 8, 8, 512, 512, 3, 1), (16, 64, 64, 96, 192, 3, 2),
-    (16, 128, 128, 48, 96, 3, 2), (16, 32, 32, 192, 384, 3, 2), (16, 64, 64, 256, 256, 3, 1), (8, 16, 16, 1024, 256, 1, 1),
-    (16, 16, 16, 384, 768, 3, 2),
+    (16, 64, 64, 96, 192, 3, 2), (16, 128, 128, 48, 96, 3, 2), (16, 32, 32, 192, 384, 3, 2), (16, 16, 16, 384, 768, 3, 2),
+    (96, 16, 16, 384, 768, 3, 2), (8, 16, 16, 1024, 256, 1, 1), (8, 16, 16, 256, 1024, 1, 1), (8, 32, 32, 512, 128, 1, 1),
+    (8, 32, 32, 128, 512, 1, 1), (8, 8, 8, 2048, 512, 1, 1), (8, 8, 8, 512, 2048, 1, 1), (8, 64, 64, 64, 256, 1, 1),
+    (8, 64, 64, 256, 64, 1, 1), (8, 32, 32, 256, 512, 1, 2), (8, 16, 16, 256, 256, 3, 1), (8, 8, 8, 512, 512, 3, 1),
 ]
 KIND = os.environ.get("CN_TUNE_KIND", "fwd")
 if len(sys.argv) > 1 and sys.argv[1] in ("fwd", "dgrad"):
