@@ -1303,7 +1303,7 @@ static int conv_fwd_impl(const CnConvGeom* gp, const float* x, const float* w, c
     // where 128- or 64-wide tiles pad a quarter of their columns
     static const int no_n96 = getenv("CN_NO_N96") ? 1 : 0;
     if (!no_n96 && g.cout % 96 == 0 && g.cout % 128 != 0 &&
-        (long)cn_cdiv(M, 128) * (g.cout / 96) >= (g.cout == 96 ? 256 : 512)) {
+        (long)cn_cdiv(M, 128) * (g.cout / 96) >= (g.cout == 96 ? 256 : 384)) {
         cfg = 4;
         tiles = (long)cn_cdiv(M, 128) * (g.cout / 96);
     }
@@ -1312,8 +1312,14 @@ static int conv_fwd_impl(const CnConvGeom* gp, const float* x, const float* w, c
     // (parity-ordered data gradients: tiles of the 4-tap class carry 4x the K of the 1-tap class, so more, smaller
     // K slices also even out the load -- conv_tune.py dgrad: 123 -> 95 us at M=16384 N=192, 124 -> 104 us at M=4096 N=384)
     const bool par_small = par && cfg == 2;          // 64 x 64 tiles of a parity-ordered data gradient
-    if (vec && tiles < (par_small ? 1024 : 512)) {
-        long nks = (long)g.k_d * g.k_h * g.k_w * (g.cin / BK);
+    const long nks_total = vec ? (long)g.k_d * g.k_h * g.k_w * (g.cin / BK) : 0;
+    // a short reduction (<= 8 steps) is all prologue and epilogue: the narrower tile spreads the stores over twice the workgroups
+    if (cfg == 0 && vec && !par && nks_total <= 8) { cfg = 1; tiles = t128x64; }
+    // one workgroup per CU and a short reduction: the zero pass, the atomics and the separate bias / activation pass of a K
+    // split cost more than the idle SIMD slots they would fill (conv_tune.py: M=8192 K=512 N=128 31 -> 25 us unsplit)
+    const bool short_full = !par && tiles >= 256 && nks_total < 64;
+    if (vec && tiles < (par_small ? 1024 : 512) && !short_full) {
+        long nks = nks_total;
         if (par) nks /= (long)g.dl_d * g.dl_h * g.dl_w;
         long want = ((par_small ? 3072 : 1024) + tiles - 1) / tiles;      // aim at ~4 (12) workgroups per CU
         if (want > 16) want = 16;

@@ -18,23 +18,33 @@ $PY $R/scripts/prof_summary.py $(ls /tmp/kt1/*/*.db | head -1) > $O/${TAG}_bench
 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/kt2 -- $PY $R/bench.py --serial --steps 10 --warmup 3 --no-cpu-baseline > $O/${TAG}_bench_serial_under_rocprof.json 2>/dev/null
 $PY $R/scripts/prof_summary.py $(ls /tmp/kt2/*/*.db | head -1) > $O/${TAG}_bench_serial_kernel_trace.txt
 $PY $R/scripts/torch_share.py /tmp/kt2 $O/${TAG}_torch_share.json > /dev/null
-# 3. PMC passes (each in its own run, --kernel-trace only)
+# 3. PMC passes (each in its own run, --kernel-trace only).  A pass that leaves no database (rocprofv3 has died at exit on
+#    this pool now and then) is repeated, up to three times.
+pmc_pass() {   # pmc_pass <out dir> <stdout file> <bench flags...> -- <counters...>
+  local out=$1 line=$2; shift 2
+  local flags=(); while [ "$1" != "--" ]; do flags+=("$1"); shift; done; shift
+  for try in 1 2 3; do
+    rm -rf $out
+    timeout 600 rocprofv3 --kernel-trace --pmc "$@" -d $out -- $PY $R/bench.py "${flags[@]}" > $line 2>/dev/null
+    if ls $out/*/*.db > /dev/null 2>&1; then return 0; fi
+    echo "pmc pass $out: no database (try $try)" >> $O/bench.err
+  done
+  return 1
+}
 CMD="bench.py --steps 2 --warmup 1 --no-cpu-baseline --serial"
-rm -rf /tmp/pf /tmp/pw /tmp/pm
-timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/pf -- $PY $R/$CMD > /tmp/pf_line.json 2>/dev/null
-timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/pw -- $PY $R/$CMD > /dev/null 2>&1
+pmc_pass /tmp/pf /tmp/pf_line.json --steps 2 --warmup 1 --no-cpu-baseline --serial -- FETCH_SIZE
+pmc_pass /tmp/pw /dev/null --steps 2 --warmup 1 --no-cpu-baseline --serial -- WRITE_SIZE
 $PY $R/scripts/pmc_traffic_json.py /tmp/pf /tmp/pw $O/${TAG}_pmc_traffic.json "python $CMD" > /dev/null
 $PY $R/scripts/pmc_traffic_by_kernel.py /tmp/pf /tmp/pw /tmp/pf_line.json $O/${TAG}_pmc_traffic_by_kernel.txt $O/${TAG}_pmc_traffic_by_kernel.json > /dev/null
-timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES -d /tmp/pm -- $PY $R/$CMD > /dev/null 2>&1
+pmc_pass /tmp/pm /dev/null --steps 2 --warmup 1 --no-cpu-baseline --serial -- SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES
 $PY $R/scripts/pmc_mfma.py /tmp/pm $O/${TAG}_pmc_mfma.json > $O/${TAG}_pmc_mfma.txt
 # 3b. the same counters for the bf16 path (configs[2]'s dtype)
 CMDB="bench.py --steps 2 --warmup 1 --no-cpu-baseline --serial --dtype bf16"
-rm -rf /tmp/pfb /tmp/pwb /tmp/pmb
-timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/pfb -- $PY $R/$CMDB > /tmp/pfb_line.json 2>/dev/null
-timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/pwb -- $PY $R/$CMDB > /dev/null 2>&1
+pmc_pass /tmp/pfb /tmp/pfb_line.json --steps 2 --warmup 1 --no-cpu-baseline --serial --dtype bf16 -- FETCH_SIZE
+pmc_pass /tmp/pwb /dev/null --steps 2 --warmup 1 --no-cpu-baseline --serial --dtype bf16 -- WRITE_SIZE
 $PY $R/scripts/pmc_traffic_json.py /tmp/pfb /tmp/pwb $O/${TAG}_pmc_traffic_bf16.json "python $CMDB" > /dev/null
-$PY $R/scripts/pmc_traffic_by_kernel.py /tmp/pfb /tmp/pwb /tmp/pfb_line.json $O/${TAG}_pmc_traffic_by_kernel_bf16.txt > /dev/null
-timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES -d /tmp/pmb -- $PY $R/$CMDB > /dev/null 2>&1
+$PY $R/scripts/pmc_traffic_by_kernel.py /tmp/pfb /tmp/pwb /tmp/pfb_line.json $O/${TAG}_pmc_traffic_by_kernel_bf16.txt $O/${TAG}_pmc_traffic_by_kernel_bf16.json > /dev/null
+pmc_pass /tmp/pmb /dev/null --steps 2 --warmup 1 --no-cpu-baseline --serial --dtype bf16 -- SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES
 $PY $R/scripts/pmc_mfma.py /tmp/pmb $O/${TAG}_pmc_mfma_bf16.json > $O/${TAG}_pmc_mfma_bf16.txt
 # 4. per-shape tables
 cd $R

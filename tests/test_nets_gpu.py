@@ -67,7 +67,7 @@ def ops_mod():
     return ops
 
 
-def check_grads(parts, recompute, tol=5e-3, max_flips=12):
+def check_grads(parts, recompute, tol=5e-3, max_flips=12, more_flips=48):
     """Gradient parity at `tol` relative L2 per tensor, with branch decisions accounted for by name.
 
     A LeakyReLU / ReLU whose pre-activation is within fp32 rounding of zero takes the other branch on the GPU than in the
@@ -76,12 +76,15 @@ def check_grads(parts, recompute, tol=5e-3, max_flips=12):
     error (2e-4 in test_ops_gpu).  Instead of a tolerance that absorbs it, the oracle lists its near-zero pre-activations
     (oracle.ref_ops.BranchControl), each candidate is flipped in a separate oracle run, and the product gradient must equal
     the oracle gradient plus the single-flip differences of a subset of them (gradients are linear in each mask element),
-    to `tol`.  recompute() reruns the oracle and returns its gradient list."""
+    to `tol`.  recompute() reruns the oracle and returns its gradient list.  The `max_flips` nearest candidates are tried
+    first; when they do not explain the difference (the accumulation order of the atomically added partial sums differs from
+    run to run, so which near-zero elements flip does too) the fit is repeated once over the `more_flips` nearest."""
     O.BranchControl.start(record=True)
     try:
         base = recompute()
         # near-zero pre-activations that a gradient actually reaches, closest to zero first
-        cands = sorted((c for c in O.BranchControl.candidates() if c[3] > 0.0), key=lambda t: t[2])[:max_flips]
+        all_cands = sorted((c for c in O.BranchControl.candidates() if c[3] > 0.0), key=lambda t: t[2])
+        cands = all_cands[:max_flips]
     finally:
         O.BranchControl.stop()
     pairs = _grad_pairs(parts, base)
@@ -94,34 +97,42 @@ def check_grads(parts, recompute, tol=5e-3, max_flips=12):
     live = [(label, got, g, float(g.norm())) for label, got, g in pairs if float(g.norm()) > 0.0]
     resid = torch.cat([((got - g) / den).reshape(-1) for _, got, g, den in live])
     cols = []
-    for cid, idx, _, _ in cands:
-        O.BranchControl.start(flips=[(cid, idx)])
-        try:
-            flipped = _grad_pairs(parts, recompute())
-        finally:
-            O.BranchControl.stop()
-        fl = {label: g for label, _, g in flipped}
-        cols.append(torch.cat([((fl[label] - g) / den).reshape(-1) for label, _, g, den in live]))
-    # a flip is taken or not: greedy selection of the single-flip differences (coefficient exactly 1) that reduce the residual
-    fit, chosen = torch.zeros_like(resid), []
-    while True:
-        cur = float((resid - fit).norm())
-        gains = [(cur - float((resid - fit - c).norm()), k) for k, c in enumerate(cols) if k not in chosen]
-        if not gains or max(gains)[0] <= 1e-3 * cur:
-            break
-        k = max(gains)[1]
-        chosen.append(k)
-        fit = fit + cols[k]
+
+    def fit_flips(cands):
+        for cid, idx, _, _ in cands[len(cols):]:
+            O.BranchControl.start(flips=[(cid, idx)])
+            try:
+                flipped = _grad_pairs(parts, recompute())
+            finally:
+                O.BranchControl.stop()
+            fl = {label: g for label, _, g in flipped}
+            cols.append(torch.cat([((fl[label] - g) / den).reshape(-1) for label, _, g, den in live]))
+        # a flip is taken or not: greedy selection of the single-flip differences (coefficient exactly 1) that reduce the residual
+        fit, chosen = torch.zeros_like(resid), []
+        while True:
+            cur = float((resid - fit).norm())
+            gains = [(cur - float((resid - fit - c).norm()), k) for k, c in enumerate(cols) if k not in chosen]
+            if not gains or max(gains)[0] <= 1e-3 * cur:
+                break
+            k = max(gains)[1]
+            chosen.append(k)
+            fit = fit + cols[k]
+        rels, o = [], 0
+        for label, got, g, den in live:
+            n = g.numel()
+            rels.append((float((resid[o:o + n] - fit[o:o + n]).norm()), label))
+            o += n
+        print("check_grads: worst rel-L2 after %d of %d flips %.3e" % (len(chosen), len(cols), max(rels)[0]))
+        return rels, chosen
+
+    rels, chosen = fit_flips(cands)
+    if max(rels)[0] > tol and len(all_cands) > len(cands):
+        cands = all_cands[:more_flips]
+        rels, chosen = fit_flips(cands)
     coef = [1 if k in chosen else 0 for k in range(len(cols))]
-    o = 0
-    print("check_grads: worst rel-L2 after %d flips %.3e" % (len(chosen), max(float((resid[a:a + g.numel()] - fit[a:a + g.numel()]).norm())
-          for a, (_, _, g, _) in zip(np.cumsum([0] + [x[2].numel() for x in live[:-1]]), live))))
-    for label, got, g, den in live:
-        n = g.numel()
-        rel = float((resid[o:o + n] - fit[o:o + n]).norm())
+    for rel, label in rels:
         assert rel <= tol, "%s: rel-L2 %.3e with %d of the %d nearest branch decisions flipped %s" % (
             label, rel, len(chosen), len(cands), coef)
-        o += n
 
 
 def close_grads(net, ref_grads, what, tol=5e-3, recompute=None):
