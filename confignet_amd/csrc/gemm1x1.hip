@@ -1,0 +1,236 @@
+// gemm1x1.hip -- 1x1 stride-1 convolutions (ResNet-50's bottleneck projections, the generator's projection conv) and their data
+// gradients as what they are: a plain row-major product C[M][N] = A[M][K] B, M = all positions, K = cin, N = cout.
+//
+// The implicit-GEMM kernel pays for generality here: a row decode with integer divisions, the output-row map, a k-major LDS
+// image written with scalar stores and read with one ds_read_b32 per MFMA operand.  This kernel keeps both tiles the way they
+// arrive:
+//   * A rows are K-contiguous in HBM and stay so in LDS ([row][16 + 4 pad]): one ds_write_b128 per 16-byte piece, and -- with the
+//     K order of an 8-deep group permuted so that half-wave h owns k = 4h .. 4h+3 -- ONE ds_read_b128 per lane feeds four MFMAs
+//     (MFMA step q contracts the pair {q, 4 + q}; any K order is fine as long as A and B agree);
+//   * forward: B = filter [K][N], N-contiguous; a lane owns TN ADJACENT output columns (TN * l31 + j), so one 8/16-byte read
+//     feeds its TN column tiles and the epilogue stores 8/16 bytes per row;
+//   * data gradient (BT): B^T = the ORIGINAL filter [N = cin][K = cout], K-contiguous like A and read like A.
+// Three LDS buffers and ONE barrier per step, placed before the last fragment group: the tile of step s+1 is written at the top
+// of step s, the barrier sits inside the MFMA stream and the first fragments of step s+1 are read before step s ends.  All loads
+// are unconditional (clamped addresses): see igemm_fwd_kernel.  scripts/dev/gemm_lab holds the stand-alone study of this loop
+// against the vendor sgemm.
+#include "common.h"
+#include "mma_tile.h"
+
+namespace {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+template <int WM, int WN, int TM, int TN, bool BT>
+__global__ __launch_bounds__(256) void gemm1x1_kernel(const float* __restrict__ A, const float* __restrict__ B,
+                                                      const float* __restrict__ bias, float* __restrict__ C, int M, int N, int K,
+                                                      int act, float slope, int ntm, int ntn, long part_stride) {
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+    static_assert(TN == 1 || TN == 2, "column tiles per wave");
+    constexpr int KB = 16, G = KB / 8, KQ = KB / 4;
+    constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN, LDA = KB + 4, LDB = BN + 4;
+    constexpr int AP = BM * KQ / 256, BP = BN * KQ / 256;
+    constexpr int BSZ = BT ? BN * LDA : KB * LDB;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const As = smem;                    // [3][BM][LDA]
+    float* const Bs = smem + 3 * BM * LDA;     // [3][KB][LDB]  or (BT)  [3][BN][LDA]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+    // XCD-aware order (as igemm_fwd_kernel, mode 2): XCD id % 8 gets a contiguous run of M tiles and, within it, the column tiles
+    // of one M tile in consecutive slots -- they read the same A rows, which then come from that XCD's L2
+    int bx, by;
+    {
+        const int id = blockIdx.x, xcd = id & 7, j = id >> 3;
+        const int q = ntm >> 3, r = ntm & 7;
+        const int mine = q + (xcd < r ? 1 : 0);
+        const int ml = j / ntn;
+        if (ml >= mine) return;
+        by = j - ml * ntn;
+        bx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + ml;
+    }
+    const int m0 = bx * BM, n0 = by * BN;
+    const int nks_all = K / KB;
+    const int per_z = (nks_all + gridDim.z - 1) / gridDim.z;
+    const int ks_beg = blockIdx.z * per_z, ks_end = min(nks_all, ks_beg + per_z);
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (ks_beg < ks_end) {
+        // per-thread source pointers (rows / columns past the end read the last valid one; their results are never stored)
+        const float* ap[AP];
+        const float* bp[BP];
+        int a_lds[AP], b_lds[BP];
+#pragma unroll
+        for (int i = 0; i < AP; ++i) {
+            const int idx = tid + 256 * i, r = idx / KQ, kq = idx % KQ;
+            ap[i] = A + (long)min(m0 + r, M - 1) * K + kq * 4;
+            a_lds[i] = r * LDA + kq * 4;
+        }
+#pragma unroll
+        for (int j = 0; j < BP; ++j) {
+            const int idx = tid + 256 * j;
+            if (BT) {
+                const int r = idx / KQ, kq = idx % KQ;
+                bp[j] = B + (long)min(n0 + r, N - 1) * K + kq * 4;
+                b_lds[j] = r * LDA + kq * 4;
+            } else {
+                const int br = idx / (BN / 4), bc = idx % (BN / 4);
+                bp[j] = B + (long)br * N + min(n0 + bc * 4, N - 4);
+                b_lds[j] = br * LDB + bc * 4;
+            }
+        }
+        f4 ra[2][AP], rb[2][BP];
+        auto load_tiles = [&](int ks, f4 (&ra)[AP], f4 (&rb)[BP]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < AP; ++i) ra[i] = *reinterpret_cast<const f4*>(ap[i] + ks * KB);
+#pragma unroll
+            for (int j = 0; j < BP; ++j) rb[j] = *reinterpret_cast<const f4*>(bp[j] + (BT ? (long)ks * KB : (long)ks * KB * N));
+        };
+        auto store_tiles = [&](int buf, const f4 (&ra)[AP], const f4 (&rb)[BP]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < AP; ++i) *reinterpret_cast<f4*>(As + buf * BM * LDA + a_lds[i]) = ra[i];
+#pragma unroll
+            for (int j = 0; j < BP; ++j) *reinterpret_cast<f4*>(Bs + buf * BSZ + b_lds[j]) = rb[j];
+        };
+        // fragment addresses: A row (wm, tile i, l31), K quad of this half-wave; B likewise (BT) or [k row][TN adjacent columns]
+        const int a_frag = (wm * 32 * TM + l31) * LDA + 4 * half;
+        const int b_frag = BT ? (wn * 32 * TN + l31) * LDA + 4 * half : (4 * half) * LDB + wn * 32 * TN + TN * l31;
+        float a[2][TM][4], b[2][4][TN];
+        auto frag = [&](int buf, int g, int set) __attribute__((always_inline)) {
+            const float* as = As + buf * BM * LDA + a_frag + 8 * g;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const f4 v = *reinterpret_cast<const f4*>(as + 32 * i * LDA);
+                a[set][i][0] = v.x; a[set][i][1] = v.y; a[set][i][2] = v.z; a[set][i][3] = v.w;
+            }
+            if (BT) {
+                const float* bs = Bs + buf * BSZ + b_frag + 8 * g;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const f4 v = *reinterpret_cast<const f4*>(bs + 32 * j * LDA);
+                    b[set][0][j] = v.x; b[set][1][j] = v.y; b[set][2][j] = v.z; b[set][3][j] = v.w;
+                }
+            } else {
+                const float* bs = Bs + buf * BSZ + b_frag + 8 * g * LDB;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (TN == 2) {
+                        const f2 v = *reinterpret_cast<const f2*>(bs + q * LDB);
+                        b[set][q][0] = v.x; b[set][q][TN - 1] = v.y;
+                    } else {
+                        b[set][q][0] = bs[q * LDB];
+                    }
+                }
+            }
+        };
+        const int ks_last = ks_end - 1;
+        load_tiles(ks_beg, ra[0], rb[0]);
+        store_tiles(0, ra[0], rb[0]);
+        load_tiles(min(ks_beg + 1, ks_last), ra[0], rb[0]);
+        load_tiles(min(ks_beg + 2, ks_last), ra[1], rb[1]);
+        __syncthreads();
+        frag(0, 0, 0);
+        int cur = 0;
+        auto step = [&](int s, f4 (&ra)[AP], f4 (&rb)[BP]) __attribute__((always_inline)) {
+            const int nxt = cur == 2 ? 0 : cur + 1;
+            store_tiles(nxt, ra, rb);                         // step s+1 (loaded two steps ago)
+            load_tiles(min(s + 3, ks_last), ra, rb);          // step s+3 into the set just stored
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                if (g == G - 1) __syncthreads();              // the step-(s+1) tile is complete; everybody is past buffer cur's reads
+                if (g + 1 < G) frag(cur, g + 1, (g + 1) & 1);
+                else frag(nxt, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g & 1][i][q], b[g & 1][q][j], acc[i][j], 0, 0, 0);
+            }
+            cur = nxt;
+        };
+        int s = ks_beg;
+        for (; s + 1 < ks_end; s += 2) {
+            step(s, ra[0], rb[0]);
+            step(s + 1, ra[1], rb[1]);
+        }
+        if (s < ks_end) step(s, ra[0], rb[0]);
+    }
+
+    // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    const bool split = gridDim.z > 1;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + wm * 32 * TM + 32 * i + 4 * half + (r & 3) + 8 * (r >> 2);
+            if (row >= M) continue;
+            if (!BT && TN == 2) {
+                const int col = n0 + wn * 64 + 2 * l31;
+                if (col >= N) continue;
+                float v0 = acc[i][0][r], v1 = acc[i][TN - 1][r];
+                if (bias && blockIdx.z == 0) { v0 += bias[col]; v1 += bias[col + 1]; }
+                float* dst = C + (long)row * N + col;
+                if (part_stride) *reinterpret_cast<f2*>(dst + (long)blockIdx.z * part_stride) = f2{v0, v1};
+                else if (split) { unsafeAtomicAdd(dst, v0); unsafeAtomicAdd(dst + 1, v1); }
+                else *reinterpret_cast<f2*>(dst) = f2{cn_apply_act(v0, act, slope), cn_apply_act(v1, act, slope)};
+            } else {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int col = n0 + wn * 32 * TN + 32 * j + l31;
+                    if (col >= N) continue;
+                    const float v = acc[i][j][r] + ((bias && blockIdx.z == 0) ? bias[col] : 0.f);
+                    float* dst = C + (long)row * N + col;
+                    if (part_stride) dst[(long)blockIdx.z * part_stride] = v;
+                    else if (split) unsafeAtomicAdd(dst, v);
+                    else *dst = cn_apply_act(v, act, slope);
+                }
+            }
+        }
+}
+
+template <int WM, int WN, int TM, int TN, bool BT>
+int launch(const float* A, const float* B, const float* bias, float* C, long M, int N, int K, int act, float slope, int splits,
+           long part_stride, hipStream_t s) {
+    constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
+    constexpr size_t lds = sizeof(float) * 3 * (BM * 20 + (BT ? BN * 20 : 16 * (BN + 4)));
+    static bool attr_set = false;
+    if (!attr_set) {
+        CN_HIP(hipFuncSetAttribute((const void*)gemm1x1_kernel<WM, WN, TM, TN, BT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    const int ntm = cn_cdiv(M, BM), ntn = cn_cdiv(N, BN);
+    dim3 grid((unsigned)(8 * cn_cdiv(ntm, 8) * ntn), 1, (unsigned)splits);
+    hipLaunchKernelGGL((gemm1x1_kernel<WM, WN, TM, TN, BT>), grid, dim3(256), lds, s, A, B, bias, C, (int)M, N, K, act, slope, ntm, ntn, part_stride);
+    CN_LAUNCH_CHECK();
+    return CN_OK;
+}
+
+}  // namespace
+
+// cfg: the implicit-GEMM tile numbering (0 = 128 x 128, 1 = 128 x 64, 2 = 64 x 64); other tiles are not provided (CN_EUNSUPPORTED:
+// the caller falls back to igemm_fwd_kernel).  bt: B is the original filter [N][K] (data gradient).  Same split-K protocol as
+// igemm_fwd_kernel: splits > 1 adds into a zeroed C (or stores slabs at part_stride), bias by split 0, no activation.
+int cn_gemm1x1(int cfg, int bt, const float* A, const float* B, const float* bias, float* C, long M, int N, int K, int act, float slope,
+               int splits, long part_stride, hipStream_t s) {
+    if (K % 16 != 0 || N % 4 != 0 || M <= 0 || M > 0x7fffffffL) return CN_EUNSUPPORTED;
+#define L(WM, WN, TM, TN) \
+    return bt ? launch<WM, WN, TM, TN, true>(A, B, bias, C, M, N, K, act, slope, splits, part_stride, s) \
+              : launch<WM, WN, TM, TN, false>(A, B, bias, C, M, N, K, act, slope, splits, part_stride, s)
+    switch (cfg) {
+        case 0: L(2, 2, 2, 2);
+        case 1: L(2, 2, 2, 1);
+        case 2: L(2, 2, 1, 1);
+        default: return CN_EUNSUPPORTED;
+    }
+#undef L
+}

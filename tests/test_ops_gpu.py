@@ -49,6 +49,8 @@ CONV_CASES = [
     ((1, 5, 7, 3), (1, 1), 3, 1, 0, None, 1, 0.3),            # from-RGB 1x1, pixel count not a multiple of 4
     ((4, 8, 8, 256), (3, 3), 512, 1, 0, None, 2, 0.0),        # VGG block4 shape, 64x64 tiles
     ((1, 8, 8, 128), (1, 1), 512, 2, 0, None, 0, 0.0),        # ResNet strided 1x1
+    ((2, 9, 7, 64), (1, 1), 36, 1, 0, None, 2, 0.0),          # 1x1 stride 1 (plain-GEMM kernel): 126 rows, 36 columns, bias + relu
+    ((2, 16, 16, 512), (1, 1), 128, 1, 0, None, 2, 0.0),      # ... with a K split
 ]
 
 
@@ -165,6 +167,8 @@ SWEEP_LAYERS = [
     # (x shape, kernel, cout, stride): every tile configuration / split-K factor the heuristic can pick, forced one by one
     ((4, 64, 64, 96), (3, 3), 192, 2),
     ((4, 32, 32, 128), (3, 3), 128, 1),
+    ((2, 30, 30, 64), (1, 1), 144, 1),            # 1x1 stride 1: the plain-GEMM kernel (gemm1x1.hip), rows and columns that fill no tile
+    ((8, 16, 16, 256), (1, 1), 64, 1),            # ... ResNet bottleneck reduce
 ]
 
 
@@ -197,6 +201,7 @@ def test_conv_forced_tile_and_split_configurations_vs_oracle(case, monkeypatch):
                     gu = torch.empty_like(x)
                     ops.check(lib.cn_conv_dgrad(__import__("ctypes").byref(g), ops._ptr(gy), ops._ptr(wt), ops._ptr(gu), ops._stream()), "cn_conv_dgrad")
                     close(gu, gur, what="dgrad cfg %d splits %d" % (cfg, splits))
+                    close(ops.conv_dgrad(gy, w, g), gur, what="dgrad from the original filter, cfg %d splits %d" % (cfg, splits))
         for wg_blocks in (256, 1024, 4096):
             ops.check(lib.cn_conv_tune(-1, 0, wg_blocks), "cn_conv_tune")
             close(ops.conv_wgrad(x, gy, g, tuple(w.shape)), gwr, tol=5e-4, what="wgrad wg_blocks %d" % wg_blocks)
