@@ -14,18 +14,24 @@
 // of step s, the barrier sits inside the MFMA stream and the first fragments of step s+1 are read before step s ends.  All loads
 // are unconditional (clamped addresses): see igemm_fwd_kernel.  scripts/dev/gemm_lab holds the stand-alone study of this loop
 // against the vendor sgemm.
+//
+// GATHER = true is the same loop for the gathered layers that are not parity-ordered (strided forward convolutions, Conv3D,
+// the 3x3 layers Winograd does not take): K walks (tap, 16-channel chunk) tap-major, a row's source offset is recomputed when the
+// tap changes, padding taps read a clamped address and are zeroed by a mask on the way into LDS.
 #include "common.h"
 #include "mma_tile.h"
+#include "conv_geom.h"
 
 namespace {
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef float f2 __attribute__((ext_vector_type(2)));
 
-template <int WM, int WN, int TM, int TN, bool BT>
-__global__ __launch_bounds__(256) void gemm1x1_kernel(const float* __restrict__ A, const float* __restrict__ B,
+template <int WM, int WN, int TM, int TN, bool BT, bool GATHER>
+__global__ __launch_bounds__(256) void gemm1x1_kernel(CnConvGeom g, const float* __restrict__ A, const float* __restrict__ B,
                                                       const float* __restrict__ bias, float* __restrict__ C, int M, int N, int K,
                                                       int act, float slope, int ntm, int ntn, long part_stride) {
+    // K: channels per tap (the reduction is T * K deep, T = 1 without GATHER)
     static_assert(WM * WN == 4, "4 waves per workgroup");
     static_assert(TN == 1 || TN == 2, "column tiles per wave");
     constexpr int KB = 16, G = KB / 8, KQ = KB / 4;
@@ -50,7 +56,9 @@ __global__ __launch_bounds__(256) void gemm1x1_kernel(const float* __restrict__ 
         bx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + ml;
     }
     const int m0 = bx * BM, n0 = by * BN;
-    const int nks_all = K / KB;
+    const int T = GATHER ? g.k_d * g.k_h * g.k_w : 1;
+    const int cpb = K / KB;
+    const int nks_all = T * cpb;
     const int per_z = (nks_all + gridDim.z - 1) / gridDim.z;
     const int ks_beg = blockIdx.z * per_z, ks_end = min(nks_all, ks_beg + per_z);
 
@@ -67,10 +75,17 @@ __global__ __launch_bounds__(256) void gemm1x1_kernel(const float* __restrict__ 
         const float* ap[AP];
         const float* bp[BP];
         int a_lds[AP], b_lds[BP];
+        RowInfo ri[AP];
+        int aoff[AP];
 #pragma unroll
         for (int i = 0; i < AP; ++i) {
             const int idx = tid + 256 * i, r = idx / KQ, kq = idx % KQ;
-            ap[i] = A + (long)min(m0 + r, M - 1) * K + kq * 4;
+            if (GATHER) {
+                ri[i] = decode_row(g, m0 + r, M);
+                ap[i] = A + kq * 4;
+            } else {
+                ap[i] = A + (long)min(m0 + r, M - 1) * K + kq * 4;
+            }
             a_lds[i] = r * LDA + kq * 4;
         }
 #pragma unroll
@@ -86,16 +101,59 @@ __global__ __launch_bounds__(256) void gemm1x1_kernel(const float* __restrict__ 
                 b_lds[j] = br * LDB + bc * 4;
             }
         }
-        f4 ra[2][AP], rb[2][BP];
-        auto load_tiles = [&](int ks, f4 (&ra)[AP], f4 (&rb)[BP]) __attribute__((always_inline)) {
+        // GATHER: (tap, channel chunk) of the most recent load; load_tiles is called with ks = ks_beg, ks_beg + 1, ... (each call
+        // the previous step + 1, or the same step again once the index is clamped at the end)
+        int ld_ks = ks_beg, ld_tap = ks_beg / cpb, ld_c0 = (ks_beg - (ks_beg / cpb) * cpb) * KB;
+        unsigned amask_cur = ~0u;
+        long b_tap = 0;                                   // filter offset of the current tap
+        auto retap = [&]() __attribute__((always_inline)) {
+            int kd, kh, kw;
+            tap_decode(g, ld_tap, kd, kh, kw);
+            amask_cur = 0;
 #pragma unroll
-            for (int i = 0; i < AP; ++i) ra[i] = *reinterpret_cast<const f4*>(ap[i] + ks * KB);
-#pragma unroll
-            for (int j = 0; j < BP; ++j) rb[j] = *reinterpret_cast<const f4*>(bp[j] + (BT ? (long)ks * KB : (long)ks * KB * N));
+            for (int i = 0; i < AP; ++i) {
+                const int off = src_off(g, ri[i], kd, kh, kw);
+                aoff[i] = max(off, 0);
+                amask_cur |= (off >= 0 ? 1u : 0u) << i;
+            }
+            b_tap = BT ? (long)(T - 1 - ld_tap) * N * K : (long)ld_tap * K * N;
         };
-        auto store_tiles = [&](int buf, const f4 (&ra)[AP], const f4 (&rb)[BP]) __attribute__((always_inline)) {
+        if (GATHER) retap();
+        f4 ra[2][AP], rb[2][BP];
+        unsigned am[2] = {~0u, ~0u};
+        auto load_tiles = [&](int ks, f4 (&ra)[AP], f4 (&rb)[BP], unsigned& amk) __attribute__((always_inline)) {
+            if (GATHER) {
+                if (ks != ld_ks) {
+                    ld_ks = ks;
+                    ld_c0 += KB;
+                    if (ld_c0 == K) {
+                        ld_c0 = 0;
+                        ++ld_tap;
+                        retap();
+                    }
+                }
+                amk = amask_cur;
 #pragma unroll
-            for (int i = 0; i < AP; ++i) *reinterpret_cast<f4*>(As + buf * BM * LDA + a_lds[i]) = ra[i];
+                for (int i = 0; i < AP; ++i) ra[i] = *reinterpret_cast<const f4*>(ap[i] + aoff[i] + ld_c0);
+#pragma unroll
+                for (int j = 0; j < BP; ++j) rb[j] = *reinterpret_cast<const f4*>(bp[j] + b_tap + (BT ? (long)ld_c0 : (long)ld_c0 * N));
+            } else {
+#pragma unroll
+                for (int i = 0; i < AP; ++i) ra[i] = *reinterpret_cast<const f4*>(ap[i] + ks * KB);
+#pragma unroll
+                for (int j = 0; j < BP; ++j) rb[j] = *reinterpret_cast<const f4*>(bp[j] + (BT ? (long)ks * KB : (long)ks * KB * N));
+            }
+        };
+        auto store_tiles = [&](int buf, const f4 (&ra)[AP], const f4 (&rb)[BP], unsigned amk) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < AP; ++i) {
+                f4 v = ra[i];
+                if (GATHER) {
+                    const bool live = (amk >> i) & 1u;      // padding taps / rows past the end: zeros
+                    v.x = live ? v.x : 0.f; v.y = live ? v.y : 0.f; v.z = live ? v.z : 0.f; v.w = live ? v.w : 0.f;
+                }
+                *reinterpret_cast<f4*>(As + buf * BM * LDA + a_lds[i]) = v;
+            }
 #pragma unroll
             for (int j = 0; j < BP; ++j) *reinterpret_cast<f4*>(Bs + buf * BSZ + b_lds[j]) = rb[j];
         };
@@ -131,17 +189,17 @@ __global__ __launch_bounds__(256) void gemm1x1_kernel(const float* __restrict__ 
             }
         };
         const int ks_last = ks_end - 1;
-        load_tiles(ks_beg, ra[0], rb[0]);
-        store_tiles(0, ra[0], rb[0]);
-        load_tiles(min(ks_beg + 1, ks_last), ra[0], rb[0]);
-        load_tiles(min(ks_beg + 2, ks_last), ra[1], rb[1]);
+        load_tiles(ks_beg, ra[0], rb[0], am[0]);
+        store_tiles(0, ra[0], rb[0], am[0]);
+        load_tiles(min(ks_beg + 1, ks_last), ra[0], rb[0], am[0]);
+        load_tiles(min(ks_beg + 2, ks_last), ra[1], rb[1], am[1]);
         __syncthreads();
         frag(0, 0, 0);
         int cur = 0;
-        auto step = [&](int s, f4 (&ra)[AP], f4 (&rb)[BP]) __attribute__((always_inline)) {
+        auto step = [&](int s, f4 (&ra)[AP], f4 (&rb)[BP], unsigned& amk) __attribute__((always_inline)) {
             const int nxt = cur == 2 ? 0 : cur + 1;
-            store_tiles(nxt, ra, rb);                         // step s+1 (loaded two steps ago)
-            load_tiles(min(s + 3, ks_last), ra, rb);          // step s+3 into the set just stored
+            store_tiles(nxt, ra, rb, amk);                    // step s+1 (loaded two steps ago)
+            load_tiles(min(s + 3, ks_last), ra, rb, amk);     // step s+3 into the set just stored
 #pragma unroll
             for (int g = 0; g < G; ++g) {
                 if (g == G - 1) __syncthreads();              // the step-(s+1) tile is complete; everybody is past buffer cur's reads
@@ -160,10 +218,10 @@ __global__ __launch_bounds__(256) void gemm1x1_kernel(const float* __restrict__ 
         };
         int s = ks_beg;
         for (; s + 1 < ks_end; s += 2) {
-            step(s, ra[0], rb[0]);
-            step(s + 1, ra[1], rb[1]);
+            step(s, ra[0], rb[0], am[0]);
+            step(s + 1, ra[1], rb[1], am[1]);
         }
-        if (s < ks_end) step(s, ra[0], rb[0]);
+        if (s < ks_end) step(s, ra[0], rb[0], am[0]);
     }
 
     // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
@@ -198,19 +256,19 @@ __global__ __launch_bounds__(256) void gemm1x1_kernel(const float* __restrict__ 
         }
 }
 
-template <int WM, int WN, int TM, int TN, bool BT>
-int launch(const float* A, const float* B, const float* bias, float* C, long M, int N, int K, int act, float slope, int splits,
-           long part_stride, hipStream_t s) {
+template <int WM, int WN, int TM, int TN, bool BT, bool GATHER>
+int launch(const CnConvGeom& g, const float* A, const float* B, const float* bias, float* C, long M, int N, int K, int act, float slope,
+           int splits, long part_stride, hipStream_t s) {
     constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
     constexpr size_t lds = sizeof(float) * 3 * (BM * 20 + (BT ? BN * 20 : 16 * (BN + 4)));
     static bool attr_set = false;
     if (!attr_set) {
-        CN_HIP(hipFuncSetAttribute((const void*)gemm1x1_kernel<WM, WN, TM, TN, BT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CN_HIP(hipFuncSetAttribute((const void*)gemm1x1_kernel<WM, WN, TM, TN, BT, GATHER>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     const int ntm = cn_cdiv(M, BM), ntn = cn_cdiv(N, BN);
     dim3 grid((unsigned)(8 * cn_cdiv(ntm, 8) * ntn), 1, (unsigned)splits);
-    hipLaunchKernelGGL((gemm1x1_kernel<WM, WN, TM, TN, BT>), grid, dim3(256), lds, s, A, B, bias, C, (int)M, N, K, act, slope, ntm, ntn, part_stride);
+    hipLaunchKernelGGL((gemm1x1_kernel<WM, WN, TM, TN, BT, GATHER>), grid, dim3(256), lds, s, g, A, B, bias, C, (int)M, N, K, act, slope, ntm, ntn, part_stride);
     CN_LAUNCH_CHECK();
     return CN_OK;
 }
@@ -220,12 +278,17 @@ int launch(const float* A, const float* B, const float* bias, float* C, long M, 
 // cfg: the implicit-GEMM tile numbering (0 = 128 x 128, 1 = 128 x 64, 2 = 64 x 64); other tiles are not provided (CN_EUNSUPPORTED:
 // the caller falls back to igemm_fwd_kernel).  bt: B is the original filter [N][K] (data gradient).  Same split-K protocol as
 // igemm_fwd_kernel: splits > 1 adds into a zeroed C (or stores slabs at part_stride), bias by split 0, no activation.
-int cn_gemm1x1(int cfg, int bt, const float* A, const float* B, const float* bias, float* C, long M, int N, int K, int act, float slope,
-               int splits, long part_stride, hipStream_t s) {
+// gp: NULL = the rows of A are the GEMM rows (1x1, stride 1); otherwise the geometry whose gather builds them (vec, not
+// parity-ordered: the caller checks).
+int cn_gemm1x1(const CnConvGeom* gp, int cfg, int bt, const float* A, const float* B, const float* bias, float* C, long M, int N, int K,
+               int act, float slope, int splits, long part_stride, hipStream_t s) {
     if (K % 16 != 0 || N % 4 != 0 || M <= 0 || M > 0x7fffffffL) return CN_EUNSUPPORTED;
-#define L(WM, WN, TM, TN) \
-    return bt ? launch<WM, WN, TM, TN, true>(A, B, bias, C, M, N, K, act, slope, splits, part_stride, s) \
-              : launch<WM, WN, TM, TN, false>(A, B, bias, C, M, N, K, act, slope, splits, part_stride, s)
+    static const CnConvGeom none = {};
+#define L(WM, WN, TM, TN)                                                                                                     \
+    return gp ? (bt ? launch<WM, WN, TM, TN, true, true>(*gp, A, B, bias, C, M, N, K, act, slope, splits, part_stride, s)      \
+                    : launch<WM, WN, TM, TN, false, true>(*gp, A, B, bias, C, M, N, K, act, slope, splits, part_stride, s))    \
+              : (bt ? launch<WM, WN, TM, TN, true, false>(none, A, B, bias, C, M, N, K, act, slope, splits, part_stride, s)    \
+                    : launch<WM, WN, TM, TN, false, false>(none, A, B, bias, C, M, N, K, act, slope, splits, part_stride, s))
     switch (cfg) {
         case 0: L(2, 2, 2, 2);
         case 1: L(2, 2, 2, 1);

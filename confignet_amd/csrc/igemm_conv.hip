@@ -1352,10 +1352,16 @@ static int conv_fwd_impl(const CnConvGeom* gp, const float* x, const float* w, c
     cn_prof_begin(s, conv_flops(g), conv_bytes(g), cfg == 0 ? CN_FAM_FWD_128x128 : cfg == 1 ? CN_FAM_FWD_128x64 : cfg == 3 ? CN_FAM_FWD_128x32 : cfg == 4 ? CN_FAM_FWD_128x96 : CN_FAM_FWD_64x64);
     int e = CN_EUNSUPPORTED;
     // 1x1, stride 1, no padding / dilation / upsample: the rows of x ARE the A matrix -- plain GEMM kernel (gemm1x1.hip)
-    static const int no_g1 = getenv("CN_NO_GEMM1X1") ? 1 : 0;
-    if (!no_g1 && vec && !par && g.k_d * g.k_h * g.k_w == 1 && g.s_d == 1 && g.s_h == 1 && g.s_w == 1 && g.dl_d == 1 && g.dl_h == 1 &&
+    // (not for <= 8-step reductions: its three-load prologue is most of such a launch -- 38 -> 45 us on 16 384 x 128 x 512)
+    static const int no_g1 = (getenv("CN_NO_GEMM1X1") ? 1 : 0);
+    const bool rows_ok = !no_g1 && nks_total > 8;
+    if (rows_ok && vec && !par && g.k_d * g.k_h * g.k_w == 1 && g.s_d == 1 && g.s_h == 1 && g.s_w == 1 && g.dl_d == 1 && g.dl_h == 1 &&
         g.dl_w == 1 && !g.up && g.p_d == 0 && g.p_h == 0 && g.p_w == 0 && g.out_d == g.in_d && g.out_h == g.in_h && g.out_w == g.in_w)
-        e = cn_gemm1x1(cfg, bt, x, w, bias, y, M, g.cout, g.cin, kact, slope, splits, part_stride, s);
+        e = cn_gemm1x1(nullptr, cfg, bt, x, w, bias, y, M, g.cout, g.cin, kact, slope, splits, part_stride, s);
+    // every other vec layer that is not parity-ordered: the same main loop over gathered rows
+    static const int no_g2 = getenv("CN_NO_IGEMM_ROWS") ? 1 : 0;
+    if (e == CN_EUNSUPPORTED && rows_ok && !no_g2 && vec && !par)
+        e = cn_gemm1x1(&g, cfg, bt, x, w, bias, y, M, g.cout, g.cin, kact, slope, splits, part_stride, s);
     if (e == CN_EUNSUPPORTED)
     switch (cfg) {
         case 3: e = launch_fwd<4, 1, 1, 1>(g, vec, par, splits, x, w, bias, y, kact, slope, s, bt, part_stride); break;   // 128 x 32
