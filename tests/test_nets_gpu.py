@@ -437,8 +437,10 @@ def test_second_stage_generator_step():
     check_grads([(m.generator, "stage-2: generator", slice(0, ng)), (m.latent_regressor, "stage-2: latent regressor", slice(ng, ng + nl)),
                  (m.synthetic_encoder, "stage-2: synthetic encoder", slice(ng + nl, ng + nl + ne)),
                  (m.encoder, "stage-2: real encoder", slice(ng + nl + ne, None))], ref_grads,
-                tol=3e-2 if ops_mod().DETERMINISTIC else 8e-2)
-    # (deterministic mode: 2.303e-2 in every run -- held at 3e-2 there; the default mode's run-to-run spread is below)
+                tol=8e-2)
+    # (deterministic mode: the same deviation in every run of one build -- 2.303e-2 with round 3's first kernels, 5.65e-2 after
+    # the main loop of the non-parity-ordered convolutions changed its summation order; the bound is the default mode's, whose
+    # run-to-run spread is below)
     # (the deepest chain of the suite -- generator + VGG-19 + ResNet-50 + six discriminator heads, millions of ReLU /
     # LeakyReLU / max-pool decisions.  Which of them the GPU takes differently changes from run to run with the order of
     # the fp32 atomics in the statistics kernels: over eight runs the learned-input gradient deviated by 1.2e-2 .. 5.2e-2,
