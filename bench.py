@@ -181,7 +181,7 @@ def main():
             "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": pmc_traffic(args.dtype),
                          "mfma_busy_pmc": pmc_mfma_busy(args.dtype),
-                         "kernel": ("igemm_fwd/igemm_wgrad/wino_fwd (implicit-GEMM + Winograd F(2x2,3x3) convolutions, v_mfma_f32_32x32x2_f32)" if args.dtype == "f32" else
+                         "kernel": ("igemm_fwd/gemm1x1/igemm_wgrad/wino_fwd (implicit-GEMM + Winograd F(2x2,3x3) convolutions, v_mfma_f32_32x32x2_f32)" if args.dtype == "f32" else
                                     "igemm_bf16/igemm_bf16_wgrad (implicit-GEMM conv, v_mfma_f32_32x32x16_bf16) + the fp32 kernels of the "
                                     "3-channel image layers"),
                          "launches_per_step": launches / max(args.steps, 1),

@@ -66,7 +66,10 @@ int cn_version(void);
 /* ---- convolution family (implicit GEMM on v_mfma_f32_32x32x2_f32) -------------------------
  * Replaces keras.layers.Conv3D/Conv2D forward (+bias +activation):
  *   building_blocks.py:29,65,91 ; hologan_generator.py:50-56,101 ; hologan_discriminator.py:20,77 ;
- *   keras.applications VGG19/VGG16/ResNet50 convs (perceptual_loss.py:19,35 ; real_encoder.py:13). */
+ *   keras.applications VGG19/VGG16/ResNet50 convs (perceptual_loss.py:19,35 ; real_encoder.py:13).
+ * Which kernel runs is the library's choice by geometry (first-layer / thin-output / image-gradient kernels, the k-major
+ * implicit-GEMM loop for parity-ordered launches, the plain-GEMM loop of gemm1x1.hip for 1x1 and every other vectorisable
+ * layer; CN_NO_* environment switches, read once, turn a route off for A/B runs) -- the results are the same convolution. */
 int cn_conv_fwd(const CnConvGeom* g, const float* x, const float* w, const float* bias,
                 float* y, int act, float slope, void* stream);
 /* w_tflip[T-1-t][co][ci] = w[t][ci][co]: the operand of the data-gradient GEMM. */

@@ -2,12 +2,15 @@
 # Everything the judged profiles/ artifacts are made from, in one GPU-box call:
 #   gpurun --timeout 3000 -- 'bash scripts/make_profiles.sh round3'
 # writes gpurun_out/profiles_<tag>/ ; copy what is to be judged into profiles/ and commit.
+# `bash scripts/make_profiles.sh round3 pmc` repeats the counter passes (section 3) only.
 TAG=${1:-round3}
+ONLY=${2:-all}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/profiles_$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 PY="python"
+if [ "$ONLY" = all ]; then
 # 1. the bench lines (default flags), fp32 and bf16
 timeout 900 $PY $R/bench.py > $O/${TAG}_bench.json 2> $O/bench.err
 timeout 300 $PY $R/bench.py --dtype bf16 --no-cpu-baseline > $O/${TAG}_bench_bf16.json 2>> $O/bench.err
@@ -18,6 +21,7 @@ $PY $R/scripts/prof_summary.py $(ls /tmp/kt1/*/*.db | head -1) > $O/${TAG}_bench
 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/kt2 -- $PY $R/bench.py --serial --steps 10 --warmup 3 --no-cpu-baseline > $O/${TAG}_bench_serial_under_rocprof.json 2>/dev/null
 $PY $R/scripts/prof_summary.py $(ls /tmp/kt2/*/*.db | head -1) > $O/${TAG}_bench_serial_kernel_trace.txt
 $PY $R/scripts/torch_share.py /tmp/kt2 $O/${TAG}_torch_share.json > /dev/null
+fi
 # 3. PMC passes (each in its own run, --kernel-trace only).  A pass that leaves no database (rocprofv3 has died at exit on
 #    this pool now and then) is repeated, up to three times.
 pmc_pass() {   # pmc_pass <out dir> <stdout file> <bench flags...> -- <counters...>
@@ -46,6 +50,7 @@ $PY $R/scripts/pmc_traffic_json.py /tmp/pfb /tmp/pwb $O/${TAG}_pmc_traffic_bf16.
 $PY $R/scripts/pmc_traffic_by_kernel.py /tmp/pfb /tmp/pwb /tmp/pfb_line.json $O/${TAG}_pmc_traffic_by_kernel_bf16.txt $O/${TAG}_pmc_traffic_by_kernel_bf16.json > /dev/null
 pmc_pass /tmp/pmb /dev/null --steps 2 --warmup 1 --no-cpu-baseline --serial --dtype bf16 -- SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES
 $PY $R/scripts/pmc_mfma.py /tmp/pmb $O/${TAG}_pmc_mfma_bf16.json > $O/${TAG}_pmc_mfma_bf16.txt
+if [ "$ONLY" = all ]; then
 # 4. per-shape tables
 cd $R
 timeout 600 $PY scripts/conv_shapes_bench.py 16 f32 > $O/${TAG}_conv_shapes.txt 2>/dev/null
@@ -53,4 +58,5 @@ timeout 600 $PY scripts/conv_shapes_bench.py 16 bf16 > $O/${TAG}_conv_shapes_bf1
 timeout 300 $PY scripts/ew_shapes_bench.py > $O/${TAG}_elementwise_shapes.txt 2>/dev/null
 timeout 300 $PY scripts/predict_latency.py > $O/${TAG}_predict_latency.txt 2>/dev/null
 timeout 900 $PY scripts/bench_configs.py > $O/${TAG}_secondary_configs.json 2>/dev/null
+fi
 ls -la $O

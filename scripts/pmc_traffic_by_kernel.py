@@ -21,6 +21,11 @@ def family(name):
         if k in name:
             t = name.split(k + "<")[1][:10]
             return "%s<%s>" % (k[:-7], TILES.get(t, t))
+    if "gemm1x1_kernel" in name:                      # the plain-GEMM main loop: same tile families as igemm_fwd_kernel
+        t = name.split("gemm1x1_kernel<")[1][:10]
+        return "igemm_fwd<%s>" % TILES.get(t, t)
+    if "s1_image_dgrad_kernel" in name:
+        return "s2_image_dgrad"                       # (one family in cn_prof_collect_by_family)
     for k, f in (("wino_fwd_kernel", "wino_fwd"), ("c3_fwd_kernel", "c3_fwd"), ("s2_image_dgrad_kernel", "s2_image_dgrad"),
                  ("c3_wgrad_kernel", "c3_wgrad"), ("up2k4_rgb_fwd_kernel", "thin / up2k4_rgb"), ("igemm_bf16_wgrad_tr_kernel", "igemm_bf16_wgrad"), ("igemm_bf16_wgrad_kernel", "igemm_bf16_wgrad"),
                  ("igemm_bf16_kernel", "igemm_bf16")):
