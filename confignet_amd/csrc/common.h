@@ -47,10 +47,10 @@ constexpr size_t CN_DET_WS_FLOATS = (size_t)16 << 20;     // 64 MiB per stream, 
 int cn_sum_parts(const float* src, float* dst, int parts, long count, int accumulate, float scale, hipStream_t s);
 
 // gemm1x1.hip: C[M][N] (+)= A[M][K] B for the 1x1 stride-1 convolutions (gp = NULL) and, with a geometry, the same main loop over
-// the gathered rows of a vec, not parity-ordered convolution (tile cfg 0 / 1 / 2 of the implicit-GEMM numbering, the same
-// split-K protocol); CN_EUNSUPPORTED for anything else
+// the gathered rows of a vec convolution (par: parity-ordered rows); tile cfg 0 / 1 / 2 / 4 of the implicit-GEMM numbering, the
+// same split-K protocol; CN_EUNSUPPORTED for anything else
 int cn_gemm1x1(const CnConvGeom* gp, int cfg, int bt, const float* A, const float* B, const float* bias, float* C, long M, int N, int K,
-               int act, float slope, int splits, long part_stride, hipStream_t s);
+               int act, float slope, int splits, long part_stride, int par, hipStream_t s);
 
 // profiling hooks (prof.hip): bracket one launch of the dominant kernel class
 // family: which kernel of the class is launched (cn_prof_collect_by_family); bytes: the launch's algorithmic HBM bytes

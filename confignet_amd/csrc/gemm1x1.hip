@@ -30,23 +30,32 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 template <int WM, int WN, int TM, int TN, bool BT, bool GATHER>
 __global__ __launch_bounds__(256) void gemm1x1_kernel(CnConvGeom g, const float* __restrict__ A, const float* __restrict__ B,
                                                       const float* __restrict__ bias, float* __restrict__ C, int M, int N, int K,
-                                                      int act, float slope, int ntm, int ntn, long part_stride) {
+                                                      int act, float slope, int ntm, int ntn, long part_stride, int par) {
     // K: channels per tap (the reduction is T * K deep, T = 1 without GATHER)
+    // par (GATHER only): parity-ordered rows of a zero-stuffed data gradient / an upsample-folded layer -- tile rows are
+    // enumerated class-major (conv_geom.h par_row), a tile inside one class walks its live taps only
     static_assert(WM * WN == 4, "4 waves per workgroup");
-    static_assert(TN == 1 || TN == 2, "column tiles per wave");
+    static_assert(TN >= 1 && TN <= 3, "column tiles per wave");
     constexpr int KB = 16, G = KB / 8, KQ = KB / 4;
     constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN, LDA = KB + 4, LDB = BN + 4;
-    constexpr int AP = BM * KQ / 256, BP = BN * KQ / 256;
+    constexpr int AP = BM * KQ / 256, BP = (BN * KQ + 255) / 256;
     constexpr int BSZ = BT ? BN * LDA : KB * LDB;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const As = smem;                    // [3][BM][LDA]
     float* const Bs = smem + 3 * BM * LDA;     // [3][KB][LDB]  or (BT)  [3][BN][LDA]
+    int* const rowmap = reinterpret_cast<int*>(smem + 3 * BM * LDA + 3 * BSZ);   // GATHER: tile row -> output row (or -1)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
     // XCD-aware order (as igemm_fwd_kernel, mode 2): XCD id % 8 gets a contiguous run of M tiles and, within it, the column tiles
     // of one M tile in consecutive slots -- they read the same A rows, which then come from that XCD's L2
     int bx, by;
-    {
+    if (GATHER && par) {
+        // class-major rows: consecutive M tiles sit in one class (1 / 2 / 2 / 4 live taps); the plain order deals them round-robin
+        // over the XCDs, a contiguous run per XCD would give one XCD the 4-tap class
+        bx = blockIdx.x % ntm;
+        by = blockIdx.x / ntm;
+        if (by >= ntn) return;
+    } else {
         const int id = blockIdx.x, xcd = id & 7, j = id >> 3;
         const int q = ntm >> 3, r = ntm & 7;
         const int mine = q + (xcd < r ? 1 : 0);
@@ -58,7 +67,14 @@ __global__ __launch_bounds__(256) void gemm1x1_kernel(CnConvGeom g, const float*
     const int m0 = bx * BM, n0 = by * BN;
     const int T = GATHER ? g.k_d * g.k_h * g.k_w : 1;
     const int cpb = K / KB;
-    const int nks_all = T * cpb;
+    unsigned long long tapmask = T >= 64 ? ~0ull : ((1ull << T) - 1ull);
+    if (GATHER && par) {
+        int c0, c1;
+        par_row(g, m0, M, c0);
+        par_row(g, min(m0 + BM, M) - 1, M, c1);
+        if (c0 == c1) tapmask = par_tap_mask(g, c0);   // whole tile in one parity class: skip dead taps
+    }
+    const int nks_all = (GATHER ? __popcll(tapmask) : 1) * cpb;
     const int per_z = (nks_all + gridDim.z - 1) / gridDim.z;
     const int ks_beg = blockIdx.z * per_z, ks_end = min(nks_all, ks_beg + per_z);
 
@@ -70,7 +86,7 @@ __global__ __launch_bounds__(256) void gemm1x1_kernel(CnConvGeom g, const float*
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    if (ks_beg < ks_end) {
+    {
         // per-thread source pointers (rows / columns past the end read the last valid one; their results are never stored)
         const float* ap[AP];
         const float* bp[BP];
@@ -81,7 +97,10 @@ __global__ __launch_bounds__(256) void gemm1x1_kernel(CnConvGeom g, const float*
         for (int i = 0; i < AP; ++i) {
             const int idx = tid + 256 * i, r = idx / KQ, kq = idx % KQ;
             if (GATHER) {
-                ri[i] = decode_row(g, m0 + r, M);
+                int mrow = m0 + r, cls;
+                if (par) mrow = par_row(g, mrow, M, cls);
+                ri[i] = decode_row(g, mrow, M);
+                if (kq == 0) rowmap[r] = ri[i].ok ? mrow : -1;
                 ap[i] = A + kq * 4;
             } else {
                 ap[i] = A + (long)min(m0 + r, M - 1) * K + kq * 4;
@@ -90,7 +109,7 @@ __global__ __launch_bounds__(256) void gemm1x1_kernel(CnConvGeom g, const float*
         }
 #pragma unroll
         for (int j = 0; j < BP; ++j) {
-            const int idx = tid + 256 * j;
+            const int idx = min(tid + 256 * j, BN * KQ - 1);          // (128 x 96: the second piece exists for half the threads)
             if (BT) {
                 const int r = idx / KQ, kq = idx % KQ;
                 bp[j] = B + (long)min(n0 + r, N - 1) * K + kq * 4;
@@ -101,9 +120,12 @@ __global__ __launch_bounds__(256) void gemm1x1_kernel(CnConvGeom g, const float*
                 b_lds[j] = br * LDB + bc * 4;
             }
         }
+        if (GATHER) __syncthreads();                      // rowmap (an empty K split goes straight to the epilogue)
+      if (ks_beg < ks_end) {
         // GATHER: (tap, channel chunk) of the most recent load; load_tiles is called with ks = ks_beg, ks_beg + 1, ... (each call
         // the previous step + 1, or the same step again once the index is clamped at the end)
-        int ld_ks = ks_beg, ld_tap = ks_beg / cpb, ld_c0 = (ks_beg - (ks_beg / cpb) * cpb) * KB;
+        int ld_ks = ks_beg, ld_tap = -1, ld_c0 = (ks_beg - (ks_beg / cpb) * cpb) * KB;
+        for (int o = ks_beg / cpb; o >= 0; --o) ld_tap += __ffsll((long long)(tapmask >> (ld_tap + 1)));   // the (ks_beg / cpb)-th live tap
         unsigned amask_cur = ~0u;
         long b_tap = 0;                                   // filter offset of the current tap
         auto retap = [&]() __attribute__((always_inline)) {
@@ -128,7 +150,7 @@ __global__ __launch_bounds__(256) void gemm1x1_kernel(CnConvGeom g, const float*
                     ld_c0 += KB;
                     if (ld_c0 == K) {
                         ld_c0 = 0;
-                        ++ld_tap;
+                        ld_tap += __ffsll((long long)(tapmask >> (ld_tap + 1)));
                         retap();
                     }
                 }
@@ -155,7 +177,8 @@ __global__ __launch_bounds__(256) void gemm1x1_kernel(CnConvGeom g, const float*
                 *reinterpret_cast<f4*>(As + buf * BM * LDA + a_lds[i]) = v;
             }
 #pragma unroll
-            for (int j = 0; j < BP; ++j) *reinterpret_cast<f4*>(Bs + buf * BSZ + b_lds[j]) = rb[j];
+            for (int j = 0; j < BP; ++j)
+                if (BN * KQ % 256 == 0 || tid + 256 * j < BN * KQ) *reinterpret_cast<f4*>(Bs + buf * BSZ + b_lds[j]) = rb[j];
         };
         // fragment addresses: A row (wm, tile i, l31), K quad of this half-wave; B likewise (BT) or [k row][TN adjacent columns]
         const int a_frag = (wm * 32 * TM + l31) * LDA + 4 * half;
@@ -183,7 +206,8 @@ __global__ __launch_bounds__(256) void gemm1x1_kernel(CnConvGeom g, const float*
                         const f2 v = *reinterpret_cast<const f2*>(bs + q * LDB);
                         b[set][q][0] = v.x; b[set][q][TN - 1] = v.y;
                     } else {
-                        b[set][q][0] = bs[q * LDB];
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) b[set][q][j] = bs[q * LDB + j];
                     }
                 }
             }
@@ -222,6 +246,7 @@ __global__ __launch_bounds__(256) void gemm1x1_kernel(CnConvGeom g, const float*
             step(s + 1, ra[1], rb[1], am[1]);
         }
         if (s < ks_end) step(s, ra[0], rb[0], am[0]);
+      }
     }
 
     // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
@@ -230,8 +255,9 @@ __global__ __launch_bounds__(256) void gemm1x1_kernel(CnConvGeom g, const float*
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int row = m0 + wm * 32 * TM + 32 * i + 4 * half + (r & 3) + 8 * (r >> 2);
-            if (row >= M) continue;
+            const int lrow = wm * 32 * TM + 32 * i + 4 * half + (r & 3) + 8 * (r >> 2);
+            const int row = GATHER ? rowmap[lrow] : m0 + lrow;
+            if (row < 0 || row >= M) continue;
             if (!BT && TN == 2) {
                 const int col = n0 + wn * 64 + 2 * l31;
                 if (col >= N) continue;
@@ -244,7 +270,7 @@ __global__ __launch_bounds__(256) void gemm1x1_kernel(CnConvGeom g, const float*
             } else {
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    const int col = n0 + wn * 32 * TN + 32 * j + l31;
+                    const int col = n0 + wn * 32 * TN + (BT ? 32 * j + l31 : TN * l31 + j);
                     if (col >= N) continue;
                     const float v = acc[i][j][r] + ((bias && blockIdx.z == 0) ? bias[col] : 0.f);
                     float* dst = C + (long)row * N + col;
@@ -258,41 +284,42 @@ __global__ __launch_bounds__(256) void gemm1x1_kernel(CnConvGeom g, const float*
 
 template <int WM, int WN, int TM, int TN, bool BT, bool GATHER>
 int launch(const CnConvGeom& g, const float* A, const float* B, const float* bias, float* C, long M, int N, int K, int act, float slope,
-           int splits, long part_stride, hipStream_t s) {
+           int splits, long part_stride, int par, hipStream_t s) {
     constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
-    constexpr size_t lds = sizeof(float) * 3 * (BM * 20 + (BT ? BN * 20 : 16 * (BN + 4)));
+    constexpr size_t lds = sizeof(float) * (3 * (BM * 20 + (BT ? BN * 20 : 16 * (BN + 4))) + BM);
     static bool attr_set = false;
     if (!attr_set) {
         CN_HIP(hipFuncSetAttribute((const void*)gemm1x1_kernel<WM, WN, TM, TN, BT, GATHER>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     const int ntm = cn_cdiv(M, BM), ntn = cn_cdiv(N, BN);
-    dim3 grid((unsigned)(8 * cn_cdiv(ntm, 8) * ntn), 1, (unsigned)splits);
-    hipLaunchKernelGGL((gemm1x1_kernel<WM, WN, TM, TN, BT, GATHER>), grid, dim3(256), lds, s, g, A, B, bias, C, (int)M, N, K, act, slope, ntm, ntn, part_stride);
+    dim3 grid((unsigned)(par ? ntm * ntn : 8 * cn_cdiv(ntm, 8) * ntn), 1, (unsigned)splits);
+    hipLaunchKernelGGL((gemm1x1_kernel<WM, WN, TM, TN, BT, GATHER>), grid, dim3(256), lds, s, g, A, B, bias, C, (int)M, N, K, act, slope, ntm, ntn, part_stride, par);
     CN_LAUNCH_CHECK();
     return CN_OK;
 }
 
 }  // namespace
 
-// cfg: the implicit-GEMM tile numbering (0 = 128 x 128, 1 = 128 x 64, 2 = 64 x 64); other tiles are not provided (CN_EUNSUPPORTED:
-// the caller falls back to igemm_fwd_kernel).  bt: B is the original filter [N][K] (data gradient).  Same split-K protocol as
-// igemm_fwd_kernel: splits > 1 adds into a zeroed C (or stores slabs at part_stride), bias by split 0, no activation.
-// gp: NULL = the rows of A are the GEMM rows (1x1, stride 1); otherwise the geometry whose gather builds them (vec, not
-// parity-ordered: the caller checks).
+// cfg: the implicit-GEMM tile numbering (0 = 128 x 128, 1 = 128 x 64, 2 = 64 x 64, 4 = 128 x 96); the 128 x 32 tile is not provided
+// (CN_EUNSUPPORTED: the caller falls back to igemm_fwd_kernel).  bt: B is the original filter [N][K] (data gradient).  Same
+// split-K protocol as igemm_fwd_kernel: splits > 1 adds into a zeroed C (or stores slabs at part_stride), bias by split 0, no
+// activation.  gp: NULL = the rows of A are the GEMM rows (1x1, stride 1); otherwise the geometry whose gather builds them (vec:
+// the caller checks), par = its rows are parity-ordered.
 int cn_gemm1x1(const CnConvGeom* gp, int cfg, int bt, const float* A, const float* B, const float* bias, float* C, long M, int N, int K,
-               int act, float slope, int splits, long part_stride, hipStream_t s) {
-    if (K % 16 != 0 || N % 4 != 0 || M <= 0 || M > 0x7fffffffL) return CN_EUNSUPPORTED;
+               int act, float slope, int splits, long part_stride, int par, hipStream_t s) {
+    if (K % 16 != 0 || N % 4 != 0 || M <= 0 || M > 0x7fffffffL || (par && !gp)) return CN_EUNSUPPORTED;
     static const CnConvGeom none = {};
-#define L(WM, WN, TM, TN)                                                                                                     \
-    return gp ? (bt ? launch<WM, WN, TM, TN, true, true>(*gp, A, B, bias, C, M, N, K, act, slope, splits, part_stride, s)      \
-                    : launch<WM, WN, TM, TN, false, true>(*gp, A, B, bias, C, M, N, K, act, slope, splits, part_stride, s))    \
-              : (bt ? launch<WM, WN, TM, TN, true, false>(none, A, B, bias, C, M, N, K, act, slope, splits, part_stride, s)    \
-                    : launch<WM, WN, TM, TN, false, false>(none, A, B, bias, C, M, N, K, act, slope, splits, part_stride, s))
+#define L(WM, WN, TM, TN)                                                                                                          \
+    return gp ? (bt ? launch<WM, WN, TM, TN, true, true>(*gp, A, B, bias, C, M, N, K, act, slope, splits, part_stride, par, s)      \
+                    : launch<WM, WN, TM, TN, false, true>(*gp, A, B, bias, C, M, N, K, act, slope, splits, part_stride, par, s))    \
+              : (bt ? launch<WM, WN, TM, TN, true, false>(none, A, B, bias, C, M, N, K, act, slope, splits, part_stride, 0, s)      \
+                    : launch<WM, WN, TM, TN, false, false>(none, A, B, bias, C, M, N, K, act, slope, splits, part_stride, 0, s))
     switch (cfg) {
         case 0: L(2, 2, 2, 2);
         case 1: L(2, 2, 2, 1);
         case 2: L(2, 2, 1, 1);
+        case 4: L(4, 1, 1, 3);
         default: return CN_EUNSUPPORTED;
     }
 #undef L

@@ -1357,11 +1357,14 @@ static int conv_fwd_impl(const CnConvGeom* gp, const float* x, const float* w, c
     const bool rows_ok = !no_g1 && nks_total > 8;
     if (rows_ok && vec && !par && g.k_d * g.k_h * g.k_w == 1 && g.s_d == 1 && g.s_h == 1 && g.s_w == 1 && g.dl_d == 1 && g.dl_h == 1 &&
         g.dl_w == 1 && !g.up && g.p_d == 0 && g.p_h == 0 && g.p_w == 0 && g.out_d == g.in_d && g.out_h == g.in_h && g.out_w == g.in_w)
-        e = cn_gemm1x1(nullptr, cfg, bt, x, w, bias, y, M, g.cout, g.cin, kact, slope, splits, part_stride, s);
-    // every other vec layer that is not parity-ordered: the same main loop over gathered rows
+        e = cn_gemm1x1(nullptr, cfg, bt, x, w, bias, y, M, g.cout, g.cin, kact, slope, splits, part_stride, 0, s);
+    // every other vec layer: the same main loop over gathered rows (parity-ordered ones included)
     static const int no_g2 = getenv("CN_NO_IGEMM_ROWS") ? 1 : 0;
-    if (e == CN_EUNSUPPORTED && rows_ok && !no_g2 && vec && !par)
-        e = cn_gemm1x1(&g, cfg, bt, x, w, bias, y, M, g.cout, g.cin, kact, slope, splits, part_stride, s);
+    static const int no_g3 = getenv("CN_NO_IGEMM_ROWS_PAR") ? 1 : 0;
+    // (thin layers stay: with 48 channels per tap the offsets are recomputed every third step, and 48 output columns pad a
+    // quarter of either kernel's tile -- same-box A/B 107 vs 109 us, 75 vs 77 us; scripts/dev/par_ab.sh)
+    if (e == CN_EUNSUPPORTED && rows_ok && !no_g2 && vec && !(par && no_g3) && g.cin >= 64 && g.cout >= 64)
+        e = cn_gemm1x1(&g, cfg, bt, x, w, bias, y, M, g.cout, g.cin, kact, slope, splits, part_stride, par, s);
     if (e == CN_EUNSUPPORTED)
     switch (cfg) {
         case 3: e = launch_fwd<4, 1, 1, 1>(g, vec, par, splits, x, w, bias, y, kact, slope, s, bt, part_stride); break;   // 128 x 32
