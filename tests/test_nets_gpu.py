@@ -450,7 +450,7 @@ def test_second_stage_generator_step():
     # LeakyReLU / max-pool decisions.  Which of them the GPU takes differently changes from run to run with the order of
     # the fp32 atomics in the statistics kernels: over eight runs the learned-input gradient deviated by 1.2e-2 .. 5.2e-2,
     # and the 12 nearest candidates (one oracle pass of ~10 s each) explain all of it in some runs and little in others.
-    # Held at round 1's 8e-2; every single network and the first-stage chain are held at 5e-3 / 7.5e-3.)
+    # Round 1 and 2 held it at 8e-2 (see above for round 3); every single network is held at 5e-3.)
 
 
 def test_full_iteration_runs_and_api(tmp_path):
