@@ -51,6 +51,22 @@ def main():
 
     import torch
     import torch.distributed as dist
+
+    env_world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # plain `python bench.py --gpus N` (no launcher): start the N ranks ourselves, one process per GPU, exactly as
+        # `python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N ...` would
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            sys.exit("bench.py: --gpus %d needs %d visible devices, this host has %d" % (args.gpus, args.gpus, have))
+        import subprocess
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--standalone",
+               "--local-addr", "127.0.0.1", os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+    if env_world != args.gpus:
+        sys.exit("bench.py: launched with WORLD_SIZE=%d but --gpus %d (the two must agree)" % (env_world, args.gpus))
+    if torch.cuda.device_count() < int(os.environ.get("LOCAL_RANK", "0")) + 1:
+        sys.exit("bench.py: rank with LOCAL_RANK=%s has no device (%d visible)" % (os.environ.get("LOCAL_RANK", "0"), torch.cuda.device_count()))
     from confignet_amd import ops, parallel
 
     ops.set_activation_dtype(args.dtype)
@@ -58,7 +74,6 @@ def main():
     rank = parallel.rank()
     if world > 1:                                     # N processes share the host: keep each rank's CPU thread pool small
         torch.set_num_threads(max(1, min(8, (os.cpu_count() or 8) // world)))
-    assert world == args.gpus or world == 1 and args.gpus == 1, "WORLD_SIZE=%d but --gpus %d" % (world, args.gpus)
     if world == 1:
         torch.cuda.set_device(0)
 
@@ -383,16 +398,20 @@ def compare_losses(got, ref, dispatch, tol=1e-3):
     """max over every scalar of the four loss dicts of |hip - cpu| / max(1, |cpu|) (north_star: 1e-3 at fp32)."""
     if ref is None:
         return {"max_err": None, "tolerance": tol, "note": "the CPU oracle run failed"}
-    worst, n = (0.0, None), 0
+    import math
+    worst, n, bad = (0.0, None), 0, []
     for g, step in zip(got, ("d", "synth_d", "latent_d", "g")):
         r = ref[step]
         assert list(g.keys()) == list(r.keys()), (step, list(g.keys()), list(r.keys()))
         for k, v in g.items():
-            e = abs(v - r[k]) / max(1.0, abs(r[k]))
             n += 1
-            if not (e <= worst[0]):
+            e = abs(v - r[k]) / max(1.0, abs(r[k]))
+            if not math.isfinite(e):               # a NaN / inf scalar on either side fails the gate whatever else was seen
+                bad.append("%s/%s: hip %r cpu %r" % (step, k, v, r[k]))
+            elif e > worst[0]:
                 worst = (e, "%s/%s: hip %.6g cpu %.6g" % (step, k, v, r[k]))
-    return {"max_err": float("%.3g" % worst[0]), "tolerance": tol, "ok": bool(worst[0] <= tol), "n_scalars": n, "worst": worst[1],
+    return {"max_err": float("%.3g" % worst[0]) if not bad else None, "tolerance": tol, "ok": bool(not bad and worst[0] <= tol),
+            "n_scalars": n, "worst": worst[1] if not bad else None, "non_finite": bad,
             "what": "all loss scalars of one whole iteration at the benchmark's size, HIP (%s) vs the torch-CPU fp32 oracle on the "
                     "same weights and batches; |hip - cpu| / max(1, |cpu|)" % dispatch}
 

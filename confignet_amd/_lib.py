@@ -66,6 +66,7 @@ SIGNATURES = {
     "cn_zero": [_p, ctypes.c_size_t, _p],
     "cn_set_deterministic": [_i],
     "cn_get_deterministic": [],
+    "cn_det_release_stream": [_p],
     "cn_gemm_acc": [_i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _p],
     "cn_sum_rows_into": [_p, _p, _i, _i, _i, _p],
     "cn_bn_act_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],

@@ -103,7 +103,8 @@ class ConfigNetFirstStage:
         self._prestaged, self._stagers = {}, {}      # cross-iteration overlap of the discriminator steps (see overlap_discriminators)
         # second stage: real / synthetic branches of the generator step on two streams (not in deterministic mode: both
         # branches add into the generator's gradient slots, and the order of those adds would depend on the race)
-        self.fork_generator_step = os.environ.get("CN_NO_FORK") is None and not ops.DETERMINISTIC
+        # (read at USE time -- `fork_generator_step` is a property: ops.set_deterministic() after construction must take effect)
+        self._fork_generator_step = os.environ.get("CN_NO_FORK") is None
         self._work_streams = []
         self.use_graphs = False       # capture each step's device half into a HIP graph (single-GPU runs)
 
@@ -319,10 +320,12 @@ class ConfigNetFirstStage:
             # otherwise share for its capture, so it gets a capture stream (and with it a workspace) of its own
             if getattr(self, "_g_capture_stream", None) is None:
                 self._g_capture_stream = torch.cuda.Stream()
+                self._release_on_exit([self._g_capture_stream])
             return self._g_capture_stream
         if not self._work_streams:
             from .graphs import independent_streams
             self._work_streams = independent_streams(4)
+            self._release_on_exit(self._work_streams)
         return self._work_streams[self._WORK_SLOTS.get(name, 1)]
 
     @contextlib.contextmanager
@@ -381,6 +384,25 @@ class ConfigNetFirstStage:
     def _graph_of(self, name, datasets, optimizer):
         return self._graphs.get(self._graph_key(name, datasets, optimizer))
 
+    def _release_on_exit(self, streams):
+        """When this model goes away (its captured graphs with it) the library may re-bind the deterministic-mode workspaces of
+        its streams (cn_det_release_stream; the streams themselves are kept alive by the finalizer until then)."""
+        import weakref
+
+        def release(streams=list(streams)):
+            from ._lib import lib
+            for st in streams:
+                lib.cn_det_release_stream(st.cuda_stream)
+        weakref.finalize(self, release)
+
+    @property
+    def fork_generator_step(self):
+        return self._fork_generator_step and not ops.DETERMINISTIC
+
+    @fork_generator_step.setter
+    def fork_generator_step(self, on):
+        self._fork_generator_step = bool(on)
+
     def _run_step(self, name, datasets, optimizer, device_fn):
         """optimizer.advance() on the host, then the device half -- eagerly, or as a captured HIP graph."""
         optimizer.advance(name)
@@ -390,6 +412,7 @@ class ConfigNetFirstStage:
             # loss scalars are returned detached: keeping the tape alive would keep the leaves' AccumulateGrad
             # nodes (and their stream binding) alive across steps
             ops.zero_pool_begin(name, self.device)
+            self._deferred_terms = []      # a term left behind by an aborted step must not join this step's backward pass
             try:
                 return {k: v.detach() for k, v in fn().items()}
             finally:

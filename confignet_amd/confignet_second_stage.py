@@ -58,13 +58,17 @@ class ConfigNet(ConfigNetFirstStage):
     def face_reco_loss(self, gt_imgs, gen_imgs, cached=None):
         return self.perceptual_loss_face_reco.loss(gen_imgs, gt_imgs, cached=cached)
 
-    def compute_normalized_latent_regression_loss(self, generator_outputs, labels):
+    def compute_normalized_latent_regression_loss(self, generator_outputs, labels, deferred=False):
         """confignet_second_stage.py:93-107.  The (N, L+3) batch statistics are latent-vector algebra
-        (host-side plumbing); the latent regressor itself runs on HIP kernels."""
+        (host-side plumbing); the latent regressor itself runs on HIP kernels.
+
+        deferred=True (only _generator_loss passes it: its _generator_update differentiates the term) selects the
+        global-batch-statistics form under data parallelism; every other caller -- fine_tune_on_img backpropagates
+        loss_sum itself -- gets the ordinary taped term with the statistics of the batch at hand."""
         out = self.latent_regressor(generator_outputs)
         # config["dp_global_batch_statistics"] (default off): under data parallelism the batch statistics of the GLOBAL batch
         # (one 2 x (L + 3)-float all-reduce forward and one backward per statistic) instead of the per-rank ones
-        if bool(self.config.get("dp_global_batch_statistics", False)) and parallel.active():
+        if deferred and bool(self.config.get("dp_global_batch_statistics", False)) and parallel.active():
             from .losses import DeferredGlobalStatsRegression
             term = DeferredGlobalStatsRegression(out, labels, self.config["latent_regression_weight"])
             self._deferred_terms.append(term)          # differentiated by _generator_update (its collectives run on this thread)
@@ -160,7 +164,7 @@ class ConfigNet(ConfigNetFirstStage):
             stacked_imgs = torch.cat((generator_output_synth, generator_output_real), dim=0)
             stacked_rotations = torch.cat((synth_rotations, real_rotations), dim=0)
             labels = torch.cat((stacked_latents, cfg["latent_regressor_rot_weight"] * stacked_rotations), dim=-1)
-            losses["latent_regression_loss"] = self.compute_normalized_latent_regression_loss(stacked_imgs, labels)
+            losses["latent_regression_loss"] = self.compute_normalized_latent_regression_loss(stacked_imgs, labels, deferred=True)
         losses["loss_sum"] = total_loss(losses.values())
         return losses
 

@@ -658,14 +658,16 @@ __global__ void gather_u8_kernel(const uint8_t* __restrict__ pool, const int64_t
         const int y = (int)(r / ((long)c * w));
         const int sx = (flip && flip[b]) ? w - 1 - x : x;
         const uint8_t v = pool[(size_t)idx[b] * per + ((long)y * w + sx) * c + ch];
-        out[i] = (float)v / 127.5f - 1.0f;
+        out[i] = __fsub_rn(__fdiv_rn((float)v, 127.5f), 1.0f);    // = NumPy's float32 (v / 127.5) - 1, bit for bit
     }
 }
 
 __global__ void to_uint8_kernel(const float* __restrict__ x, uint8_t* __restrict__ o, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const float v = fminf(fmaxf(x[i], -1.f), 1.f);
-        o[i] = (uint8_t)((v + 1.f) * 127.5f);   // numpy astype(uint8) truncates toward zero
+        // two separately rounded fp32 operations like NumPy's (clip(x) + 1) * 127.5 (no fma contraction: the byte must be
+        // bit-exact), then astype(uint8)'s truncation toward zero
+        o[i] = (uint8_t)__fmul_rn(__fadd_rn(v, 1.f), 127.5f);
     }
 }
 

@@ -1206,9 +1206,11 @@ static int conv_fwd_impl(const CnConvGeom* gp, const float* x, const float* w, c
         CN_CHECK_ARG(lds <= 64 * 1024, "thin conv: filter of %zu bytes does not fit the LDS stage", lds);
         const int T = g.k_d * g.k_h * g.k_w, CL = g.cin / 4;
         const bool dl1 = g.dl_d * g.dl_h * g.dl_w == 1;
+        static const bool no_rgb = getenv("CN_NO_RGB") != nullptr, no_s2img = getenv("CN_NO_S2IMG") != nullptr,
+                          no_s1img = getenv("CN_NO_S1IMG") != nullptr;     // read once, like every other switch
         if (g.nd == 2 && g.up == 1 && g.k_h == 4 && g.k_w == 4 && g.s_h == 1 && g.s_w == 1 && g.dl_h == 1 && g.dl_w == 1 &&
             g.cout == 3 && g.cin == 32 && g.p_h == 1 && g.p_w == 1 && g.out_h <= 2 * g.in_h && g.out_w <= 2 * g.in_w &&
-            !getenv("CN_NO_RGB")) {
+            !no_rgb) {
             dim3 grid((unsigned)(g.n * cn_cdiv(g.in_h, 8) * cn_cdiv(g.in_w, 16)));
             cn_prof_begin(s, conv_flops(g), conv_bytes(g), CN_FAM_THIN);
             hipLaunchKernelGGL((up2k4_rgb_fwd_kernel<4>), grid, dim3(256), 0, s, g, x, w, bias, y, act, slope);
@@ -1218,7 +1220,7 @@ static int conv_fwd_impl(const CnConvGeom* gp, const float* x, const float* w, c
         }
         if (g.nd == 2 && g.k_h == 3 && g.k_w == 3 && g.dl_h == 2 && g.dl_w == 2 && g.s_h == 1 && g.s_w == 1 && !g.up &&
             g.cout == 3 && g.cin == 48 && !bias && act == CN_ACT_NONE && g.p_h >= 0 && g.p_h <= 2 && g.p_w >= 0 &&
-            g.p_w <= 2 && g.out_h <= 2 * g.in_h && g.out_w <= 2 * g.in_w && !getenv("CN_NO_S2IMG")) {
+            g.p_w <= 2 && g.out_h <= 2 * g.in_h && g.out_w <= 2 * g.in_w && !no_s2img) {
             dim3 grid((unsigned)(g.n * cn_cdiv(g.in_h, 8) * cn_cdiv(g.in_w, 32)));
             cn_prof_begin(s, conv_flops(g), conv_bytes(g), CN_FAM_S2_IMAGE_DGRAD);
             hipLaunchKernelGGL((s2_image_dgrad_kernel<6>), grid, dim3(256), 0, s, g, x, w, y);
@@ -1228,7 +1230,7 @@ static int conv_fwd_impl(const CnConvGeom* gp, const float* x, const float* w, c
         }
         if (g.nd == 2 && g.k_h == 3 && g.k_w == 3 && g.dl_h == 1 && g.dl_w == 1 && g.s_h == 1 && g.s_w == 1 && !g.up &&
             g.cout == 3 && g.cin == 64 && !bias && act == CN_ACT_NONE && g.p_h >= 0 && g.p_h <= 2 && g.p_w >= 0 && g.p_w <= 2 &&
-            !getenv("CN_NO_S1IMG")) {
+            !no_s1img) {
             dim3 grid((unsigned)(g.n * cn_cdiv(g.out_h, 8) * cn_cdiv(g.out_w, 32)));
             cn_prof_begin(s, conv_flops(g), conv_bytes(g), CN_FAM_S2_IMAGE_DGRAD);
             hipLaunchKernelGGL((s1_image_dgrad_kernel<8>), grid, dim3(256), 0, s, g, x, w, y);

@@ -111,8 +111,12 @@ extern "C" int cn_prof_collect_by_family(int* launches, double* ms, double* flop
 namespace {
 int g_det = 0;
 std::mutex g_det_mu;
-float* g_det_buf[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-hipStream_t g_det_stream[8];
+constexpr int CN_DET_SLOTS = 16;
+float* g_det_buf[CN_DET_SLOTS] = {};
+hipStream_t g_det_stream[CN_DET_SLOTS];
+bool g_det_pinned[CN_DET_SLOTS] = {};      // handed out during a stream capture: a graph may replay with this pointer baked in
+unsigned long long g_det_last_use[CN_DET_SLOTS] = {};
+unsigned long long g_det_tick = 0;
 int g_det_used = 0;
 
 __global__ void sum_parts_kernel(const float* __restrict__ src, float* __restrict__ dst, int parts, long count, int accumulate,
@@ -130,7 +134,7 @@ __global__ void sum_parts_kernel(const float* __restrict__ src, float* __restric
 extern "C" int cn_set_deterministic(int on) {
     std::lock_guard<std::mutex> lk(g_det_mu);
     if (on && !g_det_buf[0]) {
-        for (int i = 0; i < 8; ++i) CN_HIP(hipMalloc((void**)&g_det_buf[i], sizeof(float) * CN_DET_WS_FLOATS));
+        for (int i = 0; i < CN_DET_SLOTS; ++i) CN_HIP(hipMalloc((void**)&g_det_buf[i], sizeof(float) * CN_DET_WS_FLOATS));
     }
     g_det = on ? 1 : 0;
     return CN_OK;
@@ -146,25 +150,45 @@ float* cn_det_ws(hipStream_t s, size_t need_floats) {
         cn_set_error("deterministic workspace: %zu floats requested, %zu available per stream", need_floats, g_det_buf[0] ? CN_DET_WS_FLOATS : (size_t)0);
         return nullptr;
     }
-    static unsigned long long tick = 0, last_use[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    const bool capturing = hipStreamIsCapturing(s, &cap) == hipSuccess && cap == hipStreamCaptureStatusActive;
     for (int i = 0; i < g_det_used; ++i)
         if (g_det_stream[i] == s) {
-            last_use[i] = ++tick;
+            g_det_last_use[i] = ++g_det_tick;
+            g_det_pinned[i] |= capturing;
             return g_det_buf[i];
         }
     int slot = g_det_used;
-    if (g_det_used == 8) {
-        // more than 8 streams over the life of the process (models come and go): the least recently used binding is handed
-        // to the new stream.  Safe as long as no more than 8 streams run deterministic launches at the same time.
-        slot = 0;
-        for (int i = 1; i < 8; ++i)
-            if (last_use[i] < last_use[slot]) slot = i;
+    if (g_det_used == CN_DET_SLOTS) {
+        // more streams than slots over the life of the process (models come and go): the least recently used binding that
+        // NO CAPTURED GRAPH can still reference is handed to the new stream.  A binding handed out during a capture is pinned
+        // until its owner calls cn_det_release_stream(): re-binding it would let a replayed graph share scratch with a live stream.
+        slot = -1;
+        for (int i = 0; i < CN_DET_SLOTS; ++i)
+            if (!g_det_pinned[i] && (slot < 0 || g_det_last_use[i] < g_det_last_use[slot])) slot = i;
+        if (slot < 0) {
+            cn_set_error("deterministic workspace: all %d per-stream workspaces are referenced by captured graphs "
+                         "(release their streams with cn_det_release_stream)", CN_DET_SLOTS);
+            return nullptr;
+        }
     } else {
         ++g_det_used;
     }
     g_det_stream[slot] = s;
-    last_use[slot] = ++tick;
+    g_det_last_use[slot] = ++g_det_tick;
+    g_det_pinned[slot] = capturing;
     return g_det_buf[slot];
+}
+
+extern "C" int cn_det_release_stream(void* stream) {
+    std::lock_guard<std::mutex> lk(g_det_mu);
+    for (int i = 0; i < g_det_used; ++i)
+        if (g_det_stream[i] == (hipStream_t)stream) {
+            g_det_pinned[i] = false;
+            g_det_last_use[i] = 0;              // first in line for re-binding
+            g_det_stream[i] = (hipStream_t)(~(uintptr_t)0 - (uintptr_t)i);   // matches no live stream handle
+        }
+    return CN_OK;
 }
 
 namespace {

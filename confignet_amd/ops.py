@@ -485,10 +485,15 @@ class grad_sink:
             st["keep"].clear()
             st["used"] = False
 
-    def __exit__(self, *exc):
+    def __exit__(self, exc_type, exc, tb):
         global _SINK
-        self.join()
-        _SINK = None
+        try:
+            if exc_type is None:
+                self.join()
+            elif _SINK is not None:                 # the pass raised: no scatter work on half-written scratch, just let go
+                _SINK["keep"].clear()
+        finally:
+            _SINK = None                            # a failed pass must not leave every later one dying on "nested gradient sinks"
 
 
 def sink_for(w):

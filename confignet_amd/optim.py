@@ -42,6 +42,7 @@ class Adam:
         self.lr, self.beta_1, self.beta_2, self.epsilon = lr, beta_1, beta_2, epsilon
         self.iterations = 0
         self._state = {}
+        self._checked_lists = set()        # (network, variable list) pairs whose Keras-form call has been checked
         self._lr_dev = {}
 
     def lr_t(self):
@@ -73,7 +74,8 @@ class Adam:
         of those networks that are not listed get a zero gradient, which Keras-Adam with zero moments leaves unchanged).
         RESTRICTION of that form: Adam runs over the owners' WHOLE arenas, so an unlisted weight of a listed network whose
         moments are already non-zero in THIS optimizer (it was listed in an earlier call) would keep moving, which Keras does
-        not do -- asserted below on the first-moment arena (the reference never mixes variable lists on one optimizer)."""
+        not do -- asserted below on the second-moment arena, once per variable list (the reference never mixes variable lists on one
+        optimizer)."""
         if not isinstance(nets, (list, tuple)) and hasattr(nets, "__iter__") and not hasattr(nets, "arena"):
             nets = list(nets)                   # zip(...) and other iterators
         if isinstance(nets, (list, tuple)) and nets and isinstance(nets[0], (list, tuple)):
@@ -87,16 +89,21 @@ class Adam:
             for g, var in pairs:
                 if g is not None:
                     var.grad.copy_(g.reshape(var.shape))
-            listed = {id(var) for _, var in pairs}
+            listed = frozenset(id(var) for _, var in pairs)
             for owner in nets:
                 st = self._state.get(id(owner))
-                if st is None or len(listed) >= len(owner.trainable_weights):
+                if st is None or (id(owner), listed) in self._checked_lists:
                     continue
+                # once per (optimizer, variable list): one masked reduction over the SECOND-moment arena (v > 0 wherever a
+                # weight has ever had a non-zero gradient in this optimizer) restricted to the unlisted weights
+                mask = torch.zeros_like(owner.arena, dtype=torch.bool)
                 for w in owner.trainable_weights:
-                    if id(w) not in listed:
+                    if id(w) not in listed and w.numel():
                         off = (w.data_ptr() - owner.arena.data_ptr()) // 4
-                        assert float(st[1][off:off + w.numel()].abs().max()) == 0.0, \
-                            "apply_gradients(zip(grads, vars)): an unlisted weight of a listed network has optimizer state"
+                        mask[off:off + w.numel()] = True
+                assert not bool((st[1].ne(0) & mask).any()), \
+                    "apply_gradients(zip(grads, vars)): an unlisted weight of a listed network has optimizer state"
+                self._checked_lists.add((id(owner), listed))
         if not isinstance(nets, (list, tuple)):
             nets = [nets]
         if _deferred is not None:

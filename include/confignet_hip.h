@@ -157,10 +157,14 @@ int cn_gemm(int trans_a, int trans_b, int m, int n, int k, const float* a, int l
 /* Deterministic mode (process-wide; switch between steps, not inside a captured graph): with on != 0 every reduction of the
  * fp32 path runs in a fixed order -- statistics passes, split-K of cn_conv_fwd / cn_gemm, filter gradients and loss reductions
  * through per-split partials that a second launch adds in index order, the rotation's scatter by one wave per (sample, 8
- * channels) in voxel order -- so two runs on the same inputs give bit-identical results (at a cost: see DESIGN.md).  Allocates 8 per-stream
- * workspaces of 64 MiB on first use.  The bf16 family is not covered. */
+ * channels) in voxel order -- so two runs on the same inputs give bit-identical results (at a cost: see DESIGN.md).  Allocates 16 per-stream
+ * workspaces of 64 MiB on first use; a workspace handed out while its stream was being captured stays bound to that stream
+ * (a replayed graph holds the pointer) until cn_det_release_stream(stream), and a launch that finds every workspace bound that
+ * way fails with CN_E* instead of sharing scratch.  The bf16 family is not covered. */
 int cn_set_deterministic(int on);
 int cn_get_deterministic(void);
+/* The caller has destroyed every graph captured on `stream` (or the stream itself): its workspace may be re-bound. */
+int cn_det_release_stream(void* stream);
 /* Clears `bytes` (a multiple of 4) at p with a kernel launch (a HIP-graph node that re-executes on replay). */
 int cn_zero(void* p, size_t bytes, void* stream);
 /* C += op(A) op(B) (fp32 atomics): a Dense layer's weight gradient added straight into its slot of the network's gradient

@@ -415,19 +415,24 @@ def test_pools_preproc_uint8():
     gy = rng.normal(size=img.shape)
     (O.caffe_preprocess(ir) * t64(gy)).sum().backward()
     close(ops.chan_affine3_bwd(dev(gy), (2, 1, 0), 127.5), ir.grad, tol=1e-5)
-    big = rng.uniform(-1.3, 1.3, size=(2, 8, 8, 3)).astype(np.float32)
-    ref = ((np.clip(big, -1.0, 1.0) + 1) * 127.5).astype(np.uint8)
-    got = ops.to_uint8(dev(big)).cpu().numpy()
-    assert np.abs(got.astype(int) - ref.astype(int)).max() <= 1 and (got != ref).mean() < 1e-2
+    # byte output is bit-exact territory: every float32 whose image lies next to an integer boundary included
+    big = np.concatenate([rng.uniform(-1.3, 1.3, size=60000).astype(np.float32),
+                          np.nextafter((np.arange(0, 256, dtype=np.float32) / np.float32(127.5) - 1).astype(np.float32), np.float32(-2)),
+                          (np.arange(0, 256, dtype=np.float32) / np.float32(127.5) - 1).astype(np.float32),
+                          np.nextafter((np.arange(0, 256, dtype=np.float32) / np.float32(127.5) - 1).astype(np.float32), np.float32(2))])
+    big = np.resize(big, (4, 40, 128, 3)).astype(np.float32)
+    ref = ((np.clip(big, np.float32(-1.0), np.float32(1.0)) + np.float32(1)) * np.float32(127.5)).astype(np.uint8)
+    got = ops.to_uint8(torch.as_tensor(big).cuda()).cpu().numpy()
+    assert np.array_equal(got, ref), "to_uint8: %d of %d bytes differ from NumPy's float32 result" % ((got != ref).sum(), ref.size)
     pool = rng.integers(0, 256, size=(10, 8, 8, 3), dtype=np.uint8)
     idx = np.array([3, 9, 0, 3])
     flip = np.array([0, 1, 1, 0], dtype=np.uint8)
     out = ops.gather_images_u8(torch.as_tensor(pool).cuda(), torch.as_tensor(idx).cuda(), torch.as_tensor(flip).cuda())
-    ref = pool[idx].astype(np.float32) / 127.5 - 1.0
+    ref = pool[idx].astype(np.float32) / np.float32(127.5) - np.float32(1.0)
     for i in range(4):
         if flip[i]:
             ref[i] = np.fliplr(ref[i])
-    np.testing.assert_allclose(out.cpu().numpy(), ref, atol=1e-6)
+    assert np.array_equal(out.cpu().numpy(), ref.astype(np.float32))          # integer -> float32: bit-exact as well
 
 
 @pytest.mark.parametrize("g,c,n", [(4, 8, 2), (16, 128, 2)])
