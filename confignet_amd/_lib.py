@@ -47,6 +47,8 @@ SIGNATURES = {
     "cn_conv_wgrad_thin_partials": [],
     "cn_conv_wgrad_thin": [_G, _p, _p, _p, _p, _i, _p],
     "cn_conv_wgrad": [_G, _p, _p, _p, _i, _p],
+    "cn_conv_wgrad_workspace_bytes": [_G],
+    "cn_conv_wgrad_ws": [_G, _p, _p, _p, _i, _p, _z, _p],
     "cn_conv_tune": [_i, _i, ctypes.c_long],
     "cn_conv_fwd_dt": [_p, _p, _i, _p, _p, _p, _i, _i, _f, _p],
     "cn_conv_dgrad_dt": [_p, _p, _i, _p, _p, _i, _p],
@@ -112,6 +114,7 @@ for _name, _args in SIGNATURES.items():
     _fn = getattr(lib, _name)          # AttributeError here == header/library mismatch
     _fn.argtypes = _args
     _fn.restype = ctypes.c_int
+lib.cn_conv_wgrad_workspace_bytes.restype = ctypes.c_size_t
 lib.cn_last_error_string.argtypes = []
 lib.cn_last_error_string.restype = ctypes.c_char_p
 

@@ -1524,6 +1524,43 @@ extern "C" int cn_conv_wgrad(const CnConvGeom* gp, const float* x, const float* 
     return e;
 }
 
+// wgrad2.hip
+bool cn_wgrad2_ok(const CnConvGeom& g);
+size_t cn_wgrad2_workspace_floats(const CnConvGeom& g);
+int cn_wgrad2_family(const CnConvGeom& g);
+void cn_wgrad2_tune(int cfg, long wg_target);
+int cn_wgrad2(const CnConvGeom& g, const float* x, const float* gy, float* gw, int accumulate, float* ws, hipStream_t s);
+
+static bool wgrad2_takes(const CnConvGeom& g) {
+    static const bool off = getenv("CN_NO_WGRAD2") != nullptr;       // A/B: the round-3 kernel (split over rows, fp32 atomics)
+    const long Ktot = (long)g.k_d * g.k_h * g.k_w * g.cin;
+    return !off && cn_wgrad2_ok(g) && Ktot >= 64;
+}
+
+// Workspace (bytes) that cn_conv_wgrad_ws needs for this geometry: room for the partial filters of its row splits; 0 = none.
+extern "C" size_t cn_conv_wgrad_workspace_bytes(const CnConvGeom* gp) {
+    if (!gp || check_geom(gp) != CN_OK || !wgrad2_takes(*gp)) return 0;
+    return sizeof(float) * cn_wgrad2_workspace_floats(*gp);
+}
+
+// Filter gradient with a CALLER-OWNED workspace (the caller owns all device memory): LDS-DMA main loop, row splits
+// through partial slabs in `workspace` + one ordered reduction -- no atomics on the tile, bit-reproducible (wgrad2.hip).
+// Geometries the new kernel does not take (channel counts that are no multiple of 4, K < 64, > 2 GiB operands) go to
+// cn_conv_wgrad and need no workspace.
+extern "C" int cn_conv_wgrad_ws(const CnConvGeom* gp, const float* x, const float* gy, float* gw, int accumulate, void* workspace,
+                                size_t workspace_bytes, void* stream) {
+    if (int e = check_geom(gp)) return e;
+    CN_CHECK_ARG(x && gy && gw, "NULL tensor");
+    if (!wgrad2_takes(*gp)) return cn_conv_wgrad(gp, x, gy, gw, accumulate, stream);
+    const size_t need = sizeof(float) * cn_wgrad2_workspace_floats(*gp);
+    CN_CHECK_ARG(workspace_bytes >= need && (need == 0 || workspace), "cn_conv_wgrad_ws: workspace of %zu bytes, %zu needed", workspace_bytes, need);
+    hipStream_t s = (hipStream_t)stream;
+    cn_prof_begin(s, conv_flops(*gp), conv_bytes(*gp), cn_wgrad2_family(*gp));
+    const int e = cn_wgrad2(*gp, x, gy, gw, accumulate, (float*)workspace, s);
+    cn_prof_end(s);
+    return e;
+}
+
 extern "C" int cn_sumpool2(const void* gu, void* gx, int nd, int n, int d, int h, int w, int c, int dt, void* stream) {
     CN_CHECK_ARG(gu && gx && (nd == 2 || nd == 3) && c % 4 == 0 && (dt == CN_F32 || dt == CN_BF16), "sumpool2: bad args (c must be a multiple of 4)");
     if (nd == 2) d = 1;
@@ -1545,5 +1582,7 @@ extern "C" int cn_conv_tune(int cfg, int splits, long wg_blocks) {
     g_tune_cfg = cfg;
     g_tune_splits = splits;
     g_tune_wg_blocks = wg_blocks;
+    // the same hook steers cn_conv_wgrad_ws: tile 0 / 4 / 2 / 3 -> 128x128 / 128x96 / 64x64 / 128x32, wg_blocks = workgroup target
+    cn_wgrad2_tune(cfg == 0 ? 0 : cfg == 4 ? 1 : cfg == 2 ? 2 : cfg == 3 ? 3 : -1, wg_blocks);
     return CN_OK;
 }

@@ -427,7 +427,10 @@ def conv_wgrad(x, gy, g, w_shape, out=None):
         check(lib.cn_conv_wgrad_bf16(ctypes.byref(g), _ptr(x), _ptr(gy), _fptr(gw), int(pre), _stream()), "cn_conv_wgrad_bf16")
         return gw
     x, gy = f32(x), f32(gy)
-    check(lib.cn_conv_wgrad(ctypes.byref(g), _ptr(x), _ptr(gy), _fptr(gw), int(pre), _stream()), "cn_conv_wgrad")
+    # caller-owned workspace for the partial filters of the kernel's row splits (0 bytes: a single split / the fall-back kernel)
+    nbytes = int(lib.cn_conv_wgrad_workspace_bytes(ctypes.byref(g)))
+    ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32) if nbytes else None
+    check(lib.cn_conv_wgrad_ws(ctypes.byref(g), _ptr(x), _ptr(gy), _fptr(gw), int(pre), _ptr(ws), nbytes, _stream()), "cn_conv_wgrad_ws")
     return gw
 
 
@@ -706,6 +709,8 @@ def nc_lin2(shape, x1=None, a1=None, x2=None, a2=None, b=None, flags=0, slope=0.
     n, c = shape[0], shape[-1]
     s = int(math.prod(shape)) // (n * c)
     x1, x2 = _unify(x1, x2)
+    if flags & 4:
+        _log_mask(x2)                              # the result is multiplied by lrelu'(x2)
     ref = x1 if x1 is not None else (x2 if x2 is not None else b)
     dtype = ref.dtype if (x1 is not None or x2 is not None) else _act_out_dtype(c)
     if out is not None:
@@ -808,6 +813,7 @@ def dual_tail_coef_bwd(H, E, u, T, U, mean, q, sm, ssd, gamma, spatial, eps=1e-3
 def dual_tail_gx(h, ta, tx, x, co, slope):
     """h / ta may hold a multiple of x's samples (batched tangent pass: the heads that share this activation, summed here)."""
     h, ta, tx, x = _unify(h, ta, tx, x)
+    _log_mask(x)
     n, s, c = _nsc(x)
     nrep = 1 if h is None else h.shape[0] // n
     assert h is None or (h.shape[0] == nrep * n and ta.shape[0] == nrep * n)
@@ -822,6 +828,7 @@ def bn_act_bwd(gy, y, x, a, act, want_g):
     """(gx, g | None, sum_c g, sum_c g*x): cn_bn_act_bwd -- activation backward, BatchNorm(inference) input gradient and the two
     per-channel parameter sums in one pass over gy / y / x."""
     gy, y, x = _unify(gy, y, x)
+    _log_mask(y, act)
     c = gy.shape[-1]
     rows = gy.numel() // c
     rep = _partial_rows(rows)
@@ -843,6 +850,7 @@ def bn_act_bwd(gy, y, x, a, act, want_g):
 def nc_reduce_dact(x1, x2, act, slope, x2_period=0, flags=0, want_dot=True):
     """(a, sum_s a, sum_s a * f2(x2)) with a = x1 * act'(x2): cn_nc_reduce_dact (one pass instead of act_bwd + nc_reduce)."""
     x1, x2 = _unify(x1, x2)
+    _log_mask(x2, act)
     n, s, c = _nsc(x1)
     a = torch.empty_like(x1)
     flags |= x2_period << 8
@@ -856,6 +864,32 @@ def nc_reduce_dact(x1, x2, act, slope, x2_period=0, flags=0, want_dot=True):
     return a, s12[0], (s12[1] if want_dot else None)
 
 
+# ---------------------------------------------------------------------------------------------
+# Test instrument (tests/test_nets_gpu.py: whole-step gradient parity): with `branch_log()` active every backward-pass site that
+# evaluates a piecewise-linear derivative -- LeakyReLU / ReLU masks, max-pool arg-max -- appends the tensor its decisions are
+# taken from (as a host-side boolean mask `t > 0`, or the pool's fp32 input) to the list.  The float64 oracle then FORCES the
+# same decisions (oracle.ref_ops.BranchControl(forced=...)), so product and oracle gradients differ by summation error only.
+# Off (None) in the product path: one `is not None` test per call.
+# ---------------------------------------------------------------------------------------------
+BRANCH_LOG = None
+
+
+class branch_log:
+    def __enter__(self):
+        global BRANCH_LOG
+        BRANCH_LOG = self.log = []
+        return self.log
+
+    def __exit__(self, *exc):
+        global BRANCH_LOG
+        BRANCH_LOG = None
+
+
+def _log_mask(t, act=None):
+    if BRANCH_LOG is not None and (act is None or act in (ACT_LRELU, ACT_RELU)):
+        BRANCH_LOG.append(("act", (t.detach().float() > 0).reshape(-1).cpu()))
+
+
 def act_fwd(x, act, slope=0.0):
     y = torch.empty_like(x)
     check(lib.cn_act_fwd(_ptr(x), _ptr(y), x.numel(), act, slope, _dt(x), _stream()), "cn_act_fwd")
@@ -864,6 +898,7 @@ def act_fwd(x, act, slope=0.0):
 
 def act_bwd(gy, y, act, slope=0.0):
     gy, y = _unify(gy, y)
+    _log_mask(y, act)
     gx = torch.empty_like(gy)
     check(lib.cn_act_bwd(_ptr(gy), _ptr(y), _ptr(gx), gy.numel(), act, slope, _dt(gy), _stream()), "cn_act_bwd")
     return gx
@@ -873,6 +908,7 @@ def act_bwd_bias(gy, y, act, slope=0.0, sink=None):
     """(gx, gb): act_bwd fused with the per-channel sum of its result (the bias gradient) -- one pass instead of two.
     sink: the bias's slot of a gradient arena (grad_sink) -- the sum is ADDED there and gb is returned as None."""
     gy, y = _unify(gy, y)
+    _log_mask(y, act)
     _, _, c = _nsc(gy)
     rows = gy.numel() // c
     rep = _partial_rows(rows)                       # as nc_reduce(per_channel=True)
@@ -986,6 +1022,8 @@ def avgpool3_same(x):
 def maxpool_bwd(x, gy, k, s, pad):
     n, h, w, c = x.shape
     x, gy = _unify(x, gy)
+    if BRANCH_LOG is not None:                     # the kernel's decision: first maximum of a window in row-major order
+        BRANCH_LOG.append(("pool", x.detach().float().cpu(), (k, s, pad)))
     gx = torch.empty_like(x)
     check(lib.cn_maxpool_bwd(_ptr(x), _ptr(gy), _ptr(gx), n, h, w, c, k, s, pad, _dt(x), _stream()), "cn_maxpool_bwd")
     return gx

@@ -85,6 +85,13 @@ int cn_conv_dgrad_w(const CnConvGeom* g, const float* gy, const float* w, float*
 /* Filter gradient (Conv*DBackpropFilter): gw[(t,ci),co] (+)= sum_m x[src(m,t),ci]*gy[m,co]; gw is overwritten,
  * or accumulated into when `accumulate` != 0 (the caller guarantees its previous content, e.g. zeros). */
 int cn_conv_wgrad(const CnConvGeom* g, const float* x, const float* gy, float* gw, int accumulate, void* stream);
+/* The same filter gradient with a CALLER-OWNED workspace of cn_conv_wgrad_workspace_bytes(g) bytes (0: none needed, NULL
+ * allowed): operand tiles by LDS-DMA four stages deep, row splits written as partial filters into the workspace and added
+ * by one ordered reduction that also folds the accumulate -- no atomics on the tile, bit-reproducible in every mode
+ * (csrc/wgrad2.hip).  Geometries it does not take fall through to cn_conv_wgrad. */
+size_t cn_conv_wgrad_workspace_bytes(const CnConvGeom* g);
+int cn_conv_wgrad_ws(const CnConvGeom* g, const float* x, const float* gy, float* gw, int accumulate, void* workspace,
+                     size_t workspace_bytes, void* stream);
 /* 3x3 stride-1 SAME 2-D convolution as Winograd F(2x2, 3x3) on the fp32 matrix cores: 16 GEMMs in the transform domain,
  * 4/9 of the multiply-adds of the direct form (exact in real arithmetic).  The same reference lines as cn_conv_fwd /
  * cn_conv_dgrad for the layers it fits (keras.applications VGG19/VGG16 and the 3x3 convolutions of ResNet50:

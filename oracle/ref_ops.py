@@ -67,26 +67,47 @@ def upsample2(x):
 class BranchControl:
     """Test instrument, not part of the restated algorithm.  A piecewise-linear activation whose input lies within the
     product's fp32 rounding of zero may take the other branch on the GPU than in this float64 oracle; the value is continuous
-    there, but the derivative mask differs, which moves every upstream gradient by ~1/sqrt(#elements).  With `record` the
-    activations list their near-zero (non-zero) inputs per call -- flat index, |x| / mean|x|, and, after a backward pass, the
-    magnitude of the gradient that reached that element; with `flips` = {(call number, flat index)} the listed elements
-    take the other branch.  The gradient tests use it to attribute a deviation to named branch decisions
-    (tests/test_nets_gpu.py: check_grads) instead of absorbing it in a loose tolerance."""
+    there, but the derivative mask differs, which moves every upstream gradient by ~1/sqrt(#elements).  Three modes:
+    * `record`: the activations list their near-zero (non-zero) inputs per call -- flat index, |x| / mean|x|, and, after a
+      backward pass, the magnitude of the gradient that reached that element;
+    * `flips` = {(call number, flat index)}: the listed elements take the other branch (tests/test_nets_gpu.py: check_grads
+      attributes a deviation to named decisions with these two);
+    * `forced` = the product's own decisions (confignet_amd.ops.branch_log: the boolean mask `t > 0` of every tensor its
+      backward pass took a LeakyReLU / ReLU derivative from, and the fp32 input of every max-pool it differentiated): an
+      activation (max-pool) of this oracle that a gradient can reach looks up the logged mask of its size that agrees with its
+      own decisions everywhere except on near-zero inputs (near-ties), and TAKES it.  With every decision forced, product and
+      oracle gradients differ by summation error only -- the whole-step chains are then held at the single networks' 5e-3.
+      `forced_report()` lists what was forced and what found no match."""
     active = False
     record = False
     delta = 1e-4
     calls = 0
     cand = {}            # call number -> (flat indices, margins, gradient magnitudes)
     flips = frozenset()
+    forced = None        # {"act": {numel: [{"mask", "pop"}]}, "pool": {key: [fp32 input]}}
+    force_margin = 2e-3  # a forced decision may differ from the oracle's own only where |x| < force_margin * mean|x|
+    report = None
 
     @classmethod
-    def start(cls, record=False, flips=()):
+    def start(cls, record=False, flips=(), forced=None):
         cls.active, cls.record, cls.flips, cls.calls, cls.cand = True, record, frozenset(flips), 0, {}
+        cls.forced, cls.report = None, {"forced_calls": 0, "forced_decisions": 0, "max_margin": 0.0, "unmatched": []}
+        if forced is not None:
+            acts, pools = {}, {}
+            for entry in forced:
+                if entry[0] == "act":
+                    mk = entry[1].reshape(-1)
+                    acts.setdefault(mk.numel(), []).append({"mask": mk, "pop": int(mk.sum())})
+                else:
+                    x32, key = entry[1], entry[2]
+                    pools.setdefault((tuple(x32.shape), tuple(key)), []).append(x32)
+            cls.forced = {"act": acts, "pool": pools}
 
     @classmethod
     def stop(cls):
         cls.active = cls.record = False
         cls.flips = frozenset()
+        cls.forced = None
 
     @classmethod
     def candidates(cls):
@@ -95,6 +116,50 @@ class BranchControl:
         for cid, (idx, mar, infl) in cls.cand.items():
             out += [(cid, int(i), float(m), float(g)) for i, m, g in zip(idx, mar, infl)]
         return out
+
+    @classmethod
+    def forced_report(cls):
+        """What the last forced run did; `unmatched` holds only calls that a gradient actually reached."""
+        r = dict(cls.report)
+        r["unmatched"] = [u for u in r["unmatched"] if u["reached"][0]]
+        return r
+
+    @classmethod
+    def _unmatched(cls, y, what, **info):
+        reached = [False]
+        cls.report["unmatched"].append(dict(info, what=what, reached=reached))
+        if y.requires_grad:
+            def note(g, reached=reached):
+                reached[0] = reached[0] or bool((g != 0).any())
+            y.register_hook(note)
+
+    @classmethod
+    def forced_mask(cls, xd):
+        """The logged product mask for this activation input, or (None, info)."""
+        flat = xd.reshape(-1)
+        own = flat > 0
+        pop = int(own.sum())
+        best = None
+        for e in sorted(cls.forced["act"].get(flat.numel(), ()), key=lambda e: abs(e["pop"] - pop)):
+            if best is not None and abs(e["pop"] - pop) >= best[0]:
+                break
+            d = int((e["mask"] != own).sum())
+            if best is None or d < best[0]:
+                best = (d, e)
+            if d == 0:
+                break
+        if best is None:
+            return None, {"numel": flat.numel(), "why": "no logged mask of this size"}
+        d, e = best
+        if d:
+            idx = torch.nonzero(e["mask"] != own).reshape(-1)
+            margin = float(flat[idx].abs().max() / (flat.abs().mean() + 1e-300))
+            if margin > cls.force_margin:
+                return None, {"numel": flat.numel(), "why": "nearest logged mask differs in %d decisions, margin %.2e" % (d, margin)}
+            cls.report["max_margin"] = max(cls.report["max_margin"], margin)
+        cls.report["forced_calls"] += 1
+        cls.report["forced_decisions"] += d
+        return e["mask"], None
 
 
 def _branch_act(x, neg):
@@ -106,6 +171,16 @@ def _branch_act(x, neg):
     if not bc.active:
         return x * m
     cid, bc.calls = bc.calls, bc.calls + 1
+    if bc.forced is not None:
+        if not x.requires_grad:
+            return x * m
+        pm, info = bc.forced_mask(xd)
+        if pm is None:
+            y = x * m
+            bc._unmatched(y, "activation", call=cid, shape=tuple(x.shape), **info)
+            return y
+        m = torch.where(pm.reshape(x.shape), torch.ones((), dtype=x.dtype), torch.full((), neg, dtype=x.dtype))
+        return x * m
     for c, i in bc.flips:
         if c == cid:
             mf = m.reshape(-1)
@@ -253,7 +328,46 @@ def maxpool(x, k, s, pad=0):
     xc = _to_cf(x)
     if pad:
         xc = F.pad(xc, [pad, pad, pad, pad])     # zero padding, as ZeroPadding2D does
+    bc = BranchControl
+    if bc.active and bc.forced is not None and x.requires_grad:
+        return _to_cl(_forced_maxpool(x, xc, k, s, pad))
     return _to_cl(F.max_pool2d(xc, k, s))
+
+
+def _forced_maxpool(x, xc, k, s, pad):
+    """BranchControl(forced=...): the window winners of the PRODUCT (first maximum in row-major window order of its fp32 input,
+    tests/test_ops_gpu.py pins that rule on tied inputs) instead of this float64 pass's own; a winner may differ only between
+    near-tied window elements."""
+    bc = BranchControl
+    own, own_idx = F.max_pool2d(xc.detach(), k, s, return_indices=True)
+    best = None
+    for x32 in bc.forced["pool"].get((tuple(x.shape), (k, s, pad)), ()):
+        p32 = _to_cf(x32)
+        if pad:
+            p32 = F.pad(p32, [pad, pad, pad, pad])
+        _, idx = F.max_pool2d(p32, k, s, return_indices=True)
+        d = int((idx != own_idx).sum())
+        if best is None or d < best[0]:
+            best = (d, idx)
+        if d == 0:
+            break
+    flat = xc.flatten(2)
+    if best is None:
+        y = F.max_pool2d(xc, k, s)
+        bc._unmatched(y, "max-pool", shape=tuple(x.shape), why="no logged pool input of this shape")
+        return y
+    d, idx = best
+    y = flat.gather(2, idx.flatten(2)).reshape(own.shape)
+    if d:
+        gap = float((own - y.detach()).abs().max() / (xc.detach().abs().mean() + 1e-300))
+        if gap > bc.force_margin:
+            y = F.max_pool2d(xc, k, s)
+            bc._unmatched(y, "max-pool", shape=tuple(x.shape), why="nearest logged pool differs in %d winners, gap %.2e" % (d, gap))
+            return y
+        bc.report["max_margin"] = max(bc.report["max_margin"], gap)
+    bc.report["forced_calls"] += 1
+    bc.report["forced_decisions"] += d
+    return y
 
 
 def bn_inference(x, gamma, beta, mean, var, eps):

@@ -406,6 +406,23 @@ def test_pools_preproc_uint8():
         gy = rng.normal(size=tuple(ref.shape))
         (ref * t64(gy)).sum().backward()
         close(ops.maxpool_bwd(dev(xr.detach().numpy()), dev(gy), k, s, pad), xr.grad, what="maxpool_bwd")
+    # tie rule of the max-pool backward (what oracle.ref_ops.BranchControl(forced=...) relies on): on inputs FULL of exact ties
+    # the gradient goes to the first maximum of a window in row-major order -- bit for bit the gather by torch-CPU's
+    # max_pool2d(return_indices=True) winners on the same fp32 input (zero padding cells take part and take it nowhere)
+    import torch.nn.functional as F
+    for (k, s, pad) in ((2, 2, 0), (3, 2, 1)):
+        xq = rng.integers(0, 3, size=(2, 12, 12, 8)).astype(np.float32)
+        gyq = rng.normal(size=(2, 6, 6, 8)).astype(np.float32)
+        xc = torch.tensor(xq).permute(0, 3, 1, 2)
+        xp = F.pad(xc, [pad] * 4) if pad else xc
+        _, idx = F.max_pool2d(xp, k, s, return_indices=True)
+        gxp = torch.zeros_like(xp).flatten(2)
+        gxp.scatter_add_(2, idx.flatten(2), torch.tensor(gyq).permute(0, 3, 1, 2).flatten(2))
+        gxp = gxp.reshape(xp.shape)
+        if pad:
+            gxp = gxp[:, :, pad:-pad, pad:-pad]
+        got = ops.maxpool_bwd(torch.tensor(xq).cuda(), torch.tensor(gyq).cuda(), k, s, pad).cpu()
+        assert torch.allclose(got, gxp.permute(0, 2, 3, 1), atol=1e-6), "max-pool backward tie rule (k=%d s=%d pad=%d)" % (k, s, pad)
     img = rng.uniform(-1, 1, size=(2, 8, 8, 3))
     close(ops.chan_affine3_fwd(dev(img), (2, 1, 0), 127.5, (127.5 - 103.939, 127.5 - 116.779, 127.5 - 123.68)),
           O.caffe_preprocess(t64(img)), tol=1e-5)

@@ -334,3 +334,51 @@ def test_pin_checker_runs_on_a_self_made_file():
     P["discriminator_out"] = torch.cat([v.reshape(2, 1) for v in o.values()], dim=1).numpy()
     pack("discriminator_w", dw)
     _check_pins(P)
+
+
+def test_forced_branch_decisions():
+    """oracle.ref_ops.BranchControl(forced=...) (the instrument behind the whole-step gradient tests): a logged product mask /
+    pool input that disagrees with the float64 pass only on near-zero inputs / near-tied windows is taken over; anything else is
+    reported as unmatched if a gradient reaches it; without gradients nothing is looked up."""
+    from oracle import ref_ops as O
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 8, 8, 4, dtype=torch.float64, generator=g)
+    x.view(-1)[5] = 1e-9                                   # the GPU sees this one on the other side of zero
+    x.view(-1)[6] = -1e-9
+    x = x.requires_grad_(True)
+    mask = (x.detach() > 0).reshape(-1).clone()
+    mask[5], mask[6] = False, True
+    O.BranchControl.start(forced=[("act", mask)])
+    try:
+        y = O.leaky_relu(x, 0.2)
+        y.sum().backward()
+        rep = O.BranchControl.forced_report()
+    finally:
+        O.BranchControl.stop()
+    assert rep["forced_calls"] == 1 and rep["forced_decisions"] == 2 and not rep["unmatched"]
+    assert float(x.grad.view(-1)[5]) == 0.2 and float(x.grad.view(-1)[6]) == 1.0
+    assert torch.equal(x.grad.view(-1)[7:], torch.where(x.detach().view(-1)[7:] > 0, torch.tensor(1.0, dtype=torch.float64), torch.tensor(0.2, dtype=torch.float64)))
+    # a mask that differs on a clearly non-zero input is NOT taken
+    bad = (x.detach() > 0).reshape(-1).clone()
+    big = int(x.detach().abs().reshape(-1).argmax())
+    bad[big] = not bool(bad[big])
+    x.grad = None
+    O.BranchControl.start(forced=[("act", bad)])
+    try:
+        O.relu(x).sum().backward()
+        rep = O.BranchControl.forced_report()
+    finally:
+        O.BranchControl.stop()
+    assert rep["forced_calls"] == 0 and len(rep["unmatched"]) == 1
+    # max-pool: a near-tie resolved the product's way (its fp32 input rounds the two candidates the other way round)
+    p = torch.zeros(1, 2, 2, 1, dtype=torch.float64)
+    p[0, 0, 0, 0], p[0, 0, 1, 0] = 1.0, 1.0 + 1e-12      # float64 winner: element 1; in fp32 both are 1.0 -> first maximum: element 0
+    p = p.requires_grad_(True)
+    O.BranchControl.start(forced=[("pool", p.detach().float(), (2, 2, 0))])
+    try:
+        O.maxpool(p, 2, 2).sum().backward()
+        rep = O.BranchControl.forced_report()
+    finally:
+        O.BranchControl.stop()
+    assert rep["forced_decisions"] == 1 and not rep["unmatched"]
+    assert p.grad.reshape(-1).tolist() == [1.0, 0.0, 0.0, 0.0]
