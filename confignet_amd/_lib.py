@@ -41,6 +41,8 @@ _G = ctypes.POINTER(CnConvGeom)
 SIGNATURES = {
     "cn_version": [],
     "cn_conv_fwd": [_G, _p, _p, _p, _p, _i, _f, _p],
+    "cn_conv_fwd_res": [_G, _p, _p, _p, _p, _p, _i, _f, _p],
+    "cn_scale_columns_segments": [_p, _p, _p, _p, _i, _z, _p],
     "cn_conv_weight_tflip": [_p, _p, _i, _i, _i, _p],
     "cn_conv_dgrad": [_G, _p, _p, _p, _p],
     "cn_conv_dgrad_w": [_G, _p, _p, _p, _p],

@@ -50,7 +50,7 @@ int cn_sum_parts(const float* src, float* dst, int parts, long count, int accumu
 // the gathered rows of a vec convolution (par: parity-ordered rows); tile cfg 0 / 1 / 2 / 4 of the implicit-GEMM numbering, the
 // same split-K protocol; CN_EUNSUPPORTED for anything else
 int cn_gemm1x1(const CnConvGeom* gp, int cfg, int bt, const float* A, const float* B, const float* bias, float* C, long M, int N, int K,
-               int act, float slope, int splits, long part_stride, int par, hipStream_t s);
+               int act, float slope, int splits, long part_stride, int par, hipStream_t s, const float* res = nullptr);
 
 // profiling hooks (prof.hip): bracket one launch of the dominant kernel class
 // family: which kernel of the class is launched (cn_prof_collect_by_family); bytes: the launch's algorithmic HBM bytes

@@ -1006,6 +1006,43 @@ extern "C" int cn_gather_images_u8(const uint8_t* pool, const int64_t* idx, cons
     const size_t total = (size_t)n * h * w * c;
     EW_LAUNCH(gather_u8_kernel, total, pool, idx, flip, out, n, h, w, c)
 }
+namespace {
+// dst (packed) = src[segment] * a[column]: every convolution filter of a network scaled per output channel in ONE launch.
+// seg: 5 ints per segment -- source offset, packed destination offset, element count, columns (cout), coefficient offset; all
+// multiples of 4 floats.  A thread owns 4 consecutive destination elements and finds its segment by bisection.
+__global__ void scale_columns_segments_kernel(const float* __restrict__ src, float* __restrict__ dst, const int* __restrict__ seg,
+                                              const float* __restrict__ a, int nseg, long total4) {
+    for (long e4 = (long)blockIdx.x * blockDim.x + threadIdx.x; e4 < total4; e4 += (long)gridDim.x * blockDim.x) {
+        const int e = (int)(e4 * 4);
+        int lo = 0, hi = nseg - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (seg[5 * mid + 1] <= e) lo = mid; else hi = mid - 1;
+        }
+        const int* sg = seg + 5 * lo;
+        const int local = e - sg[1];
+        if (local >= sg[2]) continue;                       // (padding between packed segments)
+        const int col = local % sg[3];
+        const float4 v = *reinterpret_cast<const float4*>(src + sg[0] + local);
+        const float4 c = *reinterpret_cast<const float4*>(a + sg[4] + col);
+        *reinterpret_cast<float4*>(dst + e) = make_float4(v.x * c.x, v.y * c.y, v.z * c.z, v.w * c.w);
+    }
+}
+}  // namespace
+
+// BatchNormalization (inference) folded into the preceding convolutions' filters: w'[k][c] = w[k][c] * a[c] for every listed
+// filter of one weight arena in one launch (real_encoder.py:13: keras ResNet50 called without training=).
+extern "C" int cn_scale_columns_segments(const float* src, float* dst, const int* seg, const float* a, int nseg, size_t total,
+                                         void* stream) {
+    CN_CHECK_ARG(src && dst && seg && a && nseg > 0 && total % 4 == 0, "scale_columns_segments: bad args");
+    if (!total) return CN_OK;
+    const long total4 = (long)(total / 4);
+    hipLaunchKernelGGL(scale_columns_segments_kernel, dim3(ew_blocks((size_t)total4)), dim3(256), 0, (hipStream_t)stream, src, dst, seg, a,
+                       nseg, total4);
+    CN_LAUNCH_CHECK();
+    return CN_OK;
+}
+
 extern "C" int cn_to_uint8(const float* x, uint8_t* out, size_t numel, void* stream) {
     CN_CHECK_ARG(x && out, "to_uint8: NULL");
     if (!numel) return CN_OK;

@@ -30,7 +30,9 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 template <int WM, int WN, int TM, int TN, bool BT, bool GATHER>
 __global__ __launch_bounds__(256) void gemm1x1_kernel(CnConvGeom g, const float* __restrict__ A, const float* __restrict__ B,
                                                       const float* __restrict__ bias, float* __restrict__ C, int M, int N, int K,
-                                                      int act, float slope, int ntm, int ntn, long part_stride, int par) {
+                                                      int act, float slope, int ntm, int ntn, long part_stride, int par,
+                                                      const float* __restrict__ res = nullptr) {
+    // res (unsplit launches only): a tensor of C's shape added before the activation -- the residual branch of a ResNet block
     // K: channels per tap (the reduction is T * K deep, T = 1 without GATHER)
     // par (GATHER only): parity-ordered rows of a zero-stuffed data gradient / an upsample-folded layer -- tile rows are
     // enumerated class-major (conv_geom.h par_row), a tile inside one class walks its live taps only
@@ -266,7 +268,10 @@ __global__ __launch_bounds__(256) void gemm1x1_kernel(CnConvGeom g, const float*
                 float* dst = C + (long)row * N + col;
                 if (part_stride) *reinterpret_cast<f2*>(dst + (long)blockIdx.z * part_stride) = f2{v0, v1};
                 else if (split) { unsafeAtomicAdd(dst, v0); unsafeAtomicAdd(dst + 1, v1); }
-                else *reinterpret_cast<f2*>(dst) = f2{cn_apply_act(v0, act, slope), cn_apply_act(v1, act, slope)};
+                else {
+                    if (res) { const f2 rv = *reinterpret_cast<const f2*>(res + (long)row * N + col); v0 += rv.x; v1 += rv.y; }
+                    *reinterpret_cast<f2*>(dst) = f2{cn_apply_act(v0, act, slope), cn_apply_act(v1, act, slope)};
+                }
             } else {
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
@@ -276,7 +281,7 @@ __global__ __launch_bounds__(256) void gemm1x1_kernel(CnConvGeom g, const float*
                     float* dst = C + (long)row * N + col;
                     if (part_stride) dst[(long)blockIdx.z * part_stride] = v;
                     else if (split) unsafeAtomicAdd(dst, v);
-                    else *dst = cn_apply_act(v, act, slope);
+                    else *dst = cn_apply_act(res ? v + res[(long)row * N + col] : v, act, slope);
                 }
             }
         }
@@ -284,7 +289,7 @@ __global__ __launch_bounds__(256) void gemm1x1_kernel(CnConvGeom g, const float*
 
 template <int WM, int WN, int TM, int TN, bool BT, bool GATHER>
 int launch(const CnConvGeom& g, const float* A, const float* B, const float* bias, float* C, long M, int N, int K, int act, float slope,
-           int splits, long part_stride, int par, hipStream_t s) {
+           int splits, long part_stride, int par, hipStream_t s, const float* res) {
     constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
     constexpr size_t lds = sizeof(float) * (3 * (BM * 20 + (BT ? BN * 20 : 16 * (BN + 4))) + BM);
     static bool attr_set = false;
@@ -294,7 +299,7 @@ int launch(const CnConvGeom& g, const float* A, const float* B, const float* bia
     }
     const int ntm = cn_cdiv(M, BM), ntn = cn_cdiv(N, BN);
     dim3 grid((unsigned)(par ? ntm * ntn : 8 * cn_cdiv(ntm, 8) * ntn), 1, (unsigned)splits);
-    hipLaunchKernelGGL((gemm1x1_kernel<WM, WN, TM, TN, BT, GATHER>), grid, dim3(256), lds, s, g, A, B, bias, C, (int)M, N, K, act, slope, ntm, ntn, part_stride, par);
+    hipLaunchKernelGGL((gemm1x1_kernel<WM, WN, TM, TN, BT, GATHER>), grid, dim3(256), lds, s, g, A, B, bias, C, (int)M, N, K, act, slope, ntm, ntn, part_stride, par, res);
     CN_LAUNCH_CHECK();
     return CN_OK;
 }
@@ -307,14 +312,15 @@ int launch(const CnConvGeom& g, const float* A, const float* B, const float* bia
 // activation.  gp: NULL = the rows of A are the GEMM rows (1x1, stride 1); otherwise the geometry whose gather builds them (vec:
 // the caller checks), par = its rows are parity-ordered.
 int cn_gemm1x1(const CnConvGeom* gp, int cfg, int bt, const float* A, const float* B, const float* bias, float* C, long M, int N, int K,
-               int act, float slope, int splits, long part_stride, int par, hipStream_t s) {
+               int act, float slope, int splits, long part_stride, int par, hipStream_t s, const float* res) {
+    if (res && (splits > 1 || part_stride)) return CN_EUNSUPPORTED;
     if (K % 16 != 0 || N % 4 != 0 || M <= 0 || M > 0x7fffffffL || (par && !gp)) return CN_EUNSUPPORTED;
     static const CnConvGeom none = {};
 #define L(WM, WN, TM, TN)                                                                                                          \
-    return gp ? (bt ? launch<WM, WN, TM, TN, true, true>(*gp, A, B, bias, C, M, N, K, act, slope, splits, part_stride, par, s)      \
-                    : launch<WM, WN, TM, TN, false, true>(*gp, A, B, bias, C, M, N, K, act, slope, splits, part_stride, par, s))    \
-              : (bt ? launch<WM, WN, TM, TN, true, false>(none, A, B, bias, C, M, N, K, act, slope, splits, part_stride, 0, s)      \
-                    : launch<WM, WN, TM, TN, false, false>(none, A, B, bias, C, M, N, K, act, slope, splits, part_stride, 0, s))
+    return gp ? (bt ? launch<WM, WN, TM, TN, true, true>(*gp, A, B, bias, C, M, N, K, act, slope, splits, part_stride, par, s, res)      \
+                    : launch<WM, WN, TM, TN, false, true>(*gp, A, B, bias, C, M, N, K, act, slope, splits, part_stride, par, s, res))    \
+              : (bt ? launch<WM, WN, TM, TN, true, false>(none, A, B, bias, C, M, N, K, act, slope, splits, part_stride, 0, s, res)      \
+                    : launch<WM, WN, TM, TN, false, false>(none, A, B, bias, C, M, N, K, act, slope, splits, part_stride, 0, s, res))
     switch (cfg) {
         case 0: L(2, 2, 2, 2);
         case 1: L(2, 2, 2, 1);

@@ -29,7 +29,8 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(CnConvGeom g, const floa
                                                         const float* __restrict__ W, const float* __restrict__ bias,
                                                         float* __restrict__ Y, int act, float slope, int par,
                                                         int xcd_swizzle, int ntiles_m, int ntiles_n, int bt = 0,
-                                                        long part_stride = 0) {
+                                                        long part_stride = 0, const float* __restrict__ res = nullptr) {
+    // res (unsplit launches only): a tensor of Y's shape added before the activation (residual branch of a ResNet block)
     // bt: W is the ORIGINAL filter [t][n = output channel here][k = reduction channel here] of the convolution whose data
     // gradient this launch computes (tap order reversed, the two channel axes swapped): the B tile is then loaded like the
     // gathered A tile (16-byte pieces along k, transposed on the way into LDS) -- no tap-flipped, channel-transposed copy of
@@ -287,7 +288,7 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(CnConvGeom g, const floa
                 // (deterministic mode: every K split stores its partial tile in its own slab; the slabs are added in order afterwards)
                 if (part_stride) Y[(long)blockIdx.z * part_stride + (long)row * g.cout + col] = v;
                 else if (split) unsafeAtomicAdd(&Y[(long)row * g.cout + col], v);
-                else Y[(long)row * g.cout + col] = cn_apply_act(v, act, slope);
+                else Y[(long)row * g.cout + col] = cn_apply_act(res ? v + res[(long)row * g.cout + col] : v, act, slope);
             }
         }
     }
@@ -1113,7 +1114,7 @@ static int g_xcd = getenv("CN_NO_XCD") ? 0 : 1;
 
 template <int WM, int WN, int TM, int TN>
 int launch_fwd(const CnConvGeom& g, bool vec, int par, int splits, const float* x, const float* w, const float* bias,
-               float* y, int act, float slope, hipStream_t s, int bt = 0, long part_stride = 0) {
+               float* y, int act, float slope, hipStream_t s, int bt = 0, long part_stride = 0, const float* res = nullptr) {
     const long M = (long)g.n * g.out_d * g.out_h * g.out_w;
     dim3 grid(cn_cdiv(M, 32 * WM * TM), cn_cdiv(g.cout, 32 * WN * TN), splits);
     int xcd = g_xcd;
@@ -1135,11 +1136,11 @@ int launch_fwd(const CnConvGeom& g, bool vec, int par, int splits, const float* 
     if ((xcd & 4) && (taps < 2 || taps > 9 || !vec)) xcd &= ~4;         // (offset table: taps x AP x 1 KiB of LDS)
     const size_t dyn = (xcd & 4) ? sizeof(int) * taps * (32 * WM * TM / (256 / ((kb32 ? 32 : BK) / 4))) * 256 : 0;   // taps x AP x 256 threads
     if (kb32)
-        hipLaunchKernelGGL((igemm_fwd_kernel<WM, WN, TM, TN, true, true, 32>), grid, dim3(256), dyn, s, g, x, w, bias, y, act, slope, par, xcd, ntm, ntn, bt, part_stride);
+        hipLaunchKernelGGL((igemm_fwd_kernel<WM, WN, TM, TN, true, true, 32>), grid, dim3(256), dyn, s, g, x, w, bias, y, act, slope, par, xcd, ntm, ntn, bt, part_stride, res);
     else if (vec)
-        hipLaunchKernelGGL((igemm_fwd_kernel<WM, WN, TM, TN, true>), grid, dim3(256), dyn, s, g, x, w, bias, y, act, slope, par, xcd, ntm, ntn, bt, part_stride);
+        hipLaunchKernelGGL((igemm_fwd_kernel<WM, WN, TM, TN, true>), grid, dim3(256), dyn, s, g, x, w, bias, y, act, slope, par, xcd, ntm, ntn, bt, part_stride, res);
     else
-        hipLaunchKernelGGL((igemm_fwd_kernel<WM, WN, TM, TN, false>), grid, dim3(256), 0, s, g, x, w, bias, y, act, slope, par, xcd, ntm, ntn);
+        hipLaunchKernelGGL((igemm_fwd_kernel<WM, WN, TM, TN, false>), grid, dim3(256), 0, s, g, x, w, bias, y, act, slope, par, xcd, ntm, ntn, 0, 0L, res);
     CN_LAUNCH_CHECK();
     return CN_OK;
 }
@@ -1192,12 +1193,15 @@ int launch_wgrad(const CnConvGeom& g, const float* x, const float* gy, float* gw
 // bt = 1: w is the original filter of the convolution whose data gradient g describes (see igemm_fwd_kernel); only the
 // vectorised implicit-GEMM path takes it -- every other path answers CN_EUNSUPPORTED without launching.
 static int conv_fwd_impl(const CnConvGeom* gp, const float* x, const float* w, const float* bias, float* y, int act,
-                         float slope, void* stream, int bt) {
+                         float slope, void* stream, int bt, const float* res = nullptr) {
     if (int e = check_geom(gp)) return e;
     CN_CHECK_ARG(x && w && y, "NULL tensor");
     const CnConvGeom g = *gp;
     hipStream_t s = (hipStream_t)stream;
     const long M = (long)g.n * g.out_d * g.out_h * g.out_w;
+    // res: only the unsplit implicit-GEMM launches carry the residual add in their epilogue -- anything else answers
+    // CN_EUNSUPPORTED before launching (the caller then adds it with a pass of its own)
+    if (res && (g.cout <= 4 || g.cin == 3 || g.cout % 4 != 0)) return CN_EUNSUPPORTED;
     if (bt && (g.cout <= 4 || g.cin % BK != 0 || g.cout % 4 != 0)) return CN_EUNSUPPORTED;
     if (g.cout <= 4) {
         const bool vec = g.cin % 4 == 0;
@@ -1331,6 +1335,7 @@ static int conv_fwd_impl(const CnConvGeom* gp, const float* x, const float* w, c
     }
     if (g_tune_cfg >= 0) cfg = g_tune_cfg;                        // tuning overrides (cn_conv_tune; scripts/conv_sweep.py)
     if (g_tune_splits > 0) splits = g_tune_splits;
+    if (res && splits > 1) return CN_EUNSUPPORTED;
     float* parts = nullptr;
     if (cn_det() && splits > 1) {
         // deterministic mode: the K splits write partial outputs into the stream's workspace (as many splits as it holds) and a
@@ -1359,21 +1364,21 @@ static int conv_fwd_impl(const CnConvGeom* gp, const float* x, const float* w, c
     const bool rows_ok = !no_g1 && nks_total > 8;
     if (rows_ok && vec && !par && g.k_d * g.k_h * g.k_w == 1 && g.s_d == 1 && g.s_h == 1 && g.s_w == 1 && g.dl_d == 1 && g.dl_h == 1 &&
         g.dl_w == 1 && !g.up && g.p_d == 0 && g.p_h == 0 && g.p_w == 0 && g.out_d == g.in_d && g.out_h == g.in_h && g.out_w == g.in_w)
-        e = cn_gemm1x1(nullptr, cfg, bt, x, w, bias, y, M, g.cout, g.cin, kact, slope, splits, part_stride, 0, s);
+        e = cn_gemm1x1(nullptr, cfg, bt, x, w, bias, y, M, g.cout, g.cin, kact, slope, splits, part_stride, 0, s, res);
     // every other vec layer: the same main loop over gathered rows (parity-ordered ones included)
     static const int no_g2 = getenv("CN_NO_IGEMM_ROWS") ? 1 : 0;
     static const int no_g3 = getenv("CN_NO_IGEMM_ROWS_PAR") ? 1 : 0;
     // (thin layers stay: with 48 channels per tap the offsets are recomputed every third step, and 48 output columns pad a
     // quarter of either kernel's tile -- same-box A/B 107 vs 109 us, 75 vs 77 us; scripts/dev/par_ab.sh)
     if (e == CN_EUNSUPPORTED && rows_ok && !no_g2 && vec && !(par && no_g3) && g.cin >= 64 && g.cout >= 64)
-        e = cn_gemm1x1(&g, cfg, bt, x, w, bias, y, M, g.cout, g.cin, kact, slope, splits, part_stride, par, s);
+        e = cn_gemm1x1(&g, cfg, bt, x, w, bias, y, M, g.cout, g.cin, kact, slope, splits, part_stride, par, s, res);
     if (e == CN_EUNSUPPORTED)
     switch (cfg) {
-        case 3: e = launch_fwd<4, 1, 1, 1>(g, vec, par, splits, x, w, bias, y, kact, slope, s, bt, part_stride); break;   // 128 x 32
-        case 4: e = launch_fwd<4, 1, 1, 3>(g, vec, par, splits, x, w, bias, y, kact, slope, s, bt, part_stride); break;   // 128 x 96
-        case 0: e = launch_fwd<2, 2, 2, 2>(g, vec, par, splits, x, w, bias, y, kact, slope, s, bt, part_stride); break;   // 128 x 128
-        case 1: e = launch_fwd<2, 2, 2, 1>(g, vec, par, splits, x, w, bias, y, kact, slope, s, bt, part_stride); break;   // 128 x 64
-        default: e = launch_fwd<2, 2, 1, 1>(g, vec, par, splits, x, w, bias, y, kact, slope, s, bt, part_stride); break;  // 64 x 64
+        case 3: e = launch_fwd<4, 1, 1, 1>(g, vec, par, splits, x, w, bias, y, kact, slope, s, bt, part_stride, res); break;   // 128 x 32
+        case 4: e = launch_fwd<4, 1, 1, 3>(g, vec, par, splits, x, w, bias, y, kact, slope, s, bt, part_stride, res); break;   // 128 x 96
+        case 0: e = launch_fwd<2, 2, 2, 2>(g, vec, par, splits, x, w, bias, y, kact, slope, s, bt, part_stride, res); break;   // 128 x 128
+        case 1: e = launch_fwd<2, 2, 2, 1>(g, vec, par, splits, x, w, bias, y, kact, slope, s, bt, part_stride, res); break;   // 128 x 64
+        default: e = launch_fwd<2, 2, 1, 1>(g, vec, par, splits, x, w, bias, y, kact, slope, s, bt, part_stride, res); break;  // 64 x 64
     }
     cn_prof_end(s);
     if (e == CN_OK && parts) e = cn_sum_parts(parts, y_user, splits, (long)M * g.cout, 0, 1.f, s);
@@ -1385,6 +1390,15 @@ static int conv_fwd_impl(const CnConvGeom* gp, const float* x, const float* w, c
 extern "C" int cn_conv_fwd(const CnConvGeom* gp, const float* x, const float* w, const float* bias, float* y, int act,
                            float slope, void* stream) {
     return conv_fwd_impl(gp, x, w, bias, y, act, slope, stream, 0);
+}
+
+// y = act(conv(x, w) + bias + res): the residual add of a ResNet block in the convolution's epilogue (real_encoder.py:13 --
+// keras ResNet50's `Add` + `Activation("relu")` behind the block's last 1x1 convolution).  Only unsplit implicit-GEMM launches
+// carry it; CN_EUNSUPPORTED (nothing launched) otherwise.
+extern "C" int cn_conv_fwd_res(const CnConvGeom* gp, const float* x, const float* w, const float* bias, const float* res, float* y,
+                               int act, float slope, void* stream) {
+    CN_CHECK_ARG(res, "cn_conv_fwd_res: res is NULL");
+    return conv_fwd_impl(gp, x, w, bias, y, act, slope, stream, 0, res);
 }
 
 extern "C" int cn_conv_weight_tflip(const float* w, float* wt, int taps, int cin, int cout, void* stream) {
@@ -1533,8 +1547,16 @@ int cn_wgrad2(const CnConvGeom& g, const float* x, const float* gy, float* gw, i
 
 static bool wgrad2_takes(const CnConvGeom& g) {
     static const bool off = getenv("CN_NO_WGRAD2") != nullptr;       // A/B: the round-3 kernel (split over rows, fp32 atomics)
+    static const bool all = getenv("CN_WGRAD2_ALL") != nullptr;     // A/B: every geometry the new kernel can take
     const long Ktot = (long)g.k_d * g.k_h * g.k_w * g.cin;
-    return !off && cn_wgrad2_ok(g) && Ktot >= 64;
+    const long M = (long)g.n * g.out_d * g.out_h * g.out_w;
+    if (off || !cn_wgrad2_ok(g) || Ktot < 64) return false;
+    // Measured per shape (scripts/wgrad_bench.py, profiles/round4_wgrad_shapes.txt): the LDS-DMA kernel wins where the reduction
+    // is short and the filter large (M < 16 384 rows: 40 -> 26 us, 57 -> 42, 134 -> 104, 225 -> 173).  Long reductions into small
+    // filters stay on the round-3 kernel: there the (tap, ci) tiles of a row slice drift apart while they stream it and fall out
+    // of the XCD's L2 (the old kernel's many short workgroups re-synchronise every few hundred rows), and 64-wide tiles at
+    // 16 FLOP per LDS-DMA byte are bound by operand delivery, not by the matrix pipe.
+    return all || (M < 16384 && !(g.cout <= 64 && M >= 8192));
 }
 
 // Workspace (bytes) that cn_conv_wgrad_ws needs for this geometry: room for the partial filters of its row splits; 0 = none.

@@ -283,7 +283,7 @@ Wg2Plan wg2_plan(const CnConvGeom& g) {
     else if (Ktot >= 128 && g.cout >= 128) cfg = 0;
     else cfg = 2;
     // few rows, many filter elements: the small tile gives enough workgroups without (or with fewer) row splits
-    if (cfg == 0 && cn_cdiv(Ktot, 128) * cn_cdiv(g.cout, 128) * cn_cdiv(M, 512) < 256) cfg = 2;
+    if (cfg == 0 && cn_cdiv(Ktot, 128) * cn_cdiv(g.cout, 128) * cn_cdiv(M, 512) < 128) cfg = 2;
     if (g_wg2_cfg >= 0) cfg = g_wg2_cfg;
     p.cfg = cfg;
     p.bi = cfg == 2 ? 64 : 128;

@@ -88,7 +88,7 @@ class RealEncoder(Net):
         mult = np.pi * np.array([rotation_ranges[0][1], rotation_ranges[1][1], rotation_ranges[2][1]]) / 180.0
         self.rotation_range_multiplier = torch.tensor(mult, dtype=torch.float32, device=self.device)
 
-    def _bn_coefficients(self):
+    def _bn_coefficients(self, cat=False):
         """Per-channel affine of every conv+BN pair, computed for all 53 pairs at once (3 concatenations and
         5 elementwise launches on ~53k channels instead of ~5 launches per pair):
         bn(conv + b) = a*conv + shift,  a = gamma*rsqrt(var+eps),  shift = beta + a*(b - mean).
@@ -105,6 +105,8 @@ class RealEncoder(Net):
         mean, var = self._stat_cache
         a = gamma * torch.rsqrt(var + BN_EPS)
         shift = beta + a * (bias - mean)
+        if cat:
+            return a, torch.split(shift, sizes)
         return torch.split(a, sizes), torch.split(shift, sizes)
 
     def non_trainable_changed(self):
@@ -119,12 +121,88 @@ class RealEncoder(Net):
                 cache[0].copy_(torch.cat([self.weights[b + 2] for b in bs]))
                 cache[1].copy_(torch.cat([self.weights[b + 3] for b in bs]))
 
+    # ---- inference form (no tape): BatchNorm folded into the filters, bias / residual / ReLU in the convolutions' epilogues -----
+    def _fold_table(self):
+        """(int32 (53, 5) device table, packed size, [(packed offset, shape)]) for cn_scale_columns_segments: where each conv
+        kernel lies in the weight arena, where its folded copy goes, its cout and where its BN coefficients start."""
+        if getattr(self, "_fold_tab", None) is None:
+            rows, views, dst, aoff = [], [], 0, 0
+            base = self.arena.data_ptr()
+            for kidx, _, _ in self._convs:
+                w = self.weights[kidx]
+                src = (w.data_ptr() - base) // 4
+                assert 0 <= src and src % 4 == 0 and w.numel() % 4 == 0 and w.shape[-1] % 4 == 0 and w.is_contiguous()
+                rows.append((src, dst, w.numel(), w.shape[-1], aoff))
+                views.append((dst, tuple(w.shape)))
+                dst += w.numel()
+                aoff += w.shape[-1]
+            self._fold_tab = (torch.tensor(rows, dtype=torch.int32, device=self.device), dst, views)
+        return self._fold_tab
+
+    def _folded_filters(self, a_cat):
+        """Every conv kernel times its BatchNorm scale, in one launch, cached like any derived filter copy: per weight epoch of
+        this network, per stream, and re-made INSIDE a HIP-graph capture (nn.WEIGHTS_EPOCH) so that a replay folds the weights
+        of its own iteration."""
+        from ..nn import WEIGHTS_EPOCH
+        from .. import ops
+        key = (WEIGHTS_EPOCH[0], self.epoch, torch.cuda.current_stream().cuda_stream)
+        c = getattr(self, "_fold_cache", None)
+        if c is not None and c[0] == key:
+            return c[1]
+        seg, total, views = self._fold_table()
+        packed = ops.scale_columns_segments(self.arena, seg, a_cat, total)
+        ws = [packed[o:o + int(np.prod(shp))].view(shp) for o, shp in views]
+        if ops._keepalive is not None:
+            ops._keepalive.append(packed)
+        self._fold_cache = (key, ws)
+        return ws
+
+    def _features_folded(self, img):
+        """features() without a tape (the encoder of the discriminator-type steps, predict()): conv -> BN -> ReLU as ONE launch per
+        layer -- bn(conv(x, w) + b) = conv(x, w * a) + shift with the coefficients of _bn_coefficients -- and the block's
+        Add + ReLU in the epilogue of its last convolution (ops.conv_fwd_res)."""
+        from .. import ops
+        from ..ops import ACT_NONE, ACT_RELU
+        a, shift = self._bn_coefficients(cat=True)
+        wf = self._folded_filters(a)
+
+        def conv(ci, x, res=None, relu=True):
+            spec = self._convs[ci][2]
+            g = spec.geom(tuple(x.shape), wf[ci].shape[-1])
+            if res is None:
+                return ops.conv_fwd(x, wf[ci], shift[ci], g, ACT_RELU if relu else ACT_NONE)
+            return ops.conv_fwd_res(x, wf[ci], shift[ci], res, g, ACT_RELU)
+
+        x = F.caffe_preprocess(img)
+        x = conv(0, x)
+        x = F.maxpool(x, 3, 2, 1)
+        ci = 1
+        for filters, blocks, stride1 in RESNET50_STACKS:
+            for bi in range(blocks):
+                if bi == 0:
+                    sc = conv(ci, x, relu=False)
+                    ci += 1
+                else:
+                    sc = x
+                y = conv(ci, x)
+                y = conv(ci + 1, y)
+                x = conv(ci + 2, y, res=sc)
+                ci += 3
+        return F.global_avg_pool(x)
+
     def _conv_bn(self, ci, x, coef, res=None, relu=True):
         kidx, _, spec = self._convs[ci]
         z = F.conv(x, self.weights[kidx], None, spec)           # bias folded into the affine shift
         return F.channel_affine_act(z, coef[0][ci], coef[1][ci], res, relu)
 
+    import os as _os
+    fold_inference = _os.environ.get("CN_NO_BN_FOLD") is None      # (False / CN_NO_BN_FOLD=1: the taped form in every mode -- A/B and cross-check)
+
     def features(self, img):
+        if self.fold_inference and not torch.is_grad_enabled() and img.dtype == torch.float32:
+            from .. import ops
+            if ops.ACT_DTYPE == torch.float32:
+                return self._features_folded(img)
         coef = self._bn_coefficients()
         x = F.caffe_preprocess(img)                              # real_encoder.py:24-25
         x = self._conv_bn(0, x, coef)

@@ -55,7 +55,7 @@ def _partial_rows(rows):
 def _ptr(t):
     if t is None:
         return None
-    assert t.is_cuda and t.dtype in (torch.float32, torch.bfloat16, torch.uint8, torch.int64, torch.int16) and t.is_contiguous(), \
+    assert t.is_cuda and t.dtype in (torch.float32, torch.bfloat16, torch.uint8, torch.int64, torch.int32, torch.int16) and t.is_contiguous(), \
         "confignet_amd ops need contiguous CUDA tensors (got %s %s contiguous=%s)" % (t.device, t.dtype, t.is_contiguous())
     return ctypes.c_void_p(t.data_ptr())
 
@@ -332,6 +332,31 @@ def conv_fwd(x, w, bias, g, act=ACT_NONE, slope=0.0):
     y = torch.empty(geom_out_shape(g), device=x.device, dtype=torch.float32)
     check(lib.cn_conv_fwd(ctypes.byref(g), _ptr(x), _fptr(w), _fptr(bias), _ptr(y), act, slope, _stream()), "cn_conv_fwd")
     return cast(y, out_dtype)
+
+
+def conv_fwd_res(x, w, bias, res, g, act=ACT_NONE, slope=0.0):
+    """act(conv(x, w) + bias + res): the residual add of a ResNet block in the convolution's epilogue where the launch carries it
+    (cn_conv_fwd_res: unsplit implicit-GEMM launches), else convolution + one nc_lin2 pass."""
+    assert act in (ACT_NONE, ACT_RELU)
+    if ACT_DTYPE == torch.float32 and x.dtype == torch.float32 and res.dtype == torch.float32 and not _wino_ok(g, g.cin, g.cout):
+        x, res = _c(x), _c(res)
+        y = torch.empty(geom_out_shape(g), device=x.device, dtype=torch.float32)
+        rc = lib.cn_conv_fwd_res(ctypes.byref(g), _ptr(x), _fptr(w), _fptr(bias), _ptr(res), _ptr(y), act, slope, _stream())
+        if rc == 0:
+            return y
+        if rc != CN_EUNSUPPORTED:
+            check(rc, "cn_conv_fwd_res")
+    y = conv_fwd(x, w, bias, g)
+    return nc_lin2(tuple(y.shape), y, None, res, None, None, flags=8 if act == ACT_RELU else 0)
+
+
+def scale_columns_segments(src, seg, a, total):
+    """Packed copy of the filters listed in `seg` (int32 (nseg, 5) on the device: see cn_scale_columns_segments), each scaled per
+    output channel by its slice of `a`."""
+    dst = torch.empty(total, device=src.device, dtype=torch.float32)
+    check(lib.cn_scale_columns_segments(_fptr(src), _ptr(dst), _ptr(seg), _fptr(_c(a)), seg.shape[0], total, _stream()),
+          "cn_scale_columns_segments")
+    return dst
 
 
 def weight_tflip(w):

@@ -72,6 +72,11 @@ int cn_version(void);
  * layer; CN_NO_* environment switches, read once, turn a route off for A/B runs) -- the results are the same convolution. */
 int cn_conv_fwd(const CnConvGeom* g, const float* x, const float* w, const float* bias,
                 float* y, int act, float slope, void* stream);
+/* y = act(conv(x, w) + bias + res), res of y's shape: the residual add + ReLU of a ResNet-50 block
+ * (real_encoder.py:13, keras.applications ResNet50 `Add` + `Activation`) in the epilogue of the block's last
+ * convolution.  Only launches without a K split carry it: CN_EUNSUPPORTED (nothing launched) otherwise. */
+int cn_conv_fwd_res(const CnConvGeom* g, const float* x, const float* w, const float* bias, const float* res, float* y,
+                    int act, float slope, void* stream);
 /* w_tflip[T-1-t][co][ci] = w[t][ci][co]: the operand of the data-gradient GEMM. */
 int cn_conv_weight_tflip(const float* w, float* w_tflip, int taps, int cin, int cout, void* stream);
 /* Data gradient of cn_conv_fwd(g) w.r.t. its (virtually upsampled) input: gu has extent
@@ -310,6 +315,11 @@ int cn_gather_images_u8(const uint8_t* pool, const int64_t* idx, const uint8_t* 
                         int n, int h, int w, int c, void* stream);
 /* uint8 image from generator output: clip(-1,1), (x+1)*127.5 (confignet_first_stage.py:636-637) */
 int cn_to_uint8(const float* x, uint8_t* out, size_t numel, void* stream);
+/* BatchNormalization in inference mode (keras ResNet50 called without `training=`, real_encoder.py:13) folded into the
+ * preceding convolutions: dst (packed) = src[segment][k][c] * a[c] for every filter listed in `seg` -- nseg x 5 ints: source
+ * offset, packed destination offset, element count, columns (cout), offset of the filter's coefficients in `a`; all multiples
+ * of 4 floats -- in one launch over `total` destination floats. */
+int cn_scale_columns_segments(const float* src, float* dst, const int* seg, const float* a, int nseg, size_t total, void* stream);
 
 /* ---- profiling of the dominant kernel class (implicit-GEMM convolutions) with HIP events
  * recorded on the launch stream (bench.py roofline object) -----------------------------------*/

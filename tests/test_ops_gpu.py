@@ -588,3 +588,30 @@ def test_winograd_3x3_forward_and_data_gradient(case):
         close(ops.conv_dgrad(dev(gy), dev(w), g), xr.grad, what="winograd dgrad")
     finally:
         ops.WINO_MIN_WGS, ops.WINO_MIN_FILL = keep
+
+
+@pytest.mark.parametrize("shape,cout,stride", [((2, 16, 16, 256), 1024, 1), ((2, 32, 32, 64), 256, 1), ((1, 8, 8, 512), 2048, 1),
+                                               ((2, 16, 16, 128), 96, 1), ((2, 16, 16, 64), 128, 2)])
+def test_conv_with_residual_epilogue_and_folded_batchnorm(shape, cout, stride):
+    """ops.conv_fwd_res -- relu(conv(x, w) + bias + res), the Add + ReLU of a ResNet block in the last convolution's epilogue
+    (cn_conv_fwd_res; with a pass of its own where the launch cannot carry it) -- and cn_scale_columns_segments (BatchNorm
+    folded into the filters) against float64: bn(conv(x, w) + b) == conv(x, w * a) + shift."""
+    from confignet_amd import ops
+    from confignet_amd.ops import ACT_RELU, ConvSpec
+    from oracle import ref_ops as O
+    rng = np.random.default_rng(5)
+    cin = shape[-1]
+    x, w = rng.normal(size=shape), rng.normal(size=(1, 1, cin, cout)) / np.sqrt(cin)
+    b, a = rng.normal(size=cout), rng.uniform(0.5, 1.5, size=cout)
+    spec = ConvSpec((1, 1), stride=stride)
+    g = spec.geom(shape, cout)
+    res = rng.normal(size=ops.geom_out_shape(g))
+    ref = torch.relu(O.conv_same(t64(x), t64(w * a), t64(b), stride) + t64(res))
+    # folded filter through the segment kernel: two segments so that the bisection and the packed offsets are exercised
+    arena = torch.tensor(np.concatenate([np.zeros(8), w.reshape(-1), np.zeros(4), w.reshape(-1)]), dtype=torch.float32).cuda()
+    seg = torch.tensor([[8, 0, w.size, cout, 0], [8 + w.size + 4, w.size, w.size, cout, cout]], dtype=torch.int32).cuda()
+    packed = ops.scale_columns_segments(arena, seg, dev(np.concatenate([a, 2 * a])), 2 * w.size)
+    wf = packed[:w.size].view(1, 1, cin, cout)
+    np.testing.assert_allclose(packed[w.size:].cpu().numpy(), (w * 2 * a).astype(np.float32).reshape(-1), rtol=1e-6)
+    got = ops.conv_fwd_res(dev(x), wf, dev(b), dev(res), g, ACT_RELU)
+    close(got, ref, tol=2e-4, what="conv + residual + relu")
