@@ -11,6 +11,7 @@ Tolerances are stated per test.  A bf16 value carries 8 significant bits (relati
     generator image (relative L2; single pixels up to 0.2 of the tanh range) and the loss scalars
     (scripts/dev/bf16_diag.py prints the layer-by-layer growth)."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -289,3 +290,51 @@ def test_bf16_second_stage_iteration_runs_under_graph_dispatch_and_tracks_the_fp
         extra["loss_sum"] = sum(extra.values())
         for k in a:
             assert abs(a[k] - b[k]) <= 5e-2 * max(1.0, abs(a[k])) + extra.get(k, 0.0), (k, a[k], b[k])
+
+
+def test_bf16_data_parallel_dispatch_at_full_size_matches_cpu_oracle(tmp_path):
+    """BASELINE.json configs[2]'s per-rank workload as ONE test (round 3 tested bf16 and the data-parallel dispatch apart): the
+    second-stage iteration at 256x256, batch 16, bf16 compute, step graphs + cross-iteration overlap, on a 1-rank RCCL group
+    (CN_FORCE_DP=1) -- with and without config["dp_global_batch_statistics"] -- and in the single-process dispatch:
+    * every one of the 60 loss scalars of a whole iteration against the fp32 CPU oracle on the same weights and batches, at the
+      bf16 bound of this file (5e-2 of the scalar; the heads on fake images by the R1-scaled allowance);
+    * the data-parallel runs against the single-process bf16 run at the same bound (a 1-rank mean is the identity, but the bf16
+      kernels' atomics are not covered by the deterministic mode: two runs drift apart over the warm-up iterations)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    helper = os.path.join(root, "tests", "dp_bf16_helper.py")
+    dp_env = {"CN_FORCE_DP": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29549", "RANK": "0", "WORLD_SIZE": "1"}
+    runs = {}
+    for tag, extra, flag in (("single", {}, 0), ("dp", dp_env, 0), ("dp_stats", dp_env, 1)):
+        env = {k: v for k, v in os.environ.items() if k not in ("CN_FORCE_DP",)}
+        env.update(extra)
+        path = str(tmp_path / (tag + ".npz"))
+        r = subprocess.run([sys.executable, helper, path, str(flag), "bf16"], env=env, cwd=root, capture_output=True, text=True, timeout=1500)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        runs[tag] = (json.load(open(path + ".json")), np.load(path))
+    assert not runs["single"][0]["dp"] and runs["dp"][0]["dp"] and all(runs["dp"][0]["split"]) and not any(runs["single"][0]["split"])
+    for tag, (info, _) in runs.items():
+        assert "pre-replayed" in info["dispatch"], (tag, info["dispatch"])
+        n = 0
+        for got, step in zip(info["losses"], ("d", "synth_d", "latent_d", "g")):
+            ref = info["ref"][step]
+            assert list(got.keys()) == list(ref.keys())
+            extra = {k: 0.02 * np.sqrt(ref["gp_loss_" + k.rsplit("_", 1)[1]]) for k in ref if k.startswith("GAN_loss_fake_") and "gp_loss_0" in ref}
+            if "gp_loss_0" not in ref:
+                extra = {k: 0.1 * max(1.0, abs(ref[k])) for k in ref if k.startswith("GAN_loss_")}
+            extra["loss_sum"] = sum(extra.values())
+            for k in ref:
+                n += 1
+                assert np.isfinite(got[k]) and abs(got[k] - ref[k]) <= 5e-2 * max(1.0, abs(ref[k])) + extra.get(k, 0.0), (tag, step, k, got[k], ref[k])
+        assert n == 19 + 19 + 4 + len(info["losses"][3])
+    # data-parallel against single-process: each run trains five iterations from the same initial state before the compared one,
+    # and the bf16 kernels' atomics (not covered by the deterministic mode) make two runs of ONE configuration drift apart through
+    # lr * sign(g) steps (6e-3 on a head's loss measured), so the two dispatches are compared at the bf16 bound as well -- the
+    # bit-for-bit statement about the dispatch is test_steps_gpu.py::test_data_parallel_dispatch_with_overlap_matches_single_process
+    for tag in ("dp", "dp_stats"):
+        a, b = runs["single"], runs[tag]
+        for la, lb in zip(a[0]["losses"], b[0]["losses"]):
+            for k in la:
+                assert abs(la[k] - lb[k]) <= 5e-2 * max(1.0, abs(la[k])), (tag, k, la[k], lb[k])

@@ -382,3 +382,156 @@ def test_forced_branch_decisions():
         O.BranchControl.stop()
     assert rep["forced_decisions"] == 1 and not rep["unmatched"]
     assert p.grad.reshape(-1).tolist() == [1.0, 0.0, 0.0, 0.0]
+
+
+# ---- whole networks and DERIVATIVES against the independent NumPy restatement (oracle/np_nets.py) ----------------------------
+def _rand_weights(shapes, rng, scale=1.0):
+    return [rng.normal(size=s) * (scale / np.sqrt(max(1, int(np.prod(s[:-1]))))) if len(s) > 1 else rng.normal(size=s) * 0.1 for s in shapes]
+
+
+def test_generator_forward_against_numpy_restatement():
+    """oracle.ref_nets.generator_forward (torch) == oracle.np_nets.generator_forward (tap loops, per-voxel resampling, written
+    from hologan_generator.py on its own) on one seeded sample at the smallest resolution: max abs 1e-9 of a tanh image."""
+    from oracle import np_nets as NN
+    from oracle import ref_nets as R
+    rng = np.random.default_rng(3)
+    L, res = 12, 128
+    ws = _rand_weights(R.generator_weight_shapes(L, res), rng)
+    ws[0] = np.zeros_like(ws[0])
+    ws[1] = rng.normal(size=ws[1].shape)
+    z, rot = rng.normal(size=(1, L)), np.array([[0.3, -0.2, 0.1]])
+    ref = R.generator_forward([torch.tensor(w) for w in ws], torch.tensor(z), torch.tensor(rot), res).numpy()
+    got = NN.generator_forward(ws, z, rot, res)
+    assert got.shape == ref.shape == (1, res, res, 3)
+    assert np.abs(ref).max() > 1e-3
+    np.testing.assert_allclose(got, ref, atol=1e-9)
+
+
+def test_discriminator_forward_against_numpy_restatement():
+    from oracle import np_nets as NN
+    from oracle import ref_nets as R
+    rng = np.random.default_rng(4)
+    res = 32
+    ws = _rand_weights(R.discriminator_weight_shapes(res), rng, 2.0)
+    img = rng.uniform(-1, 1, size=(2, res, res, 3))
+    ref = R.discriminator_forward([torch.tensor(w) for w in ws], torch.tensor(img))
+    got = NN.discriminator_forward(ws, img)
+    assert list(ref.keys()) == ["discr_style_%d" % i for i in range(5)] + ["discr_final"]
+    for r, g in zip(ref.values(), got):
+        np.testing.assert_allclose(g, r.numpy(), atol=1e-10)
+
+
+def _block_case(seed):
+    """A small DiscrBlock (3 -> 4 channels, 8 x 8 input) whose LeakyReLU inputs all keep a distance from zero: finite
+    differences with steps far below that distance never cross a kink."""
+    from oracle import np_ops as NP
+    for s in range(seed, seed + 200):
+        rng = np.random.default_rng(s)
+        x = rng.uniform(-1, 1, size=(2, 8, 8, 3))
+        ws = [rng.normal(size=(3, 3, 3, 4)) * 0.4, rng.normal(size=4) * 0.2, 1 + 0.3 * rng.normal(size=4), 0.2 * rng.normal(size=4)]
+        head = rng.normal(size=(8, 1))
+        if np.abs(NP.conv_same(x, ws[0], ws[1], stride=2)).min() > 2e-2:
+            return x, ws, head, rng
+    raise AssertionError("no kink-free case found")
+
+
+def test_discr_block_backward_against_finite_differences_of_the_numpy_restatement():
+    """First derivatives of DiscrBlock (conv s2 + style statistics + LeakyReLU + instance norm) -- torch autograd on
+    oracle.ref_nets.discr_block against central differences of oracle.np_nets.discr_block (no autograd involved), for a scalar
+    that uses BOTH outputs: entries of every parameter tensor and of the input, 1e-6 relative."""
+    from oracle import np_nets as NN
+    from oracle import ref_nets as R
+    x, ws, head, rng = _block_case(100)
+    cy = rng.normal(size=(2, 4, 4, 4))
+
+    def scalar_np(xx, ww):
+        y, st = NN.discr_block(xx, *ww)
+        return float((y * cy).sum() + (st @ head).sum())
+
+    xt = torch.tensor(x, requires_grad=True)
+    wt = [torch.tensor(w, requires_grad=True) for w in ws]
+    y, st = R.discr_block(xt, *wt, return_styles=True)
+    ((y * torch.tensor(cy)).sum() + (st @ torch.tensor(head)).sum()).backward()
+    assert abs(scalar_np(x, ws) - float((y * torch.tensor(cy)).sum() + (st @ torch.tensor(head)).sum())) < 1e-10
+    for ti, w in enumerate(ws):
+        for _ in range(4):
+            idx = tuple(int(rng.integers(0, d)) for d in w.shape)
+            fd = NN.central_difference(lambda v, ti=ti: scalar_np(x, ws[:ti] + [v] + ws[ti + 1:]), w, idx, 1e-4)
+            an = float(wt[ti].grad[idx])
+            assert abs(fd - an) <= 1e-6 * max(1.0, abs(an)), ("parameter", ti, idx, fd, an)
+    for _ in range(6):
+        idx = tuple(int(rng.integers(0, d)) for d in x.shape)
+        fd = NN.central_difference(lambda v: scalar_np(v, ws), x, idx, 1e-4)
+        an = float(xt.grad[idx])
+        assert abs(fd - an) <= 1e-6 * max(1.0, abs(an)), ("input", idx, fd, an)
+
+
+def test_r1_penalty_double_backward_against_nested_finite_differences():
+    """The gradient-of-gradient behind gradient_regularization (losses.py:75-82): oracle.ref_ops.r1_penalty differentiates
+    |d out / d x|^2 w.r.t. the weights through torch's double backward.  Here the inner gradient is taken by central differences
+    of the NumPy DiscrBlock + style head over EVERY input element, the outer derivative by central differences of that -- no
+    autograd anywhere -- and compared at 1e-5 relative (nested differences: ~1e-7 of noise)."""
+    from oracle import np_nets as NN
+    from oracle import ref_nets as R
+    from oracle import ref_ops as O
+    x, ws, head, rng = _block_case(300)
+    hb = rng.normal(size=1)
+
+    def out_np(xx, ww):                                  # (N,) head output of the block's styles
+        return (NN.discr_block(xx, *ww)[1] @ head + hb)[:, 0]
+
+    def penalty_np(ww, h=1e-5):
+        g = np.zeros_like(x)
+        xx = x.copy()
+        for idx in np.ndindex(*x.shape):
+            old = xx[idx]
+            xx[idx] = old + h
+            fp = out_np(xx, ww).sum()
+            xx[idx] = old - h
+            fm = out_np(xx, ww).sum()
+            xx[idx] = old
+            g[idx] = (fp - fm) / (2 * h)
+        return 10 * 0.5 * (g.reshape(g.shape[0], -1) ** 2).sum(axis=1).mean()
+
+    xt = torch.tensor(x, requires_grad=True)
+    wt = [torch.tensor(w, requires_grad=True) for w in ws]
+    st = R.discr_block(xt, *wt, return_styles=True)[1]
+    pen = O.r1_penalty(st @ torch.tensor(head) + torch.tensor(hb), xt)
+    assert abs(float(pen) - penalty_np(ws)) <= 1e-7 * max(1.0, float(pen))
+    grads = torch.autograd.grad(pen, wt[:2])
+    for ti in (0, 1):                                    # conv kernel and bias (gamma / beta do not reach the pre-activation styles)
+        for _ in range(3):
+            idx = tuple(int(rng.integers(0, d)) for d in ws[ti].shape)
+            fd = NN.central_difference(lambda v, ti=ti: penalty_np(ws[:ti] + [v] + ws[ti + 1:]), ws[ti], idx, 2e-3)
+            an = float(grads[ti][idx])
+            assert abs(fd - an) <= 1e-5 * max(1.0, abs(an)), (ti, idx, fd, an)
+
+
+def test_rotation_gradient_through_the_interpolation_weights_against_finite_differences():
+    """transform_3d_grid_tf (confignet_utils.py:100-159) is differentiable w.r.t. the rotation only through the interpolation
+    weights (the cell indices come from floor()): d/d angles of a scalar of the resampled volume -- torch autograd through
+    oracle.ref_ops.transform_3d_grid and euler_angles_to_matrix -- equals central differences of the per-voxel NumPy loop
+    (no voxel changes its cell within the step; clamped coordinates carry no gradient either way)."""
+    from oracle import np_nets as NN
+    rng = np.random.default_rng(8)
+    grid = rng.normal(size=(1, 4, 4, 4, 3))
+    ang = np.array([[0.37, -0.21, 0.11]])
+    cw = rng.normal(size=grid.shape)
+
+    def scalar_np(a):
+        return float((NP.transform_3d_grid(grid, NP.euler_angles_to_matrix(a)) * cw).sum())
+
+    at = torch.tensor(ang, requires_grad=True)
+    gt = torch.tensor(grid, requires_grad=True)
+    out = O.transform_3d_grid(gt, O.euler_angles_to_matrix(at))
+    (out * torch.tensor(cw)).sum().backward()
+    assert abs(scalar_np(ang) - float((out * torch.tensor(cw)).sum())) < 1e-10
+    for k in range(3):
+        fd = NN.central_difference(scalar_np, ang, (0, k), 1e-6)
+        assert abs(fd - float(at.grad[0, k])) <= 1e-6 * max(1.0, abs(float(at.grad[0, k]))), (k, fd, float(at.grad[0, k]))
+    # the volume itself enters linearly: its gradient is the transposed interpolation
+    idx = (0, 1, 2, 1, 0)
+    g2 = grid.copy()
+    g2[idx] += 1.0
+    lin = float((NP.transform_3d_grid(g2, NP.euler_angles_to_matrix(ang)) * cw).sum()) - scalar_np(ang)
+    assert abs(lin - float(gt.grad[idx])) < 1e-10
