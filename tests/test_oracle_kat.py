@@ -385,7 +385,7 @@ def test_forced_branch_decisions():
 
 
 # ---- whole networks and DERIVATIVES against the independent NumPy restatement (oracle/np_nets.py) ----------------------------
-def _rand_weights(shapes, rng, scale=1.0):
+def _np_weights(shapes, rng, scale=1.0):
     return [rng.normal(size=s) * (scale / np.sqrt(max(1, int(np.prod(s[:-1]))))) if len(s) > 1 else rng.normal(size=s) * 0.1 for s in shapes]
 
 
@@ -396,7 +396,7 @@ def test_generator_forward_against_numpy_restatement():
     from oracle import ref_nets as R
     rng = np.random.default_rng(3)
     L, res = 12, 128
-    ws = _rand_weights(R.generator_weight_shapes(L, res), rng)
+    ws = _np_weights(R.generator_weight_shapes(L, res), rng)
     ws[0] = np.zeros_like(ws[0])
     ws[1] = rng.normal(size=ws[1].shape)
     z, rot = rng.normal(size=(1, L)), np.array([[0.3, -0.2, 0.1]])
@@ -412,7 +412,7 @@ def test_discriminator_forward_against_numpy_restatement():
     from oracle import ref_nets as R
     rng = np.random.default_rng(4)
     res = 32
-    ws = _rand_weights(R.discriminator_weight_shapes(res), rng, 2.0)
+    ws = _np_weights(R.discriminator_weight_shapes(res), rng, 2.0)
     img = rng.uniform(-1, 1, size=(2, res, res, 3))
     ref = R.discriminator_forward([torch.tensor(w) for w in ws], torch.tensor(img))
     got = NN.discriminator_forward(ws, img)
