@@ -164,18 +164,33 @@ def time_second_stage_iteration(res=256, batch=2, repeats=1, threads=None, warmu
     return batch / sec, sec, threads
 
 
-def best_thread_count(res, candidates, probe_batch=2):
-    """torch-CPU eager on these op sizes stops scaling (and can collapse from oversubscription) beyond a few dozen threads:
-    one probe iteration at a small batch per candidate, the fastest wins."""
-    best, best_ips, seen = None, -1.0, {}
+def probe_thread_counts(res, batch, candidates, per_probe_s=45.0, budget_s=150.0):
+    """One iteration AT THE BENCHMARK'S BATCH per candidate thread count, each in its own subprocess with a hard time limit
+    (torch-CPU eager collapses from oversubscription somewhere beyond a few dozen threads on a 256-core host: an all-cores
+    iteration did not finish in 14 minutes), threads pinned to the first c cores (OMP_PLACES=cores, OMP_PROC_BIND=close).
+    Returns (best count, {count: seconds | "timeout"}).  The probe stops once `budget_s` is spent."""
+    import json
+    import subprocess
+    import sys
+    seen, best, best_sec, spent = {}, None, float("inf"), 0.0
+    env = dict(os.environ, OMP_PLACES="cores", OMP_PROC_BIND="close")
     for c in candidates:
-        ips, sec, _ = time_second_stage_iteration(res, probe_batch, repeats=1, threads=c)
-        seen[c] = round(sec, 2)
-        if ips > best_ips:
-            best, best_ips = c, ips
-        else:
-            break           # past the knee: on a 256-core host the 64-thread probe is 3x slower than the 16-thread one and
-                            # an all-cores iteration did not finish in 14 minutes -- never probe beyond a slowdown
+        if spent >= budget_s:
+            seen[c] = "not probed (probe budget spent)"
+            continue
+        t0 = time.perf_counter()
+        try:
+            p = subprocess.run([sys.executable, "-m", "oracle.cpu_baseline", str(batch), str(res), "--one", str(c)], env=env,
+                               capture_output=True, text=True, timeout=per_probe_s, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+            sec = float(json.loads(p.stdout.strip().splitlines()[-1])["seconds"])
+            seen[c] = round(sec, 2)
+            if sec < best_sec:
+                best, best_sec = c, sec
+        except subprocess.TimeoutExpired:
+            seen[c] = "timeout (> %d s)" % per_probe_s
+        except Exception as e:                      # a failed probe never blocks the baseline
+            seen[c] = "failed: %r" % (e,)
+        spent += time.perf_counter() - t0
     return best, seen
 
 
@@ -191,8 +206,15 @@ if __name__ == "__main__":
         _, _, cores, parity = time_second_stage_iteration(r, b, repeats=0, threads=min(16, host), warmup=1, state=state)
         print(json.dumps({"cores": cores, "parity_losses": parity}))
         sys.exit(0)
-    cands = sorted({min(8, host), min(16, host), min(32, host), min(64, host)})
-    threads, probe = best_thread_count(r, cands)
+    if "--one" in sys.argv:                         # one probe iteration at a given thread count (probe_thread_counts)
+        c = int(sys.argv[sys.argv.index("--one") + 1])
+        _, sec, _ = time_second_stage_iteration(r, b, repeats=1, threads=c)
+        print(json.dumps({"seconds": sec, "threads": c}))
+        sys.exit(0)
+    cands = sorted({min(c, host) for c in (16, 32, 64, 128)})
+    threads, probe = probe_thread_counts(r, b, cands)
+    if threads is None:
+        threads = min(16, host)
     res_ = time_second_stage_iteration(r, b, repeats=3, threads=threads, warmup=1, state=state)     # 1 warm-up (= the parity iteration, if any) + median of 3
     v, sec, cores = res_[:3]
     print(json.dumps({"value": v, "seconds": sec, "cores": cores, "host_cores": host, "thread_probe_seconds": probe,
