@@ -60,6 +60,7 @@ SIGNATURES = {
     "cn_conv_fwd_wino": [_i, _i, _i, _i, _i, _p, _p, _p, _p, _i, _f, _p],
     "cn_sumpool2": [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "cn_gemm": [_i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _p, _i, _f, _p],
+    "cn_nc_reduce4": [_p, _p, _i, _i, _i, _f, _i, _i, _p],
     "cn_nc_reduce": [_p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _p],
     "cn_nc_lin2": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _p],
     "cn_norm_coef_fwd": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _p],

@@ -113,6 +113,8 @@ class ConfigNet(ConfigNetFirstStage):
         and in the loss sum, so the real branch is issued on a second stream: forward here, and backward too, since
         autograd replays every node on the stream its forward ran on.  Captured into the step's HIP graph the two
         branches become parallel paths, and the many small launches of one overlap the big ones of the other."""
+        if self.merge_generator_passes:
+            return self._generator_loss_merged(facemodel_params, synth_rotations, synth_imgs, eye_masks, real_imgs)
         cfg = self.config
         n_synth, n_real = synth_imgs.shape[0], real_imgs.shape[0]
         losses = {}
@@ -163,6 +165,71 @@ class ConfigNet(ConfigNetFirstStage):
             stacked_latents = torch.cat((synth_latents, real_latents), dim=0)
             stacked_imgs = torch.cat((generator_output_synth, generator_output_real), dim=0)
             stacked_rotations = torch.cat((synth_rotations, real_rotations), dim=0)
+            labels = torch.cat((stacked_latents, cfg["latent_regressor_rot_weight"] * stacked_rotations), dim=-1)
+            losses["latent_regression_loss"] = self.compute_normalized_latent_regression_loss(stacked_imgs, labels, deferred=True)
+        losses["loss_sum"] = total_loss(losses.values())
+        return losses
+
+    # OFF by default -- measured (round 4, profiles/round4_schedule_experiments.txt): 478 instead of 537 convolution launches and
+    # 1.2 ms less convolution kernel time per iteration, but the step takes 28.9 instead of 26.9 ms and the iteration 49.4 instead
+    # of 45.5: in the two-pass form the real branch (encoder -> generator -> VGG -> heads) and the synthetic branch run side by
+    # side on two streams from start to end, and that concurrency fills the CUs which the small launches of one chain leave idle;
+    # the stacked form has to wait for the encoder before its only generator pass can start.  CN_G_MERGE=1 selects it.
+    merge_generator_passes = os.environ.get("CN_G_MERGE") == "1"
+
+    def _generator_loss_merged(self, facemodel_params, synth_rotations, synth_imgs, eye_masks, real_imgs):
+        """(See merge_generator_passes: an option, slower end to end.)  The same loss dict from FEWER, LARGER launches: the synthetic and the real half go through the generator as ONE
+        stacked batch (synthetic samples first -- the order the latent regressor's stack has anyway, l.188-197), through VGG-19 as
+        one stacked batch per side (generated / ground truth), and the perceptual terms of the two halves come out of one
+        reduction each (PerceptualLoss.loss_groups).  Every sample sees exactly the arithmetic of the two-pass form: all layers
+        are per-sample (AdaIN / instance statistics are per sample; no batch statistics before the latent regression).
+        Second stream: the ground-truth VGG pass (no tape, depends on nothing) runs beside encoder + generator, and the
+        discriminator heads of the real half beside those of the synthetic half, as before."""
+        cfg = self.config
+        n_synth, n_real = synth_imgs.shape[0], real_imgs.shape[0]
+        losses = {}
+        main = torch.cuda.current_stream()
+        side = self._branch_stream if self.fork_generator_step else main
+        from .graphs import segment_break
+        if side is not main:
+            side.wait_stream(main)
+        with torch.cuda.stream(side):
+            gt_features = self.perceptual_loss.features(torch.cat((synth_imgs, real_imgs), dim=0))
+        real_latents, real_rotations = self.encoder(real_imgs)
+        self._g_cut = ([real_latents, real_rotations], [self.encoder])     # the encoder hangs on the tape by these two only
+        synth_latents = self.synthetic_encoder(facemodel_params)
+        stacked_latents = torch.cat((synth_latents, real_latents), dim=0)
+        stacked_rotations = torch.cat((synth_rotations, real_rotations), dim=0)
+        stacked_imgs = self.generator((stacked_latents, stacked_rotations))
+        generator_output_synth, generator_output_real = stacked_imgs[:n_synth], stacked_imgs[n_synth:]
+        if side is not main:
+            main.wait_stream(side)
+            if not torch.cuda.is_current_stream_capturing():
+                for t in gt_features:
+                    t.record_stream(main)
+        image_losses = cfg["image_loss_weight"] * self.perceptual_loss.loss_groups(stacked_imgs, gt_features, (n_synth, n_real))
+        losses["image_loss_synth"] = image_losses[0]
+        losses["image_loss_real"] = image_losses[1]
+        losses["eye_loss"] = cfg["eye_loss_weight"] * eye_loss(synth_imgs, generator_output_synth, eye_masks)
+        segment_break(early=True)                                      # nothing above reads a discriminator weight
+        if side is not main:
+            side.wait_stream(main)
+        with torch.cuda.stream(side):
+            gan_real = [GAN_G_loss(o) for o in self.discriminator(generator_output_real).values()]
+            out_real = self.latent_discriminator(real_latents)
+        for i, o in enumerate(self.synth_discriminator(generator_output_synth).values()):
+            losses["GAN_loss_synth_" + str(i)] = GAN_G_loss(o)
+        out_synth = self.latent_discriminator(synth_latents)
+        if side is not main:
+            main.wait_stream(side)
+            if not torch.cuda.is_current_stream_capturing():
+                for t in [out_real] + gan_real:
+                    t.record_stream(main)
+        for i, l in enumerate(gan_real):
+            losses["GAN_loss_real_" + str(i)] = l
+        latent_gan_loss = (n_real * GAN_D_loss(0.0, out_real) + n_synth * GAN_D_loss(1.0, out_synth)) / (n_real + n_synth)
+        losses["latent_GAN_loss"] = cfg["domain_adverserial_loss_weight"] * latent_gan_loss
+        if cfg["latent_regression_weight"] > 0.0:
             labels = torch.cat((stacked_latents, cfg["latent_regressor_rot_weight"] * stacked_rotations), dim=-1)
             losses["latent_regression_loss"] = self.compute_normalized_latent_regression_loss(stacked_imgs, labels, deferred=True)
         losses["loss_sum"] = total_loss(losses.values())

@@ -120,6 +120,60 @@ __global__ __launch_bounds__(256) void nc_reduce_kernel(const T* __restrict__ x1
     }
 }
 
+// ---- nc_reduce4: the four statistics of a DiscrBlock's tail in ONE pass over its pre-activation tensor ----
+// out[0] = sum x, out[1] = sum x^2 (the layer style, confignet_utils.py:147-159), out[2] = sum l, out[3] = sum l^2 with
+// l = leaky_relu(x) (the instance normalisation behind the activation, building_blocks.py:100-106); out is (4, N, C), zeroed by
+// the caller unless gridDim.y == 1.  Same grid as nc_reduce_kernel<4>.
+template <typename T>
+__global__ __launch_bounds__(256) void nc_reduce4_kernel(const T* __restrict__ x, float* __restrict__ out, int S, int C,
+                                                         int rows_per_block, float slope, float* __restrict__ parts) {
+    const int CG = C / 4;
+    const int tx = threadIdx.x, ty = threadIdx.y, TX = blockDim.x, TY = blockDim.y;
+    const int cg = blockIdx.x * TX + tx;
+    const int n = blockIdx.z;
+    const int sbeg = blockIdx.y * rows_per_block, send = min(S, sbeg + rows_per_block);
+    float acc[4][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[q][e] = 0.f;
+    if (cg < CG) {
+        const long base = (long)n * S * C + (long)cg * 4;
+        for (int s = sbeg + ty; s < send; s += TY) {
+            const float4 v = ld4<T>(x + base + (long)s * C);
+            const float4 l = lrelu4(v, slope);
+            const float a[4] = {v.x, v.y, v.z, v.w}, b[4] = {l.x, l.y, l.z, l.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc[0][e] += a[e];
+                acc[1][e] += a[e] * a[e];
+                acc[2][e] += b[e];
+                acc[3][e] += b[e] * b[e];
+            }
+        }
+    }
+    __shared__ float red[4][256 * 4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) red[q][(ty * TX + tx) * 4 + e] = acc[q][e];
+    __syncthreads();
+    if (ty == 0 && cg < CG) {
+        const long nc = (long)gridDim.z * C;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float t = 0.f;
+                for (int y = 0; y < TY; ++y) t += red[q][(y * TX + tx) * 4 + e];
+                const long o = (long)n * C + (long)cg * 4 + e;
+                if (parts) parts[((long)q * gridDim.y + blockIdx.y) * nc + o] = t;     // deterministic mode: ordered second pass
+                else if (gridDim.y == 1) out[q * nc + o] = t;
+                else unsafeAtomicAdd(&out[q * nc + o], t);
+            }
+    }
+}
+
 // ---- nc_lin2: y = A1*f1(x1) + A2*f2(x2) + B ----
 template <int V, typename T>
 __global__ __launch_bounds__(256) void nc_lin2_kernel(const T* __restrict__ x1, const float* __restrict__ a1,
@@ -731,6 +785,43 @@ static int nc_reduce_launch(const void* x1, const void* x2, float* s1, float* s2
     if (parts) {
         if (s1) { if (int e = cn_sum_parts(parts, s1, sblk, (long)n * c, 0, 1.f, st)) return e; }
         if (s2) { if (int e = cn_sum_parts(parts + (size_t)sblk * n * c, s2, sblk, (long)n * c, 0, 1.f, st)) return e; }
+    }
+    return CN_OK;
+}
+
+// out (4, n, c) = sum x, sum x^2, sum lrelu(x), sum lrelu(x)^2 over s: the style statistics and the instance-norm statistics of a
+// DiscrBlock's pre-activation tensor in one pass (c % 4 == 0).  flags bit4: `out` is already zero.
+extern "C" int cn_nc_reduce4(const void* x, float* out, int n, int s, int c, float slope, int flags, int dt, void* stream) {
+    CN_CHECK_ARG(x && out && n > 0 && s > 0 && c > 0 && c % 4 == 0 && (dt == CN_F32 || dt == CN_BF16), "nc_reduce4: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    const int CG = c / 4;
+    int TX = 1;
+    while (TX < CG && TX < 64) TX <<= 1;
+    const int TY = 256 / TX;
+    const int cblk = cn_cdiv(CG, TX);
+    long want = 512 / ((long)cblk * n);
+    if (cn_det()) {
+        const long cap = (long)(CN_DET_WS_FLOATS / (4 * (size_t)n * c));
+        if (want > cap) want = cap;
+    }
+    if (want < 1) want = 1;
+    if (want > 256) want = 256;
+    long rpb = (s + want - 1) / want;
+    if (rpb < 4 * TY) rpb = 4 * TY;
+    const int sblk = cn_cdiv(s, rpb);
+    float* parts = nullptr;
+    if (cn_det() && sblk > 1) {
+        parts = cn_det_ws(st, 4 * (size_t)sblk * n * c);
+        if (!parts) return CN_EINVAL;
+    } else if (sblk > 1 && !(flags & 16)) {
+        if (int ez__ = cn_zero_async(out, sizeof(float) * 4 * (size_t)n * c, st)) return ez__;
+    }
+    dim3 grid(cblk, sblk, n), block(TX, TY);
+    CN_DISPATCH_DT(dt, hipLaunchKernelGGL((nc_reduce4_kernel<T>), grid, block, 0, st, (const T*)x, out, s, c, (int)rpb, slope, parts));
+    CN_LAUNCH_CHECK();
+    if (parts) {
+        for (int q = 0; q < 4; ++q)
+            if (int e = cn_sum_parts(parts + (size_t)q * sblk * n * c, out + (size_t)q * n * c, sblk, (long)n * c, 0, 1.f, st)) return e;
     }
     return CN_OK;
 }

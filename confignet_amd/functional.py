@@ -17,6 +17,7 @@ from .ops import ACT_LRELU, ACT_NONE, ACT_RELU, ACT_TANH, ConvSpec  # noqa: F401
 
 _INPUT_GRADS_ONLY = False
 import os as _os
+FUSED_TAIL_STATS = _os.environ.get("CN_NO_TAIL_STATS4") is None    # DiscrBlock tail: the two statistics passes as one (cn_nc_reduce4)
 BN_BWD_FUSED = _os.environ.get("CN_NO_BN_BWD_FUSED") is None      # conv -> BN(inference) -> ReLU backward as one pass (cn_bn_act_bwd)
 
 
@@ -446,10 +447,14 @@ class DiscrTailFn(Function):
         x, gamma, beta = _cg(x), _cg(gamma), _cg(beta)
         sp = _spatial(x)
         style = smean = ssd = None
-        if want_style:
-            s1, s2 = ops.nc_reduce(x)
+        if want_style and FUSED_TAIL_STATS and x.shape[-1] % 4 == 0:
+            s1, s2, a1, a2 = ops.nc_reduce4(x, slope)          # style + instance-norm statistics: one pass over x instead of two
             style, _, smean, ssd = ops.norm_coef_fwd(ops.NORM_STYLE, s1, s2, None, None, sp, 1e-6)
-        a1, a2 = ops.nc_reduce(x, flags=1, slope=slope)
+        else:
+            if want_style:
+                s1, s2 = ops.nc_reduce(x)
+                style, _, smean, ssd = ops.norm_coef_fwd(ops.NORM_STYLE, s1, s2, None, None, sp, 1e-6)
+            a1, a2 = ops.nc_reduce(x, flags=1, slope=slope)
         a, b, mean, q = ops.norm_coef_fwd(ops.NORM_INSTANCE, a1, a2, gamma, beta, sp, 1e-3)
         y = ops.nc_lin2(tuple(x.shape), x, a, b=b, flags=1, slope=slope)
         ctx.save_for_backward(x, gamma, mean, q, smean, ssd)
@@ -732,6 +737,36 @@ class SqDiffSumFn(Function):
     def backward(ctx, g):
         a, b = ctx.saved_tensors
         return ops.row_scale_diff(a, b, _cg(g.reshape(1)), 2.0 * ctx.scale), None, None
+
+
+class SqDiffGroupSumFn(Function):
+    """(G,) vector of mean((a - b)^2) over consecutive groups of samples (sizes along the batch axis); gradient only to `a`.
+    One stacked VGG pass serves the synthetic and the real half of the generator step, whose perceptual terms stay separate
+    entries of the loss dict: forward = one reduction per group over its (contiguous) slice, backward = ONE pass over the whole
+    tensor with a per-sample scale (cn_row_scale_diff) -- no autograd slices of activation-sized tensors."""
+
+    @staticmethod
+    def forward(ctx, a, b, sizes):
+        a, b = _cg(a), _cg(b)
+        per = a.numel() // a.shape[0]
+        outs, n0 = [], 0
+        for sz in sizes:
+            outs.append(ops.sqdiff_sum(a[n0:n0 + sz], b[n0:n0 + sz], 1.0 / (sz * per)))
+            n0 += sz
+        assert n0 == a.shape[0]
+        ctx.save_for_backward(a, b)
+        ctx.sizes, ctx.per = tuple(sizes), per
+        return torch.cat(outs)
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        s = torch.cat([g[i:i + 1].expand(sz) * (1.0 / (sz * ctx.per)) for i, sz in enumerate(ctx.sizes)]).contiguous()
+        return ops.row_scale_diff(a, b, s, 2.0), None, None
+
+
+def mse_group_sums(a, b, sizes):
+    return SqDiffGroupSumFn.apply(a, b.detach(), tuple(int(s) for s in sizes))
 
 
 def mse_sum(a, b):

@@ -474,6 +474,15 @@ def conv_wgrad(x, gy, g, w_shape, out=None):
 # ---------------------------------------------------------------------------------------------
 GRAD_SINK = os.environ.get("CN_NO_GRAD_SINK") is None
 WGRAD_FORK = os.environ.get("CN_WGRAD_FORK") == "1"
+# Round 4 experiment, OFF (CN_WGRAD_BALANCE=1 switches it on): load balancing between the TWO streams a forked step already has.
+# The backward pass of the generator step runs as two chains -- the real branch (VGG, generator, the whole ResNet-50 encoder) on
+# the model's branch stream, the synthetic branch on the calling stream -- and the real chain is the longer one by the encoder's
+# backward.  Filter / dense-weight gradients are leaves of the tape (nothing on a chain waits for them), so the sink launches
+# issued on a stream other than the one the pass was started on were queued and handed to the calling stream in groups (one
+# cross-stream edge per WGRAD_GROUP launches; no extra stream, no extra hardware queue -- what sank CN_WGRAD_FORK).  Measured
+# (profiles/round4_schedule_experiments.txt): 335 / 327 / 334 images/s with an edge per 8 / 4 / 16 launches against 352 without --
+# every cross-branch edge inside a captured graph costs more than the idle tail of the shorter chain it would fill.
+WGRAD_BALANCE = os.environ.get("CN_WGRAD_BALANCE") == "1"
 _SINK = None              # {"slots": {data_ptr: grad view}, "side": stream | None, "keep": [...], "used": bool}
 _SIDE_STREAMS = {}
 
@@ -493,13 +502,15 @@ class grad_sink:
             side = _SIDE_STREAMS.get(dev)
             if side is None:
                 side = _SIDE_STREAMS[dev] = torch.cuda.Stream(device=dev)
-        _SINK = {"slots": {p.data_ptr(): p.grad for p in self.params if p.grad is not None}, "side": side, "keep": [], "used": False}
+        _SINK = {"slots": {p.data_ptr(): p.grad for p in self.params if p.grad is not None}, "side": side, "keep": [], "used": False,
+                 "home": torch.cuda.current_stream(dev)}
         return self
 
     def join(self):
         """Order the calling stream after everything the sinks launched; drop the tensors kept alive for them."""
         st = _SINK
         _sink_flush()
+        _balance_flush()
         if st is not None and st["side"] is not None and st["used"]:
             torch.cuda.current_stream().wait_stream(st["side"])
         if st is not None:
@@ -549,6 +560,21 @@ def _sink_flush():
             fn()
 
 
+def _balance_flush():
+    """WGRAD_BALANCE: launch the sinks queued from branch streams on the stream the backward pass was started on, ordered after
+    what their operands' streams have been issued so far."""
+    st = _SINK
+    if st is None or not st.get("bq"):
+        return
+    queue, st["bq"] = st["bq"], []
+    home = st["home"]
+    for s_ in st.pop("bq_streams", ()):
+        home.wait_stream(s_)
+    with torch.cuda.stream(home):
+        for fn in queue:
+            fn()
+
+
 def _sink_run(fn, keep):
     """Run one sink launch: immediately on the calling stream (no fork), or queued for the side stream -- every WGRAD_GROUP
     launches one cross-stream edge (an edge per layer made the captured graph a ladder that replayed 35 % slower than the
@@ -558,6 +584,19 @@ def _sink_run(fn, keep):
         cur0 = torch.cuda.current_stream()
         if all(cur0 != s_ for s_ in st.setdefault("touched", [])):
             st["touched"].append(cur0)
+    if st is not None and st["side"] is None and WGRAD_BALANCE and not DETERMINISTIC and cur0 != st["home"]:
+        capturing = torch.cuda.is_current_stream_capturing()
+        for t in keep:
+            if t is not None:
+                st["keep"].append(t)
+                if not capturing:
+                    t.record_stream(st["home"])       # (eager dispatch: the block was allocated on the branch stream)
+        st.setdefault("bq", []).append(fn)
+        if all(cur0 != s_ for s_ in st.setdefault("bq_streams", [])):
+            st["bq_streams"].append(cur0)
+        if len(st["bq"]) >= WGRAD_GROUP:
+            _balance_flush()
+        return
     if st is None or st["side"] is None:
         fn()
         return
@@ -725,6 +764,17 @@ def nc_reduce(x1, x2=None, want_sum=True, want_dot=True, flags=0, slope=0.0, per
         s1 = s1.sum(0, keepdim=True) if s1 is not None else None
         s2 = s2.sum(0, keepdim=True) if s2 is not None else None
     return s1, s2
+
+
+def nc_reduce4(x, slope):
+    """(sum x, sum x^2, sum l, sum l^2) per (n, c) with l = leaky_relu(x, slope): cn_nc_reduce4 (one pass instead of two)."""
+    n, s, c = _nsc(x)
+    out = zero_pool_alloc((4, n, c), x.device)
+    flags = 16
+    if out is None:
+        out, flags = torch.empty((4, n, c), device=x.device, dtype=torch.float32), 0
+    check(lib.cn_nc_reduce4(_ptr(x), _ptr(out), n, s, c, slope, flags, _dt(x), _stream()), "cn_nc_reduce4")
+    return out[0], out[1], out[2], out[3]
 
 
 def nc_lin2(shape, x1=None, a1=None, x2=None, a2=None, b=None, flags=0, slope=0.0, per_channel=False, a3=None, b3=None,

@@ -49,3 +49,14 @@ class PerceptualLoss:
         for a, b in zip(fl, fc):
             total = total + F.mse_sum(a, b)
         return total
+
+    def loss_groups(self, predicted, const_features, sizes):
+        """The perceptual term of consecutive groups of samples of ONE stacked batch as separate scalars: `predicted` (the
+        generated images of all groups, carrying gradient) goes through the feature stack once, `const_features` are the
+        activations of the stacked ground-truth images from features().  Returns a (G,) tensor; element g equals
+        loss(predicted[group g], data[group g])."""
+        fl = self._activations(predicted, True)
+        total = 0
+        for a, b in zip(fl, const_features):
+            total = total + F.mse_group_sums(a, b, sizes)
+        return total

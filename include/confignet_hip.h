@@ -195,6 +195,10 @@ int cn_sum_rows_into(const float* src, float* dst, int rows, int cols, int accum
  *   (skip the clearing launch); bits 8..: x2 holds only (flags >> 8) samples and sample n reads x2[n % period] (the batched
  *   R1 input-gradient pass stacks the cotangents of several heads along n against ONE copy of the activations).
  *   Outputs are overwritten. */
+/* The four statistics of a DiscrBlock's tail (building_blocks.py:97-106) in ONE pass over its pre-activation tensor:
+ * out (4, n, c) = sum x, sum x^2 (get_layer_style of the pre-activation), sum l, sum l^2 with l = leaky_relu(x, slope) (the
+ * InstanceNormalization behind the activation); c % 4 == 0; flags bit4: `out` is already zero. */
+int cn_nc_reduce4(const void* x, float* out, int n, int s, int c, float slope, int flags, int dt, void* stream);
 int cn_nc_reduce(const void* x1, const void* x2, float* sum1, float* sum2, int n, int s, int c,
                  int flags, float slope, int dt, void* stream);
 /* a = x1 * act'(f2(x2)) (the activation derivative taken from the sign / value of x2 as in cn_act_bwd), written to dact_out,

@@ -427,11 +427,15 @@ def test_first_stage_generator_step_and_adam():
         close(p, r, tol=1e-6, what="EMA weight")
 
 
-def test_second_stage_generator_step():
+@pytest.mark.parametrize("stacked", [False, True])
+def test_second_stage_generator_step(stacked):
+    """stacked: ConfigNet.merge_generator_passes (CN_G_MERGE=1; off by default -- it measured slower end to end): one stacked
+    generator / VGG pass for the synthetic and the real half, held to the same oracle comparison as the two-pass form."""
     from confignet_amd import ConfigNet
     from confignet_amd.confignet_first_stage import frozen
     res, ns, nr = 128, 1, 1
     m = _make_model(ConfigNet, res, ns + nr, seed=1)
+    m.merge_generator_passes = stacked
     rng = np.random.default_rng(12)
     params, rot, imgs, masks = _batch(m, res, ns, nr, rng)
     W = _oracle_weights(m)

@@ -615,3 +615,27 @@ def test_conv_with_residual_epilogue_and_folded_batchnorm(shape, cout, stride):
     np.testing.assert_allclose(packed[w.size:].cpu().numpy(), (w * 2 * a).astype(np.float32).reshape(-1), rtol=1e-6)
     got = ops.conv_fwd_res(dev(x), wf, dev(b), dev(res), g, ACT_RELU)
     close(got, ref, tol=2e-4, what="conv + residual + relu")
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 64, 48), (3, 8, 8, 512), (16, 4, 4, 96), (1, 128, 128, 8)])
+def test_tail_statistics_in_one_pass(shape):
+    """cn_nc_reduce4: sum x, sum x^2, sum l, sum l^2 (l = leaky_relu(x, 0.3)) per (sample, channel) -- the style statistics and the
+    instance-norm statistics of a DiscrBlock's pre-activation tensor (building_blocks.py:97-106) -- against float64, with and
+    without the step's zero pool."""
+    from confignet_amd import ops
+    rng = np.random.default_rng(9)
+    x = rng.normal(size=shape)
+    xd = dev(x)
+    x64 = t64(x)
+    l64 = torch.where(x64 > 0, x64, 0.3 * x64)
+    refs = [x64.sum((1, 2)), (x64 ** 2).sum((1, 2)), l64.sum((1, 2)), (l64 ** 2).sum((1, 2))]
+    for pooled in (False, True):
+        if pooled:
+            ops.zero_pool_begin("test", xd.device)
+        try:
+            got = ops.nc_reduce4(xd, 0.3)
+            for g, r in zip(got, refs):
+                close(g, r, tol=2e-5, what="nc_reduce4")
+        finally:
+            if pooled:
+                ops.zero_pool_end()
