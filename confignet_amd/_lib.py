@@ -58,6 +58,8 @@ SIGNATURES = {
     "cn_conv_wgrad_c3": [_p, _p, _p, _i, _p, _p, _i, _p],
     "cn_conv_wino_filter": [_p, _p, _i, _i, _i, _p],
     "cn_conv_fwd_wino": [_i, _i, _i, _i, _i, _p, _p, _p, _p, _i, _f, _p],
+    "cn_conv_fwd_wino4": [_i, _i, _i, _i, _i, _p, _p, _p, _p, _i, _f, _p],
+    "cn_conv_wino4_filter": [_p, _p, _i, _i, _i, _p],
     "cn_sumpool2": [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "cn_gemm": [_i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _p, _i, _f, _p],
     "cn_nc_reduce4": [_p, _p, _i, _i, _i, _f, _i, _i, _p],

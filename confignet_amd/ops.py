@@ -296,6 +296,37 @@ def _wino_ok(g, cin, cout):
     return g.n * bh * bw * (cout // 64) >= WINO_MIN_WGS
 
 
+WINO4 = os.environ.get("CN_NO_WINO4") is None
+WINO4_MIN_WGS = 192
+
+
+def _wino4_ok(g, cin, cout):
+    """Winograd F(4x4, 3x3) (csrc/winograd4.hip) takes the 3x3 stride-1 SAME layers whose image divides into its 16 x 32-pixel
+    blocks and that fill the chip with them (VGG-19 conv1_2 .. conv3_4 at the benchmark's size); cin / cout as in _wino_ok."""
+    if not (WINO4 and WINOGRAD and g.nd == 2 and g.k_h == 3 and g.k_w == 3 and g.s_h == 1 and g.s_w == 1 and g.dl_h == 1 and g.dl_w == 1
+            and g.up == 0 and g.p_h == 1 and g.p_w == 1 and g.out_h == g.in_h and g.out_w == g.in_w):
+        return False
+    if g.in_h % 16 or g.in_w % 32 or cin % 16 or cout % 64:
+        return False
+    return g.n * (g.in_h // 16) * (g.in_w // 32) * (cout // 64) >= WINO4_MIN_WGS
+
+
+def _wino4_filter(w, dgrad):
+    def make(wd_):
+        wd_ = _c(wd_)
+        cin, cout = wd_.shape[-2], wd_.shape[-1]
+        u = torch.empty((36, cout, cin) if dgrad else (36, cin, cout), device=wd_.device, dtype=torch.float32)
+        check(lib.cn_conv_wino4_filter(_fptr(wd_), _ptr(u), cin, cout, int(dgrad), _stream()), "cn_conv_wino4_filter")
+        return u
+    return _weight_cache(w, "_cn_wino4_d" if dgrad else "_cn_wino4_f", make)
+
+
+def wino4_saved_flops(g):
+    """Direct-convolution multiply-adds (border taps counted) minus the 36 per 4x4 tile that F(4x4, 3x3) issues."""
+    tiles = g.n * (g.in_h // 4) * (g.in_w // 4)
+    return 2.0 * g.cin * g.cout * (9.0 * g.n * g.in_h * g.in_w - 36.0 * tiles)
+
+
 def _wino_filter(w, dgrad):
     def make(wd_):
         wd_ = _c(wd_)
@@ -308,6 +339,12 @@ def _wino_filter(w, dgrad):
 
 def conv_fwd(x, w, bias, g, act=ACT_NONE, slope=0.0):
     out_dtype = _act_out_dtype(g.cout)
+    if ACT_DTYPE == torch.float32 and x.dtype == torch.float32 and _wino4_ok(g, g.cin, g.cout):
+        y = torch.empty(geom_out_shape(g), device=x.device, dtype=torch.float32)
+        check(lib.cn_conv_fwd_wino4(g.n, g.in_h, g.in_w, g.cin, g.cout, _ptr(_c(x)), _ptr(_wino4_filter(w, False)), _fptr(bias), _ptr(y),
+                                    act, slope, _stream()), "cn_conv_fwd_wino4")
+        prof_note_saved(wino4_saved_flops(g))
+        return y
     if ACT_DTYPE == torch.float32 and x.dtype == torch.float32 and _wino_ok(g, g.cin, g.cout):
         y = torch.empty(geom_out_shape(g), device=x.device, dtype=torch.float32)
         check(lib.cn_conv_fwd_wino(g.n, g.in_h, g.in_w, g.cin, g.cout, _ptr(x), _ptr(_wino_filter(w, False)), _fptr(bias), _ptr(y),
@@ -388,6 +425,11 @@ def conv_dgrad(gy, w, g):
             check(rc, "cn_conv_dgrad_dt")
     gy = f32(gy)
     gu = torch.empty(shape, device=gy.device, dtype=torch.float32)
+    if ACT_DTYPE == torch.float32 and _wino4_ok(g, g.cout, g.cin):
+        check(lib.cn_conv_fwd_wino4(g.n, g.in_h, g.in_w, g.cout, g.cin, _ptr(_c(gy)), _ptr(_wino4_filter(w, True)), None, _ptr(gu),
+                                    ACT_NONE, 0.0, _stream()), "cn_conv_fwd_wino4")
+        prof_note_saved(wino4_saved_flops(g))
+        return gu
     if ACT_DTYPE == torch.float32 and _wino_ok(g, g.cout, g.cin):
         check(lib.cn_conv_fwd_wino(g.n, g.in_h, g.in_w, g.cout, g.cin, _ptr(gy), _ptr(_wino_filter(w, True)), None, _ptr(gu),
                                    ACT_NONE, 0.0, _stream()), "cn_conv_fwd_wino")

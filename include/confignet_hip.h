@@ -125,6 +125,13 @@ int cn_conv_wgrad_thin(const CnConvGeom* g, const float* x, const float* gy, flo
 int cn_conv_wino_filter(const float* w, float* u, int cin, int cout, int dgrad, void* stream);
 int cn_conv_fwd_wino(int n, int h, int w, int cin, int cout, const float* x, const float* u, const float* bias, float* y,
                      int act, float slope, void* stream);
+/* The same convolutions as Winograd F(4x4, 3x3) (csrc/winograd4.hip): 36 GEMMs per 4x4 output tile, 2.25 MFMA products per
+ * output pixel and (ci, co) instead of 4.  u from cn_conv_wino4_filter ([36][cin][cout]; dgrad != 0: the flipped,
+ * channel-swapped filter of the data gradient).  cn_conv_fwd_wino4 returns CN_EUNSUPPORTED (nothing launched) unless
+ * h % 16 == 0, w % 32 == 0, cin % 16 == 0 and cout % 64 == 0. */
+int cn_conv_wino4_filter(const float* w, float* u, int cin, int cout, int dgrad, void* stream);
+int cn_conv_fwd_wino4(int n, int h, int w, int cin, int cout, const float* x, const float* u, const float* bias,
+                      float* y, int act, float slope, void* stream);
 /* Tuning hook: force the tile configuration (0 = 128x128, 1 = 128x64, 2 = 64x64, 3 = 128x32, 4 = 128x96; -1 = heuristic), the
  * split-K factor of cn_conv_fwd / cn_conv_dgrad (0 = heuristic) and the workgroup target of cn_conv_wgrad (0 = default). */
 int cn_conv_tune(int cfg, int splits, long wg_blocks);

@@ -19,5 +19,9 @@ for xs, cout in shapes:
     ops.WINOGRAD = False
     td = t(lambda: ops.conv_fwd(x, w, b, g, 2, 0.0))
     ops.WINOGRAD = True
+    ops.WINO4 = False
     tw = t(lambda: ops.conv_fwd(x, w, b, g, 2, 0.0))
+    ops.WINO4 = True
+    t4 = t(lambda: ops.conv_fwd(x, w, b, g, 2, 0.0)) if ops._wino4_ok(g, xs[-1], cout) else float("nan")
+    print("F(4x4) %7.1f us (%5.1f TF-equivalent, MFMA %5.1f TF)   " % (t4, fl / t4 / 1e6, fl / 4 / t4 / 1e6), end="")
     print("%-22s cout %-4d direct %7.1f us (%5.1f TF)  winograd %7.1f us (%5.1f TF-equivalent, MFMA %5.1f TF)" % (xs, cout, td, fl / td / 1e6, tw, fl / tw / 1e6, fl * 4 / 9 / tw / 1e6))

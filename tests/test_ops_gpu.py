@@ -639,3 +639,44 @@ def test_tail_statistics_in_one_pass(shape):
         finally:
             if pooled:
                 ops.zero_pool_end()
+
+
+WINO4_CASES = [
+    # (x shape, cout): 3x3 stride-1 SAME layers whose image divides into 16 x 32-pixel blocks (cn_conv_fwd_wino4)
+    ((1, 16, 32, 16), 64),        # one block, one raw stage pair
+    ((2, 32, 64, 64), 64),        # several blocks per image: every border of the zero padding
+    ((1, 16, 64, 32), 128),       # two channel blocks, reduction channels != output channels
+    ((2, 48, 32, 128), 64),
+    ((1, 64, 64, 256), 256),      # VGG-19 conv3_x at one sample
+]
+
+
+@pytest.mark.parametrize("case", WINO4_CASES, ids=[str(i) for i in range(len(WINO4_CASES))])
+def test_winograd_f4x4_forward_and_data_gradient(case):
+    """Winograd F(4x4, 3x3) forward (+ bias + ReLU epilogue) and data gradient against the float64 oracle of the direct convolution
+    at the same 2e-4 bar as every other convolution kernel (its larger transform coefficients cost about one digit more than
+    F(2x2): the margin is printed)."""
+    from confignet_amd import ops
+    xs, cout = case
+    rng = np.random.default_rng(abs(hash(case)) % 2 ** 31)
+    cin = xs[-1]
+    x = rng.normal(size=xs)
+    w = rng.normal(size=(3, 3, cin, cout)) / math.sqrt(9 * cin)
+    b = rng.normal(size=cout)
+    g = ops.ConvSpec((3, 3)).geom(xs, cout)
+    keep, ops.WINO4_MIN_WGS = ops.WINO4_MIN_WGS, 0
+    try:
+        assert ops._wino4_ok(g, cin, cout)
+        y = ops.conv_fwd(dev(x), dev(w), dev(b), g, 2, 0.0)
+        xr, wr = t64(x).requires_grad_(True), t64(w)
+        ref = torch.relu(O.conv_same(xr, wr, t64(b)))
+        print("F(4x4) fwd max abs err %.2e of scale %.2e" % (float((y.cpu().double() - ref.detach()).abs().max()), float(ref.abs().max())))
+        close(y, ref, what="winograd F(4x4) fwd")
+        yr0 = O.conv_same(xr, wr, None)
+        gy = rng.normal(size=tuple(yr0.shape))
+        (yr0 * t64(gy)).sum().backward()
+        if cin % 64 == 0:
+            assert ops._wino4_ok(g, cout, cin)
+        close(ops.conv_dgrad(dev(gy), dev(w), g), xr.grad, what="winograd F(4x4) dgrad")
+    finally:
+        ops.WINO4_MIN_WGS = keep
