@@ -12,6 +12,13 @@
 // One workgroup = 12 waves = a block of 4 x 8 tiles (16 x 32 output pixels) x 64 output channels.  Wave w owns row i = w % 6 of
 // the 6 x 6 transform domain for the channel half cb = w / 6: six 32 x 32 accumulators (96 registers; three waves per SIMD), so
 // the row pass of the output transform is per-lane arithmetic and only its column pass goes through LDS.
+//
+// Measured (round 4, scripts/dev/wino_bench.py, profiles/round4_winograd_f4x4.txt): 1.25 - 1.35 x faster than F(2x2) on the VGG-19
+// layers it takes, at 0.33 - 0.47 of the fp32 MFMA peak on the work it issues.  Ablation on conv3_x (141 us): multiply alone 71 us,
+// transform alone 23 us, loads alone 52 us, skeleton (launch, prologue, 64 barriers, epilogue) 41 us -- the step's parts run back
+// to back more than side by side.  Tried and dropped: register-blocked multiply with 8-byte filter reads + partial-sum epilogue
+// (accumulator spills: 1.4 - 2.3 x slower), one fused instruction stream of MFMAs and transform with hand-counted LDS waits
+// (spills again under the 168-register cap of 3 waves per SIMD: 4.9 x slower), K walked from a rotated start per block (no change).
 // K (= cin) is walked 4 channels at a time:
 //   * the filter slice U[p][4][64] of all 36 positions and the raw (16+2) x (32+2)-pixel input block (8 channels = two steps
 //     at a time: one 32-byte sector per pixel) arrive by LDS-DMA (`buffer_load ... lds`, per-lane source offsets; an offset
@@ -121,7 +128,10 @@ __global__ __launch_bounds__(768) void wino4_fwd_kernel(Wino4Geom g, const float
         const int r = sl / 36, rem = sl - r * 36, cm = rem / 9, c = (rem - cm * 9) * 4 + cm;
         const int yy = by * 16 - 1 + r, xx = bx * 32 - 1 + c;
         const bool in = q < W4_RAW_PIECES && r < 18 && c < 34 && yy >= 0 && yy < g.h && xx >= 0 && xx < g.w;
-        xoff[j] = in ? (unsigned)(((img * g.h + yy) * g.w + xx) * g.cin + (lane & 1) * 4) * 4u : 0x80000000u;
+        // (in pixel rows with bit 2 set the two 4-channel halves of a slot are SWAPPED: the transform's reads of two tile rows,
+        // 4 pixel rows apart, then fall into different banks -- a 32-lane group of 4 channels x 4 tile columns x 2 tile rows
+        // covers all 32 banks)
+        xoff[j] = in ? (unsigned)(((img * g.h + yy) * g.w + xx) * g.cin + (((lane & 1) ^ (r >> 2)) & 1) * 4) * 4u : 0x80000000u;
     }
     auto issue_u = [&](int s) {            // filter slice of K step s -> U stage s & 1
         float* dst = BUF + (s & 1) * W4_U;
@@ -143,7 +153,10 @@ __global__ __launch_bounds__(768) void wino4_fwd_kernel(Wino4Geom g, const float
     // B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]; row i reads patch rows
     // r_q with coefficients c_q (wave-uniform): i = 0: (0, 2, 4 | 4, -5, 1), i = 5: (1, 3, 5 | 4, -5, 1), else rows 1..4.
     // lane = (tile, channel): tile (wave / 6) * 16 + lane / 4, channel lane % 4 of the step; all 12 waves share the work.
-    const int tt = (wave / 6) * 16 + (lane >> 2), tk = lane & 3, tty = tt >> 3, ttx = tt & 7;
+    // lane = (channel tk, tile column txl + 4 txh, tile row 2 (wave / 6) + tyl); the tile's index in the V planes (= MFMA row) is
+    // tt = txl + 4 tyl + 8 txh + 16 (wave / 6): a 32-lane group's stores (8 tiles x 4 channel rows of pitch 40) hit 32 banks.
+    const int tk = lane & 3, txl = (lane >> 2) & 3, tyl = (lane >> 4) & 1, txh = lane >> 5;
+    const int ttx = txl + 4 * txh, tty = 2 * (wave / 6) + tyl, tt = txl + 4 * tyl + 8 * txh + 16 * (wave / 6);
     int trow[4];
     float tco[4];
     {
@@ -159,15 +172,19 @@ __global__ __launch_bounds__(768) void wino4_fwd_kernel(Wino4Geom g, const float
     }
     // byte address of patch element (row q of this wave's row list, column j) of the lane's tile and channel, less the stage /
     // sub-step term: a per-lane base per row (4 registers) + an immediate for the column
-    unsigned rbase[4];
+    unsigned rbase[4], rsw[4];                       // rsw: the row's half-swap bit << 4
 #pragma unroll
-    for (int q = 0; q < 4; ++q) rbase[q] = buf0 + 4u * (unsigned)(2 * W4_U) + 32u * (unsigned)((4 * tty + trow[q]) * 36 + ttx) + 4u * (unsigned)tk;
+    for (int q = 0; q < 4; ++q) {
+        const int r = 4 * tty + trow[q];
+        rbase[q] = buf0 + 4u * (unsigned)(2 * W4_U) + 32u * (unsigned)(r * 36 + ttx) + 4u * (unsigned)tk;
+        rsw[q] = (unsigned)((r >> 2) & 1) << 4;
+    }
 #define W4_RD(q, j, dst) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(dst) : "v"(ra[q]), "i"((((j) & 3) * 9 + ((j) >> 2)) * 32))
     auto transform = [&](int s) {
-        const unsigned so = 4u * (unsigned)(((s >> 1) & 1) * W4_RAW) + 16u * (unsigned)(s & 1);
+        const unsigned so = 4u * (unsigned)(((s >> 1) & 1) * W4_RAW), sub = (unsigned)(s & 1) << 4;
         unsigned ra[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) ra[q] = rbase[q] + so;
+        for (int q = 0; q < 4; ++q) ra[q] = rbase[q] + so + (sub ^ rsw[q]);
         float t[6];
 #define W4_COLS(j0, j1)                                                                                                       \
         {                                                                                                                      \
@@ -263,23 +280,28 @@ __global__ __launch_bounds__(768) void wino4_fwd_kernel(Wino4Geom g, const float
             }
         }
         __syncthreads();
-        for (int idx = tid; idx < 4096; idx += 768) {
-            const int c = idx & 31, tl = (idx >> 5) & 31, y = idx >> 10;
-            float m[6];
+        // column pass: a thread owns 4 consecutive channels of one (tile, y): 16-byte LDS reads and 16-byte stores
+        for (int idx = tid; idx < 1024; idx += 768) {
+            const int c4 = idx & 7, tl = (idx >> 3) & 31, y = idx >> 8;
+            float4 m[6];
 #pragma unroll
-            for (int i = 0; i < 6; ++i) m[i] = E[((i * 4 + y) * 32 + tl) * 32 + c];
-            const float s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
-            float o[4];
-            o[0] = m[0] + s12 + s34;
-            o[1] = d12 + 2.f * d34;
-            o[2] = s12 + 4.f * s34;
-            o[3] = d12 + 8.f * d34 + m[5];
-            const int co = co0 + rb * 32 + c;
-            const float bv = bias ? bias[co] : 0.f;
-            const int row0 = by * 16 + 4 * (tl >> 3), col = bx * 32 + 4 * (tl & 7) + y;
-#pragma unroll
-            for (int x = 0; x < 4; ++x)
-                Y[((long)(img * g.h + row0 + x) * g.w + col) * g.cout + co] = cn_apply_act(o[x] + bv, act, slope);
+            for (int i = 0; i < 6; ++i) m[i] = *reinterpret_cast<const float4*>(E + ((i * 4 + y) * 32 + tl) * 32 + 4 * c4);
+            const int co = co0 + rb * 32 + 4 * c4;
+            const float4 bv = bias ? *reinterpret_cast<const float4*>(bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const int otx = (tl & 3) + 4 * ((tl >> 3) & 1), oty = ((tl >> 2) & 1) + 2 * (tl >> 4);     // (the V planes' tile order)
+            const int row0 = by * 16 + 4 * oty, col = bx * 32 + 4 * otx + y;
+#define W4_O(f)                                                                                                          \
+            const float s12##f = m[1].f + m[2].f, d12##f = m[1].f - m[2].f, s34##f = m[3].f + m[4].f, d34##f = m[3].f - m[4].f; \
+            const float o0##f = m[0].f + s12##f + s34##f + bv.f, o1##f = d12##f + 2.f * d34##f + bv.f,                     \
+                        o2##f = s12##f + 4.f * s34##f + bv.f, o3##f = d12##f + 8.f * d34##f + m[5].f + bv.f;
+            W4_O(x) W4_O(y) W4_O(z) W4_O(w)
+#undef W4_O
+            float* dst = Y + ((long)(img * g.h + row0) * g.w + col) * g.cout + co;
+            const long rs = (long)g.w * g.cout;
+            *reinterpret_cast<float4*>(dst) = make_float4(cn_apply_act(o0x, act, slope), cn_apply_act(o0y, act, slope), cn_apply_act(o0z, act, slope), cn_apply_act(o0w, act, slope));
+            *reinterpret_cast<float4*>(dst + rs) = make_float4(cn_apply_act(o1x, act, slope), cn_apply_act(o1y, act, slope), cn_apply_act(o1z, act, slope), cn_apply_act(o1w, act, slope));
+            *reinterpret_cast<float4*>(dst + 2 * rs) = make_float4(cn_apply_act(o2x, act, slope), cn_apply_act(o2y, act, slope), cn_apply_act(o2z, act, slope), cn_apply_act(o2w, act, slope));
+            *reinterpret_cast<float4*>(dst + 3 * rs) = make_float4(cn_apply_act(o3x, act, slope), cn_apply_act(o3y, act, slope), cn_apply_act(o3z, act, slope), cn_apply_act(o3w, act, slope));
         }
         __syncthreads();
     }
