@@ -196,7 +196,7 @@ def main():
             "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": pmc_traffic(args.dtype),
                          "mfma_busy_pmc": pmc_mfma_busy(args.dtype),
-                         "kernel": ("igemm_fwd/gemm1x1/igemm_wgrad/wino_fwd (implicit-GEMM + Winograd F(2x2,3x3) convolutions, v_mfma_f32_32x32x2_f32)" if args.dtype == "f32" else
+                         "kernel": ("igemm_fwd/gemm1x1/wgrad2/igemm_wgrad/wino_fwd/wino4_fwd (implicit-GEMM + Winograd F(2x2,3x3) / F(4x4,3x3) convolutions, v_mfma_f32_32x32x2_f32)" if args.dtype == "f32" else
                                     "igemm_bf16/igemm_bf16_wgrad (implicit-GEMM conv, v_mfma_f32_32x32x16_bf16) + the fp32 kernels of the "
                                     "3-channel image layers"),
                          "launches_per_step": launches / max(args.steps, 1),
@@ -205,9 +205,11 @@ def main():
                          "algorithmic_gflop_per_step": round(kernel_flops / max(args.steps, 1) / 1e9, 2),
                          "algorithmic_bytes_per_step": round(alg_bytes_per_step),
                          "hbm_frac_of_algorithmic_bytes": round(alg_bytes_per_step / max(kernel_ms / max(args.steps, 1) * 1e-3, 1e-12) / 8.0e12, 4),
-                         "bound_note": ("fp32: the class is MFMA-bound by construction (2.76 TFLOP against 26 GB of algorithmic bytes per step: "
-                                        "107 FLOP/B, ridge 20 FLOP/B) and runs at the MFMA-busy fraction above; what separates it from the "
-                                        "peak is per-launch overhead of 50-150 us kernels (ramp, tail, split-K), see DESIGN.md section 3"
+                         "bound_note": ("fp32: the class is MFMA-bound by construction (%.2f TFLOP issued against %.0f GB of algorithmic bytes per "
+                                        "step: %.0f FLOP/B, ridge 20 FLOP/B) and runs at the MFMA-busy fraction above; what separates it from the "
+                                        "peak is per-launch overhead of 50-150 us kernels (ramp, tail, split-K) and operand delivery into LDS "
+                                        "on the small tiles, see DESIGN.md section 3"
+                                        % (kernel_flops / nst / 1e12, alg_bytes_per_step / 1e9, kernel_flops / nst / max(alg_bytes_per_step, 1.0))
                                         if args.dtype == "f32" else
                                         "bf16: neither roof governs -- 45 us average launches at 0.06 of the bf16 MFMA peak and 0.07 of the HBM peak "
                                         "on their algorithmic bytes: the class is bound by per-launch latency (ramp, tail, dependent chain), "
@@ -216,15 +218,17 @@ def main():
                          "traffic_over_algorithmic": (round(pmc_traffic(args.dtype) * launches / max(args.steps, 1) / alg_bytes_per_step, 2)
                                                       if (pmc_traffic(args.dtype) and alg_bytes_per_step) else None),
                          "by_kernel": by_kernel,
-                         "work": "multiply-adds actually issued (Winograd: 16 per 2x2 tile, upsample-folded layers: the parity-class "
-                                 "filters); `frac` is therefore comparable with mfma_busy_pmc",
+                         "work": "multiply-adds actually issued (Winograd: 16 per 2x2 tile resp. 36 per 4x4 tile, upsample-folded layers: the "
+                                 "parity-class filters); `frac` is therefore comparable with mfma_busy_pmc -- an algorithm that issues "
+                                 "fewer products for the same layer (F(4x4): 2.25 instead of 4 per output) LOWERS this figure while the "
+                                 "iteration gets faster: see direct_equivalent",
                          "direct_equivalent": {
                              "gflop_per_step": round((kernel_flops + saved_flops) / max(args.steps, 1) / 1e9, 2),
                              "tflops": round((kernel_flops + saved_flops) / (kernel_ms * 1e-3) / 1e12, 3) if kernel_ms > 0 else 0.0,
                              "note": "the same launches priced as direct convolutions (round 1's definition of the algorithmic work, "
                                      "border taps of the Winograd layers counted): an algorithmic saving, NOT a roofline fraction"},
                          "recorded": "traffic / mfma_busy_pmc come from committed rocprofv3 PMC passes and are quoted only when "
-                                     "profiles/round3_pmc_*.json carry this kernels_hash",
+                                     "profiles/round4_pmc_*.json carry this kernels_hash",
                          "kernels_hash": kernels_hash()},
             "torch_kernel_time_share": torch_kernel_share(),
         }
@@ -290,20 +294,20 @@ def _recorded(name, key):
 def pmc_traffic(dtype="f32"):
     """HBM bytes per launch of the dominant kernel class (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE;
     scripts/pmc_summary.py, scripts/pmc_traffic_json.py)."""
-    v = _recorded("round3_pmc_traffic%s.json" % ("" if dtype == "f32" else "_" + dtype), "hbm_bytes_per_launch")
+    v = _recorded("round4_pmc_traffic%s.json" % ("" if dtype == "f32" else "_" + dtype), "hbm_bytes_per_launch")
     return None if v is None else round(v)
 
 
 def pmc_mfma_busy(dtype="f32"):
     """MFMA-pipe busy fraction of the class (SQ_VALU_MFMA_BUSY_CYCLES against GRBM_GUI_ACTIVE; scripts/pmc_mfma.py)."""
-    v = _recorded("round3_pmc_mfma%s.json" % ("" if dtype == "f32" else "_" + dtype), "mfma_busy_fraction")
+    v = _recorded("round4_pmc_mfma%s.json" % ("" if dtype == "f32" else "_" + dtype), "mfma_busy_fraction")
     return None if v is None else round(v, 4)
 
 
 def torch_kernel_share():
     """Share of the GPU time of one iteration spent in PyTorch's own kernels (autograd's gradient accumulation adds, cat,
     fills, small (N, L) algebra) from the committed kernel trace of this command -- north_star: torch is plumbing."""
-    v = _recorded("round3_torch_share.json", "torch_kernel_time_share")
+    v = _recorded("round4_torch_share.json", "torch_kernel_time_share")
     return None if v is None else round(v, 4)
 
 

@@ -298,8 +298,7 @@ def test_bf16_data_parallel_dispatch_at_full_size_matches_cpu_oracle(tmp_path):
     (CN_FORCE_DP=1) -- with and without config["dp_global_batch_statistics"] -- and in the single-process dispatch:
     * every one of the 60 loss scalars of a whole iteration against the fp32 CPU oracle on the same weights and batches, at the
       bf16 bound of this file (5e-2 of the scalar; the heads on fake images by the R1-scaled allowance);
-    * the data-parallel runs against the single-process bf16 run at the same bound (a 1-rank mean is the identity, but the bf16
-      kernels' atomics are not covered by the deterministic mode: two runs drift apart over the warm-up iterations)."""
+    * each of the three runs on its own weights and batches (runs are not compared with each other: see the end of the test)."""
     import json
     import subprocess
     import sys
@@ -329,12 +328,8 @@ def test_bf16_data_parallel_dispatch_at_full_size_matches_cpu_oracle(tmp_path):
                 n += 1
                 assert np.isfinite(got[k]) and abs(got[k] - ref[k]) <= 5e-2 * max(1.0, abs(ref[k])) + extra.get(k, 0.0), (tag, step, k, got[k], ref[k])
         assert n == 19 + 19 + 4 + len(info["losses"][3])
-    # data-parallel against single-process: each run trains five iterations from the same initial state before the compared one,
-    # and the bf16 kernels' atomics (not covered by the deterministic mode) make two runs of ONE configuration drift apart through
-    # lr * sign(g) steps (6e-3 on a head's loss measured), so the two dispatches are compared at the bf16 bound as well -- the
-    # bit-for-bit statement about the dispatch is test_steps_gpu.py::test_data_parallel_dispatch_with_overlap_matches_single_process
-    for tag in ("dp", "dp_stats"):
-        a, b = runs["single"], runs[tag]
-        for la, lb in zip(a[0]["losses"], b[0]["losses"]):
-            for k in la:
-                assert abs(la[k] - lb[k]) <= 5e-2 * max(1.0, abs(la[k])), (tag, k, la[k], lb[k])
+    # (No run-against-run comparison: each run trains five iterations before the compared one, the bf16 kernels' atomics are not
+    # covered by the deterministic mode, and lr * sign(g) steps of a fresh GAN make two runs of ONE configuration drift apart by more
+    # than any useful bound (0.33 against 0.23 on a real-image head measured).  Every run is held to the oracle ON ITS OWN weights
+    # and batches above; the bit-for-bit statement about the dispatch itself is
+    # test_steps_gpu.py::test_data_parallel_dispatch_with_overlap_matches_single_process in fp32 deterministic mode.)
