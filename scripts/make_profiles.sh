@@ -58,5 +58,7 @@ timeout 600 $PY scripts/conv_shapes_bench.py 16 bf16 > $O/${TAG}_conv_shapes_bf1
 timeout 300 $PY scripts/ew_shapes_bench.py > $O/${TAG}_elementwise_shapes.txt 2>/dev/null
 timeout 300 $PY scripts/predict_latency.py > $O/${TAG}_predict_latency.txt 2>/dev/null
 timeout 900 $PY scripts/bench_configs.py > $O/${TAG}_secondary_configs.json 2>/dev/null
+timeout 600 $PY scripts/wgrad_bench.py 16 > $O/${TAG}_wgrad_shapes.txt 2>/dev/null
+timeout 300 $PY scripts/dev/wino_bench.py > $O/${TAG}_winograd_f4x4.txt 2>/dev/null
 fi
 ls -la $O

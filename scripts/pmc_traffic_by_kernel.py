@@ -21,6 +21,11 @@ def family(name):
         if k in name:
             t = name.split(k + "<")[1][:10]
             return "%s<%s>" % (k[:-7], TILES.get(t, t))
+    if "wgrad2_kernel" in name:                       # the LDS-DMA filter gradient: same tile families as igemm_wgrad_kernel
+        t = name.split("wgrad2_kernel<")[1][:10]      # (its ordered reduction, sum_parts_kernel, is not a kernel of the class)
+        return "igemm_wgrad<%s>" % TILES.get(t, t)
+    if "wino4_fwd_kernel" in name:
+        return "wino_fwd"                             # (F(2x2) and F(4x4) are one family in cn_prof_collect_by_family)
     if "gemm1x1_kernel" in name:                      # the plain-GEMM main loop: same tile families as igemm_fwd_kernel
         t = name.split("gemm1x1_kernel<")[1][:10]
         return "igemm_fwd<%s>" % TILES.get(t, t)
