@@ -164,8 +164,9 @@ def time_second_stage_iteration(res=256, batch=2, repeats=1, threads=None, warmu
     return batch / sec, sec, threads
 
 
-def probe_thread_counts(res, batch, candidates, per_probe_s=45.0, budget_s=150.0):
-    """One iteration AT THE BENCHMARK'S BATCH per candidate thread count, each in its own subprocess with a hard time limit
+def probe_thread_counts(res, batch, candidates, per_probe_s=80.0, budget_s=170.0):
+    """The SECOND iteration (the first one pays one-off costs: 40 s against 8 s measured at 16 threads) AT THE BENCHMARK'S BATCH per
+    candidate thread count, each in its own subprocess with a hard time limit
     (torch-CPU eager collapses from oversubscription somewhere beyond a few dozen threads on a 256-core host: an all-cores
     iteration did not finish in 14 minutes), threads pinned to the first c cores (OMP_PLACES=cores, OMP_PROC_BIND=close).
     Returns (best count, {count: seconds | "timeout"}).  The probe stops once `budget_s` is spent."""
@@ -208,7 +209,7 @@ if __name__ == "__main__":
         sys.exit(0)
     if "--one" in sys.argv:                         # one probe iteration at a given thread count (probe_thread_counts)
         c = int(sys.argv[sys.argv.index("--one") + 1])
-        _, sec, _ = time_second_stage_iteration(r, b, repeats=1, threads=c)
+        _, sec, _ = time_second_stage_iteration(r, b, repeats=1, threads=c, warmup=1)
         print(json.dumps({"seconds": sec, "threads": c}))
         sys.exit(0)
     cands = sorted({min(c, host) for c in (16, 32, 64, 128)})

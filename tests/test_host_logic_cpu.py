@@ -60,3 +60,21 @@ def test_work_stream_slots():
     slots = ConfigNetFirstStage._WORK_SLOTS
     assert slots["g"] == slots["d"] and len({slots["main"], slots["d"], slots["sd"], slots["ld"]}) == 4
     assert max(slots.values()) == 3
+
+
+def test_bench_launches_its_own_ranks_or_says_what_is_missing():
+    """`python bench.py --gpus N` without a launcher environment starts its own N ranks; on a host with fewer devices it must
+    say so and exit non-zero (it used to die on an assert about WORLD_SIZE), and a launcher environment that
+    disagrees with --gpus is refused by name."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["HIP_VISIBLE_DEVICES"] = ""                      # (no device is visible to this check, whatever the host has)
+    env["CUDA_VISIBLE_DEVICES"] = ""
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and "needs 2 visible devices" in (p.stderr + p.stdout), (p.returncode, p.stderr[-500:])
+    env.update(RANK="0", WORLD_SIZE="2")
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4"], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and "WORLD_SIZE=2 but --gpus 4" in (p.stderr + p.stdout), (p.returncode, p.stderr[-500:])

@@ -364,15 +364,18 @@ def test_full_size_iteration_in_the_benchmarked_dispatch_matches_cpu_oracle():
 
 
 # ------------------------------------------------------------------------------------------------------------
-def test_latent_gan_steps_and_ema_match_oracle():
+@pytest.mark.parametrize("bs", [128, 4096])
+def test_latent_gan_steps_and_ema_match_oracle(bs):
+    """bs = 4096: BASELINE.json configs[4] at its own batch size (the skinny-M dense kernels of bs = 128 give way to the MFMA
+    tile and its split-K at 4096 rows)."""
     from confignet_amd import LatentGAN, optim
-    L, bs = 145, 128
+    L = 145
     gan = LatentGAN({"latent_dim": L, "batch_size": bs}, seed=1)
     rng = np.random.default_rng(2)
     for net in (gan.generator, gan.discriminator):
         net.set_weights([(w + rng.normal(size=w.shape) * 0.05).astype(np.float32) if w.ndim == 1 else w for w in net.get_weights()])
     gan.generator_smoothed.copy_weights_from(gan.generator)
-    emb = rng.normal(size=(500, L)).astype(np.float32)
+    emb = rng.normal(size=(max(500, 2 * bs), L)).astype(np.float32)
     opt = optim.Adam(**gan.config["optimizer"])
     g_w, d_w = w64(gan.generator), w64(gan.discriminator)
     sm = [w.detach().clone() for w in w64(gan.generator_smoothed)]
