@@ -313,10 +313,10 @@ def torch_kernel_share():
 
 def cpu_baseline(args, state_path=None):
     """The oracle's restatement of one whole second-stage iteration, timed on the host cores in a subprocess with a hard
-    time limit: thread count = the fastest of {16, 32, 64, 128} in a one-iteration probe AT THE BENCHMARK'S BATCH (each probe in
-    its own subprocess with an 80 s limit and 170 s for all probes together, the second of two iterations timed, threads pinned to the first c cores: OMP_PLACES=cores, OMP_PROC_BIND=close), then
-    1 warm-up + the median of 3 iterations at that count.  state_path: a dump_parity_state() file -- the warm-up iteration then
-    runs on the HIP path's own weights and batch and its loss dicts come back as the second return value."""
+    time limit: 1 warm-up iteration on 16 threads (it pays the one-off costs), then ONE iteration AT THE BENCHMARK'S BATCH on each of
+    {16, 32, 64, 128} threads (pinned: OMP_PLACES=cores, OMP_PROC_BIND=close; 25 s limit each), then the median of 3 iterations at the
+    fastest count.  state_path: a dump_parity_state() file -- the warm-up iteration then runs on the HIP path's own weights and batch
+    and its loss dicts come back as the second return value."""
     import subprocess
     cmd = [sys.executable, "-m", "oracle.cpu_baseline", str(args.cpu_batch), str(args.res)] + ([state_path] if state_path else [])
     try:
@@ -325,8 +325,8 @@ def cpu_baseline(args, state_path=None):
         r = json.loads(p.stdout.strip().splitlines()[-1])
         return {"value": round(r["value"], 4), "unit": "images/sec", "cores": r["cores"], "kind": "port",
                 "sample": "second-stage iteration at %dx%d, batch %d: 1 warm-up + median of 3 (%.1f s each) on %d threads of the %d host cores, "
-                          "pinned (OMP_PLACES=cores, OMP_PROC_BIND=close); thread count = the fastest of a probe at this batch over "
-                          "{16, 32, 64, 128} (second iteration of a fresh process each, 80 s limit per probe, 170 s in all): %s s; torch-CPU fp32 restatement of the reference (oracle/) -- TensorFlow 2.1 itself "
+                          "pinned (OMP_PLACES=cores, OMP_PROC_BIND=close); thread count = the fastest of one iteration each at this batch on "
+                          "{16, 32, 64, 128} threads after the warm-up (25 s limit per probe): %s s; torch-CPU fp32 restatement of the reference (oracle/) -- TensorFlow 2.1 itself "
                           "cannot be installed here"
                           % (args.res, args.res, args.cpu_batch, r["seconds"], r["cores"], r["host_cores"], r["thread_probe_seconds"])}, \
             r.get("parity_losses")

@@ -122,7 +122,7 @@ def load_state(path, dtype=torch.float32):
     return W, vgg, batch, post_d
 
 
-def time_second_stage_iteration(res=256, batch=2, repeats=1, threads=None, warmup=0, state=None):
+def time_second_stage_iteration(res=256, batch=2, repeats=1, threads=None, warmup=0, state=None, probe_threads=(), probe_limit_s=25):
     """Returns (images_per_sec, median seconds per iteration, threads used[, loss dicts of the state iteration]).
     state: path of a bench.py parity dump -- its weights replace the seeded ones and its batch is the FIRST iteration run
     (with fresh Adam moments, as the device path ran it); that iteration's four loss dicts are returned as floats."""
@@ -149,7 +149,32 @@ def time_second_stage_iteration(res=256, batch=2, repeats=1, threads=None, warmu
     d_opt = O.KerasAdam(lr=4e-4, beta_1=0.0, beta_2=0.9)
     g_opt = O.KerasAdam(lr=4e-4, beta_1=0.0, beta_2=0.9)
     times = []
+    probe = {}
     for i in range(warmup + repeats):
+        if i == warmup and probe_threads:
+            # Thread-count probe, after the warm-up iteration has paid the one-off costs (40 s against 8 s per iteration measured):
+            # one iteration AT THIS BATCH per candidate, threads pinned by the caller's OMP_PLACES / OMP_PROC_BIND, each under a
+            # SIGALRM limit (torch-CPU eager collapses from oversubscription somewhere beyond a few dozen threads on a 256-core
+            # host: an all-cores iteration did not finish in 14 minutes).  The fastest count times the remaining iterations.
+            import signal
+            best, best_sec = threads, float("inf")
+            for c in probe_threads:
+                torch.set_num_threads(c)
+                signal.signal(signal.SIGALRM, _alarm)
+                signal.alarm(int(probe_limit_s))
+                t0 = time.perf_counter()
+                try:
+                    S.second_stage_iteration(W, cfg, make_batch(res, batch, rng), d_opt, g_opt, vgg)
+                    sec_c = time.perf_counter() - t0
+                    probe[c] = round(sec_c, 2)
+                    if sec_c < best_sec:
+                        best, best_sec = c, sec_c
+                except _Timeout:
+                    probe[c] = "> %d s" % probe_limit_s
+                finally:
+                    signal.alarm(0)
+            threads = best
+            torch.set_num_threads(threads)
         use_state = first is not None and i == 0
         b = first if use_state else make_batch(res, batch, rng)
         t0 = time.perf_counter()
@@ -159,40 +184,19 @@ def time_second_stage_iteration(res=256, batch=2, repeats=1, threads=None, warmu
         if use_state:
             parity = {step: {k: float(v.detach()) for k, v in d.items()} for step, d in out.items()}
     sec = float(np.median(times)) if times else float("nan")
+    if probe_threads:
+        time_second_stage_iteration.last_probe = probe
     if state is not None:
         return batch / sec, sec, threads, parity
     return batch / sec, sec, threads
 
 
-def probe_thread_counts(res, batch, candidates, per_probe_s=80.0, budget_s=170.0):
-    """The SECOND iteration (the first one pays one-off costs: 40 s against 8 s measured at 16 threads) AT THE BENCHMARK'S BATCH per
-    candidate thread count, each in its own subprocess with a hard time limit
-    (torch-CPU eager collapses from oversubscription somewhere beyond a few dozen threads on a 256-core host: an all-cores
-    iteration did not finish in 14 minutes), threads pinned to the first c cores (OMP_PLACES=cores, OMP_PROC_BIND=close).
-    Returns (best count, {count: seconds | "timeout"}).  The probe stops once `budget_s` is spent."""
-    import json
-    import subprocess
-    import sys
-    seen, best, best_sec, spent = {}, None, float("inf"), 0.0
-    env = dict(os.environ, OMP_PLACES="cores", OMP_PROC_BIND="close")
-    for c in candidates:
-        if spent >= budget_s:
-            seen[c] = "not probed (probe budget spent)"
-            continue
-        t0 = time.perf_counter()
-        try:
-            p = subprocess.run([sys.executable, "-m", "oracle.cpu_baseline", str(batch), str(res), "--one", str(c)], env=env,
-                               capture_output=True, text=True, timeout=per_probe_s, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-            sec = float(json.loads(p.stdout.strip().splitlines()[-1])["seconds"])
-            seen[c] = round(sec, 2)
-            if sec < best_sec:
-                best, best_sec = c, sec
-        except subprocess.TimeoutExpired:
-            seen[c] = "timeout (> %d s)" % per_probe_s
-        except Exception as e:                      # a failed probe never blocks the baseline
-            seen[c] = "failed: %r" % (e,)
-        spent += time.perf_counter() - t0
-    return best, seen
+class _Timeout(Exception):
+    pass
+
+
+def _alarm(signum, frame):
+    raise _Timeout()
 
 
 if __name__ == "__main__":
@@ -207,16 +211,10 @@ if __name__ == "__main__":
         _, _, cores, parity = time_second_stage_iteration(r, b, repeats=0, threads=min(16, host), warmup=1, state=state)
         print(json.dumps({"cores": cores, "parity_losses": parity}))
         sys.exit(0)
-    if "--one" in sys.argv:                         # one probe iteration at a given thread count (probe_thread_counts)
-        c = int(sys.argv[sys.argv.index("--one") + 1])
-        _, sec, _ = time_second_stage_iteration(r, b, repeats=1, threads=c, warmup=1)
-        print(json.dumps({"seconds": sec, "threads": c}))
-        sys.exit(0)
     cands = sorted({min(c, host) for c in (16, 32, 64, 128)})
-    threads, probe = probe_thread_counts(r, b, cands)
-    if threads is None:
-        threads = min(16, host)
-    res_ = time_second_stage_iteration(r, b, repeats=3, threads=threads, warmup=1, state=state)     # 1 warm-up (= the parity iteration, if any) + median of 3
+    # 1 warm-up at 16 threads (= the parity iteration, if any), the thread-count probe, then the median of 3 at the fastest count
+    res_ = time_second_stage_iteration(r, b, repeats=3, threads=min(16, host), warmup=1, state=state, probe_threads=cands)
     v, sec, cores = res_[:3]
-    print(json.dumps({"value": v, "seconds": sec, "cores": cores, "host_cores": host, "thread_probe_seconds": probe,
+    print(json.dumps({"value": v, "seconds": sec, "cores": cores, "host_cores": host,
+                      "thread_probe_seconds": getattr(time_second_stage_iteration, "last_probe", {}),
                       "parity_losses": res_[3] if state is not None else None}))

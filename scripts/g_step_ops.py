@@ -1,0 +1,62 @@
+"""Every launch-producing call of ONE generator step (second stage, 256x256, batch 16), eager, in order of frequency: library entry
+points (ctypes) and torch's own operators with their shapes -- the list behind the launch-count work of DESIGN.md section 3.
+    python scripts/g_step_ops.py"""
+import collections
+import os
+import sys
+
+import torch
+from torch.utils._python_dispatch import TorchDispatchMode
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+from confignet_amd import _lib
+
+model, real_set, synth_set, d_opt, g_opt, cfg = bench.setup(16, 256, 64)
+model.use_graphs = False
+for _ in range(2):
+    model.training_iteration(real_set, synth_set, d_opt, g_opt)
+torch.cuda.synchronize()
+
+lib_calls = collections.Counter()
+for name in _lib.SIGNATURES:
+    fn = getattr(_lib.lib, name)
+
+    def wrap(*a, _fn=fn, _n=name):
+        lib_calls[_n] += 1
+        return _fn(*a)
+    setattr(_lib.lib, name, wrap)
+import confignet_amd.ops as ops
+ops.lib = _lib.lib
+
+torch_calls = collections.Counter()
+
+
+class Log(TorchDispatchMode):
+    def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+        out = func(*args, **(kwargs or {}))
+        shapes = tuple(tuple(a.shape) for a in args if torch.is_tensor(a))[:3]
+        dev = any(torch.is_tensor(a) and a.is_cuda for a in args) or (torch.is_tensor(out) and out.is_cuda)
+        if dev:
+            torch_calls[(str(func), shapes)] += 1
+        return out
+
+
+with Log():
+    with model._main_line():
+        model.generator_training_step(real_set, synth_set, g_opt)
+torch.cuda.synchronize()
+print("library entry points: %d calls" % sum(lib_calls.values()))
+for k, v in lib_calls.most_common(40):
+    print("%5d  %s" % (v, k))
+view_like = ("view", "reshape", "detach", "alias", "expand", "t.default", "transpose", "slice", "select", "unsqueeze", "squeeze", "permute", "as_strided", "split", "unbind", "_unsafe_view", "is_", "size", "stride", "empty", "record_stream", "set_")
+dev_calls = {k: v for k, v in torch_calls.items() if not any(t in k[0] for t in view_like)}
+print("torch operators that launch (views / allocations left out): %d calls" % sum(dev_calls.values()))
+agg = collections.Counter()
+for (f, sh), v in dev_calls.items():
+    agg[f] += v
+for k, v in agg.most_common(25):
+    print("%5d  %s" % (v, k))
+print("by shape:")
+for (f, sh), v in sorted(dev_calls.items(), key=lambda kv: -kv[1])[:60]:
+    print("%5d  %-40s %s" % (v, f, sh))
