@@ -95,6 +95,8 @@ SIGNATURES = {
     "cn_chan_affine3_bwd": [_p, _p, _z, ctypes.POINTER(_i), _f, _p],
     "cn_gan_loss_fwd": [_p, _p, _i, _f, _p],
     "cn_gan_loss_bwd": [_p, _p, _p, _i, _f, _p],
+    "cn_euler_matrix": [_p, _p, _i, _p],
+    "cn_euler_matrix_bwd": [_p, _p, _p, _i, _p],
     "cn_rotate3d_fwd": [_p, _p, _p, _i, _i, _i, _p],
     "cn_rotate3d_bwd": [_p, _p, _p, _p, _p, _i, _i, _i, _p],
     "cn_adam_step": [_p, _p, _p, _p, _p, _z, _p, _f, _f, _f, _f, _p],

@@ -307,6 +307,53 @@ __global__ __launch_bounds__(64) void rotate3d_bwd_det_kernel(const float* __res
 
 }  // namespace
 
+namespace {
+// euler_angles_to_matrix (confignet_utils.py:122-145) and its transposed Jacobian: one thread per sample.  (As 9 products of
+// sines and cosines in torch this was ~110 launches per generator pass forward and ~150 backward, on 8-element vectors.)
+__global__ void euler_matrix_kernel(const float* __restrict__ a, float* __restrict__ R, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s0, c0, s1, c1, s2, c2;
+    sincosf(a[3 * i + 0], &s0, &c0);
+    sincosf(a[3 * i + 1], &s1, &c1);
+    sincosf(a[3 * i + 2], &s2, &c2);
+    float* r = R + 9 * i;
+    r[0] = c2 * c1;                 r[1] = -s2;      r[2] = c2 * s1;
+    r[3] = s0 * s1 + c0 * c1 * s2;  r[4] = c0 * c2;  r[5] = c0 * s2 * s1 - c1 * s0;
+    r[6] = c1 * s0 * s2 - c0 * s1;  r[7] = c2 * s0;  r[8] = c0 * c1 + s0 * s1 * s2;
+}
+
+__global__ void euler_matrix_bwd_kernel(const float* __restrict__ a, const float* __restrict__ gR, float* __restrict__ ga, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s0, c0, s1, c1, s2, c2;
+    sincosf(a[3 * i + 0], &s0, &c0);
+    sincosf(a[3 * i + 1], &s1, &c1);
+    sincosf(a[3 * i + 2], &s2, &c2);
+    const float* g = gR + 9 * i;
+    ga[3 * i + 0] = g[3] * (c0 * s1 - s0 * c1 * s2) + g[4] * (-s0 * c2) + g[5] * (-s0 * s2 * s1 - c1 * c0) +
+                    g[6] * (c1 * c0 * s2 + s0 * s1) + g[7] * (c2 * c0) + g[8] * (-s0 * c1 + c0 * s1 * s2);
+    ga[3 * i + 1] = g[0] * (-c2 * s1) + g[2] * (c2 * c1) + g[3] * (s0 * c1 - c0 * s1 * s2) + g[5] * (c0 * s2 * c1 + s1 * s0) +
+                    g[6] * (-s1 * s0 * s2 - c0 * c1) + g[8] * (-c0 * s1 + s0 * c1 * s2);
+    ga[3 * i + 2] = g[0] * (-s2 * c1) + g[1] * (-c2) + g[2] * (-s2 * s1) + g[3] * (c0 * c1 * c2) + g[4] * (-c0 * s2) +
+                    g[5] * (c0 * c2 * s1) + g[6] * (c1 * s0 * c2) + g[7] * (-s2 * s0) + g[8] * (s0 * s1 * c2);
+}
+}  // namespace
+
+extern "C" int cn_euler_matrix(const float* angles, float* rot, int n, void* stream) {
+    CN_CHECK_ARG(angles && rot && n > 0, "euler_matrix: bad args");
+    hipLaunchKernelGGL(euler_matrix_kernel, dim3(cn_cdiv(n, 64)), dim3(64), 0, (hipStream_t)stream, angles, rot, n);
+    CN_LAUNCH_CHECK();
+    return CN_OK;
+}
+
+extern "C" int cn_euler_matrix_bwd(const float* angles, const float* grot, float* gangles, int n, void* stream) {
+    CN_CHECK_ARG(angles && grot && gangles && n > 0, "euler_matrix_bwd: bad args");
+    hipLaunchKernelGGL(euler_matrix_bwd_kernel, dim3(cn_cdiv(n, 64)), dim3(64), 0, (hipStream_t)stream, angles, grot, gangles, n);
+    CN_LAUNCH_CHECK();
+    return CN_OK;
+}
+
 extern "C" int cn_rotate3d_fwd(const float* grid, const float* rot, float* out, int n, int g, int c, void* stream) {
     CN_CHECK_ARG(grid && rot && out && n > 0 && g > 1 && c > 0 && c % 4 == 0, "rotate3d: bad args (c %% 4 == 0 required)");
     const long work = (long)g * g * g * (c / 4);

@@ -707,8 +707,28 @@ class Rotate3dFn(Function):
         return ggrid, grot
 
 
+class EulerMatrixFn(Function):
+    """euler_angles_to_matrix (confignet_utils.py:122-145) as one launch forward and one backward (cn_euler_matrix): as nine
+    products of sines and cosines in torch it was ~110 launches per generator pass forward and ~150 in the backward pass."""
+
+    @staticmethod
+    def forward(ctx, angles):
+        ctx.save_for_backward(angles)
+        ctx.shape = angles.shape
+        return ops.euler_matrix(angles)
+
+    @staticmethod
+    def backward(ctx, g):
+        (angles,) = ctx.saved_tensors
+        return ops.euler_matrix_bwd(angles, _cg(g)).reshape(ctx.shape)
+
+
 def euler_angles_to_matrix(angles):
-    """confignet_utils.py:122-145 on an (N, 3) tensor (9 scalars per sample: host-side plumbing)."""
+    return EulerMatrixFn.apply(angles)
+
+
+def euler_angles_to_matrix_composite(angles):
+    """The same matrix from torch operators (twice differentiable; kept as the cross-check of EulerMatrixFn)."""
     a = angles.reshape(-1, 3)
     s, c = torch.sin(a), torch.cos(a)
     rows = [c[:, 2] * c[:, 1], -s[:, 2], c[:, 2] * s[:, 1],

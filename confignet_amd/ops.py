@@ -1174,6 +1174,20 @@ def gan_loss_bwd(s, gout, label):
     return gs
 
 
+def euler_matrix(angles):
+    a = _c(f32(angles)).reshape(-1, 3)
+    out = torch.empty((a.shape[0], 3, 3), device=a.device, dtype=torch.float32)
+    check(lib.cn_euler_matrix(_ptr(a), _ptr(out), a.shape[0], _stream()), "cn_euler_matrix")
+    return out
+
+
+def euler_matrix_bwd(angles, grot):
+    a, g = _c(f32(angles)).reshape(-1, 3), _c(f32(grot)).reshape(-1, 9)
+    out = torch.empty_like(a)
+    check(lib.cn_euler_matrix_bwd(_ptr(a), _ptr(g), _ptr(out), a.shape[0], _stream()), "cn_euler_matrix_bwd")
+    return out
+
+
 def rotate3d_fwd(grid, rot):
     keep = grid.dtype
     grid = f32(grid)                           # fp32 kernel; a bf16 grid is converted on the way in and out

@@ -307,6 +307,10 @@ int cn_gan_loss_fwd(const float* s, float* out, int n, float label, void* stream
 int cn_gan_loss_bwd(const float* s, const float* gout, float* gs, int n, float label, void* stream);
 
 /* ---- 3-D rigid resample (confignet_utils.py:63-120): trilinear, clamp to edge ---------------*/
+/* euler_angles_to_matrix (confignet_utils.py:122-145): rot (N,3,3) from angles (N,3), and the gradient to the angles from the
+ * gradient to the matrices -- one launch each (the generator's rotation input, hologan_generator.py:147). */
+int cn_euler_matrix(const float* angles, float* rot, int n, void* stream);
+int cn_euler_matrix_bwd(const float* angles, const float* grot, float* gangles, int n, void* stream);
 int cn_rotate3d_fwd(const float* grid, const float* rot /* (N,3,3) */, float* out, int n, int g, int c, void* stream);
 /* ggrid (overwritten) and grot (N,3,3) (overwritten; through `diffs` only, l.105) */
 int cn_rotate3d_bwd(const float* grid, const float* rot, const float* gout, float* ggrid, float* grot,

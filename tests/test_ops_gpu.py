@@ -474,6 +474,18 @@ def test_rotate3d(g, c, n):
     # identity rotation is an exact identity
     eye = torch.eye(3).expand(n, 3, 3).contiguous().cuda()
     assert torch.equal(ops.rotate3d_fwd(dev(grid), eye), dev(grid))
+    # euler_angles_to_matrix as one launch (cn_euler_matrix) and its gradient (cn_euler_matrix_bwd), all three angles non-zero
+    from confignet_amd import functional as F
+    ang3 = rng.uniform(-1.2, 1.2, size=(n + 3, 3))
+    a64 = t64(ang3).requires_grad_(True)
+    R64 = O.euler_angles_to_matrix(a64)
+    cot = rng.normal(size=tuple(R64.shape))
+    (R64 * t64(cot)).sum().backward()
+    ad = dev(ang3).requires_grad_(True)
+    Rd = F.euler_angles_to_matrix(ad)
+    close(Rd, R64, tol=1e-6, what="euler matrix")
+    (Rd * dev(cot)).sum().backward()
+    close(ad.grad, a64.grad, tol=1e-5, what="euler matrix gradient")
 
 
 def test_adam_ema():
