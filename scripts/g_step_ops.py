@@ -46,6 +46,19 @@ with Log():
     with model._main_line():
         model.generator_training_step(real_set, synth_set, g_opt)
 torch.cuda.synchronize()
+# every thread's operators (the backward pass runs on autograd's device thread, which the dispatch mode above does not see)
+from torch.profiler import ProfilerActivity, profile
+with profile(activities=[ProfilerActivity.CPU], record_shapes=True) as prof:
+    with model._main_line():
+        model.generator_training_step(real_set, synth_set, g_opt)
+    torch.cuda.synchronize()
+rows = [e for e in prof.key_averages(group_by_input_shape=True) if e.key.startswith("aten::")]
+skip = ("view", "reshape", "detach", "alias", "expand", "transpose", "slice", "select", "unsqueeze", "squeeze", "permute", "as_strided",
+        "split", "unbind", "_unsafe_view", "empty", "record_stream", "set_", "is_", "to", "item", "_local_scalar", "resolve", "lift", "contiguous", "t", "narrow", "chunk", "flatten", "result_type", "numpy")
+rows = [e for e in rows if e.key[6:] not in skip and not e.key[6:].startswith(("empty", "_reshape", "view"))]
+print("torch operators of one generator step, all threads (profiler): %d calls" % sum(e.count for e in rows))
+for e in sorted(rows, key=lambda e: -e.count)[:70]:
+    print("%5d  %-28s %s" % (e.count, e.key, str(e.input_shapes)[:110]))
 print("library entry points: %d calls" % sum(lib_calls.values()))
 for k, v in lib_calls.most_common(40):
     print("%5d  %s" % (v, k))
