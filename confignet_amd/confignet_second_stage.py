@@ -58,14 +58,16 @@ class ConfigNet(ConfigNetFirstStage):
     def face_reco_loss(self, gt_imgs, gen_imgs, cached=None):
         return self.perceptual_loss_face_reco.loss(gen_imgs, gt_imgs, cached=cached)
 
-    def compute_normalized_latent_regression_loss(self, generator_outputs, labels, deferred=False):
+    def compute_normalized_latent_regression_loss(self, generator_outputs, labels, deferred=False, regressor_output=None):
         """confignet_second_stage.py:93-107.  The (N, L+3) batch statistics are latent-vector algebra
         (host-side plumbing); the latent regressor itself runs on HIP kernels.
 
         deferred=True (only _generator_loss passes it: its _generator_update differentiates the term) selects the
         global-batch-statistics form under data parallelism; every other caller -- fine_tune_on_img backpropagates
         loss_sum itself -- gets the ordinary taped term with the statistics of the batch at hand."""
-        out = self.latent_regressor(generator_outputs)
+        # regressor_output: the latent regressor's output for these images, already computed (the generator step runs the two
+        # halves of the stack on its two streams: the regressor is per-sample up to this point)
+        out = self.latent_regressor(generator_outputs) if regressor_output is None else regressor_output
         # config["dp_global_batch_statistics"] (default off): under data parallelism the batch statistics of the GLOBAL batch
         # (one 2 x (L + 3)-float all-reduce forward and one backward per statistic) instead of the per-rank ones
         if deferred and bool(self.config.get("dp_global_batch_statistics", False)) and parallel.active():
@@ -141,19 +143,29 @@ class ConfigNet(ConfigNetFirstStage):
         segment_break(early=True)
         if side is not main:
             side.wait_stream(main)
+        # The latent regressor is per-sample (instance normalisation) up to its output: the two halves of the reference's stacked
+        # batch (l.188-197) go through it on the two streams, each right behind its own branch's heads, instead of one pass over
+        # the concatenation after the join -- the single-stream stretch of the step's tail (regressor forward, and its backward
+        # before the branches' backward passes can start) is halved, and the pixel-sized torch.cat is gone.
+        split_lr = cfg["latent_regression_weight"] > 0.0 and self.split_latent_regressor
+        reg_real = reg_synth = None
         with torch.cuda.stream(side):
             gan_real = [GAN_G_loss(o) for o in self.discriminator(generator_output_real).values()]
             out_real = self.latent_discriminator(real_latents)
+            if split_lr:
+                reg_real = self.latent_regressor(generator_output_real)
         for i, o in enumerate(self.synth_discriminator(generator_output_synth).values()):
             losses["GAN_loss_synth_" + str(i)] = GAN_G_loss(o)
         out_synth = self.latent_discriminator(synth_latents)
+        if split_lr:
+            reg_synth = self.latent_regressor(generator_output_synth)
         if side is not main:
             main.wait_stream(side)                            # join: everything below needs both branches
             if not torch.cuda.is_current_stream_capturing():
                 # eager dispatch: blocks allocated on the side stream are consumed on the main stream from here on -- tell the
                 # caching allocator, which otherwise hands them back to the side stream's pool on free (wait_stream orders the
                 # kernels, not the allocator).  Captured graphs allocate from their private pool.
-                for t in [real_latents, real_rotations, generator_output_real, image_loss_real, out_real] + gan_real:
+                for t in [real_latents, real_rotations, generator_output_real, image_loss_real, out_real] + gan_real + ([reg_real] if split_lr else []):
                     t.record_stream(main)
         losses["image_loss_real"] = image_loss_real
         for i, l in enumerate(gan_real):
@@ -163,12 +175,18 @@ class ConfigNet(ConfigNetFirstStage):
         losses["latent_GAN_loss"] = cfg["domain_adverserial_loss_weight"] * latent_gan_loss
         if cfg["latent_regression_weight"] > 0.0:
             stacked_latents = torch.cat((synth_latents, real_latents), dim=0)
-            stacked_imgs = torch.cat((generator_output_synth, generator_output_real), dim=0)
             stacked_rotations = torch.cat((synth_rotations, real_rotations), dim=0)
             labels = torch.cat((stacked_latents, cfg["latent_regressor_rot_weight"] * stacked_rotations), dim=-1)
-            losses["latent_regression_loss"] = self.compute_normalized_latent_regression_loss(stacked_imgs, labels, deferred=True)
+            if split_lr:
+                losses["latent_regression_loss"] = self.compute_normalized_latent_regression_loss(
+                    None, labels, deferred=True, regressor_output=torch.cat((reg_synth, reg_real), dim=0))
+            else:
+                stacked_imgs = torch.cat((generator_output_synth, generator_output_real), dim=0)
+                losses["latent_regression_loss"] = self.compute_normalized_latent_regression_loss(stacked_imgs, labels, deferred=True)
         losses["loss_sum"] = total_loss(losses.values())
         return losses
+
+    split_latent_regressor = os.environ.get("CN_NO_SPLIT_LR") is None
 
     # OFF by default -- measured (round 4, profiles/round4_schedule_experiments.txt): 478 instead of 537 convolution launches and
     # 1.2 ms less convolution kernel time per iteration, but the step takes 28.9 instead of 26.9 ms and the iteration 49.4 instead

@@ -160,6 +160,29 @@ class BranchControl:
                     k = int(dist.argmin())
                     if best is None or int(dist[k]) < best[0]:
                         best = (int(dist[k]), {"mask": blocks[k], "pop": int(blocks[k].sum())})
+        if best is None or best[0] > 0.01 * flat.numel():
+            # ... or the other way round: this oracle call works on a stack whose halves the product ran as separate launches
+            # (the second-stage generator step runs the latent regressor per branch): assemble the mask from the logged
+            # masks of the contiguous sample blocks
+            for k in (2, 4):
+                if flat.numel() % k or not cls.forced["act"].get(flat.numel() // k):
+                    continue
+                parts, total = [], 0
+                for blk in own.reshape(k, -1):
+                    bp, bb = int(blk.sum()), None
+                    for e in sorted(cls.forced["act"][blk.numel()], key=lambda e: abs(e["pop"] - bp)):
+                        if bb is not None and abs(e["pop"] - bp) >= bb[0]:
+                            break
+                        d = int((e["mask"] != blk).sum())
+                        if bb is None or d < bb[0]:
+                            bb = (d, e["mask"])
+                        if d == 0:
+                            break
+                    parts.append(bb[1])
+                    total += bb[0]
+                if best is None or total < best[0]:
+                    m = torch.cat(parts)
+                    best = (total, {"mask": m, "pop": int(m.sum())})
         if best is None:
             return None, {"numel": flat.numel(), "why": "no logged mask of this size"}
         d, e = best

@@ -370,6 +370,18 @@ def test_forced_branch_decisions():
     finally:
         O.BranchControl.stop()
     assert rep["forced_calls"] == 0 and len(rep["unmatched"]) == 1
+    # the product ran the two halves of this call's stack as separate launches (either order in the log): assembled per block
+    x.grad = None
+    good = (x.detach() > 0).reshape(2, -1).clone()
+    good[0, 5], good[0, 6] = False, True
+    O.BranchControl.start(forced=[("act", good[1].clone()), ("act", good[0].clone())])
+    try:
+        O.leaky_relu(x, 0.2).sum().backward()
+        rep = O.BranchControl.forced_report()
+    finally:
+        O.BranchControl.stop()
+    assert rep["forced_calls"] == 1 and rep["forced_decisions"] == 2 and not rep["unmatched"]
+    assert float(x.grad.view(-1)[5]) == 0.2 and float(x.grad.view(-1)[6]) == 1.0
     # max-pool: a near-tie resolved the product's way (its fp32 input rounds the two candidates the other way round)
     p = torch.zeros(1, 2, 2, 1, dtype=torch.float64)
     p[0, 0, 0, 0], p[0, 0, 1, 0] = 1.0, 1.0 + 1e-12      # float64 winner: element 1; in fp32 both are 1.0 -> first maximum: element 0
