@@ -268,6 +268,13 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(CnConvGeom g, const floa
             __syncthreads();
         }
         if (ks < ks_end) mma_step<TM, TN, LDA, LDB, KB>(As[0], Bs[0], acc, a_col, b_col, half);   // odd number of steps: the last one
+    } else {
+        // no K step at all (an empty K split; a parity-ordered tile whose class has no live tap: three of the four classes of a 1x1
+        // stride-2 data gradient): the epilogue below reads rowmap entries that OTHER waves wrote, and without the loop's barriers
+        // nothing ordered those writes before the reads -- a wave that ran ahead stored its (zero) rows through whatever the LDS
+        // held before (found with the real halves of the discriminator steps shifted under the generator tail: ResNet-50's
+        // 64x64x256 <- 32x32x128 data gradient wrote through stale floats and faulted)
+        __syncthreads();
     }
 
     // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)

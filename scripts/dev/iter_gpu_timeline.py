@@ -16,6 +16,7 @@ for _ in range(5):
     m.training_iteration(ds, ds, dopt, gopt)
 torch.cuda.synchronize()
 marks = []
+line_marks = []
 def ev():
     e = torch.cuda.Event(enable_timing=True); e.record(); return e
 orig = ConfigNetFirstStage._flush_deferred
@@ -26,6 +27,7 @@ def flush(self):
     follower = pending.pop() if (self._deferred_then and len(pending) > 1 and pending[-1].early_cut) else None
     cur = torch.cuda.current_stream()
     a = ev()
+    lines = {}
     for g in pending:
         g.stream.wait_stream(cur)
         with torch.cuda.stream(g.stream):
@@ -34,8 +36,10 @@ def flush(self):
             else:
                 g.replay()
             g.finish()
+            lines[getattr(g, "name", "?")] = ev()
     if follower is not None and self.early_generator_forward:
         follower.replay(0, follower.early_cut)
+        lines["g_early"] = ev()
     for g in pending:
         cur.wait_stream(g.stream)
     b = ev()
@@ -51,11 +55,13 @@ def flush(self):
                 with torch.cuda.stream(g.stream):
                     stage(training_set)
                     g.replay(0, g.early_cut)
+                    lines["real_" + g.name] = ev()
                 g.prelaunched = True
                 net = self.discriminator if g.name == "d" else self.synth_discriminator
                 self._prestaged[g.name] = (id(training_set), id(optimizer), net.epoch, self._bufs.generation)
     c = ev()
     marks.append([a, b, c])
+    line_marks.append(lines)
 ConfigNetFirstStage._flush_deferred = flush
 K = 12
 for _ in range(K):
@@ -67,3 +73,4 @@ for i, (a, b, c, d) in enumerate(marks):
     nxt = marks[i + 1][0] if i + 1 < len(marks) else None
     print("iter %2d: start %8.2f  d_phase %6.2f  g_tail %6.2f  ema+rest %5.2f  gap to next start %5.2f" % (
         i, t0.elapsed_time(a), a.elapsed_time(b), b.elapsed_time(c), c.elapsed_time(d), d.elapsed_time(nxt) if nxt else 0.0))
+    print("         lines (ms after the iteration's start): " + "  ".join("%s %.2f" % (k, a.elapsed_time(e)) for k, e in line_marks[i].items()))

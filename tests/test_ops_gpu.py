@@ -126,7 +126,43 @@ FULL_SIZE_LAYERS = [
     ((8, 16, 16, 16, 256), (3, 3, 3), 128, 1, 1),  # generator Conv3D 16^3 -> 32^3 with folded upsample
     ((8, 32, 32, 256), (4, 4), 64, 1, 1),         # generator k4 + upsample to 64^2
     ((8, 256, 256, 3), (3, 3), 64, 1, 0),         # VGG block1_conv1: c3_fwd, s1_image_dgrad, thin filter gradient
+    ((8, 64, 64, 256), (1, 1), 128, 2, 0),        # ResNet-50 conv3_block1_1 (1x1, stride 2): three of the four parity classes of its data gradient have no live tap
 ]
+
+
+@pytest.mark.gpu
+def test_data_gradient_tiles_without_a_live_tap_under_concurrency():
+    """Regression (round 4): the parity-ordered data gradient of a 1x1 stride-2 convolution has whole workgroup tiles with NO K
+    step (their parity class has no tap); such a workgroup went from filling its row map in LDS straight to the epilogue that
+    reads entries written by other waves, without a barrier.  A wave that ran ahead stored its zero rows through stale LDS contents
+    -- seen only when the step graphs were scheduled differently (other kernels resident on the CU, floats left in LDS): a memory
+    fault in ResNet-50's first strided block.  Here: that launch many times next to launches on a second stream that leave float
+    tiles in LDS; every result must equal the float64 reference (and be exactly zero at the positions no tap reaches)."""
+    from confignet_amd import ops
+    rng = np.random.default_rng(5)
+    xs, cout = (8, 64, 64, 256), 128
+    g = ops.ConvSpec((1, 1), stride=2).geom(xs, cout)
+    w = dev(rng.normal(size=(1, 1, 256, cout)) / 16.0)
+    gy = dev(rng.normal(size=ops.geom_out_shape(g)))
+    ref = torch.zeros(xs, dtype=torch.float64)
+    ref[:, ::2, ::2, :] = torch.einsum("nhwo,co->nhwc", gy.cpu().double(), w.cpu().double()[0, 0])
+    g2 = ops.ConvSpec((3, 3)).geom((8, 32, 32, 128), 256)
+    x2, w2 = dev(rng.normal(size=(8, 32, 32, 128))), dev(rng.normal(size=(3, 3, 128, 256)))
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    outs = []
+    for _ in range(25):
+        with torch.cuda.stream(sb):
+            for _ in range(4):
+                ops.conv_fwd(x2, w2, None, g2)
+        with torch.cuda.stream(sa):
+            outs += [ops.conv_dgrad(gy, w, g) for _ in range(4)]
+    torch.cuda.synchronize()
+    dead = torch.ones(64, 64, dtype=torch.bool)
+    dead[::2, ::2] = False
+    for o in outs:
+        assert not bool(o[:, dead.to(o.device)].any()), "rows that no tap reaches must be exactly zero"
+        close(o, ref, tol=2e-4, what="1x1 stride-2 data gradient")
 
 
 def _full_size_oracle(xs, k, cout, stride, up, x, w, gy):
