@@ -355,6 +355,9 @@ def dump_parity_state(model, real_set, synth_set, d_opt, g_opt, path=None):
     torch.cuda.synchronize()
     pipelined = bool(model.use_graphs and model.overlap_discriminators and
                      all(getattr(g, "prelaunched", False) for g in model._graphs.values() if g.name in ("d", "sd")))
+    # (the latent-discriminator and generator steps' host halves move with them when the generator step's ground-truth VGG
+    # passes are replayed ahead: ConfigNet._prelaunch_generator_targets)
+    ahead = (("d/", "sd/") if pipelined else ()) + (("ld/", "g/") if (pipelined and "g" in model._prestaged) else ())
     for o in (d_opt, g_opt):
         o.iterations = 0
         for mom, var in o._state.values():
@@ -376,7 +379,7 @@ def dump_parity_state(model, real_set, synth_set, d_opt, g_opt, path=None):
     log, model._bufs.log = model._bufs.log, None
     # this iteration's batch per key: what it staged itself (first entry after `mark`), except the image-discriminator steps
     # of the pipelined loop, whose batch was staged by the PREVIOUS iteration's tail (last entry before `mark`)
-    B = {k: v[mark[k] - 1 if (pipelined and k.startswith(("d/", "sd/"))) else mark[k]] for k, v in log.items()}
+    B = {k: v[mark[k] - 1 if (ahead and k.startswith(ahead)) else mark[k]] for k, v in log.items()}
     assert len(log["g/rot"]) == mark["g/rot"] + 1 and len(log["d/real_idx"]) >= mark["d/real_idx"] + 1, "unexpected staging sequence"
     for name in ("discriminator", "synth_discriminator", "latent_discriminator"):
         for i, w in enumerate(nets[name].get_weights()):
@@ -394,7 +397,7 @@ def dump_parity_state(model, real_set, synth_set, d_opt, g_opt, path=None):
         fd, path = tempfile.mkstemp(prefix="cn_parity_", suffix=".npz")
         os.close(fd)
     np.savez(path, **z)
-    dispatch = ("hip-graph replay, real halves of this iteration's discriminator steps pre-replayed under the previous generator tail"
+    dispatch = ("hip-graph replay, real halves of this iteration's discriminator steps" + (" and the generator step's ground-truth VGG passes" if "g/" in ahead else "") + " pre-replayed under the previous generator tail"
                 if pipelined else "hip-graph replay" if model.use_graphs else "eager")
     return {"path": path, "losses": losses, "dispatch": dispatch}
 

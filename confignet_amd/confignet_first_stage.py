@@ -362,12 +362,15 @@ class ConfigNetFirstStage:
     def _real_imgs(self, key, dataset):
         return ops.gather_images_u8(self._pool(dataset)["imgs"], self._bufs[key + "/real_idx"], self._bufs[key + "/real_flip"])
 
-    def _stage_synth(self, key, dataset, n):
+    def _stage_synth(self, key, dataset, n, late=None):
+        """late: a stream for the copies of everything but the image indices (see _prelaunch_generator_targets: the index buffer
+        is read by gathers only, the parameter / rotation buffers may still be read by the step that is running)."""
         idx = np.random.randint(0, dataset.imgs.shape[0], n)
         self._stage(key + "/synth_idx", idx, torch.int64)
-        for name in self.config["facemodel_inputs"].keys():
-            self._stage(key + "/p/" + name, dataset.metadata_inputs[name][idx])
-        self._stage(key + "/rot", dataset.metadata_inputs["rotations"][idx])
+        with (torch.cuda.stream(late) if late is not None else contextlib.nullcontext()):
+            for name in self.config["facemodel_inputs"].keys():
+                self._stage(key + "/p/" + name, dataset.metadata_inputs[name][idx])
+            self._stage(key + "/rot", dataset.metadata_inputs["rotations"][idx])
 
     def _synth_batch(self, key, dataset, imgs=True):
         params = [self._bufs[key + "/p/" + name] for name in self.config["facemodel_inputs"].keys()]
@@ -483,8 +486,11 @@ class ConfigNetFirstStage:
                 else:
                     g.replay()
                 g.finish()
+        ev_early = None
         if follower is not None and self.early_generator_forward:
             follower.replay(0, follower.early_cut)
+            ev_early = torch.cuda.Event()
+            ev_early.record(cur)
         for g in pending:
             cur.wait_stream(g.stream)
         if follower is not None:
@@ -508,6 +514,10 @@ class ConfigNetFirstStage:
                     g.prelaunched = True
                     net = self.discriminator if g.name == "d" else self.synth_discriminator
                     self._prestaged[g.name] = (id(training_set), id(optimizer), net.epoch, self._bufs.generation)
+                self._prelaunch_generator_targets(pending, follower, ev_early)
+
+    def _prelaunch_generator_targets(self, pending, follower, ev_early):
+        """(Second stage; no-op otherwise.)"""
 
     early_generator_forward = os.environ.get("CN_NO_EARLY_G") is None
 

@@ -94,10 +94,26 @@ class ConfigNet(ConfigNetFirstStage):
             latent_vector, rotation = self.encoder(input_imgs)
             return self.generator([latent_vector, rotation])
 
-    def latent_discriminator_training_step(self, real_training_set, synth_training_set, optimizer):
+    def _prestage_key(self, datasets, optimizer):
+        """What a batch staged ahead of its step (see _prelaunch_generator_targets) was staged for: the call's arguments, every
+        network's weight version (set_weights / load between the two invalidates it) and the static buffers' generation."""
+        nets = [n for n in self.all_networks() if n is not self.generator_smoothed]        # (the EMA copy moves after every iteration)
+        return (tuple(id(d) for d in datasets), id(optimizer), tuple(n.epoch for n in nets), self._bufs.generation)
+
+    def _stage_ld_batch(self, real_training_set, synth_training_set):
         n = self.get_batch_size()
         self._stage_real("ld", real_training_set, n)
         self._stage_synth("ld", synth_training_set, n)
+
+    def _stage_g_batch(self, real_training_set, synth_training_set, late=None):
+        n_synth = self.get_batch_size() // 2
+        self._stage_synth("g", synth_training_set, n_synth, late=late)
+        self._stage_real("g", real_training_set, self.get_batch_size() - n_synth)
+
+    def latent_discriminator_training_step(self, real_training_set, synth_training_set, optimizer):
+        if self._prestaged.pop("ld", None) != self._prestage_key((real_training_set, synth_training_set), optimizer):
+            self._stage_ld_batch(real_training_set, synth_training_set)
+        self._stagers["ld"] = (real_training_set, synth_training_set, optimizer)
 
         def device():
             with torch.no_grad():
@@ -107,8 +123,9 @@ class ConfigNet(ConfigNetFirstStage):
             return self._latent_discriminator_update(real_latents, fake_latents, optimizer)
         return self._run_step("ld", (real_training_set, synth_training_set), optimizer, device)
 
-    def _generator_loss(self, facemodel_params, synth_rotations, synth_imgs, eye_masks, real_imgs):
-        """The taped part of ConfigNet.generator_training_step (l.167-211).
+    def _generator_loss(self, facemodel_params, synth_rotations, synth_imgs, eye_masks, real_imgs, target_features=None):
+        """The taped part of ConfigNet.generator_training_step (l.167-211).  target_features: (VGG activations of synth_imgs, of
+        real_imgs) computed ahead of the step (_generator_targets), else they are computed here.
 
         The real-image branch (encoder -> generator -> perceptual / adversarial terms) and the synthetic branch
         (synthetic encoder -> generator -> perceptual / eye / adversarial terms) only meet in the latent regressor
@@ -129,10 +146,12 @@ class ConfigNet(ConfigNetFirstStage):
             real_latents, real_rotations = self.encoder(real_imgs)
             self._g_cut = ([real_latents, real_rotations], [self.encoder])     # the encoder hangs on the tape by these two only
             generator_output_real = self.generator((real_latents, real_rotations))
-            image_loss_real = cfg["image_loss_weight"] * self.perceptual_loss.loss(real_imgs, generator_output_real)
+            image_loss_real = cfg["image_loss_weight"] * self.perceptual_loss.loss(
+                real_imgs, generator_output_real, cached=None if target_features is None else target_features[1])
         synth_latents = self.synthetic_encoder(facemodel_params)
         generator_output_synth = self.generator((synth_latents, synth_rotations))
-        losses["image_loss_synth"] = cfg["image_loss_weight"] * self.perceptual_loss.loss(synth_imgs, generator_output_synth)
+        losses["image_loss_synth"] = cfg["image_loss_weight"] * self.perceptual_loss.loss(
+            synth_imgs, generator_output_synth, cached=None if target_features is None else target_features[0])
         losses["image_loss_real"] = None                      # (keeps the reference's key order; filled after the join)
         losses["eye_loss"] = cfg["eye_loss_weight"] * eye_loss(synth_imgs, generator_output_synth, eye_masks)
         # Everything above -- encoder, both generator passes, the four VGG-19 passes: the heavy MFMA-bound half of the step's
@@ -258,19 +277,95 @@ class ConfigNet(ConfigNetFirstStage):
         n_real = self.get_batch_size() - n_synth
         assert n_synth > 0, "the generator step splits the batch into a synthetic and a real half: batch_size >= 2 " \
                             "(the reference's losses are means over an empty synthetic batch, i.e. NaN, at batch_size 1)"
-        self._stage_synth("g", synth_training_set, n_synth)
-        self._stage_real("g", real_training_set, n_real)
+        datasets = (real_training_set, synth_training_set)
+        key = self._prestage_key(datasets, optimizer)
+        if self._prestaged.pop("g", None) != key:
+            self._stage_g_batch(real_training_set, synth_training_set)
+        self._stagers["g"] = (real_training_set, synth_training_set, optimizer)
         nets = [self.generator, self.latent_regressor, self.synthetic_encoder, self.encoder]
+        self._targets_now = targets = self._generator_targets(datasets, optimizer, key)
 
         def device():
+            targets = self._targets_now          # (read at run time: the step graph keeps the closure of its FIRST call)
             params, synth_rot, synth_imgs, eye_masks = self._synth_batch("g", synth_training_set)
             real_imgs = self._real_imgs("g", real_training_set)
+            # (copies: the step keeps the activations for its backward pass, and the next iteration's targets are written while
+            # this step's tail is still running)
+            feats = None if targets is None else tuple([f.clone() for f in fs] for fs in targets)
             with frozen(self.discriminator, self.synth_discriminator, self.latent_discriminator):
-                losses = self._generator_loss(params, synth_rot, synth_imgs, eye_masks, real_imgs)
+                losses = self._generator_loss(params, synth_rot, synth_imgs, eye_masks, real_imgs, feats)
                 self._generator_update(losses, nets, optimizer, cut=self._g_cut)
                 self._g_cut = None
             return losses
-        return self._run_step("g", (real_training_set, synth_training_set), optimizer, device)
+        out = self._run_step("g", datasets, optimizer, device)
+        g = self._graph_of("g", datasets, optimizer)
+        if g is not None and targets is not None:
+            g.target_graph = self._target_graph_now
+        return out
+
+    # The perceptual terms compare the generated images with the VGG-19 activations of the step's GROUND-TRUTH images (l.171-176):
+    # two of the step's four VGG passes read nothing but the batch and the frozen VGG weights.  In the pipelined loop (graphs +
+    # overlap_discriminators) they are a graph of their own, replayed for iteration t+1 behind the real half of the discriminator
+    # step under iteration t's generator tail -- whose last third (generator and encoder backward: chains of small launches) has
+    # the chip almost to itself, while the generator step's forward at the start of t+1 competes with three discriminator lines.
+    # The batch of t+1 is drawn with it: all four host halves move to the end of iteration t, in the reference's order (D,
+    # synth-D, latent-D, G).  CN_NO_PRE_G=1: the four passes inside the step as before.
+    prelaunch_generator_targets = os.environ.get("CN_NO_PRE_G") is None
+
+    def _generator_targets(self, datasets, optimizer, key):
+        """The ground-truth VGG activations for the batch staged under "g": None (the step computes them itself) outside the
+        pipelined loop; otherwise the outputs of the target graph -- already written if it was replayed ahead for this batch."""
+        if not self.use_graphs:
+            return None
+        real_training_set, synth_training_set = datasets
+        g = self._graph_of("g", datasets, optimizer)
+        tg = getattr(g, "target_graph", None) if g is not None else None
+        # (decided when the step's graph is created and kept for its lifetime: a captured step reads the target graph's outputs)
+        if (tg is None) if g is not None else not (self.prelaunch_generator_targets and self.overlap_discriminators and not self.merge_generator_passes):
+            return None
+        if tg is None:
+            from .graphs import StepGraph
+
+            def fn():
+                with torch.no_grad():
+                    synth = ops.gather_images_u8(self._pool(synth_training_set)["imgs"], self._bufs["g/synth_idx"], None)
+                    real = self._real_imgs("g", real_training_set)
+                    return (self.perceptual_loss.features(synth), self.perceptual_loss.features(real))
+            tg = StepGraph(fn, stream=self._work_stream("main"))
+        self._target_graph_now = tg
+        ahead, self._targets_ahead = self._targets_ahead, None
+        if ahead is not None and ahead[0] == key and ahead[1] is tg:
+            torch.cuda.current_stream().wait_stream(ahead[2])       # replayed on that stream under the previous generator tail
+            return tg.out
+        if ahead is not None:
+            torch.cuda.current_stream().wait_stream(ahead[2])       # (for another batch: let it finish before the buffers are rewritten)
+        return tg()
+
+    _targets_ahead = None
+    _target_graph_now = None
+    _targets_now = None
+
+    def _prelaunch_generator_targets(self, pending, follower, ev_early):
+        tg = getattr(follower, "target_graph", None)
+        st_ld, st_g = self._stagers.get("ld"), self._stagers.get("g")
+        ld = next((g for g in pending if getattr(g, "name", None) == "ld"), None)
+        ahead = next((g for g in pending if getattr(g, "prelaunched", False)), None)
+        if tg is None or tg.graph is None or st_ld is None or st_g is None or ld is None or ahead is None or ev_early is None:
+            return
+        cur = torch.cuda.current_stream()
+        with torch.cuda.stream(ld.stream):                   # the latent-discriminator step's host half (its draws come third)
+            self._stage_ld_batch(st_ld[0], st_ld[1])
+        with torch.cuda.stream(ahead.stream):
+            # the index / flip buffers are read by gathers at the very start of the generator step and by the target graph: free
+            # once this iteration's early generator forward has run; everything else is copied behind the tail on the main line
+            ahead.stream.wait_event(ev_early)
+            self._stage_g_batch(st_g[0], st_g[1], late=cur)
+            tg.replay()
+        # (keys AFTER the tail's finish(): every network's weight version is the one the next iteration's steps will see)
+        self._prestaged["ld"] = self._prestage_key((st_ld[0], st_ld[1]), st_ld[2])
+        key = self._prestage_key((st_g[0], st_g[1]), st_g[2])
+        self._prestaged["g"] = key
+        self._targets_ahead = (key, tg, ahead.stream)
 
     def training_iteration(self, real_training_set, synth_training_set, discriminator_optimizer, generator_optimizer):
         """One reference training iteration (confignet_second_stage.py:277-288): D, synth-D, latent-D,

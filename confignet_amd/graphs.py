@@ -74,6 +74,9 @@ class StepGraph:
             net.mark_updated()             # find derived filter copies / inference graphs of the previous weights (nn.Net.epoch)
         if self._result is not None and self.packed is not None:
             self._result.copy_(self.packed)
+            # allocated by result() on the CALLER's stream, written here on the stream the replay was issued on: the caching
+            # allocator must not hand the block to the caller's stream again (once the caller drops the dict) before this copy ran
+            self._result.record_stream(torch.cuda.current_stream())
             self._result = None
 
     def result(self):

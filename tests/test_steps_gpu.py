@@ -234,6 +234,7 @@ def test_whole_second_stage_iteration_under_graph_dispatch_matches_oracle(overla
     if overlap:                                                # the split graphs are in use and a real half is in flight
         assert all(g.early_cut > 0 for g in m._graphs.values() if g.name in ("d", "sd", "g"))
         assert all(g.prelaunched for g in m._graphs.values() if g.name in ("d", "sd"))
+        assert m._targets_ahead is not None and "g" in m._prestaged        # ... and the generator step's ground-truth VGG passes
     # back to the initial state: weights, Adam moments and the shared step counters (the captured graphs stay; the real halves
     # pre-replayed by the last warm-up iteration are for other weights and are redone by iteration 1)
     for n, w0 in zip(nets, start):
@@ -258,7 +259,7 @@ def test_whole_second_stage_iteration_under_graph_dispatch_matches_oracle(overla
         assert d_opt.iterations == 3 * (it + 1) and g_opt.iterations == it + 1   # one shared counter for D, synth-D, latent-D (R10)
     log, m._bufs.log = m._bufs.log, None
     # with the overlap the image-discriminator steps staged once more at the end (the batch of iteration n_iters + 1)
-    assert len(log["g/rot"]) == n_iters and len(log["d/real_idx"]) == n_iters + (1 if overlap else 0)
+    assert len(log["g/rot"]) == len(log["ld/rot"]) == len(log["d/real_idx"]) == n_iters + (1 if overlap else 0)
 
     okw = {k: v for k, v in m.config["optimizer"].items() if k != "amsgrad"}
     ro_d, ro_g = O.KerasAdam(**okw), O.KerasAdam(**okw)
@@ -654,9 +655,10 @@ def test_cross_iteration_overlap_of_the_discriminator_steps():
         runs[flag] = (hist, draws, segs, m, ds, dopt, gopt)
     (h0, d0, s0, _, _, _, _), (h1, d1, s1, m, ds, dopt, gopt) = runs[False], runs[True]
     assert s0["d"] == (1, 0) and s1["d"] == (2, 1) and s1["sd"] == (2, 1) and s1["g"] == s0["g"]
-    # the overlapped run has drawn the NEXT iteration's two discriminator batches already, nothing else differs
-    assert d1[:len(d0)] == d0 and [k for k, _ in d1[len(d0):]] == ["d", "sd"]
-    assert set(m._prestaged) == {"d", "sd"}
+    # the overlapped run has drawn the NEXT iteration's batches already (all four host halves, in the iteration's order: the
+    # generator step's ground-truth VGG passes are replayed ahead with the discriminators' real halves), nothing else differs
+    assert d1[:len(d0)] == d0 and [k for k, _ in d1[len(d0):]] == ["d", "sd", "ld", "g"]
+    assert set(m._prestaged) == {"d", "sd", "ld", "g"} and m._targets_ahead is not None
     for a, b in zip(h0[0], h1[0]):                                   # first iteration: the split update against the single one
         for k in a:
             assert abs(a[k] - b[k]) <= 1e-3 * max(1.0, abs(a[k])), (k, a[k], b[k])
