@@ -37,9 +37,12 @@ def flush(self):
                 g.replay()
             g.finish()
             lines[getattr(g, "name", "?")] = ev()
+    ev_early = None
     if follower is not None and self.early_generator_forward:
         follower.replay(0, follower.early_cut)
         lines["g_early"] = ev()
+        ev_early = torch.cuda.Event()
+        ev_early.record(cur)
     for g in pending:
         cur.wait_stream(g.stream)
     b = ev()
@@ -59,6 +62,10 @@ def flush(self):
                 g.prelaunched = True
                 net = self.discriminator if g.name == "d" else self.synth_discriminator
                 self._prestaged[g.name] = (id(training_set), id(optimizer), net.epoch, self._bufs.generation)
+            self._prelaunch_generator_targets(pending, follower, ev_early)
+            if self._targets_ahead is not None:
+                with torch.cuda.stream(self._targets_ahead[2]):
+                    lines["targets"] = ev()
     c = ev()
     marks.append([a, b, c])
     line_marks.append(lines)

@@ -1,5 +1,6 @@
 """Collect every nc_reduce / nc_lin2 launch of one second-stage iteration (256x256, batch 16), time each distinct
-(shape, operands, flags) in isolation and report achieved GB/s against the bytes the launch must move."""
+(shape, operands, flags) in isolation (20 launches back to back in a replayed graph) and report achieved GB/s against the bytes
+the launch must move."""
 import sys
 from collections import OrderedDict
 
@@ -47,17 +48,25 @@ del m
 torch.cuda.empty_cache()
 
 
-def timeit(fn, reps=10):
-    for _ in range(3):
+def timeit(fn, inner=20, reps=5):
+    """Per-call time inside a replayed graph (no host dispatch in the figure: eager launches of these kernels are host-bound)."""
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
         fn()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        fn()
-    e1.record()
-    torch.cuda.synchronize()
-    return e0.elapsed_time(e1) * 1e3 / reps
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=st):
+            for _ in range(inner):
+                fn()
+        g.replay()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / (inner * reps)
 
 
 rows = []

@@ -21,6 +21,12 @@ $PY $R/scripts/prof_summary.py $(ls /tmp/kt1/*/*.db | head -1) > $O/${TAG}_bench
 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/kt2 -- $PY $R/bench.py --serial --steps 10 --warmup 3 --no-cpu-baseline > $O/${TAG}_bench_serial_under_rocprof.json 2>/dev/null
 $PY $R/scripts/prof_summary.py $(ls /tmp/kt2/*/*.db | head -1) > $O/${TAG}_bench_serial_kernel_trace.txt
 $PY $R/scripts/torch_share.py /tmp/kt2 $O/${TAG}_torch_share.json > /dev/null
+# 2b. the generator step alone (eager, one stream: the kernel composition of the iteration's backbone) and the device timeline
+#     of the pipelined loop (phase lengths, end of every line)
+rm -rf /tmp/kt3
+timeout 600 rocprofv3 --kernel-trace -d /tmp/kt3 -- $PY $R/scripts/g_step_trace.py 20 > /dev/null 2>&1
+$PY $R/scripts/prof_summary.py $(ls /tmp/kt3/*/*.db | head -1) > $O/${TAG}_generator_step_kernel_trace.txt
+timeout 300 $PY $R/scripts/dev/iter_gpu_timeline.py 2>/dev/null | tail -26 > $O/${TAG}_iteration_timeline.txt
 fi
 # 3. PMC passes (each in its own run, --kernel-trace only).  A pass that leaves no database (rocprofv3 has died at exit on
 #    this pool now and then) is repeated, up to three times.
