@@ -190,7 +190,7 @@ def main():
                                       if model.overlap_discriminators else "none (every iteration starts after the previous one has finished)"),
                        "dispatch": ("eager, one stream" if args.serial else "eager" if args.no_graphs else
                                     "hip-graph replay per step function, D-type steps concurrent, G step forked over 2 streams" +
-                                    (", real half of the next iteration's discriminator steps under the generator tail" if model.overlap_discriminators else "") +
+                                    (", real half of the next iteration's discriminator steps" + (" and the generator step's ground-truth VGG passes" if getattr(model, "_targets_ahead", None) is not None else "") + " under the generator tail" if model.overlap_discriminators else "") +
                                     ("" if not parallel.active() else " (fwd+bwd), eager RCCL all-reduce + Adam"))},
             "step_functions_ms": step_ms,
             "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
