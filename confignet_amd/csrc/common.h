@@ -60,6 +60,19 @@ enum { CN_FAM_FWD_128x128 = 0, CN_FAM_FWD_128x64, CN_FAM_FWD_64x64, CN_FAM_FWD_1
 void cn_prof_begin(hipStream_t s, double flops, double bytes = 0.0, int family = 31);
 void cn_prof_end(hipStream_t s);
 
+// q = m / d, r = m % d for m >= 0, d > 0.  The extents of this path are powers of two almost everywhere (256 / 128 / ... / 4 pixels,
+// 2 x 2 parity classes): a shift and a mask behind a wave-uniform test instead of the ~40-instruction software division (the target
+// has no integer divide) -- a workgroup's prologue decodes its rows with 3 - 11 of them per row.
+__device__ __forceinline__ void divmod_pos(int m, int d, int& q, int& r) {
+    if ((d & (d - 1)) == 0) {
+        q = m >> (__builtin_ctz(d));
+        r = m & (d - 1);
+    } else {
+        q = m / d;
+        r = m - q * d;
+    }
+}
+
 __device__ __forceinline__ float cn_apply_act(float v, int act, float slope) {
     switch (act) {
         case CN_ACT_LRELU: return v > 0.f ? v : v * slope;

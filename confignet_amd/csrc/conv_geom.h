@@ -15,12 +15,10 @@ __device__ __forceinline__ RowInfo decode_row(const CnConvGeom& g, int m, int M)
     RowInfo r;
     r.ok = m < M;
     if (!r.ok) m = 0;
-    int ow = m % g.out_w;
-    int t = m / g.out_w;
-    int oh = t % g.out_h;
-    t /= g.out_h;
-    int od = t % g.out_d;
-    int n = t / g.out_d;
+    int ow, oh, od, n, t;
+    divmod_pos(m, g.out_w, t, ow);
+    divmod_pos(t, g.out_h, t, oh);
+    divmod_pos(t, g.out_d, n, od);
     r.nbase = n * g.in_d;
     r.vd = od * g.s_d - g.p_d;
     r.vh = oh * g.s_h - g.p_h;
@@ -33,16 +31,19 @@ __device__ __forceinline__ RowInfo decode_row(const CnConvGeom& g, int m, int M)
 // that all rows of a tile hit the zero-stuffed positions for the SAME taps and those taps are skipped as a
 // whole (4x fewer MFMAs for the 2-D stride-2 discriminator blocks).  Returns the true output row.
 __device__ __forceinline__ int par_row(const CnConvGeom& g, int mp, int M, int& cls) {
-    const int qd = g.out_d / g.dl_d, qh = g.out_h / g.dl_h, qw = g.out_w / g.dl_w;
+    int qd, qh, qw, z_;
+    divmod_pos(g.out_d, g.dl_d, qd, z_);
+    divmod_pos(g.out_h, g.dl_h, qh, z_);
+    divmod_pos(g.out_w, g.dl_w, qw, z_);
     const int per = g.n * qd * qh * qw;
     if (mp >= M) { cls = -1; return M; }
-    cls = mp / per;
-    int rem = mp - cls * per;
-    const int cw = cls % g.dl_w, ch = (cls / g.dl_w) % g.dl_h, cd = cls / (g.dl_w * g.dl_h);
-    const int xw = rem % qw; rem /= qw;
-    const int xh = rem % qh; rem /= qh;
-    const int xd = rem % qd;
-    const int n = rem / qd;
+    int rem, cw, ch, cd, xw, xh, xd, n, t;
+    divmod_pos(mp, per, cls, rem);
+    divmod_pos(cls, g.dl_w, t, cw);
+    divmod_pos(t, g.dl_h, cd, ch);
+    divmod_pos(rem, qw, rem, xw);
+    divmod_pos(rem, qh, rem, xh);
+    divmod_pos(rem, qd, n, xd);
     return ((n * g.out_d + xd * g.dl_d + cd) * g.out_h + xh * g.dl_h + ch) * g.out_w + xw * g.dl_w + cw;
 }
 
@@ -63,8 +64,10 @@ __device__ __forceinline__ unsigned long long par_tap_mask(const CnConvGeom& g, 
 __device__ __forceinline__ bool map1(int v, int dl, int ext, int up, int& q) {
     if (v < 0) return false;
     if (dl > 1) {
-        if (v % dl) return false;
-        v /= dl;
+        int q_, r_;
+        divmod_pos(v, dl, q_, r_);
+        if (r_) return false;
+        v = q_;
     }
     if (v >= ext) return false;
     q = v >> up;

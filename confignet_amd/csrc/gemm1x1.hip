@@ -54,21 +54,20 @@ __global__ __launch_bounds__(256) void gemm1x1_kernel(CnConvGeom g, const float*
     if (GATHER && par) {
         // class-major rows: consecutive M tiles sit in one class (1 / 2 / 2 / 4 live taps); the plain order deals them round-robin
         // over the XCDs, a contiguous run per XCD would give one XCD the 4-tap class
-        bx = blockIdx.x % ntm;
-        by = blockIdx.x / ntm;
+        divmod_pos((int)blockIdx.x, ntm, by, bx);
         if (by >= ntn) return;
     } else {
         const int id = blockIdx.x, xcd = id & 7, j = id >> 3;
         const int q = ntm >> 3, r = ntm & 7;
         const int mine = q + (xcd < r ? 1 : 0);
-        const int ml = j / ntn;
+        int ml;
+        divmod_pos(j, ntn, ml, by);
         if (ml >= mine) return;
-        by = j - ml * ntn;
         bx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + ml;
     }
     const int m0 = bx * BM, n0 = by * BN;
     const int T = GATHER ? g.k_d * g.k_h * g.k_w : 1;
-    const int cpb = K / KB;
+    const int cpb = K >> 4;          // KB == 16
     unsigned long long tapmask = T >= 64 ? ~0ull : ((1ull << T) - 1ull);
     if (GATHER && par) {
         int c0, c1;

@@ -61,9 +61,9 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(CnConvGeom g, const floa
         const int id = blockIdx.x, xcd = id & 7, j = id >> 3;
         const int q = nmt >> 3, r = nmt & 7;                              // M tiles per XCD: q (+1 for the first r XCDs)
         const int mine = q + (xcd < r ? 1 : 0);
-        const int ml = j / nt;
+        int ml;
+        divmod_pos(j, nt, ml, by);
         if (ml >= mine) return;                                           // padding slot of the rounded-up launch
-        by = j - ml * nt;
         bx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + ml;
     } else if (xcd_swizzle && !par) {   // parity-ordered rows: classes have 1/2/2/4 live taps, keep them interleaved over XCDs
         const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bx & 7, idx = bx >> 3;
@@ -374,10 +374,9 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(CnConvGeom g, const fl
     for (int ii = 0; ii < AP; ++ii) {
         int m = mbeg + a_krow[ii];
         p_m[ii] = m;
-        p_w[ii] = m % g.out_w; m /= g.out_w;
-        p_h[ii] = m % g.out_h; m /= g.out_h;
-        p_d[ii] = m % g.out_d;
-        p_n[ii] = m / g.out_d;
+        divmod_pos(m, g.out_w, m, p_w[ii]);
+        divmod_pos(m, g.out_h, m, p_h[ii]);
+        divmod_pos(m, g.out_d, p_n[ii], p_d[ii]);
     }
 
     auto load_tiles = [&](int ks) {
@@ -591,10 +590,11 @@ __global__ __launch_bounds__(256) void thin_conv_coop_kernel(CnConvGeom g, const
             mrow[p] = ((n * g.out_d + xd[p] * g.dl_d + cd) * g.out_h + xh[p] * g.dl_h + chh) * g.out_w + xw[p] * g.dl_w + cw;
         } else {
             int m = mp;
-            const int ow = m % g.out_w; m /= g.out_w;
-            const int oh = m % g.out_h; m /= g.out_h;
-            const int od = m % g.out_d;
-            nb[p] = (m / g.out_d) * g.in_d;
+            int ow, oh, od, nn;
+            divmod_pos(m, g.out_w, m, ow);
+            divmod_pos(m, g.out_h, m, oh);
+            divmod_pos(m, g.out_d, nn, od);
+            nb[p] = nn * g.in_d;
             xd[p] = od * g.s_d - g.p_d; xh[p] = oh * g.s_h - g.p_h; xw[p] = ow * g.s_w - g.p_w;
             cls[p] = 0;
             mrow[p] = mp;

@@ -90,17 +90,18 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(CnConvGeom g, const float* 
     // per axis (dl == 1 in a filter-gradient geometry; the folded x2 upsample is the shift).
     const int bw = a_kw - g.p_w, bh = a_kh - g.p_h, bd = a_kd - g.p_d;
     const unsigned ext_w = (unsigned)(g.in_w << g.up), ext_h = (unsigned)(g.in_h << g.up), ext_d = (unsigned)(g.in_d << g.up);
-    const int dg_w = KB % g.out_w, dg_t = KB / g.out_w, dg_h = dg_t % g.out_h, dg_u = dg_t / g.out_h, dg_d = dg_u % g.out_d,
-              dg_n = dg_u / g.out_d;
+    int dg_w, dg_t, dg_h, dg_u, dg_d, dg_n;
+    divmod_pos(KB, g.out_w, dg_t, dg_w);
+    divmod_pos(dg_t, g.out_h, dg_u, dg_h);
+    divmod_pos(dg_u, g.out_d, dg_n, dg_d);
     int p_m[JA], p_n[JA], p_d[JA], p_h[JA], p_w[JA];
 #pragma unroll
     for (int j = 0; j < JA; ++j) {
         int m = mbeg + ((wave + 4 * j) * 64 + lane) / PA;
         p_m[j] = m;
-        p_w[j] = m % g.out_w; m /= g.out_w;
-        p_h[j] = m % g.out_h; m /= g.out_h;
-        p_d[j] = m % g.out_d;
-        p_n[j] = m / g.out_d;
+        divmod_pos(m, g.out_w, m, p_w[j]);
+        divmod_pos(m, g.out_h, m, p_h[j]);
+        divmod_pos(m, g.out_d, p_n[j], p_d[j]);
     }
     // B pieces: row = idx / (BN / 4), float4 column idx % (BN / 4); pieces past the tile (QB not a multiple of 4) and columns
     // past the filter are dummies (offset out of range: they land as zeros in the stage's padding / unused columns)

@@ -81,7 +81,9 @@ __global__ __launch_bounds__(512, 1) void wino_fwd_kernel(WinoGeom g, const floa
     int wg = blockIdx.x;
     if (total % 8 == 0) wg = (wg & 7) * (total >> 3) + (wg >> 3);
     const int blk = wg % nblk, c0 = (wg / nblk) * BC;
-    const int img = blk / (g.bh * g.bw), brem = blk - img * (g.bh * g.bw), bty = brem / g.bw, btx = brem - bty * g.bw;
+    int img, brem, bty, btx;
+    divmod_pos(blk, g.bh * g.bw, img, brem);
+    divmod_pos(brem, g.bw, bty, btx);
 
     // this thread's transform task: tile (tid >> 3) = (ty, tx) of the block, channel (tid & 7) of every step
     const int gt = tid >> 3, ch = tid & 7, ty = gt >> 3, tx = gt & 7;

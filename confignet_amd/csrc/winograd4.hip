@@ -106,7 +106,9 @@ __global__ __launch_bounds__(768) void wino4_fwd_kernel(Wino4Geom g, const float
     int wg = blockIdx.x;
     if (total % 8 == 0) wg = (wg & 7) * (total >> 3) + (wg >> 3);
     const int blk = wg % nblk, co0 = (wg / nblk) * W4_C;
-    const int img = blk / (g.bh * g.bw), brem = blk - img * (g.bh * g.bw), by = brem / g.bw, bx = brem - by * g.bw;
+    int img, brem, by, bx;
+    divmod_pos(blk, g.bh * g.bw, img, brem);
+    divmod_pos(brem, g.bw, by, bx);
 
     const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X), 0, g.n * g.h * g.w * g.cin * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t ures = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(U), 0, 36 * g.cin * g.cout * 4, 0x00020000);
