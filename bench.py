@@ -322,7 +322,11 @@ def cpu_baseline(args, state_path=None):
     try:
         p = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600,
                            env=dict(os.environ, OMP_PLACES="cores", OMP_PROC_BIND="close"))
-        r = json.loads(p.stdout.strip().splitlines()[-1])
+        lines = p.stdout.strip().splitlines()
+        if not lines:                  # the subprocess died: say how, with the end of what it wrote to stderr
+            raise RuntimeError("oracle.cpu_baseline exited with code %s and no result; stderr ends: %s"
+                               % (p.returncode, " | ".join(p.stderr.strip().splitlines()[-6:])[-900:]))
+        r = json.loads(lines[-1])
         return {"value": round(r["value"], 4), "unit": "images/sec", "cores": r["cores"], "kind": "port",
                 "sample": "second-stage iteration at %dx%d, batch %d: 1 warm-up + median of 3 (%.1f s each) on %d threads of the %d host cores, "
                           "pinned (OMP_PLACES=cores, OMP_PROC_BIND=close); thread count = the fastest of one iteration each at this batch on "

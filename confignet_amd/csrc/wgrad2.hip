@@ -187,19 +187,25 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(CnConvGeom g, const float* 
                 for (int j = 0; j < TN; ++j) asm volatile("ds_read_b32 %0, %1" : "=v"(b[set][j]) : "v"(bp + 128u * j));
             }
         };
-        // wait until at most `pending` DS instructions are outstanding; the set's registers pass through the asm so that the
-        // MFMAs that use them cannot be scheduled ahead of the wait
+        // wait until at most RD DS instructions (the next operand set's) are outstanding.  The set's registers are plain INPUTS of the
+        // wait and a scheduling barrier follows it, so that the MFMAs that use them stay behind it.  NOT "+v" (read-write) operands:
+        // a tied operand that the register allocator does not coalesce becomes a v_mov from the ds_read's destination IN FRONT of
+        // the asm, i.e. before the wait -- the copy reads the register before the LDS data has landed.  That was the round-4 form of
+        // this loop; right as long as LDS answered within the ~100 cycles between the read and the copy, wrong under LDS contention
+        // (another kernel's workgroups on the CU): tile-shaped errors of a few per cent, NaN when the stale register held one.
+        // scripts/isa_lds_hazard.py checks the compiled loops for exactly this (tests/test_abi_cpu.py runs it).
         auto ready = [&](int set, bool more) {
             if (TM == 1 && TN == 1) {
-                if (more) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a[set][0]), "+v"(b[set][0]) : "n"(RD));
-                else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[set][0]), "+v"(b[set][0]));
+                if (more) asm volatile("s_waitcnt lgkmcnt(%2)" : : "v"(a[set][0]), "v"(b[set][0]), "n"(RD));
+                else asm volatile("s_waitcnt lgkmcnt(0)" : : "v"(a[set][0]), "v"(b[set][0]));
             } else if (TM == 2 && TN == 2) {
-                if (more) asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a[set][0]), "+v"(a[set][TM - 1]), "+v"(b[set][0]), "+v"(b[set][TN - 1]) : "n"(RD));
-                else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[set][0]), "+v"(a[set][TM - 1]), "+v"(b[set][0]), "+v"(b[set][TN - 1]));
+                if (more) asm volatile("s_waitcnt lgkmcnt(%4)" : : "v"(a[set][0]), "v"(a[set][TM - 1]), "v"(b[set][0]), "v"(b[set][TN - 1]), "n"(RD));
+                else asm volatile("s_waitcnt lgkmcnt(0)" : : "v"(a[set][0]), "v"(a[set][TM - 1]), "v"(b[set][0]), "v"(b[set][TN - 1]));
             } else {      // TM == 1, TN == 3
-                if (more) asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a[set][0]), "+v"(b[set][0]), "+v"(b[set][1 % TN]), "+v"(b[set][2 % TN]) : "n"(RD));
-                else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[set][0]), "+v"(b[set][0]), "+v"(b[set][1 % TN]), "+v"(b[set][2 % TN]));
+                if (more) asm volatile("s_waitcnt lgkmcnt(%4)" : : "v"(a[set][0]), "v"(b[set][0]), "v"(b[set][1 % TN]), "v"(b[set][2 % TN]), "n"(RD));
+                else asm volatile("s_waitcnt lgkmcnt(0)" : : "v"(a[set][0]), "v"(b[set][0]), "v"(b[set][1 % TN]), "v"(b[set][2 % TN]));
             }
+            __builtin_amdgcn_sched_barrier(0);
         };
         fetch(0, 0);
 #pragma unroll

@@ -43,3 +43,31 @@ def test_geometry_same_padding_rules():
     assert (g.out_d, g.out_h, g.out_w, g.p_d) == (8, 8, 8, 1)
     g = ConvSpec((7, 7), stride=2, explicit_pad=3).geom((1, 256, 256, 3), 64)
     assert (g.out_h, g.p_h) == (128, 3)
+
+
+def test_no_register_of_an_in_flight_lds_read_is_touched_before_its_wait(tmp_path):
+    """The LDS-DMA kernels (wgrad2, Winograd F(2x2) / F(4x4)) read their MFMA operands with ds_read instructions inside inline asm
+    and wait for them with hand-counted s_waitcnt lgkmcnt(n): the compiler does not know the asm's result arrives later, so any
+    copy it places between the asm and the wait reads the register too early (round 4: tied "+v" operands of the wait became
+    v_mov copies in wgrad2_kernel<128x128> -- tile-shaped errors and NaN under LDS contention, never in isolation).
+    scripts/isa_lds_hazard.py replays the compiled ISA (hipcc cross-compiles here) and must find no such access."""
+    import shutil
+    import subprocess
+    import sys
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        import pytest
+        pytest.skip("no hipcc")
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import isa_lds_hazard
+    csrc = os.path.join(ROOT, "confignet_amd", "csrc")
+    for name in ("wgrad2", "winograd", "winograd4"):
+        subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-save-temps", "-c",
+                        os.path.join(csrc, name + ".hip"), "-I" + csrc, "-I" + os.path.join(ROOT, "include"), "-o", name + ".o"],
+                       cwd=tmp_path, check=True, capture_output=True)
+        isa = os.path.join(tmp_path, name + "-hip-amdgcn-amd-amdhsa-gfx950.s")
+        assert os.path.exists(isa)
+        text = open(isa).read()
+        assert "ds_read" in text and "lds" in text                       # (the check below is not vacuous)
+        sys.argv = ["isa_lds_hazard.py", isa]
+        assert isa_lds_hazard.main() == 0, "a ds_read destination is read before its s_waitcnt in " + name

@@ -165,6 +165,43 @@ def test_data_gradient_tiles_without_a_live_tap_under_concurrency():
         close(o, ref, tol=2e-4, what="1x1 stride-2 data gradient")
 
 
+@pytest.mark.gpu
+def test_filter_gradient_kernel_under_lds_contention():
+    """Regression (round 4): wgrad2_kernel<128x128> read its MFMA operands through inline-asm ds_reads whose hand-placed wait had
+    tied ("+v") operands; the register allocator turned two of them into v_mov copies IN FRONT of the wait, which read the
+    ds_read's destination before the data had landed.  Right in isolation (LDS answers within the ~100 cycles in between), wrong
+    when another kernel's workgroups load the CU's LDS: tile-shaped errors of a few per cent in ~2 % of the launches of the
+    generator's Conv3D filter gradients, NaN when the stale register held one -- the pipelined training loop went non-finite in
+    about half of the 60-iteration runs.  Here: that filter gradient (no row split: 4^3 grid) next to forward convolutions on a
+    second stream, every launch against its own serial result.  (The static check of the compiled loop: tests/test_abi_cpu.py.)"""
+    from confignet_amd import ops
+    torch.manual_seed(0)
+    r = lambda *s: torch.randn(*s, device="cuda") * 0.05
+    g = ops.ConvSpec((3, 3, 3), up=1).geom((8, 4, 4, 4, 512), 256)
+    _, wd, _, g2 = ops.upfold_prepare(r(3, 3, 3, 512, 256), g)
+    x, gy = r(8, 4, 4, 4, 512), r(*ops.geom_out_shape(g))
+    ga = ops.ConvSpec((3, 3)).geom((8, 64, 64, 64), 256)
+    xa, wa = r(8, 64, 64, 64), r(3, 3, 64, 256)
+    old, ops.WINOGRAD = ops.WINOGRAD, False
+    try:
+        ref = ops.conv_wgrad(gy, x, g2, tuple(wd.shape)).clone()
+        torch.cuda.synchronize()
+        scale = float(ref.abs().max())
+        sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+        worst = 0.0
+        for _ in range(200):
+            with torch.cuda.stream(sb):
+                for _ in range(3):
+                    ops.conv_fwd(xa, wa, None, ga)
+            with torch.cuda.stream(sa):
+                outs = [ops.conv_wgrad(gy, x, g2, tuple(wd.shape)) for _ in range(2)]
+            torch.cuda.synchronize()
+            worst = max(worst, max(float((o - ref).abs().max()) for o in outs))
+    finally:
+        ops.WINOGRAD = old
+    assert worst <= 1e-5 * scale, "filter gradient differs from its serial result under contention: %.3e of %.3e" % (worst, scale)
+
+
 def _full_size_oracle(xs, k, cout, stride, up, x, w, gy):
     """float64 forward / data gradient (at the upsampled extent) / filter gradient of one layer on the host."""
     torch.set_num_threads(min(16, torch.get_num_threads()))

@@ -364,6 +364,29 @@ def test_full_size_iteration_in_the_benchmarked_dispatch_matches_cpu_oracle():
     assert cmp["n_scalars"] == 19 + 19 + 4 + len(st["losses"][3]) and cmp["ok"], cmp
 
 
+def test_pipelined_loop_at_benchmark_size_stays_finite():
+    """60 iterations of the benchmarked dispatch at 256x256, batch 16: every loss scalar, every weight and every gradient finite
+    after every iteration.  (Round 4: a filter-gradient kernel that was only wrong under LDS contention -- i.e. only inside this
+    loop, where four lines share the chip -- put NaN into a generator filter gradient in about half of such runs, somewhere
+    between iteration 3 and 40; the two-iteration oracle comparisons never saw it.  tests/test_ops_gpu.py has the kernel-level
+    regression, tests/test_abi_cpu.py the static one.)"""
+    sys.path.insert(0, ROOT)
+    import bench
+    model, real_set, synth_set, d_opt, g_opt, _ = bench.setup(16, 256, 64)
+    model.use_graphs = True
+    model.overlap_discriminators = True
+    outs = []
+    for it in range(60):
+        outs.append(model.training_iteration(real_set, synth_set, d_opt, g_opt))
+    torch.cuda.synchronize()
+    for it, out in enumerate(outs):
+        for step, d in zip(("d", "synth_d", "latent_d", "g"), out):
+            for k, v in d.items():
+                assert np.isfinite(float(v)), (it, step, k, float(v))
+    for net in model.all_networks():
+        assert bool(torch.isfinite(net.arena).all()) and bool(torch.isfinite(net.grad_arena).all())
+
+
 # ------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("bs", [128, 4096])
 def test_latent_gan_steps_and_ema_match_oracle(bs):
