@@ -240,6 +240,10 @@ def main():
                     os.remove(parity_state["path"])
                 except OSError:
                     pass
+        if not finite:
+            # a timed loop whose losses went non-finite is not a measurement of the workload (round 4: such runs were also faster)
+            out["invalid"] = "non-finite losses in the timed loop"
+            print("bench.py: NON-FINITE LOSSES in the timed loop -- this line is not a valid measurement", file=sys.stderr, flush=True)
         print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.barrier()
