@@ -153,6 +153,7 @@ def geom_in_shape(g, upsampled=False):
     return (g.n, g.in_h << u, g.in_w << u, g.cin)
 
 
+_CACHE_SINGLE = os.environ.get("CN_NO_STREAM_CACHE") is not None      # A/B: one derived copy per filter, re-derived whenever the other branch used it
 _keepalive = None        # a list while an InferenceGraph is captured: every derived filter copy the capture references
 
 
@@ -184,14 +185,22 @@ def _weight_cache_lookup(w, slot, make):
             setattr(w, slot, (key, val))
             return val
         return make(w.detach())                    # first use happens inside a capture: a graph-private copy
-    key = (WEIGHTS_EPOCH[0], owner.epoch if owner is not None else -1, w._version, w.data_ptr(),
-           torch.cuda.current_stream().cuda_stream if w.is_cuda else 0)
+    stream = torch.cuda.current_stream().cuda_stream if w.is_cuda else 0
+    key = (WEIGHTS_EPOCH[0], owner.epoch if owner is not None else -1, w._version, w.data_ptr(), stream)
     c = getattr(w, slot, None)
-    if c is not None and c[0] == key:
-        return c[1]
+    # one entry PER STREAM (a dict): the two branches of a forked step use the same generator / regressor filters alternately --
+    # forward on one stream, forward on the other, then the two backward passes -- and a single entry made each of them derive its
+    # copy again (the key holds the stream, so the other branch's entry never matched and was replaced)
+    if isinstance(c, dict) and not _CACHE_SINGLE:
+        e = c.get(stream)
+        if e is not None and e[0] == key:
+            return e[1]
     val = make(w.detach())
     try:
-        setattr(w, slot, (key, val))
+        if not isinstance(c, dict) or any(e[0][:4] != key[:4] for e in c.values()):
+            c = {}                                   # another epoch / version / storage: drop every stream's stale copy
+        c[stream] = (key, val)
+        setattr(w, slot, c)
     except Exception:
         pass
     return val
