@@ -171,7 +171,7 @@ class ConfigNet(ConfigNetFirstStage):
         with torch.cuda.stream(side):
             gan_real = [GAN_G_loss(o) for o in self.discriminator(generator_output_real).values()]
             out_real = self.latent_discriminator(real_latents)
-            if split_lr:
+            if split_lr and not self.regressor_real_half_on_main:
                 reg_real = self.latent_regressor(generator_output_real)
         for i, o in enumerate(self.synth_discriminator(generator_output_synth).values()):
             losses["GAN_loss_synth_" + str(i)] = GAN_G_loss(o)
@@ -184,8 +184,14 @@ class ConfigNet(ConfigNetFirstStage):
                 # eager dispatch: blocks allocated on the side stream are consumed on the main stream from here on -- tell the
                 # caching allocator, which otherwise hands them back to the side stream's pool on free (wait_stream orders the
                 # kernels, not the allocator).  Captured graphs allocate from their private pool.
-                for t in [real_latents, real_rotations, generator_output_real, image_loss_real, out_real] + gan_real + ([reg_real] if split_lr else []):
+                for t in [real_latents, real_rotations, generator_output_real, image_loss_real, out_real] + gan_real + ([reg_real] if reg_real is not None else []):
                     t.record_stream(main)
+        if split_lr and reg_real is None:
+            # the REAL half's regressor pass on the calling stream as well: the real branch (encoder -> generator -> VGG -> heads) is
+            # the longer chain of the step by the whole ResNet-50 forward and backward; the synthetic branch's stream has that much
+            # slack, and the regressor's backward then runs there next to the real branch's VGG / discriminator backward
+            reg_real = self.latent_regressor(generator_output_real)
+            # (the discriminator heads of the real half moved the same way: 373.5 against 381.0 images/s -- they stay on the branch)
         losses["image_loss_real"] = image_loss_real
         for i, l in enumerate(gan_real):
             losses["GAN_loss_real_" + str(i)] = l
@@ -206,6 +212,7 @@ class ConfigNet(ConfigNetFirstStage):
         return losses
 
     split_latent_regressor = os.environ.get("CN_NO_SPLIT_LR") is None
+    regressor_real_half_on_main = os.environ.get("CN_LR_REAL_ON_SIDE") is None
 
     # OFF by default -- measured (round 4, profiles/round4_schedule_experiments.txt): 478 instead of 537 convolution launches and
     # 1.2 ms less convolution kernel time per iteration, but the step takes 28.9 instead of 26.9 ms and the iteration 49.4 instead
