@@ -57,7 +57,7 @@ def main():
         # plain `python bench.py --gpus N` (no launcher): start the N ranks ourselves, one process per GPU, exactly as
         # `python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N ...` would
         have = torch.cuda.device_count()
-        if have < args.gpus:
+        if have < args.gpus and os.environ.get("CN_DP_SHARE_DEVICE", "0") != "1":
             sys.exit("bench.py: --gpus %d needs %d visible devices, this host has %d" % (args.gpus, args.gpus, have))
         import subprocess
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--standalone",
@@ -65,7 +65,7 @@ def main():
         sys.exit(subprocess.call(cmd))
     if env_world != args.gpus:
         sys.exit("bench.py: launched with WORLD_SIZE=%d but --gpus %d (the two must agree)" % (env_world, args.gpus))
-    if torch.cuda.device_count() < int(os.environ.get("LOCAL_RANK", "0")) + 1:
+    if torch.cuda.device_count() < int(os.environ.get("LOCAL_RANK", "0")) + 1 and os.environ.get("CN_DP_SHARE_DEVICE", "0") != "1":
         sys.exit("bench.py: rank with LOCAL_RANK=%s has no device (%d visible)" % (os.environ.get("LOCAL_RANK", "0"), torch.cuda.device_count()))
     from confignet_amd import ops, parallel
 
@@ -165,7 +165,7 @@ def main():
 
     t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
     if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        parallel.all_reduce_max(t)
     elapsed = float(t.item())
 
     if rank == 0:

@@ -113,6 +113,10 @@ class ConfigNet(ConfigNetFirstStage):
     def latent_discriminator_training_step(self, real_training_set, synth_training_set, optimizer):
         if self._prestaged.pop("ld", None) != self._prestage_key((real_training_set, synth_training_set), optimizer):
             self._stage_ld_batch(real_training_set, synth_training_set)
+        else:
+            # staged ahead on the step's own stream (_prelaunch_generator_targets): a call that does not replay there (the step on
+            # its own, eager dispatch) must not read the buffers before those uploads have run
+            self._bufs.wait_staged("ld/")
         self._stagers["ld"] = (real_training_set, synth_training_set, optimizer)
 
         def device():
@@ -288,6 +292,8 @@ class ConfigNet(ConfigNetFirstStage):
         key = self._prestage_key(datasets, optimizer)
         if self._prestaged.pop("g", None) != key:
             self._stage_g_batch(real_training_set, synth_training_set)
+        else:
+            self._bufs.wait_staged("g/")         # (uploaded on two other streams under the previous generator tail)
         self._stagers["g"] = (real_training_set, synth_training_set, optimizer)
         nets = [self.generator, self.latent_regressor, self.synthetic_encoder, self.encoder]
         self._targets_now = targets = self._generator_targets(datasets, optimizer, key)
@@ -525,7 +531,12 @@ class ConfigNet(ConfigNetFirstStage):
         # N = 1 makes this loop latency-bound: the step is captured once into a HIP graph and replayed
         if self.use_graphs:
             from .graphs import StepGraph
-            runner = StepGraph(device_step)
+            # one capture stream for every fine-tune call of this model (a stream per call would leave a deterministic-mode
+            # workspace pinned per call: cn_det_ws)
+            if getattr(self, "_fine_tune_stream", None) is None:
+                self._fine_tune_stream = torch.cuda.Stream()
+                self._release_on_exit([self._fine_tune_stream])
+            runner = StepGraph(device_step, stream=self._fine_tune_stream)
         else:
             runner = device_step
         log = getattr(self, "fine_tune_loss_log", None)       # a list: receives every step's losses as floats (one sync per step)

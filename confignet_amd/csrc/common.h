@@ -42,7 +42,7 @@ int cn_zero_async(void* p, size_t bytes, hipStream_t s);
 // need room for their partial results take it from a per-stream workspace (allocated when the mode is switched on).
 int cn_det();
 float* cn_det_ws(hipStream_t s, size_t need_floats);     // NULL (+ error string) if the request does not fit
-constexpr size_t CN_DET_WS_FLOATS = (size_t)16 << 20;     // 64 MiB per stream, up to 8 streams
+constexpr size_t CN_DET_WS_FLOATS = (size_t)16 << 20;     // 64 MiB per stream, 16 streams (prof.hip: CN_DET_SLOTS; 1 GiB, allocated when the mode is first switched on)
 // dst[i] (+)= scale * sum_{p < parts} src[p * count + i], parts added in index order (one thread per i)
 int cn_sum_parts(const float* src, float* dst, int parts, long count, int accumulate, float scale, hipStream_t s);
 

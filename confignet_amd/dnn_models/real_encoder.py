@@ -145,17 +145,17 @@ class RealEncoder(Net):
         of its own iteration."""
         from ..nn import WEIGHTS_EPOCH
         from .. import ops
-        key = (WEIGHTS_EPOCH[0], self.epoch, torch.cuda.current_stream().cuda_stream)
-        c = getattr(self, "_fold_cache", None)
-        if c is not None and c[0] == key:
-            return c[1]
-        seg, total, views = self._fold_table()
-        packed = ops.scale_columns_segments(self.arena, seg, a_cat, total)
-        ws = [packed[o:o + int(np.prod(shp))].view(shp) for o, shp in views]
-        if ops._keepalive is not None:
-            ops._keepalive.append(packed)
-        self._fold_cache = (key, ws)
-        return ws
+        stream = torch.cuda.current_stream().cuda_stream
+        key = (WEIGHTS_EPOCH[0], self.epoch)
+        cache = self.__dict__.setdefault("_fold_cache", {})            # one entry per stream (two streams alternating must not re-fold)
+        c = cache.get(stream)
+        if c is None or c[0] != key:
+            seg, total, views = self._fold_table()
+            packed = ops.scale_columns_segments(self.arena, seg, a_cat, total)
+            c = cache[stream] = (key, [packed[o:o + int(np.prod(shp))].view(shp) for o, shp in views], packed)
+        if ops._keepalive is not None:                                 # on a cache hit too: a graph captured now reads `packed`
+            ops._keepalive.append(c[2])
+        return c[1]
 
     def _features_folded(self, img):
         """features() without a tape (the encoder of the discriminator-type steps, predict()): conv -> BN -> ReLU as ONE launch per

@@ -718,8 +718,9 @@ class EulerMatrixFn(Function):
         return ops.euler_matrix(angles)
 
     @staticmethod
-    def backward(ctx, g):
-        (angles,) = ctx.saved_tensors
+    @torch.autograd.function.once_differentiable      # (a raw kernel: a double backward through the angles must raise, not treat
+    def backward(ctx, g):                              # the Jacobian as constant -- euler_angles_to_matrix_composite is the twice
+        (angles,) = ctx.saved_tensors                  # differentiable form)
         return ops.euler_matrix_bwd(angles, _cg(g)).reshape(ctx.shape)
 
 

@@ -35,6 +35,11 @@ def segment_break(action=None, early=False):
             g.early_cut = len(g.segments)
 
 
+def _release_det_stream(stream):
+    from ._lib import lib
+    lib.cn_det_release_stream(stream.cuda_stream)
+
+
 class StepGraph:
     """fn() -> dict of detached device scalars.  Call 1..warmup run eagerly ON THE CAPTURE STREAM (autograd's
     per-leaf AccumulateGrad nodes are bound to the stream they are created on, so the leaves must first be
@@ -49,6 +54,11 @@ class StepGraph:
         self.fn, self.warmup = fn, warmup
         self.calls, self.graph, self.out = 0, None, None
         self.stream = stream if stream is not None else torch.cuda.Stream()
+        if stream is None:
+            # a stream of our own: in deterministic mode the library pins a per-stream workspace to it while a graph captured on it
+            # may replay (cn_det_ws); hand the slot back when this StepGraph (and with it its graphs) is dropped
+            import weakref
+            weakref.finalize(self, _release_det_stream, self.stream)
         self.split = parallel.active()
         self.tail = []
         self.packed, self._result = None, None      # all loss scalars of the step in one static tensor / this call's copy
@@ -269,8 +279,13 @@ class StaticBuffers:
         self.log = None         # a dict key -> [host array of every stage() call, in order] while a checker records the batches
                                 # (tests / bench.py's loss parity: with the cross-iteration overlap the buffers of the
                                 # discriminator steps already hold the NEXT iteration's batch when an iteration returns)
+        self.replay = None      # a dict key -> [host arrays]: while set, the n-th stage() call of a key uploads the n-th array of its
+                                # list INSTEAD of the caller's draw (tests: a single process re-runs the concatenated batches that
+                                # the ranks of a data-parallel run logged); a key without entries left stages the caller's array
 
     def stage(self, key, array, dtype=None):
+        if self.replay is not None and self.replay.get(key):
+            array = self.replay[key].pop(0)
         t = torch.as_tensor(array)
         if dtype is not None:
             t = t.to(dtype)
@@ -292,6 +307,14 @@ class StaticBuffers:
         b.copy_(self._pinned[key], non_blocking=True)
         ev.record()
         return b
+
+    def wait_staged(self, prefix):
+        """Orders the CURRENT stream after the last upload of every key that starts with `prefix`: for a consumer that may run on
+        another stream than the one the batch was staged on (batches staged ahead of their step on a sibling step's stream)."""
+        cur = torch.cuda.current_stream()
+        for key, ev in self._events.items():
+            if ev is not None and key.startswith(prefix):
+                cur.wait_event(ev)
 
     def __getitem__(self, key):
         return self.bufs[key]

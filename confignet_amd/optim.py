@@ -42,7 +42,7 @@ class Adam:
         self.lr, self.beta_1, self.beta_2, self.epsilon = lr, beta_1, beta_2, epsilon
         self.iterations = 0
         self._state = {}
-        self._checked_lists = set()        # (network, variable list) pairs whose Keras-form call has been checked
+        self._checked_lists = {}           # network -> the variable list its last Keras-form call was checked with
         self._lr_dev = {}
 
     def lr_t(self):
@@ -92,7 +92,9 @@ class Adam:
             listed = frozenset(id(var) for _, var in pairs)
             for owner in nets:
                 st = self._state.get(id(owner))
-                if st is None or (id(owner), listed) in self._checked_lists:
+                # (re-checked whenever the list differs from the owner's PREVIOUS call: A, superset B, A again must fail on the
+                # third call -- B's extra weights carry moments by then)
+                if st is None or self._checked_lists.get(id(owner)) == listed:
                     continue
                 # once per (optimizer, variable list): one masked reduction over the SECOND-moment arena (v > 0 wherever a
                 # weight has ever had a non-zero gradient in this optimizer) restricted to the unlisted weights
@@ -103,7 +105,7 @@ class Adam:
                         mask[off:off + w.numel()] = True
                 assert not bool((st[1].ne(0) & mask).any()), \
                     "apply_gradients(zip(grads, vars)): an unlisted weight of a listed network has optimizer state"
-                self._checked_lists.add((id(owner), listed))
+                self._checked_lists[id(owner)] = listed
         if not isinstance(nets, (list, tuple)):
             nets = [nets]
         if _deferred is not None:

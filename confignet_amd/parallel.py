@@ -26,11 +26,95 @@ def init_from_env():
         os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-    backend = "nccl" if torch.cuda.is_available() else "gloo"
-    if backend == "nccl":
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    backend = os.environ.get("CN_DP_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+    assert backend in ("nccl", "gloo"), "CN_DP_BACKEND must be nccl or gloo"
+    if torch.cuda.is_available():
+        # CN_DP_SHARE_DEVICE=1 (with CN_DP_BACKEND=gloo): the ranks share the visible devices round-robin -- the way N > 1
+        # ranks of the product path run on a one-GPU box (RCCL refuses two ranks on one device)
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        if os.environ.get("CN_DP_SHARE_DEVICE", "0") == "1":
+            assert backend == "gloo", "CN_DP_SHARE_DEVICE=1 needs CN_DP_BACKEND=gloo (RCCL wants one device per rank)"
+            local %= torch.cuda.device_count()
+        torch.cuda.set_device(local)
     dist.init_process_group(backend=backend, init_method="env://")
     return world
+
+
+def _host_staged(t):
+    """True when the collective on `t` goes through a host copy: a device tensor on a gloo group (CN_DP_BACKEND=gloo, the
+    N-ranks-on-one-GPU test configuration).  The copy down is issued on the calling stream and waited for, the copy back is
+    issued on the calling stream again: the same ordering against the caller's launches as RCCL's stream-ordered form."""
+    return t.is_cuda and dist.get_backend() == "gloo"
+
+
+class _HostWork:
+    """An in-flight SUM all-reduce of a device tensor through its host copy (gloo); wait() writes the result back (scaled)."""
+
+    def __init__(self, t, scale, async_op):
+        self.t, self.scale = t, scale
+        self.host = t.detach().to("cpu")                      # waits for the calling stream up to here
+        self.work = dist.all_reduce(self.host, op=dist.ReduceOp.SUM, async_op=True)
+        if not async_op:
+            self.wait()
+
+    def wait(self):
+        self.work.wait()
+        if self.scale != 1.0:
+            self.host.mul_(self.scale)
+        self.t.copy_(self.host)                               # on the calling stream
+
+
+def _all_reduce_mean(t, async_op=False):
+    """Mean over ranks of `t`, in place.  Returns None, or with async_op an object with wait() that the caller MUST call
+    before it reads `t` (for RCCL the wait orders the calling stream after the collective; no host blocking)."""
+    ws = world_size()
+    if _host_staged(t):
+        w = _HostWork(t, 1.0 / ws, async_op)
+        return w if async_op else None
+    if t.is_cuda:
+        return dist.all_reduce(t, op=dist.ReduceOp.AVG, async_op=async_op)     # ncclAvg: no scaling pass
+
+    class _Scaled:                                  # gloo on host tensors (CPU tests): no AVG
+        def __init__(self, work):
+            self.work = work
+
+        def wait(self):
+            self.work.wait()
+            t.mul_(1.0 / ws)
+    w = _Scaled(dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True))
+    if async_op:
+        return w
+    w.wait()
+    return None
+
+
+def all_reduce_sum(t):
+    """SUM over ranks of `t`, in place, ordered against the calling stream."""
+    if _host_staged(t):
+        _HostWork(t, 1.0, False)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t
+
+
+def all_reduce_max(t):
+    if _host_staged(t):
+        h = t.detach().to("cpu")
+        dist.all_reduce(h, op=dist.ReduceOp.MAX)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return t
+
+
+def broadcast_(t, src=0):
+    if _host_staged(t):
+        h = t.detach().to("cpu")
+        dist.broadcast(h, src=src)
+        t.copy_(h)
+    else:
+        dist.broadcast(t, src=src)
+    return t
 
 
 def world_size():
@@ -53,14 +137,8 @@ def allreduce_flat_(buffers):
     a hand-rolled side-stream + 1/world pass cost 12 ms per iteration in cross-stream hops, this form costs none)."""
     if not active():
         return
-    if buffers[0].is_cuda:
-        for b in buffers:
-            dist.all_reduce(b, op=dist.ReduceOp.AVG)
-    else:                                          # gloo (CPU tests): no AVG
-        ws = world_size()
-        for b in buffers:
-            dist.all_reduce(b, op=dist.ReduceOp.SUM)
-            b.mul_(1.0 / ws)
+    for b in buffers:
+        _all_reduce_mean(b)
 
 
 def allreduce_sum_inline(t):
@@ -70,7 +148,7 @@ def allreduce_sum_inline(t):
     if not active():
         return t
     from . import graphs
-    graphs.segment_break(lambda: dist.all_reduce(t, op=dist.ReduceOp.SUM))
+    graphs.segment_break(lambda: all_reduce_sum(t))
     return t
 
 
@@ -83,13 +161,9 @@ def begin_allreduce(nets):
     with compute (the rest of the backward pass).  `allreduce_gradients` later waits for it instead of reducing again."""
     if not active():
         return
-    ws = world_size()
     for n in nets:
         assert id(n) not in _pending, "gradient all-reduce already in flight"
-        if n.grad_arena.is_cuda:
-            _pending[id(n)] = (dist.all_reduce(n.grad_arena, op=dist.ReduceOp.AVG, async_op=True), None)
-        else:                                      # gloo (CPU tests): no AVG
-            _pending[id(n)] = (dist.all_reduce(n.grad_arena, op=dist.ReduceOp.SUM, async_op=True), 1.0 / ws)
+        _pending[id(n)] = _all_reduce_mean(n.grad_arena, async_op=True)
 
 
 def allreduce_gradients(nets):
@@ -103,10 +177,7 @@ def allreduce_gradients(nets):
         if pend is None:
             rest.append(n.grad_arena)
         else:
-            work, scale = pend
-            work.wait()
-            if scale is not None:
-                n.grad_arena.mul_(scale)
+            pend.wait()
     if rest:
         allreduce_flat_(rest)
 
@@ -116,9 +187,9 @@ def broadcast_weights(nets, src=0):
     if world_size() == 1:
         return
     for n in nets:
-        dist.broadcast(n.arena, src=src)
+        broadcast_(n.arena, src=src)
         for w in n.weights:
             if not w.requires_grad:
-                dist.broadcast(w, src=src)
+                broadcast_(w, src=src)
         n.mark_updated()
         n.non_trainable_changed()

@@ -153,6 +153,46 @@ def test_fine_tune_force_neutral_expression_keeps_the_expression_slice_fixed():
     _check_loss_trajectory(m.fine_tune_loss_log, hist)
 
 
+def test_fine_tune_at_the_stated_size_runs_200_steps_and_starts_on_the_oracle(monkeypatch):
+    """BASELINE.json configs[3] at its stated size (reference confignet_second_stage.py:321-403): one 256 x 256 image, 200 steps,
+    replayed step graph.  The first step (identical weights) must agree with the float64 oracle at 256 x 256 in every loss scalar
+    to 1e-3 and in the embedding / rotation after that step; the 200-step run must stay finite, keep moving exactly the
+    trainable slices, and bring the objective down (the optimizer minimises loss_sum over the embedding, the rotation and the
+    generator copy: a wrong sign / stale graph input / lr_t shows up as a flat or rising curve)."""
+    monkeypatch.setattr(MG, "RES", 256)
+    m, W, inp = _fine_tune_model()
+    imgs = inp["ft_imgs"].astype(np.float32)
+    assert imgs.shape == (1, 256, 256, 3)
+    cfg = dict(MG.FT_CFG, output_shape=(256, 256, 3))
+    Wt = {k: [t64(w) for w in v] for k, v in W.items()}
+    vgg = [t64(w) for w in m.perceptual_loss._pretrained_dnn_activations.get_weights()]
+    vggface = [t64(w) for w in m.perceptual_loss_face_reco._pretrained_dnn_activations.get_weights()]
+    emb_r, rot_r, hist, _ = S.fine_tune_on_img(Wt, cfg, t64(imgs), 1, vgg, vggface, MG.FT_EXPR)
+    m.use_graphs = True
+    m.fine_tune_loss_log = []
+    emb0, rot0 = m.encode_images(imgs)
+    emb, rot = m.fine_tune_on_img(imgs, n_iters=200)
+    log = m.fine_tune_loss_log
+    assert len(log) == 200 and list(log[0].keys()) == list(hist[0].keys())
+    for k, v in hist[0].items():
+        assert abs(log[0][k] - v) <= 1e-3 * max(1.0, abs(v)), ("step 0", k, log[0][k], v)
+    vals = np.array([[d[k] for k in log[0].keys()] for d in log])
+    assert np.isfinite(vals).all() and np.isfinite(emb).all() and np.isfinite(rot).all()
+    total = vals[:, list(log[0].keys()).index("loss_sum")]
+    print("fine-tune 256^2: loss_sum first %.4f, mean of steps 0-9 %.4f, 95-104 %.4f, 190-199 %.4f" %
+          (total[0], total[:10].mean(), total[95:105].mean(), total[190:].mean()))
+    assert total[190:].mean() < total[:10].mean() and total[95:105].mean() < total[:10].mean()
+    # every embedding entry and rotation is a variable of the loop (l.340-352): none can move further than 200 Adam steps of
+    # lr = 1e-4 (|step| <= lr up to the bias correction), and the loop must have moved them
+    d = np.abs(emb.astype(np.float64) - emb0.astype(np.float64))[0]
+    assert 2e-4 < d.max() <= 200 * 1e-4 * 1.05, d.max()
+    assert np.abs(rot - rot0).max() <= 200 * 1e-4 * 1.05
+    # a second call of ONE step from the same state reproduces the oracle's first step
+    emb1, rot1 = m.fine_tune_on_img(imgs, n_iters=1)
+    err = np.abs(emb1 - emb_r.numpy()).ravel()
+    assert np.quantile(err, 0.9) < 5e-5 and err.max() < 2.5e-4 and np.abs(rot1 - rot_r.numpy()).max() < 1e-4, (err.max(), rot1, rot_r)
+
+
 # ------------------------------------------------------------------------------------------------------------
 def _oracle_batch(m, real_set, synth_set, dtype=torch.float64, staged=None):
     """The batches of one iteration, rebuilt on the host from the indices / flags / parameters the step functions
@@ -832,3 +872,101 @@ def test_data_parallel_dispatch_with_overlap_matches_single_process(tmp_path):
         if k[0] == "f":
             wrong = float((np.abs(a[k] - c[k]) > 0.1 * lr).mean())
             assert wrong < 0.02, (k, wrong)
+
+
+def _run_two_ranks(tmp_path, tag, global_stats, deterministic, port):
+    """Two processes of tests/dp2_run_helper.py on the ONE device, a gloo group between them (RCCL refuses two ranks on one
+    device; gloo moves the same arenas through the host).  Returns the two ranks' result files."""
+    import subprocess
+    helper = os.path.join(ROOT, "tests", "dp2_run_helper.py")
+    procs, paths = [], []
+    for r in range(2):
+        env = {k: v for k, v in os.environ.items() if k not in ("CN_FORCE_DP",)}
+        env.update({"CN_DP_BACKEND": "gloo", "CN_DP_SHARE_DEVICE": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port),
+                    "RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": "2", "OMP_NUM_THREADS": "8"})
+        path = str(tmp_path / ("%s_rank%d.npz" % (tag, r)))
+        paths.append(path)
+        log = open(str(tmp_path / ("%s_rank%d.log" % (tag, r))), "w")
+        procs.append((subprocess.Popen([sys.executable, helper, path, "rank", "8", str(global_stats), str(deterministic)],
+                                       env=env, cwd=ROOT, stdout=log, stderr=subprocess.STDOUT), log))
+    try:
+        for p, log in procs:
+            rc = p.wait(timeout=1500)
+            log.close()
+            assert rc == 0, open(log.name).read()[-4000:]
+    finally:
+        for p, _ in procs:
+            if p.poll() is None:
+                p.kill()
+    return paths
+
+
+def _rel_l2(a, b):
+    a, b = a.astype(np.float64), b.astype(np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+@pytest.mark.parametrize("deterministic", [0, 1])
+def test_two_rank_data_parallel_run_of_the_benchmarked_dispatch(tmp_path, deterministic):
+    """BASELINE.json configs[2] with N > 1 (reference confignet_second_stage.py:277-288 on every rank): TWO
+    processes run the benchmark's own model at 256 x 256, batch 8 each, in the benchmark's dispatch -- step graphs that end after
+    the backward pass, gradient all-reduce + Adam issued eagerly after every replay, split discriminator graphs whose real half
+    is pre-replayed under the previous generator tail, the generator step's two-part backward with the early buckets, per-rank
+    seeds -- for three iterations, once with the per-rank batch statistics and once with dp_global_batch_statistics.
+    (a) the replicas stay BIT-IDENTICAL (weights and both Adam moments of every network on the two ranks);
+    (b) the gradient Adam saw in iteration 1 (beta_1 = 0: its first moment) equals the gradient of ONE process that runs the
+        concatenated batch of 16 -- for every network with the global statistics, for the discriminator-type networks (whose
+        losses are per-sample means) in either form;
+    (c) the ranks drew different batches."""
+    import subprocess
+    runs = {}
+    for gs in (0, 1):
+        paths = _run_two_ranks(tmp_path, "gs%d" % gs, gs, deterministic, 29561 + gs + 2 * deterministic)
+        runs[gs] = [np.load(p) for p in paths]
+    helper = os.path.join(ROOT, "tests", "dp2_run_helper.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("CN_FORCE_DP", "CN_DP_BACKEND", "CN_DP_SHARE_DEVICE", "RANK", "WORLD_SIZE")}
+    single_path = str(tmp_path / "single.npz")
+    r = subprocess.run([sys.executable, helper, single_path, "single", "16", "0", str(deterministic)] +
+                       [str(tmp_path / ("gs1_rank%d.npz" % i)) for i in range(2)],
+                       env=env, cwd=ROOT, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    single = np.load(single_path)
+    assert not bool(single["dp"][0]) and not bool(single["split"].any())
+    for gs in (0, 1):
+        r0, r1 = runs[gs]
+        assert bool(r0["dp"][0]) and bool(r0["split"].all()) and int(r0["g_segments"][0]) >= 2       # early-bucket cut(s) present
+        assert np.isfinite(r0["losses"]).all() and np.isfinite(r1["losses"]).all()
+        # (a) replicas bit for bit
+        for k in r0.files:
+            if k[0] == "w" or k.startswith(("first_", "last_")):
+                assert np.array_equal(r0[k], r1[k]), (gs, k, float(np.abs(r0[k] - r1[k]).max()))
+        # (c) different batches per rank, and the two configurations drew the same ones
+        assert not np.array_equal(r0["log/d/real_idx"], r1["log/d/real_idx"]) and not np.array_equal(r0["log/g/rot"], r1["log/g/rot"])
+        assert np.array_equal(r0["log/g/synth_idx"], runs[1][0]["log/g/synth_idx"])
+    # (b) rank-mean gradient == global-batch gradient.  Networks in moment order: d_opt -> discriminator, synth-D, latent-D;
+    # g_opt -> the generator step's networks.  The per-rank and the single run use different tiles / row splits for batch 8 and
+    # 16, so the comparison is at fp32 summation noise plus the odd LeakyReLU decision taken differently
+    keys = sorted(k for k in single.files if k.startswith("first_m"))
+    assert len(keys) >= 6
+    worst = {}
+    for gs in (0, 1):
+        for k in keys:
+            g_dp, g_one = runs[gs][0][k], single[k]
+            assert np.abs(g_one).max() > 0
+            worst[(gs, k)] = _rel_l2(g_dp, g_one)
+    print("rank-mean vs global-batch gradient, rel L2:", {("%d/%s" % k): "%.2e" % v for k, v in worst.items()})
+    n_d = 3                                           # discriminator, synthetic discriminator, latent discriminator
+    for (gs, k), e in worst.items():
+        idx = int(k[len("first_m"):])
+        if gs == 1 or idx < n_d:
+            assert e <= 2e-4, (gs, k, e)
+    # per-rank statistics are a DIFFERENT objective for the generator step's networks (SURVEY.md section 8e option (ii)): the
+    # gradient must differ there, or the flag does nothing
+    assert max(worst[(0, k)] for k in keys[n_d:]) > 10 * max(worst[(1, k)] for k in keys[n_d:])
+    # loss scalars that are per-sample means: mean over ranks == global batch (first iteration; same weights)
+    names = [str(n) for n in single["loss_names"]]
+    l_dp = 0.5 * (runs[1][0]["losses"][0] + runs[1][1]["losses"][0])
+    l_one = single["losses"][0]
+    for i, n in enumerate(names):
+        if "GAN" in n or "gp" in n.lower() or "r1" in n.lower():
+            assert abs(l_dp[i] - l_one[i]) <= 1e-4 * max(1.0, abs(l_one[i])), (n, l_dp[i], l_one[i])
