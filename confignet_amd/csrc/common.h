@@ -52,6 +52,12 @@ int cn_sum_parts(const float* src, float* dst, int parts, long count, int accumu
 int cn_gemm1x1(const CnConvGeom* gp, int cfg, int bt, const float* A, const float* B, const float* bias, float* C, long M, int N, int K,
                int act, float slope, int splits, long part_stride, int par, hipStream_t s, const float* res = nullptr);
 
+// fwd2.hip: the same contract on the LDS-DMA main loop (both operands straight into LDS, NS stages deep); x_elems / w_elems size the
+// buffer descriptors
+int cn_fwd2(const CnConvGeom* gp, int cfg, int bt, const float* A, const float* B, const float* bias, float* C, long M, int N, int K,
+            int act, float slope, int splits, long part_stride, int par, hipStream_t s, const float* res, double x_elems, double w_elems);
+void cn_fwd2_tune(int kb, int ns);
+
 // profiling hooks (prof.hip): bracket one launch of the dominant kernel class
 // family: which kernel of the class is launched (cn_prof_collect_by_family); bytes: the launch's algorithmic HBM bytes
 enum { CN_FAM_FWD_128x128 = 0, CN_FAM_FWD_128x64, CN_FAM_FWD_64x64, CN_FAM_FWD_128x32, CN_FAM_FWD_128x96, CN_FAM_WGRAD_128x128,

@@ -1118,6 +1118,8 @@ static int g_tune_cfg = getenv("CN_CFG") ? atoi(getenv("CN_CFG")) : -1;         
 static int g_tune_splits = getenv("CN_SPLITS") ? atoi(getenv("CN_SPLITS")) : 0;
 static long g_tune_wg_blocks = getenv("CN_WG_BLOCKS") ? atol(getenv("CN_WG_BLOCKS")) : 0;
 static int g_xcd = getenv("CN_NO_XCD") ? 0 : 1;
+static int g_fwd2_env = getenv("CN_FWD2") ? atoi(getenv("CN_FWD2")) : 1;      // the LDS-DMA forward loop (fwd2.hip): on unless CN_FWD2=0
+static int g_fwd2_sel = -1;                                                    // cn_conv_loop_select override
 
 template <int WM, int WN, int TM, int TN>
 int launch_fwd(const CnConvGeom& g, bool vec, int par, int splits, const float* x, const float* w, const float* bias,
@@ -1340,6 +1342,63 @@ static int conv_fwd_impl(const CnConvGeom* gp, const float* x, const float* w, c
         if (want > nks / min_steps) want = nks / min_steps;
         if (want > 1) splits = (int)want;
     }
+    // The LDS-DMA main loop (fwd2.hip) keeps the matrix pipe fed from ONE workgroup per CU (its loads run NS steps ahead of the
+    // MFMAs and none of its instructions sits outside an MFMA's shadow), so it does not need the 4 workgroups per CU the
+    // register-staged loops are split for -- and every K split it avoids saves the zero pass, a tile of atomics per workgroup and
+    // the separate bias / activation pass (13 us of a 60 us launch at M = 4096, K = 2304, N = 256; scripts/dev/fwd2_sweep.py).
+    const int fwd2_on = g_fwd2_sel >= 0 ? g_fwd2_sel : g_fwd2_env;
+    const bool fwd2_takes = fwd2_on && vec && nks_total > 8 && g.cin >= 64 && g.cout >= 64 && g.dl_d <= 2 && g.dl_h <= 2 && g.dl_w <= 2 &&
+                            (double)g.n * g.in_d * g.in_h * g.in_w * g.cin < 5.3e8 && (double)g.k_d * g.k_h * g.k_w * g.cin * g.cout < 5.3e8;
+    if (fwd2_takes) {
+        const int T = g.k_d * g.k_h * g.k_w;
+        // a parity-ordered 1x1 data gradient (ResNet's strided projections) has ONE live class: only M / (dl_d dl_h dl_w) of
+        // its rows do any work, the tiles of the other classes store zeros and leave
+        const long Me = (par && T == 1) ? M / ((long)g.dl_d * g.dl_h * g.dl_w) : M;
+        long nks = nks_total;
+        if (par) nks /= (long)g.dl_d * g.dl_h * g.dl_w;
+        splits = 1;
+        if (par && T > 1) {
+            // classes of 1 / 2 / 2 / 4 live taps (a quarter of the rows each): the 64 x 64 tile (128 x 96 for cout = 96 once it fills
+            // the chip twice), K slices only for the 64 x 64 tile, where they also even out the load between the classes
+            cfg = 2;
+            tiles = (long)cn_cdiv(M, 64) * cn_cdiv(g.cout, 64);
+            if (!no_n96 && g.cout % 96 == 0 && g.cout % 64 != 0 && (long)cn_cdiv(M, 128) * (g.cout / 96) >= 512) {
+                cfg = 4;
+                tiles = (long)cn_cdiv(M, 128) * (g.cout / 96);
+            }
+            if (cfg == 2 && tiles < 1024) {
+                long want = (1536 + tiles / 2) / tiles;
+                if (want > 16) want = 16;
+                if (want > nks / 8) want = nks / 8;
+                if (want > 1) splits = (int)want;
+            }
+        } else {
+            // Tile and K split together from a cost model of the launch (microseconds): the workgroups of one CU share its matrix
+            // pipes, so a launch of W workgroups takes ceil(W / 256) workgroup lifetimes of (K steps) x (MFMA time of a step +
+            // what the tile leaves exposed: measured per tile, scripts/dev/fwd2_sweep.py), plus a fixed start / drain, plus --
+            // with a K split -- the zero pass, the separate bias / activation pass and one tile of atomics per workgroup.  What
+            // the thresholds of the register-staged loops could not see is the quantisation: 384 workgroups on 256 CUs take as
+            // long as 512.
+            // The 64 x 64 tile wins the tile sweep almost everywhere with this loop (16 accumulator registers and 32 KB of LDS: five
+            // workgroups per CU, so their barriers and fills interleave, and 4x finer load balance than a 128 x 128 tile); the one
+            // exception is cout = 96, where 64-wide tiles pad a quarter of their columns and the 128 x 96 tile pads nothing.
+            struct Cand { int cfg, bm, bn; double step_us; };
+            const Cand cands[2] = {{2, 64, 64, 0.265}, {4, 128, 96, 0.68}};
+            double best = 0.0;
+            bool have = false;
+            for (const Cand& c : cands) {
+                if (c.cfg == 4 && (no_n96 || g.cout % 96 != 0 || g.cout % 64 == 0 || (long)cn_cdiv(Me, 128) * (g.cout / 96) < 256)) continue;
+                const long tl = (long)cn_cdiv(Me, c.bm) * cn_cdiv(g.cout, c.bn);
+                const long smax = nks / 8 > 1 ? (nks / 8 > 16 ? 16 : nks / 8) : 1;
+                for (long s_ = 1; s_ <= smax; ++s_) {
+                    const double waves = (double)cn_cdiv(tl * s_, 256);
+                    double t = 10.0 + waves * (double)cn_cdiv(nks, s_) * c.step_us * (waves == 1.0 ? 1.06 : 1.0);
+                    if (s_ > 1) t += 9.0 + (double)s_ * (double)M * g.cout * 4.0 / 6.0e6;
+                    if (!have || t < best) { have = true; best = t; cfg = c.cfg; tiles = tl; splits = (int)s_; }
+                }
+            }
+        }
+    }
     if (g_tune_cfg >= 0) cfg = g_tune_cfg;                        // tuning overrides (cn_conv_tune; scripts/conv_sweep.py)
     if (g_tune_splits > 0) splits = g_tune_splits;
     if (res && splits > 1) return CN_EUNSUPPORTED;
@@ -1369,8 +1428,17 @@ static int conv_fwd_impl(const CnConvGeom* gp, const float* x, const float* w, c
     // (not for <= 8-step reductions: its three-load prologue is most of such a launch -- 38 -> 45 us on 16 384 x 128 x 512)
     static const int no_g1 = (getenv("CN_NO_GEMM1X1") ? 1 : 0);
     const bool rows_ok = !no_g1 && nks_total > 8;
+    // the LDS-DMA main loop (fwd2.hip)
+    if (fwd2_takes && rows_ok && cfg != 3) {
+        const bool plain = !par && g.k_d * g.k_h * g.k_w == 1 && g.s_d == 1 && g.s_h == 1 && g.s_w == 1 && g.dl_d == 1 && g.dl_h == 1 &&
+                           g.dl_w == 1 && !g.up && g.p_d == 0 && g.p_h == 0 && g.p_w == 0 && g.out_d == g.in_d && g.out_h == g.in_h &&
+                           g.out_w == g.in_w;
+        const double xe = (double)g.n * g.in_d * g.in_h * g.in_w * g.cin, we = (double)g.k_d * g.k_h * g.k_w * g.cin * g.cout;
+        e = cn_fwd2(plain ? nullptr : &g, cfg, bt, x, w, bias, y, M, g.cout, g.cin, kact, slope, splits, part_stride, plain ? 0 : par, s, res, xe, we);
+    }
     if (rows_ok && vec && !par && g.k_d * g.k_h * g.k_w == 1 && g.s_d == 1 && g.s_h == 1 && g.s_w == 1 && g.dl_d == 1 && g.dl_h == 1 &&
-        g.dl_w == 1 && !g.up && g.p_d == 0 && g.p_h == 0 && g.p_w == 0 && g.out_d == g.in_d && g.out_h == g.in_h && g.out_w == g.in_w)
+        g.dl_w == 1 && !g.up && g.p_d == 0 && g.p_h == 0 && g.p_w == 0 && g.out_d == g.in_d && g.out_h == g.in_h && g.out_w == g.in_w &&
+        e == CN_EUNSUPPORTED)
         e = cn_gemm1x1(nullptr, cfg, bt, x, w, bias, y, M, g.cout, g.cin, kact, slope, splits, part_stride, 0, s, res);
     // every other vec layer: the same main loop over gathered rows (parity-ordered ones included)
     static const int no_g2 = getenv("CN_NO_IGEMM_ROWS") ? 1 : 0;
@@ -1607,6 +1675,13 @@ extern "C" int cn_sumpool2(const void* gu, void* gx, int nd, int n, int d, int h
 // Tuning hook (scripts/conv_sweep.py): force the tile configuration (0 = 128x128, 1 = 128x64, 2 = 64x64, 3 = 128x32, 4 = 128x96;
 // -1 = heuristic), the split-K factor of cn_conv_fwd / cn_conv_dgrad (0 = heuristic) and the workgroup target of cn_conv_wgrad
 // (0 = default).  Process-wide; not for production use.
+extern "C" int cn_conv_loop_select(int loop, int kb, int ns) {
+    CN_CHECK_ARG(loop >= -1 && loop <= 1 && (kb == 0 || kb == 16 || kb == 32) && (ns == 0 || ns == 3 || ns == 4), "cn_conv_loop_select: bad argument");
+    g_fwd2_sel = loop;
+    cn_fwd2_tune(kb, ns);
+    return CN_OK;
+}
+
 extern "C" int cn_conv_tune(int cfg, int splits, long wg_blocks) {
     g_tune_cfg = cfg;
     g_tune_splits = splits;

@@ -54,6 +54,12 @@ def check(lines, name):
         if op.startswith("ds_"):
             pending.append(("lds", set()))
         inflight = set().union(*[p[1] for p in pending]) if pending else set()
+        if op.startswith("v_mad_u64_u32") and len(toks) >= 5:
+            # 32-bit a * b + c compiled as the 64-bit multiply-add: the addend is a register PAIR whose high half is undefined (the
+            # compiler takes whatever register follows c) and only the low half of the result is used; carries go upward only, so a
+            # stale high addend cannot reach it.  Reading that register is benign; every other operand is checked as usual.
+            hi = regs(toks[4]) - {min(regs(toks[4]))} if len(regs(toks[4])) == 2 else set()
+            used = used - (hi - set().union(*[regs(t) for t in toks[:4]]))
         if used & inflight:
             bad += 1
             print("%s:%d  %s   <- touches in-flight %s" % (name, no, ins, sorted(used & inflight)))

@@ -46,7 +46,7 @@ def test_geometry_same_padding_rules():
 
 
 def test_no_register_of_an_in_flight_lds_read_is_touched_before_its_wait(tmp_path):
-    """The LDS-DMA kernels (wgrad2, Winograd F(2x2) / F(4x4)) read their MFMA operands with ds_read instructions inside inline asm
+    """The LDS-DMA kernels (wgrad2, fwd2, Winograd F(2x2) / F(4x4)) read their MFMA operands with ds_read instructions inside inline asm
     and wait for them with hand-counted s_waitcnt lgkmcnt(n): the compiler does not know the asm's result arrives later, so any
     copy it places between the asm and the wait reads the register too early (round 4: tied "+v" operands of the wait became
     v_mov copies in wgrad2_kernel<128x128> -- tile-shaped errors and NaN under LDS contention, never in isolation).
@@ -61,7 +61,7 @@ def test_no_register_of_an_in_flight_lds_read_is_touched_before_its_wait(tmp_pat
     sys.path.insert(0, os.path.join(ROOT, "scripts"))
     import isa_lds_hazard
     csrc = os.path.join(ROOT, "confignet_amd", "csrc")
-    for name in ("wgrad2", "winograd", "winograd4"):
+    for name in ("wgrad2", "winograd", "winograd4", "fwd2"):
         subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-save-temps", "-c",
                         os.path.join(csrc, name + ".hip"), "-I" + csrc, "-I" + os.path.join(ROOT, "include"), "-o", name + ".o"],
                        cwd=tmp_path, check=True, capture_output=True)

@@ -906,6 +906,20 @@ def _rel_l2(a, b):
     return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
 
 
+def _run_single(tmp_path, tag, batch, deterministic, replay):
+    """One process of tests/dp2_run_helper.py re-running the batches that ranks of a two-rank run logged (concatenated)."""
+    import subprocess
+    helper = os.path.join(ROOT, "tests", "dp2_run_helper.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("CN_FORCE_DP", "CN_DP_BACKEND", "CN_DP_SHARE_DEVICE", "RANK", "WORLD_SIZE")}
+    path = str(tmp_path / (tag + ".npz"))
+    r = subprocess.run([sys.executable, helper, path, "single", str(batch), "0", str(deterministic)] + list(replay),
+                       env=env, cwd=ROOT, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    out = np.load(path)
+    assert not bool(out["dp"][0]) and not bool(out["split"].any())
+    return out
+
+
 @pytest.mark.parametrize("deterministic", [0, 1])
 def test_two_rank_data_parallel_run_of_the_benchmarked_dispatch(tmp_path, deterministic):
     """BASELINE.json configs[2] with N > 1 (reference confignet_second_stage.py:277-288 on every rank): TWO
@@ -913,60 +927,82 @@ def test_two_rank_data_parallel_run_of_the_benchmarked_dispatch(tmp_path, determ
     the backward pass, gradient all-reduce + Adam issued eagerly after every replay, split discriminator graphs whose real half
     is pre-replayed under the previous generator tail, the generator step's two-part backward with the early buckets, per-rank
     seeds -- for three iterations, once with the per-rank batch statistics and once with dp_global_batch_statistics.
-    (a) the replicas stay BIT-IDENTICAL (weights and both Adam moments of every network on the two ranks);
-    (b) the gradient Adam saw in iteration 1 (beta_1 = 0: its first moment) equals the gradient of ONE process that runs the
-        concatenated batch of 16 -- for every network with the global statistics, for the discriminator-type networks (whose
-        losses are per-sample means) in either form;
+    (a) the replicas stay BIT-IDENTICAL (weights and both Adam moments of every network on the two ranks, after 1 and 3 iterations);
+    (b) the gradient Adam saw in iteration 1 (beta_1 = 0: its first moment IS the all-reduced gradient)
+        * deterministic mode, discriminator-type networks: equals 0.5 * (g_0 + g_1) BIT FOR BIT, g_r = the gradient of a single
+          process that runs rank r's logged batches at batch 8 (same kernels, same launch shapes: the exchange adds nothing but
+          the mean);
+        * equals the gradient of ONE process that runs the concatenated batch of 16, to what two fp32 runs with different launch
+          shapes (batch 8 / 16 pick different tiles and row splits) can agree on: 1e-3 relative L2 for the discriminator-type
+          networks (measured 8e-5 ... 5.5e-4; the latent discriminator, an MLP, 1.2e-7), 4e-2 for the generator step's networks
+          with the global batch statistics (measured 2e-3 ... 1.5e-2: the chain generator -> VGG-19 -> ResNet-50 -> six heads
+          differs by 1e-2 ... 1e-1 between ANY two summation orders through LeakyReLU / ReLU / max-pool decisions on near-zero
+          inputs, DESIGN.md section 7 -- the exact statement of this identity is the float64 gloo test, tests/test_parallel_cpu.py);
+        * the flag does what it says: with dp_global_batch_statistics the rank mean of the latent-regression loss equals the
+          batch-16 value, with per-rank statistics (SURVEY.md section 8e option (ii)) it does not;
     (c) the ranks drew different batches."""
-    import subprocess
     runs = {}
     for gs in (0, 1):
         paths = _run_two_ranks(tmp_path, "gs%d" % gs, gs, deterministic, 29561 + gs + 2 * deterministic)
         runs[gs] = [np.load(p) for p in paths]
-    helper = os.path.join(ROOT, "tests", "dp2_run_helper.py")
-    env = {k: v for k, v in os.environ.items() if k not in ("CN_FORCE_DP", "CN_DP_BACKEND", "CN_DP_SHARE_DEVICE", "RANK", "WORLD_SIZE")}
-    single_path = str(tmp_path / "single.npz")
-    r = subprocess.run([sys.executable, helper, single_path, "single", "16", "0", str(deterministic)] +
-                       [str(tmp_path / ("gs1_rank%d.npz" % i)) for i in range(2)],
-                       env=env, cwd=ROOT, capture_output=True, text=True, timeout=1500)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
-    single = np.load(single_path)
-    assert not bool(single["dp"][0]) and not bool(single["split"].any())
+    single = _run_single(tmp_path, "single16", 16, deterministic, [str(tmp_path / ("gs1_rank%d.npz" % i)) for i in range(2)])
     for gs in (0, 1):
         r0, r1 = runs[gs]
         assert bool(r0["dp"][0]) and bool(r0["split"].all()) and int(r0["g_segments"][0]) >= 2       # early-bucket cut(s) present
         assert np.isfinite(r0["losses"]).all() and np.isfinite(r1["losses"]).all()
         # (a) replicas bit for bit
+        n_checked = 0
         for k in r0.files:
             if k[0] == "w" or k.startswith(("first_", "last_")):
                 assert np.array_equal(r0[k], r1[k]), (gs, k, float(np.abs(r0[k] - r1[k]).max()))
+                n_checked += 1
+        assert n_checked >= 8 + 2 * 2 * 7
         # (c) different batches per rank, and the two configurations drew the same ones
         assert not np.array_equal(r0["log/d/real_idx"], r1["log/d/real_idx"]) and not np.array_equal(r0["log/g/rot"], r1["log/g/rot"])
         assert np.array_equal(r0["log/g/synth_idx"], runs[1][0]["log/g/synth_idx"])
-    # (b) rank-mean gradient == global-batch gradient.  Networks in moment order: d_opt -> discriminator, synth-D, latent-D;
-    # g_opt -> the generator step's networks.  The per-rank and the single run use different tiles / row splits for batch 8 and
-    # 16, so the comparison is at fp32 summation noise plus the odd LeakyReLU decision taken differently
     keys = sorted(k for k in single.files if k.startswith("first_m"))
-    assert len(keys) >= 6
+    assert len(keys) == 7                             # d_opt: discriminator, synth-D, latent-D; g_opt: the generator step's four
+    # (b) deterministic mode: the exchanged gradient is exactly the mean of the two local ones
+    if deterministic:
+        local = [_run_single(tmp_path, "single8_r%d" % r, 8, 1, [str(tmp_path / ("gs0_rank%d.npz" % r))]) for r in range(2)]
+        # (the three discriminator-type networks: their steps come first in the iteration, so every rank and the lone processes
+        # differentiate at the same weights.  The generator step follows the discriminator updates -- made with the EXCHANGED
+        # gradient in the two-rank run, with the local one in a lone process -- so its gradients are not comparable this way.)
+        for k in keys[:3]:
+            mean = (local[0][k] + local[1][k]) * np.float32(0.5)
+            assert np.abs(mean).max() > 0
+            assert np.array_equal(runs[0][0][k], mean), (k, _rel_l2(runs[0][0][k], mean))
+        # ... and each rank computed what a lone process computes: every scalar of the three discriminator-type steps
+        names0 = [str(n) for n in single["loss_names"]]
+        n_dtype = [i for i, n in enumerate(names0) if n == "loss_sum"][2] + 1
+        assert np.array_equal(local[0]["losses"][0][:n_dtype], runs[0][0]["losses"][0][:n_dtype])
+    # (b) rank mean against the global batch
     worst = {}
     for gs in (0, 1):
         for k in keys:
-            g_dp, g_one = runs[gs][0][k], single[k]
-            assert np.abs(g_one).max() > 0
-            worst[(gs, k)] = _rel_l2(g_dp, g_one)
+            assert np.abs(single[k]).max() > 0
+            worst[(gs, k)] = _rel_l2(runs[gs][0][k], single[k])
     print("rank-mean vs global-batch gradient, rel L2:", {("%d/%s" % k): "%.2e" % v for k, v in worst.items()})
-    n_d = 3                                           # discriminator, synthetic discriminator, latent discriminator
+    n_d = 3
     for (gs, k), e in worst.items():
         idx = int(k[len("first_m"):])
-        if gs == 1 or idx < n_d:
-            assert e <= 2e-4, (gs, k, e)
-    # per-rank statistics are a DIFFERENT objective for the generator step's networks (SURVEY.md section 8e option (ii)): the
-    # gradient must differ there, or the flag does nothing
-    assert max(worst[(0, k)] for k in keys[n_d:]) > 10 * max(worst[(1, k)] for k in keys[n_d:])
-    # loss scalars that are per-sample means: mean over ranks == global batch (first iteration; same weights)
+        if idx < n_d:
+            assert e <= 1e-3, (gs, k, e)
+        elif gs == 1:
+            assert e <= 4e-2, (gs, k, e)
+    # loss scalars, first iteration (same weights everywhere): per-sample means agree between the rank mean and the global batch;
+    # the latent-regression term only with the global statistics
     names = [str(n) for n in single["loss_names"]]
-    l_dp = 0.5 * (runs[1][0]["losses"][0] + runs[1][1]["losses"][0])
     l_one = single["losses"][0]
-    for i, n in enumerate(names):
-        if "GAN" in n or "gp" in n.lower() or "r1" in n.lower():
-            assert abs(l_dp[i] - l_one[i]) <= 1e-4 * max(1.0, abs(l_one[i])), (n, l_dp[i], l_one[i])
+    dev = {}
+    for gs in (0, 1):
+        l_dp = 0.5 * (runs[gs][0]["losses"][0] + runs[gs][1]["losses"][0])
+        for i, n in enumerate(names):
+            if n.startswith("GAN_loss") or n == "latent_GAN_loss":
+                # (forward-only scalars; the deepest heads of the discriminators on GENERATED images sit behind generator + five
+                # blocks and differ by up to ~1e-3 between two launch-shape sets: measured 5e-4 ... 6e-4 on GAN_loss_synth_5)
+                assert abs(l_dp[i] - l_one[i]) <= 3e-3 * max(1.0, abs(l_one[i])), (gs, n, l_dp[i], l_one[i])
+        i = [j for j, n in enumerate(names) if n == "latent_regression_loss"][-1]
+        dev[gs] = abs(l_dp[i] - l_one[i]) / abs(l_one[i])
+    print("latent-regression loss, |rank mean - global batch| / global:", dev)
+    assert dev[1] <= 2e-4 and dev[0] > 20 * max(dev[1], 1e-6), dev
