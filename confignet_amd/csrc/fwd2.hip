@@ -445,9 +445,11 @@ int cn_fwd2(const CnConvGeom* gp, int cfg, int bt, const float* A, const float* 
     if (x_elems * 4.0 >= 2147483647.0 || w_elems * 4.0 >= 2147483647.0) return CN_EUNSUPPORTED;      // 32-bit byte offsets
     const unsigned ab = (unsigned)(x_elems * 4.0), bb = (unsigned)(w_elems * 4.0);
     static const CnConvGeom none = {};
-    // stage count: four where they fit next to a second workgroup's (64 x 64: 32 KB, 128 x 64: 48 KB), three for the 128-wide
-    // tiles (48 KB instead of 64 KB) -- same-shape A/B: 128 x 96 101 vs 121 us at M = 65 536, 64 x 64 84 vs 111 us at M = 8 192
-    int kb = g_fwd2_kb ? g_fwd2_kb : 16, ns = g_fwd2_ns ? g_fwd2_ns : ((cfg == 0 || cfg == 4) ? 3 : 4);
+    // stage count: three (24 / 36 / 48 KB: more workgroups per CU) unless the launch is so small that a CU holds one or two
+    // workgroups anyway -- then the fourth stage's extra step of look-ahead is what hides the fill latency (same-shape A/B: 64 x 64
+    // 388 vs 418 us at M = 1 310 720, 84 vs 111 us the other way round at M = 8 192 with two K slices)
+    const long wgs = (long)cn_cdiv(M, cfg == 2 ? 64 : 128) * cn_cdiv(N, cfg == 0 ? 128 : cfg == 4 ? 96 : 64) * splits;
+    int kb = g_fwd2_kb ? g_fwd2_kb : 16, ns = g_fwd2_ns ? g_fwd2_ns : ((cfg == 0 || cfg == 4 || wgs >= 2048) ? 3 : 4);
     if (kb == 32 && (K % 32 != 0 || cfg != 2)) kb = 16;            // 32-deep stages: the 64 x 64 tile only
     if (kb == 32) ns = 3;
 #define L3(WM, WN, TM, TN, KB_, NS_)                                                                                                          \

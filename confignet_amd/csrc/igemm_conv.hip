@@ -1120,6 +1120,7 @@ static long g_tune_wg_blocks = getenv("CN_WG_BLOCKS") ? atol(getenv("CN_WG_BLOCK
 static int g_xcd = getenv("CN_NO_XCD") ? 0 : 1;
 static int g_fwd2_env = getenv("CN_FWD2") ? atoi(getenv("CN_FWD2")) : 1;      // the LDS-DMA forward loop (fwd2.hip): on unless CN_FWD2=0
 static int g_fwd2_sel = -1;                                                    // cn_conv_loop_select override
+static int g_fwd2_min_c = getenv("CN_FWD2_MINC") ? atoi(getenv("CN_FWD2_MINC")) : 48;   // thinnest layer it takes (A/B: 64 = round-5 first form)
 
 template <int WM, int WN, int TM, int TN>
 int launch_fwd(const CnConvGeom& g, bool vec, int par, int splits, const float* x, const float* w, const float* bias,
@@ -1347,7 +1348,7 @@ static int conv_fwd_impl(const CnConvGeom* gp, const float* x, const float* w, c
     // register-staged loops are split for -- and every K split it avoids saves the zero pass, a tile of atomics per workgroup and
     // the separate bias / activation pass (13 us of a 60 us launch at M = 4096, K = 2304, N = 256; scripts/dev/fwd2_sweep.py).
     const int fwd2_on = g_fwd2_sel >= 0 ? g_fwd2_sel : g_fwd2_env;
-    const bool fwd2_takes = fwd2_on && vec && nks_total > 8 && g.cin >= 64 && g.cout >= 64 && g.dl_d <= 2 && g.dl_h <= 2 && g.dl_w <= 2 &&
+    const bool fwd2_takes = fwd2_on && vec && nks_total > 8 && g.cin >= g_fwd2_min_c && g.cout >= g_fwd2_min_c && g.dl_d <= 2 && g.dl_h <= 2 && g.dl_w <= 2 &&
                             (double)g.n * g.in_d * g.in_h * g.in_w * g.cin < 5.3e8 && (double)g.k_d * g.k_h * g.k_w * g.cin * g.cout < 5.3e8;
     if (fwd2_takes) {
         const int T = g.k_d * g.k_h * g.k_w;

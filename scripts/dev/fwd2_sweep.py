@@ -1,6 +1,7 @@
 """Sweep of the forward / data-gradient main loops over the iteration's own shapes: for every captured conv_fwd / conv_dgrad
 launch with >= 64 channels on both sides that Winograd does not take, time tile cfg x split-K for the register-staged loop
 (gemm1x1.hip) and the LDS-DMA loop (fwd2.hip, NS = 3 / 4).  python scripts/dev/fwd2_sweep.py [batch] > out.txt"""
+import os
 import sys
 from collections import OrderedDict
 
@@ -67,7 +68,9 @@ tot = {"old_auto": 0.0, "new_auto3": 0.0, "new_auto4": 0.0, "old_best": 0.0, "ne
 for kk, cnt in calls.items():
     kind = kk[0]
     g = ops.CnConvGeom(*kk[1:])
-    if g.cin < 64 or g.cout < 64 or g.cin % 16 or g.cout % 16:
+    MINC = int(os.environ.get('SWEEP_MINC', '64'))
+    MAXC = int(os.environ.get('SWEEP_MAXC', '100000'))
+    if min(g.cin, g.cout) < MINC or min(g.cin, g.cout) > MAXC or g.cin % 16 or g.cout % 16:
         continue
     if ops._wino_ok(g, g.cin, g.cout) if kind == "fwd" else ops._wino_ok(g, g.cout, g.cin):
         continue                                     # Winograd's
