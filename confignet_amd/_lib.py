@@ -52,7 +52,7 @@ SIGNATURES = {
     "cn_conv_wgrad_workspace_bytes": [_G],
     "cn_conv_wgrad_ws": [_G, _p, _p, _p, _i, _p, _z, _p],
     "cn_conv_tune": [_i, _i, ctypes.c_long],
-    "cn_conv_loop_select": [_i, _i, _i],
+    "cn_conv_loop_select": [_i, _i, _i, _i],
     "cn_conv_fwd_dt": [_p, _p, _i, _p, _p, _p, _i, _i, _f, _p],
     "cn_conv_dgrad_dt": [_p, _p, _i, _p, _p, _i, _p],
     "cn_conv_wgrad_c3_partials": [],

@@ -76,7 +76,7 @@ __device__ __forceinline__ void f2_static_for(F&& f) {
 
 // (the body is a device function: with generic lambdas directly inside the __global__ template hipcc 7.2 leaves the kernel's
 // host-side launch stub undefined)
-template <int WM, int WN, int TM, int TN, bool BT, bool GATHER, int KB, int NS>
+template <int WM, int WN, int TM, int TN, bool BT, bool GATHER, int KB, int NS, int NP>
 __device__ __forceinline__ void fwd2_body(const CnConvGeom& g, const float* __restrict__ A, const float* __restrict__ B,
                                           const float* __restrict__ bias, float* __restrict__ C, int M, int N, int K,
                                           int act, float slope, int ntm, int ntn, long part_stride, int par,
@@ -88,12 +88,18 @@ __device__ __forceinline__ void fwd2_body(const CnConvGeom& g, const float* __re
     constexpr int FSH = KP == 4 ? 2 : 1;             // swizzle: piece ^= (row >> FSH) & (KP - 1)
     constexpr int G = KB / 8;                        // 8-deep MFMA groups per stage
     constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
-    constexpr int IA = BM / RPI, JA = IA / 4;        // A: wave instructions per stage / per wave
-    static_assert(IA % 4 == 0, "A pieces divide over the 4 waves");
+    // NP = 0: the four MFMA waves also issue the LDS-DMA pieces (behind their last MFMAs).  NP = 1 / 2: that many LOADER waves
+    // (waves 4 ..) issue all of them and the MFMA waves never touch the vector memory path: an LDS-DMA instruction holds its
+    // wave's issue for 60 - 70 cycles -- longer than the 64-cycle shadow of the MFMA it sits behind -- and the 64 x 64 tile has
+    // one per four MFMAs (ablation: 7.7 us of a 56 us launch).
+    constexpr int NL = NP > 0 ? NP : 4;              // waves that load
+    constexpr int IA = BM / RPI, JA = IA / NL;       // A: wave instructions per stage / per loading wave
+    static_assert(IA % NL == 0, "A pieces divide over the loading waves");
+    static_assert(NP == 0 || KB == 16, "loader waves: 16-deep stages");
     constexpr int IB = BT ? BN / RPI : KB * BN / 256;
-    constexpr int JB = (IB + 3) / 4;
-    constexpr int LPW = JA + JB;                     // LDS-DMA instructions per wave and step (dummies keep it uniform)
-    constexpr int SA = BM * KB, SB = JB * 4 * 256;   // floats per stage
+    constexpr int JB = (IB + NL - 1) / NL;
+    constexpr int LPW = JA + JB;                     // LDS-DMA instructions per loading wave and step (dummies keep it uniform)
+    constexpr int SA = BM * KB, SB = JB * NL * 256;  // floats per stage
     constexpr int NB = BT ? TN : 4 * (TN == 2 ? 1 : TN);
     constexpr int RD = TM + NB;                      // DS instructions per operand set
     static_assert((NS - 1) * LPW < 64, "vmcnt range");
@@ -102,7 +108,9 @@ __device__ __forceinline__ void fwd2_body(const CnConvGeom& g, const float* __re
 
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // (an SGPR: LDS-DMA destinations and tile offsets stay scalar)
-    const int wm = wave / WN, wn = wave % WN;
+    const bool loader = NP == 0 || wave >= 4, worker = wave < 4;      // (NP = 0: every wave is both)
+    const int lw = NP > 0 ? wave - 4 : wave;                          // index among the loading waves
+    const int wm = (wave & 3) / WN, wn = (wave & 3) % WN;
     // workgroup order (parity-ordered launches keep the plain order: see gemm1x1_kernel)
     int bx, by;
     if (GATHER && par) {
@@ -149,12 +157,16 @@ __device__ __forceinline__ void fwd2_body(const CnConvGeom& g, const float* __re
     // the 1 KB block = (row I * RPI + L / KP, piece slot L % KP) and therefore FETCHES piece (L % KP) ^ f(row)
     RowInfo ri[JA];
     int a_base[JA];                                  // element offset of the row's channel 0 at the current tap, or -1
-    // f(row) = (row >> FSH) & (KP - 1) with row = (wave + 4 j) * RPI + L / KP: 4 j * RPI is a multiple of 32 and drops out
-    const int a_piece = 4 * ((lane % KP) ^ (((wave * RPI + lane / KP) >> FSH) & (KP - 1)));
+    // f(row) = (row >> FSH) & (KP - 1) with row = I * RPI + L / KP: for 16-deep stages (RPI = 16) I drops out; for 32-deep ones
+    // (RPI = 8, NP = 0 only) I = wave + 4 j contributes wave & 1
+    const int a_piece = 4 * ((lane % KP) ^ ((((lw & 1) * RPI + lane / KP) >> FSH) & (KP - 1)));
 #pragma unroll
     for (int j = 0; j < JA; ++j) {
-        const int r = (wave + 4 * j) * RPI + lane / KP;
-        if (GATHER) {
+        const int r = (lw + NL * j) * RPI + lane / KP;
+        if (!loader) {
+            ri[j] = RowInfo{};
+            a_base[j] = -1;
+        } else if (GATHER) {
             int mrow = m0 + r, cls;
             if (par) mrow = par_row(g, mrow, M, cls);
             ri[j] = decode_row(g, mrow, M);
@@ -168,7 +180,7 @@ __device__ __forceinline__ void fwd2_body(const CnConvGeom& g, const float* __re
     int b_krow[JB];
 #pragma unroll
     for (int j = 0; j < JB; ++j) {
-        const int I = wave + 4 * j;
+        const int I = lw + NL * j;
         if (BT) {
             const int n = n0 + I * RPI + lane / KP;
             b_off[j] = (I < IB && n < N) ? n * K + a_piece : -1;
@@ -224,9 +236,9 @@ __device__ __forceinline__ void fwd2_body(const CnConvGeom& g, const float* __re
     set_so();
     auto issue_piece = [&](int stage, int p) __attribute__((always_inline)) {
         if (p < JA)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(ares, (lds_float*)(SM + stage * SA + (wave + 4 * p) * 256), 16, a_vo[p], a_so, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ares, (lds_float*)(SM + stage * SA + (lw + NL * p) * 256), 16, a_vo[p], a_so, 0, 0);
         else
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(bres, (lds_float*)(SM + NS * SA + stage * SB + (wave + 4 * (p - JA)) * 256), 16,
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(bres, (lds_float*)(SM + NS * SA + stage * SB + (lw + NL * (p - JA)) * 256), 16,
                                                      b_vo[p - JA], b_so, 0, 0);
     };
     auto advance = [&]() __attribute__((always_inline)) {      // after the last piece of a step
@@ -291,15 +303,44 @@ __device__ __forceinline__ void fwd2_body(const CnConvGeom& g, const float* __re
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i][j], 0, 0, 0);
     };
 
+    if (NP > 0 && !worker) {
+        // ---- a loader wave: the same protocol as the MFMA waves' (one barrier per step: step t+1 has landed / stage t is free),
+        // nothing but LDS-DMA
+        if (nks > 0) {
+#pragma unroll 1
+            for (int s = 0; s < NS; ++s) {
+#pragma unroll
+                for (int p = 0; p < LPW; ++p) issue_piece(s, p);
+                advance();
+            }
+            f2_wait_vmcnt<(NS - 1) * LPW>();
+            __builtin_amdgcn_s_barrier();
+            int st = 0;
+#pragma unroll 1
+            for (int t = 0; t < nks; ++t) {
+                f2_wait_vmcnt<(NS - 2) * LPW>();
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int p = 0; p < LPW; ++p) issue_piece(st, p);
+                advance();
+                st = st + 1 == NS ? 0 : st + 1;
+            }
+            f2_wait_vmcnt<0>();
+        }
+        return;
+    }
     if (nks > 0) {
         // prologue: NS steps in flight (stage s holds step s)
+        if (NP == 0) {
 #pragma unroll 1
-        for (int s = 0; s < NS; ++s) {
+            for (int s = 0; s < NS; ++s) {
 #pragma unroll
-            for (int p = 0; p < LPW; ++p) issue_piece(s, p);
-            advance();
+                for (int p = 0; p < LPW; ++p) issue_piece(s, p);
+                advance();
+            }
+            f2_wait_vmcnt<(NS - 1) * LPW>();         // step 0: own pieces landed
         }
-        f2_wait_vmcnt<(NS - 1) * LPW>();             // step 0: own pieces landed
         __builtin_amdgcn_s_barrier();                //         everybody's pieces landed
         __builtin_amdgcn_sched_barrier(0);
         read_base(0, 0);
@@ -335,7 +376,7 @@ __device__ __forceinline__ void fwd2_body(const CnConvGeom& g, const float* __re
             // every operand of stage st is in registers once the reads retire; step t+1 has landed for this wave; barrier: for
             // everybody, and everybody is done reading stage st.  All of it in the shadow of the MFMA issued last.
             f2_wait_lgkm<0>();
-            if (!(FWD2_ABLATE & 2)) f2_wait_vmcnt<(NS - 2) * LPW>();
+            if (NP == 0 && !(FWD2_ABLATE & 2)) f2_wait_vmcnt<(NS - 2) * LPW>();
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
             // last group: group 0 of step t+1 behind its first MFMAs, then the refill of stage st (step t + NS)
@@ -352,7 +393,7 @@ __device__ __forceinline__ void fwd2_body(const CnConvGeom& g, const float* __re
                 f2_static_for<LPW>([&](auto pc) __attribute__((always_inline)) {
                     constexpr int pp = decltype(pc)::value;
                     constexpr int slot = LPW <= NM - NSL ? NM - LPW + pp : NSL + pp * (NM - NSL) / LPW;
-                    if constexpr (slot == m) {
+                    if constexpr (slot == m && NP == 0) {
                         if (!(FWD2_ABLATE & 2)) {
                             issue_piece(st, pp);
                             if (pp == LPW - 1) advance();
@@ -364,7 +405,7 @@ __device__ __forceinline__ void fwd2_body(const CnConvGeom& g, const float* __re
             st = st_next;
         }
         f2_wait_lgkm<0>();                           // (the read-ahead of the step past the end)
-        f2_wait_vmcnt<0>();                          // (the tail's re-issued loads target LDS: they must not outlive the allocation)
+        if (NP == 0) f2_wait_vmcnt<0>();             // (the tail's re-issued loads target LDS: they must not outlive the allocation)
     }
 
 
@@ -404,21 +445,21 @@ __device__ __forceinline__ void fwd2_body(const CnConvGeom& g, const float* __re
         }
 }
 
-template <int WM, int WN, int TM, int TN, bool BT, bool GATHER, int KB, int NS>
-__global__ __launch_bounds__(256) void fwd2_kernel(CnConvGeom g, const float* __restrict__ A, const float* __restrict__ B,
+template <int WM, int WN, int TM, int TN, bool BT, bool GATHER, int KB, int NS, int NP>
+__global__ __launch_bounds__(256 + 64 * NP) void fwd2_kernel(CnConvGeom g, const float* __restrict__ A, const float* __restrict__ B,
                                                    const float* __restrict__ bias, float* __restrict__ C, int M, int N, int K,
                                                    int act, float slope, int ntm, int ntn, long part_stride, int par,
                                                    const float* __restrict__ res, unsigned a_bytes, unsigned b_bytes) {
-    fwd2_body<WM, WN, TM, TN, BT, GATHER, KB, NS>(g, A, B, bias, C, M, N, K, act, slope, ntm, ntn, part_stride, par, res, a_bytes, b_bytes);
+    fwd2_body<WM, WN, TM, TN, BT, GATHER, KB, NS, NP>(g, A, B, bias, C, M, N, K, act, slope, ntm, ntn, part_stride, par, res, a_bytes, b_bytes);
 }
 
-template <int WM, int WN, int TM, int TN, bool BT, bool GATHER, int KB, int NS>
+template <int WM, int WN, int TM, int TN, bool BT, bool GATHER, int KB, int NS, int NP>
 int launch2(const CnConvGeom& g, const float* A, const float* B, const float* bias, float* C, long M, int N, int K, int act, float slope,
             int splits, long part_stride, int par, hipStream_t s, const float* res, unsigned a_bytes, unsigned b_bytes) {
     constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
     const int ntm = cn_cdiv(M, BM), ntn = cn_cdiv(N, BN);
     dim3 grid((unsigned)(par ? ntm * ntn : 8 * cn_cdiv((long)ntm * ntn, 8)), 1, (unsigned)splits);
-    hipLaunchKernelGGL((fwd2_kernel<WM, WN, TM, TN, BT, GATHER, KB, NS>), grid, dim3(256), 0, s, g, A, B, bias, C, (int)M, N, K, act, slope,
+    hipLaunchKernelGGL((fwd2_kernel<WM, WN, TM, TN, BT, GATHER, KB, NS, NP>), grid, dim3(256 + 64 * NP), 0, s, g, A, B, bias, C, (int)M, N, K, act, slope,
                        ntm, ntn, part_stride, par, res, a_bytes, b_bytes);
     CN_LAUNCH_CHECK();
     return CN_OK;
@@ -426,12 +467,14 @@ int launch2(const CnConvGeom& g, const float* A, const float* B, const float* bi
 
 int g_fwd2_kb = getenv("CN_FWD2_KB") ? atoi(getenv("CN_FWD2_KB")) : 0;     // 0: per-tile default
 int g_fwd2_ns = getenv("CN_FWD2_NS") ? atoi(getenv("CN_FWD2_NS")) : 0;
+int g_fwd2_np = getenv("CN_FWD2_NP") ? atoi(getenv("CN_FWD2_NP")) : -1;    // loader waves: -1 = per-tile default
 
 }  // namespace
 
-void cn_fwd2_tune(int kb, int ns) {
+void cn_fwd2_tune(int kb, int ns, int np) {
     g_fwd2_kb = kb;
     g_fwd2_ns = ns;
+    g_fwd2_np = np;
 }
 
 // Same contract as cn_gemm1x1 (gemm1x1.hip): tile cfg 0 / 1 / 2 / 4, bt = B is the original filter [N][K] (data gradient), split-K
@@ -452,19 +495,26 @@ int cn_fwd2(const CnConvGeom* gp, int cfg, int bt, const float* A, const float* 
     int kb = g_fwd2_kb ? g_fwd2_kb : 16, ns = g_fwd2_ns ? g_fwd2_ns : ((cfg == 0 || cfg == 4 || wgs >= 2048) ? 3 : 4);
     if (kb == 32 && (K % 32 != 0 || cfg != 2)) kb = 16;            // 32-deep stages: the 64 x 64 tile only
     if (kb == 32) ns = 3;
-#define L3(WM, WN, TM, TN, KB_, NS_)                                                                                                          \
-    return gp ? (bt ? launch2<WM, WN, TM, TN, true, true, KB_, NS_>(*gp, A, B, bias, C, M, N, K, act, slope, splits, part_stride, par, s, res, ab, bb)   \
-                    : launch2<WM, WN, TM, TN, false, true, KB_, NS_>(*gp, A, B, bias, C, M, N, K, act, slope, splits, part_stride, par, s, res, ab, bb)) \
-              : (bt ? launch2<WM, WN, TM, TN, true, false, KB_, NS_>(none, A, B, bias, C, M, N, K, act, slope, splits, part_stride, 0, s, res, ab, bb)   \
-                    : launch2<WM, WN, TM, TN, false, false, KB_, NS_>(none, A, B, bias, C, M, N, K, act, slope, splits, part_stride, 0, s, res, ab, bb))
+    // loader waves: for 64 x 64 launches of at most three workgroups per CU (above that the other workgroups' MFMAs cover a wave's
+    // LDS-DMA issue anyway and the two extra waves only cost residency: 266 -> 303 us at 8 192 workgroups); not for
+    // parity-ordered launches (their tiles differ 4 : 1 in length, the long ones run alone at the end either way: measured slower)
+    int np = g_fwd2_np >= 0 ? g_fwd2_np : ((cfg == 2 && wgs <= 768 && !par) ? 2 : 0);
+    if (cfg != 2 || kb == 32) np = 0;
+#define L3(WM, WN, TM, TN, KB_, NS_, NP_)                                                                                                          \
+    return gp ? (bt ? launch2<WM, WN, TM, TN, true, true, KB_, NS_, NP_>(*gp, A, B, bias, C, M, N, K, act, slope, splits, part_stride, par, s, res, ab, bb)   \
+                    : launch2<WM, WN, TM, TN, false, true, KB_, NS_, NP_>(*gp, A, B, bias, C, M, N, K, act, slope, splits, part_stride, par, s, res, ab, bb)) \
+              : (bt ? launch2<WM, WN, TM, TN, true, false, KB_, NS_, NP_>(none, A, B, bias, C, M, N, K, act, slope, splits, part_stride, 0, s, res, ab, bb)   \
+                    : launch2<WM, WN, TM, TN, false, false, KB_, NS_, NP_>(none, A, B, bias, C, M, N, K, act, slope, splits, part_stride, 0, s, res, ab, bb))
 #define L2(WM, WN, TM, TN)                 \
-    if (ns == 3) { L3(WM, WN, TM, TN, 16, 3); } \
-    else { L3(WM, WN, TM, TN, 16, 4); }
+    if (ns == 3) { L3(WM, WN, TM, TN, 16, 3, 0); } \
+    else { L3(WM, WN, TM, TN, 16, 4, 0); }
     switch (cfg) {
         case 0: L2(2, 2, 2, 2);
         case 1: L2(2, 2, 2, 1);
         case 2:
-            if (kb == 32) { L3(2, 2, 1, 1, 32, 3); }
+            if (kb == 32) { L3(2, 2, 1, 1, 32, 3, 0); }
+            if (np == 1) { if (ns == 3) { L3(2, 2, 1, 1, 16, 3, 1); } else { L3(2, 2, 1, 1, 16, 4, 1); } }
+            if (np == 2) { if (ns == 3) { L3(2, 2, 1, 1, 16, 3, 2); } else { L3(2, 2, 1, 1, 16, 4, 2); } }
             L2(2, 2, 1, 1);
         case 4: L2(4, 1, 1, 3);
         default: return CN_EUNSUPPORTED;

@@ -1676,10 +1676,11 @@ extern "C" int cn_sumpool2(const void* gu, void* gx, int nd, int n, int d, int h
 // Tuning hook (scripts/conv_sweep.py): force the tile configuration (0 = 128x128, 1 = 128x64, 2 = 64x64, 3 = 128x32, 4 = 128x96;
 // -1 = heuristic), the split-K factor of cn_conv_fwd / cn_conv_dgrad (0 = heuristic) and the workgroup target of cn_conv_wgrad
 // (0 = default).  Process-wide; not for production use.
-extern "C" int cn_conv_loop_select(int loop, int kb, int ns) {
-    CN_CHECK_ARG(loop >= -1 && loop <= 1 && (kb == 0 || kb == 16 || kb == 32) && (ns == 0 || ns == 3 || ns == 4), "cn_conv_loop_select: bad argument");
+extern "C" int cn_conv_loop_select(int loop, int kb, int ns, int np) {
+    CN_CHECK_ARG(loop >= -1 && loop <= 1 && (kb == 0 || kb == 16 || kb == 32) && (ns == 0 || ns == 3 || ns == 4) && np >= -1 && np <= 2,
+                 "cn_conv_loop_select: bad argument");
     g_fwd2_sel = loop;
-    cn_fwd2_tune(kb, ns);
+    cn_fwd2_tune(kb, ns, np);
     return CN_OK;
 }
 

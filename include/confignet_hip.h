@@ -136,8 +136,9 @@ int cn_conv_fwd_wino4(int n, int h, int w, int cin, int cout, const float* x, co
  * split-K factor of cn_conv_fwd / cn_conv_dgrad (0 = heuristic) and the workgroup target of cn_conv_wgrad (0 = default). */
 int cn_conv_tune(int cfg, int splits, long wg_blocks);
 /* Tuning hook of the forward / data-gradient main loop (csrc/fwd2.hip, the LDS-DMA loop): loop = 1 / 0 forces it on / off for the
- * layers it can take, -1 = the built-in choice; kb = 16 / 32 its stage depth (0 = default), ns = 3 / 4 its stage count (0 = default). */
-int cn_conv_loop_select(int loop, int kb, int ns);
+ * layers it can take, -1 = the built-in choice; kb = 16 / 32 its stage depth (0 = default), ns = 3 / 4 its stage count (0 = default),
+ * np = 0 / 1 / 2 its loader waves (waves that only issue the LDS-DMA; -1 = default). */
+int cn_conv_loop_select(int loop, int kb, int ns, int np);
 /* Backward of the folded nearest x2 upsample: out[n,p,c] = sum of the 2^nd children of p. */
 int cn_sumpool2(const void* gu, void* gx, int nd, int n, int d, int h, int w, int c, int dt, void* stream);
 

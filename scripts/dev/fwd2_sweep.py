@@ -7,6 +7,8 @@ from collections import OrderedDict
 
 import numpy as np
 import torch
+import os as _os
+NP = int(_os.environ.get("SWEEP_NP", "-1"))
 
 sys.path.insert(0, ".")
 from confignet_amd import ConfigNet, SyntheticFaceDataset, ops, optim
@@ -82,7 +84,7 @@ for kk, cnt in calls.items():
     fn = (lambda: ops.conv_fwd(xin, w, bias, g, 1, 0.3)) if kind == "fwd" else (lambda: ops.conv_dgrad(yout, w, g))
     res = {}
     for loop, ns in ((0, 0), (1, 3), (1, 4)):
-        ops.check(lib.cn_conv_loop_select(loop, 0, ns), "select")
+        ops.check(lib.cn_conv_loop_select(loop, 0, ns, NP), "select")
         for c in CFGS:
             for s in SPLITS:
                 ops.check(lib.cn_conv_tune(c, s, 0), "tune")
@@ -91,7 +93,7 @@ for kk, cnt in calls.items():
                 except Exception as e:      # unsupported combination
                     res[(loop, ns, c, s)] = float("inf")
     ops.check(lib.cn_conv_tune(-1, 0, 0), "tune")
-    ops.check(lib.cn_conv_loop_select(-1, 0, 0), "select")
+    ops.check(lib.cn_conv_loop_select(-1, 0, 0, -1), "select")
     old = {k: v for k, v in res.items() if k[0] == 0}
     new = {k: v for k, v in res.items() if k[0] == 1}
     bo, bn = min(old, key=old.get), min(new, key=new.get)
