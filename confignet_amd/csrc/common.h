@@ -57,6 +57,8 @@ int cn_gemm1x1(const CnConvGeom* gp, int cfg, int bt, const float* A, const floa
 int cn_fwd2(const CnConvGeom* gp, int cfg, int bt, const float* A, const float* B, const float* bias, float* C, long M, int N, int K,
             int act, float slope, int splits, long part_stride, int par, hipStream_t s, const float* res, double x_elems, double w_elems);
 void cn_fwd2_tune(int kb, int ns, int np);
+int cn_fwd2_bf16(const CnConvGeom& g, int cfg, int flip, const void* x, const void* wb, const float* bias, void* y, int act, float slope,
+                 int par, hipStream_t s);
 
 // profiling hooks (prof.hip): bracket one launch of the dominant kernel class
 // family: which kernel of the class is launched (cn_prof_collect_by_family); bytes: the launch's algorithmic HBM bytes

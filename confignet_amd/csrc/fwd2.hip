@@ -30,6 +30,7 @@
 #include "common.h"
 #include "mma_tile.h"
 #include "conv_geom.h"
+#include "typed.h"
 
 // Ablation builds (scripts/dev/fwd2_ablate.sh; never defined in the product build): bit 0 = no MFMAs, bit 1 = no LDS-DMA inside the
 // loop (the prologue's stages are re-read), bit 2 = no operand reads.  Results are garbage; only the durations mean something.
@@ -42,6 +43,7 @@ namespace {
 typedef __attribute__((address_space(3))) float lds_float;
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef float f2 __attribute__((ext_vector_type(2)));
+typedef __bf16 f2_bf16x8 __attribute__((ext_vector_type(8)));
 
 template <int N>
 __device__ __forceinline__ void f2_wait_vmcnt() {
@@ -76,11 +78,18 @@ __device__ __forceinline__ void f2_static_for(F&& f) {
 
 // (the body is a device function: with generic lambdas directly inside the __global__ template hipcc 7.2 leaves the kernel's
 // host-side launch stub undefined)
-template <int WM, int WN, int TM, int TN, bool BT, bool GATHER, int KB, int NS, int NP>
+// BF: bf16 storage on v_mfma_f32_32x32x16_bf16 (the compute path of BASELINE.json configs[2]): A, B and C hold bf16, K counts
+// bf16 elements, a stage row is still 64 bytes (32 elements: one 16-byte piece = the 8 consecutive k of one MFMA operand), B is
+// always K-contiguous rows ([tap][N][K]: the two prepared filter copies of igemm_bf16.hip; flip = the data gradient walks the
+// taps backwards), the output tile goes back through LDS and leaves as 16-byte row pieces.  No K split.
+template <int WM, int WN, int TM, int TN, bool BT, bool GATHER, int KB, int NS, int NP, bool BF>
 __device__ __forceinline__ void fwd2_body(const CnConvGeom& g, const float* __restrict__ A, const float* __restrict__ B,
                                           const float* __restrict__ bias, float* __restrict__ C, int M, int N, int K,
                                           int act, float slope, int ntm, int ntn, long part_stride, int par,
-                                          const float* __restrict__ res, unsigned a_bytes, unsigned b_bytes) {
+                                          const float* __restrict__ res, unsigned a_bytes, unsigned b_bytes, int flip) {
+    static_assert(!BF || BT, "bf16: both operands are K-contiguous rows");
+    constexpr int ES = BF ? 2 : 4;                   // bytes per element
+    constexpr int KE = KB * 4 / ES;                  // elements of the reduction axis per stage
     static_assert(WM * WN == 4, "4 waves per workgroup");
     static_assert(KB == 16 || KB == 32, "stage depth");
     constexpr int KP = KB / 4;                       // 16-byte pieces per row and stage
@@ -100,7 +109,10 @@ __device__ __forceinline__ void fwd2_body(const CnConvGeom& g, const float* __re
     constexpr int JB = (IB + NL - 1) / NL;
     constexpr int LPW = JA + JB;                     // LDS-DMA instructions per loading wave and step (dummies keep it uniform)
     constexpr int SA = BM * KB, SB = JB * NL * 256;  // floats per stage
-    constexpr int NB = BT ? TN : 4 * (TN == 2 ? 1 : TN);
+    // B reads per operand set: K-contiguous rows one ds_read_b128 per tile; k-major rows one read per k row (8 bytes for two
+    // adjacent columns), for a single column two k rows per ds_read2_b32 (rows 64 dwords apart: offsets 0 / 64 and 128 / 192)
+    constexpr bool B2 = !BT && TN == 1 && BN == 64;
+    constexpr int NB = BT ? TN : B2 ? 2 : 4 * (TN == 2 ? 1 : TN);
     constexpr int RD = TM + NB;                      // DS instructions per operand set
     static_assert((NS - 1) * LPW < 64, "vmcnt range");
     __shared__ __attribute__((aligned(1024))) float SM[NS * (SA + SB)];     // stage s: A at s * SA, B at NS * SA + s * SB
@@ -128,7 +140,7 @@ __device__ __forceinline__ void fwd2_body(const CnConvGeom& g, const float* __re
     }
     const int m0 = bx * BM, n0 = by * BN;
     const int T = GATHER ? g.k_d * g.k_h * g.k_w : 1;
-    const int cpb = K / KB;
+    const int cpb = K / KE;
     unsigned long long tapmask = T >= 64 ? ~0ull : ((1ull << T) - 1ull);
     if (GATHER && par) {
         int c0, c1;
@@ -159,7 +171,7 @@ __device__ __forceinline__ void fwd2_body(const CnConvGeom& g, const float* __re
     int a_base[JA];                                  // element offset of the row's channel 0 at the current tap, or -1
     // f(row) = (row >> FSH) & (KP - 1) with row = I * RPI + L / KP: for 16-deep stages (RPI = 16) I drops out; for 32-deep ones
     // (RPI = 8, NP = 0 only) I = wave + 4 j contributes wave & 1
-    const int a_piece = 4 * ((lane % KP) ^ ((((lw & 1) * RPI + lane / KP) >> FSH) & (KP - 1)));
+    const int a_piece = 16 * ((lane % KP) ^ ((((lw & 1) * RPI + lane / KP) >> FSH) & (KP - 1)));     // bytes
 #pragma unroll
     for (int j = 0; j < JA; ++j) {
         const int r = (lw + NL * j) * RPI + lane / KP;
@@ -183,7 +195,7 @@ __device__ __forceinline__ void fwd2_body(const CnConvGeom& g, const float* __re
         const int I = lw + NL * j;
         if (BT) {
             const int n = n0 + I * RPI + lane / KP;
-            b_off[j] = (I < IB && n < N) ? n * K + a_piece : -1;
+            b_off[j] = (I < IB && n < N) ? n * K * ES + a_piece : -1;             // bytes
             b_krow[j] = 0;
         } else {
             const int idx = I * 64 + lane, col = n0 + 4 * (idx % (BN / 4));
@@ -198,7 +210,7 @@ __device__ __forceinline__ void fwd2_body(const CnConvGeom& g, const float* __re
     // the per-lane byte offsets change only when the tap does.  Past the last step the loader re-issues the last step (valid
     // addresses, stages nobody reads): the vmcnt bookkeeping stays uniform without a per-piece select.
     int ld_left = nks;                               // steps still to issue
-    int ld_tap = -1, ld_c0 = (ks_beg - (ks_beg / cpb) * cpb) * KB;
+    int ld_tap = -1, ld_c0 = (ks_beg - (ks_beg / cpb) * cpb) * KE;
     if (GATHER)
         for (int o = ks_beg / cpb; o >= 0; --o) ld_tap += __ffsll((long long)(tapmask >> (ld_tap + 1)));   // the (ks_beg / cpb)-th live tap
     else
@@ -220,18 +232,18 @@ __device__ __forceinline__ void fwd2_body(const CnConvGeom& g, const float* __re
                 const bool ok = ri[j].ok & ((vd | vh | vw) >= 0) & (((vd & sh_d) | (vh & sh_h) | (vw & sh_w)) == 0) &
                                 (qd < ext_d) & (qh < ext_h) & (qw < ext_w);
                 const int off = (((ri[j].nbase + (qd >> g.up)) * g.in_h + (qh >> g.up)) * g.in_w + (qw >> g.up)) * g.cin;
-                a_vo[j] = ok ? (unsigned)(off + a_piece) * 4u : OOB;
+                a_vo[j] = ok ? (unsigned)(off * ES + a_piece) : OOB;
             }
         }
     };
     auto set_so = [&]() __attribute__((always_inline)) {
-        a_so = ld_c0 * 4;
-        b_so = BT ? ((T - 1 - ld_tap) * N * K + ld_c0) * 4 : (ld_tap * K + ld_c0) * N * 4;
+        a_so = ld_c0 * ES;
+        b_so = BT ? ((flip ? T - 1 - ld_tap : ld_tap) * N * K + ld_c0) * ES : (ld_tap * K + ld_c0) * N * 4;
     };
 #pragma unroll
-    for (int j = 0; j < JA; ++j) a_vo[j] = (!GATHER && a_base[j] >= 0) ? (unsigned)(a_base[j] + a_piece) * 4u : OOB;
+    for (int j = 0; j < JA; ++j) a_vo[j] = (!GATHER && a_base[j] >= 0) ? (unsigned)(a_base[j] * ES + a_piece) : OOB;
 #pragma unroll
-    for (int j = 0; j < JB; ++j) b_vo[j] = b_off[j] >= 0 ? (unsigned)(BT ? b_off[j] : b_krow[j] * N + b_off[j]) * 4u : OOB;
+    for (int j = 0; j < JB; ++j) b_vo[j] = b_off[j] >= 0 ? (BT ? (unsigned)b_off[j] : (unsigned)(b_krow[j] * N + b_off[j]) * 4u) : OOB;
     retap();
     set_so();
     auto issue_piece = [&](int stage, int p) __attribute__((always_inline)) {
@@ -243,7 +255,7 @@ __device__ __forceinline__ void fwd2_body(const CnConvGeom& g, const float* __re
     };
     auto advance = [&]() __attribute__((always_inline)) {      // after the last piece of a step
         if (--ld_left > 0) {
-            ld_c0 += KB;
+            ld_c0 += KE;
             if (ld_c0 == K) {
                 ld_c0 = 0;
                 if (GATHER) {
@@ -280,6 +292,12 @@ __device__ __forceinline__ void fwd2_body(const CnConvGeom& g, const float* __re
         } else if constexpr (BT) {
             constexpr int j = r - TM;
             asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(btv[set][BT ? j : 0]) : "v"(bp_cur), "n"(4 * 32 * KB * j));
+        } else if constexpr (B2) {
+            constexpr int q = 2 * (r - TM);
+            f2 v;
+            asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(v) : "v"(bp_cur), "n"(BN * q), "n"(BN * (q + 1)));
+            bnv[set][BT ? 0 : q][0] = v.x;
+            bnv[set][BT ? 0 : q + 1][0] = v.y;
         } else if constexpr (TN == 2) {
             constexpr int q = r - TM;
             f2 v;
@@ -294,13 +312,21 @@ __device__ __forceinline__ void fwd2_body(const CnConvGeom& g, const float* __re
     // Note on the TN == 2 form above: the asm writes a temporary pair and two v_mov follow it -- those copies READ the ds_read's
     // destination, so they must sit behind the wait.  They do: the copies are emitted where the values are first used (the MFMA
     // operands), which is behind f2_wait_lgkm; scripts/isa_lds_hazard.py checks exactly this on the compiled loop.
-    constexpr int NM = 4 * TM * TN;                  // MFMAs per 8-deep group
+    constexpr int NM = (BF ? 1 : 4) * TM * TN;       // MFMAs per group (fp32: 8 deep = 4 contraction pairs; bf16: one 16-deep MFMA)
     auto mfma_one = [&](auto mc, int set) __attribute__((always_inline)) {
         constexpr int m = decltype(mc)::value, q = m / (TM * TN), i = (m % (TM * TN)) / TN, j = m % TN;
         if (FWD2_ABLATE & 1) return;
-        const float a = av[set][i][q];
-        const float b = BT ? btv[set][BT ? j : 0][q] : bnv[set][BT ? 0 : q][j];
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i][j], 0, 0, 0);
+        if constexpr (BF) {
+            (void)q;
+            union { f4 f; f2_bf16x8 h; } ua, ub;
+            ua.f = av[set][i];
+            ub.f = btv[set][BT ? j : 0];
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua.h, ub.h, acc[i][j], 0, 0, 0);
+        } else {
+            const float a = av[set][i][q];
+            const float b = BT ? btv[set][BT ? j : 0][q] : bnv[set][BT ? 0 : q][j];
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i][j], 0, 0, 0);
+        }
     };
 
     if (NP > 0 && !worker) {
@@ -328,9 +354,9 @@ __device__ __forceinline__ void fwd2_body(const CnConvGeom& g, const float* __re
             }
             f2_wait_vmcnt<0>();
         }
-        return;
+        if (!BF) return;                             // (bf16: the loader waves help to move the output tile out of LDS)
     }
-    if (nks > 0) {
+    if (nks > 0 && worker) {
         // prologue: NS steps in flight (stage s holds step s)
         if (NP == 0) {
 #pragma unroll 1
@@ -361,7 +387,7 @@ __device__ __forceinline__ void fwd2_body(const CnConvGeom& g, const float* __re
                 read_base(st, gq + 1);
                 f2_static_for<NM>([&](auto mc) __attribute__((always_inline)) {
                     constexpr int m = decltype(mc)::value;
-                    constexpr int NSL = NM / 2;          // the reads go behind the FIRST half of the MFMAs: an LDS read issued one
+                    constexpr int NSL = NM > 1 ? NM / 2 : 1;   // the reads go behind the FIRST half of the MFMAs: an LDS read issued one
                                                          // MFMA (64 cycles) before its wait is not back yet (~100+ cycles)
                     mfma_one(mc, gq & 1);
                     __builtin_amdgcn_sched_barrier(0);
@@ -383,7 +409,7 @@ __device__ __forceinline__ void fwd2_body(const CnConvGeom& g, const float* __re
             read_base(st_next, 0);
             f2_static_for<NM>([&](auto mc) __attribute__((always_inline)) {
                 constexpr int m = decltype(mc)::value;
-                constexpr int NSL = NM / 2;              // reads behind the first half of the MFMAs, LDS-DMA pieces behind the second
+                constexpr int NSL = NM > 1 ? NM / 2 : 1; // reads behind the first half of the MFMAs, LDS-DMA pieces behind the second
                 mfma_one(mc, (G - 1) & 1);
                 __builtin_amdgcn_sched_barrier(0);
                 f2_static_for<RD>([&](auto rc) __attribute__((always_inline)) {
@@ -392,7 +418,8 @@ __device__ __forceinline__ void fwd2_body(const CnConvGeom& g, const float* __re
                 });
                 f2_static_for<LPW>([&](auto pc) __attribute__((always_inline)) {
                     constexpr int pp = decltype(pc)::value;
-                    constexpr int slot = LPW <= NM - NSL ? NM - LPW + pp : NSL + pp * (NM - NSL) / LPW;
+                    constexpr int slot_ = LPW <= NM - NSL ? NM - LPW + pp : NSL + pp * (NM - NSL) / LPW;
+                    constexpr int slot = slot_ < NM ? slot_ : NM - 1;
                     if constexpr (slot == m && NP == 0) {
                         if (!(FWD2_ABLATE & 2)) {
                             issue_piece(st, pp);
@@ -409,6 +436,37 @@ __device__ __forceinline__ void fwd2_body(const CnConvGeom& g, const float* __re
     }
 
 
+    if constexpr (BF) {
+        // bf16 epilogue: bias + activation in fp32, the tile as bf16 through LDS (over the operand stages: every wave is past its
+        // last operand read and every LDS-DMA has landed once the barrier releases), 16-byte row pieces out
+        constexpr int LDC = BN + 8;
+        static_assert(BM * LDC * 2 <= NS * (SA + SB) * 4, "output tile fits the operand stages");
+        bf16_t* const Cs = reinterpret_cast<bf16_t*>(SM);
+        bf16_t* const Y = reinterpret_cast<bf16_t*>(C);
+        __syncthreads();
+        if (worker) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int ct = wn * 32 * TN + 32 * j + l31, col = n0 + ct;
+                const float bv = (bias && col < N) ? bias[col] : 0.f;
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        Cs[(wm * 32 * TM + 32 * i + 4 * half + (r & 3) + 8 * (r >> 2)) * LDC + ct] =
+                            f32_to_bf16(cn_apply_act(acc[i][j][r] + bv, act, slope));
+            }
+        }
+        __syncthreads();
+        constexpr int NPC = BN / 8;
+        for (int idx = tid; idx < BM * NPC; idx += 256 + 64 * NP) {
+            const int row = idx / NPC, pc = idx - row * NPC;
+            const int orow = GATHER ? rowmap[row] : (m0 + row < M ? m0 + row : -1), col = n0 + pc * 8;
+            if (orow >= 0 && col < N)
+                *reinterpret_cast<uint4*>(Y + (long)orow * N + col) = *reinterpret_cast<const uint4*>(Cs + row * LDC + pc * 8);
+        }
+        return;
+    }
     // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
     const bool split = gridDim.z > 1;
 #pragma unroll
@@ -445,22 +503,23 @@ __device__ __forceinline__ void fwd2_body(const CnConvGeom& g, const float* __re
         }
 }
 
-template <int WM, int WN, int TM, int TN, bool BT, bool GATHER, int KB, int NS, int NP>
+template <int WM, int WN, int TM, int TN, bool BT, bool GATHER, int KB, int NS, int NP, bool BF>
 __global__ __launch_bounds__(256 + 64 * NP) void fwd2_kernel(CnConvGeom g, const float* __restrict__ A, const float* __restrict__ B,
                                                    const float* __restrict__ bias, float* __restrict__ C, int M, int N, int K,
                                                    int act, float slope, int ntm, int ntn, long part_stride, int par,
-                                                   const float* __restrict__ res, unsigned a_bytes, unsigned b_bytes) {
-    fwd2_body<WM, WN, TM, TN, BT, GATHER, KB, NS, NP>(g, A, B, bias, C, M, N, K, act, slope, ntm, ntn, part_stride, par, res, a_bytes, b_bytes);
+                                                   const float* __restrict__ res, unsigned a_bytes, unsigned b_bytes, int flip) {
+    fwd2_body<WM, WN, TM, TN, BT, GATHER, KB, NS, NP, BF>(g, A, B, bias, C, M, N, K, act, slope, ntm, ntn, part_stride, par, res, a_bytes,
+                                                          b_bytes, flip);
 }
 
-template <int WM, int WN, int TM, int TN, bool BT, bool GATHER, int KB, int NS, int NP>
+template <int WM, int WN, int TM, int TN, bool BT, bool GATHER, int KB, int NS, int NP, bool BF = false>
 int launch2(const CnConvGeom& g, const float* A, const float* B, const float* bias, float* C, long M, int N, int K, int act, float slope,
-            int splits, long part_stride, int par, hipStream_t s, const float* res, unsigned a_bytes, unsigned b_bytes) {
+            int splits, long part_stride, int par, hipStream_t s, const float* res, unsigned a_bytes, unsigned b_bytes, int flip = 1) {
     constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
     const int ntm = cn_cdiv(M, BM), ntn = cn_cdiv(N, BN);
     dim3 grid((unsigned)(par ? ntm * ntn : 8 * cn_cdiv((long)ntm * ntn, 8)), 1, (unsigned)splits);
-    hipLaunchKernelGGL((fwd2_kernel<WM, WN, TM, TN, BT, GATHER, KB, NS, NP>), grid, dim3(256 + 64 * NP), 0, s, g, A, B, bias, C, (int)M, N, K, act, slope,
-                       ntm, ntn, part_stride, par, res, a_bytes, b_bytes);
+    hipLaunchKernelGGL((fwd2_kernel<WM, WN, TM, TN, BT, GATHER, KB, NS, NP, BF>), grid, dim3(256 + 64 * NP), 0, s, g, A, B, bias, C, (int)M, N, K, act,
+                       slope, ntm, ntn, part_stride, par, res, a_bytes, b_bytes, flip);
     CN_LAUNCH_CHECK();
     return CN_OK;
 }
@@ -521,4 +580,38 @@ int cn_fwd2(const CnConvGeom* gp, int cfg, int bt, const float* A, const float* 
     }
 #undef L2
 #undef L3
+}
+
+// The bf16 family on the same loop (igemm_bf16.hip's contract for the forward / data-gradient GEMM: x and y bf16, wb = the prepared
+// filter copy [tap][N][K] with K = g.cin contiguous, flip = walk the taps backwards).  tile cfg as above; np as cn_fwd2's loader
+// waves.  CN_EUNSUPPORTED (nothing launched) unless K % 32 == 0 and N % 8 == 0.
+int cn_fwd2_bf16(const CnConvGeom& g, int cfg, int flip, const void* x, const void* wb, const float* bias, void* y, int act, float slope,
+                 int par, hipStream_t s) {
+    const long M = (long)g.n * g.out_d * g.out_h * g.out_w;
+    const int N = g.cout, K = g.cin;
+    if (K % 32 != 0 || N % 8 != 0 || M <= 0 || M > 0x7fffffffL) return CN_EUNSUPPORTED;
+    if (g.dl_d > 2 || g.dl_h > 2 || g.dl_w > 2) return CN_EUNSUPPORTED;
+    const double xe = (double)g.n * g.in_d * g.in_h * g.in_w * g.cin, we = (double)g.k_d * g.k_h * g.k_w * g.cin * g.cout;
+    if (xe * 2.0 >= 2147483647.0 || we * 2.0 >= 2147483647.0) return CN_EUNSUPPORTED;
+    const unsigned ab = (unsigned)(xe * 2.0), bb = (unsigned)(we * 2.0);
+    const float* A = reinterpret_cast<const float*>(x);
+    const float* B = reinterpret_cast<const float*>(wb);
+    float* C = reinterpret_cast<float*>(y);
+    const long wgs = (long)cn_cdiv(M, cfg == 2 ? 64 : 128) * cn_cdiv(N, cfg == 0 ? 128 : cfg == 4 ? 96 : 64);
+    const int np = g_fwd2_np >= 0 ? g_fwd2_np : 2;
+    const int ns = g_fwd2_ns ? g_fwd2_ns : ((cfg == 0 || cfg == 4 || wgs >= 2048) ? 3 : 4);
+#define LB(WM, WN, TM, TN, NS_, NP_) \
+    return launch2<WM, WN, TM, TN, true, true, 16, NS_, NP_, true>(g, A, B, bias, C, M, N, K, act, slope, 1, 0, par, s, nullptr, ab, bb, flip)
+#define LB2(WM, WN, TM, TN, NP_)   \
+    if (ns == 3) { LB(WM, WN, TM, TN, 3, NP_); } \
+    else { LB(WM, WN, TM, TN, 4, NP_); }
+    switch (cfg) {
+        case 0: if (np) { LB2(2, 2, 2, 2, 2); } LB2(2, 2, 2, 2, 0);
+        case 1: if (np) { LB2(2, 2, 2, 1, 2); } LB2(2, 2, 2, 1, 0);
+        case 2: if (np) { LB2(2, 2, 1, 1, 2); } LB2(2, 2, 1, 1, 0);
+        case 4: if (np) { LB2(4, 1, 1, 3, 2); } LB2(4, 1, 1, 3, 0);
+        default: return CN_EUNSUPPORTED;
+    }
+#undef LB2
+#undef LB
 }

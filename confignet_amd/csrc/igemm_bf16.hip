@@ -594,8 +594,14 @@ int conv_bf16(const CnConvGeom& g, int flip, const bf16_t* x, const bf16_t* wb, 
     else if (t128x64 >= 512) cfg = 1;
     else cfg = 2;
     if (g.cout % 96 == 0 && g.cout % 128 != 0 && (long)cn_cdiv(M, 128) * (g.cout / 96) >= 256) cfg = 4;
+    static const int cfg_force = getenv("CN_BF16_CFG") ? atoi(getenv("CN_BF16_CFG")) : -1;      // A/B: force the tile
+    if (cfg_force >= 0) cfg = cfg_force;
     cn_prof_begin(s, conv_flops(g), conv_bytes(g, 2.0, 2.0, 2.0), CN_FAM_BF16_FWD);
-    int e;
+    int e = CN_EUNSUPPORTED;
+    // the LDS-DMA main loop (fwd2.hip) where the reduction axis is a whole number of 32-element stages per tap
+    static const int fwd2_on = getenv("CN_FWD2_BF16") ? atoi(getenv("CN_FWD2_BF16")) : 1;
+    if (fwd2_on && cfg != 3 && g.cin % 32 == 0 && g.cout >= 48) e = cn_fwd2_bf16(g, cfg, flip, x, wb, bias, y, act, slope, par, s);
+    if (e == CN_EUNSUPPORTED)
     switch (cfg) {
         case 3: e = launch_bf16<4, 1, 1, 1>(g, par, flip, x, wb, bias, y, act, slope, s); break;   // 128 x 32
         case 4: e = launch_bf16<4, 1, 1, 3>(g, par, flip, x, wb, bias, y, act, slope, s); break;   // 128 x 96

@@ -323,6 +323,10 @@ def test_bf16_data_parallel_dispatch_at_full_size_matches_cpu_oracle(tmp_path):
             extra = {k: 0.02 * np.sqrt(ref["gp_loss_" + k.rsplit("_", 1)[1]]) for k in ref if k.startswith("GAN_loss_fake_") and "gp_loss_0" in ref}
             if "gp_loss_0" not in ref:
                 extra = {k: 0.1 * max(1.0, abs(ref[k])) for k in ref if k.startswith("GAN_loss_")}
+            # (5 x the latent discriminator's loss on bf16-encoded latents, ~15 after five training iterations: 5.5 % seen once in
+            # six runs of one build, 2 - 4 % otherwise)
+            if "latent_GAN_loss" in ref:
+                extra["latent_GAN_loss"] = 3e-2 * abs(ref["latent_GAN_loss"])
             extra["loss_sum"] = sum(extra.values())
             for k in ref:
                 n += 1
