@@ -196,8 +196,8 @@ def main():
             "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": pmc_traffic(args.dtype),
                          "mfma_busy_pmc": pmc_mfma_busy(args.dtype),
-                         "kernel": ("igemm_fwd/gemm1x1/wgrad2/igemm_wgrad/wino_fwd/wino4_fwd (implicit-GEMM + Winograd F(2x2,3x3) / F(4x4,3x3) convolutions, v_mfma_f32_32x32x2_f32)" if args.dtype == "f32" else
-                                    "igemm_bf16/igemm_bf16_wgrad (implicit-GEMM conv, v_mfma_f32_32x32x16_bf16) + the fp32 kernels of the "
+                         "kernel": ("fwd2/igemm_fwd/gemm1x1/wgrad2/igemm_wgrad/wino_fwd/wino4_fwd (implicit-GEMM + Winograd F(2x2,3x3) / F(4x4,3x3) convolutions, v_mfma_f32_32x32x2_f32)" if args.dtype == "f32" else
+                                    "fwd2<bf16>/igemm_bf16/igemm_bf16_wgrad (implicit-GEMM conv, v_mfma_f32_32x32x16_bf16) + the fp32 kernels of the "
                                     "3-channel image layers"),
                          "launches_per_step": launches / max(args.steps, 1),
                          "kernel_ms_per_step": round(kernel_ms / max(args.steps, 1), 3),
@@ -228,7 +228,7 @@ def main():
                              "note": "the same launches priced as direct convolutions (round 1's definition of the algorithmic work, "
                                      "border taps of the Winograd layers counted): an algorithmic saving, NOT a roofline fraction"},
                          "recorded": "traffic / mfma_busy_pmc come from committed rocprofv3 PMC passes and are quoted only when "
-                                     "profiles/round4_pmc_*.json carry this kernels_hash",
+                                     "profiles/round5_pmc_*.json carry this kernels_hash",
                          "kernels_hash": kernels_hash()},
             "torch_kernel_time_share": torch_kernel_share(),
         }
@@ -298,20 +298,20 @@ def _recorded(name, key):
 def pmc_traffic(dtype="f32"):
     """HBM bytes per launch of the dominant kernel class (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE;
     scripts/pmc_summary.py, scripts/pmc_traffic_json.py)."""
-    v = _recorded("round4_pmc_traffic%s.json" % ("" if dtype == "f32" else "_" + dtype), "hbm_bytes_per_launch")
+    v = _recorded("round5_pmc_traffic%s.json" % ("" if dtype == "f32" else "_" + dtype), "hbm_bytes_per_launch")
     return None if v is None else round(v)
 
 
 def pmc_mfma_busy(dtype="f32"):
     """MFMA-pipe busy fraction of the class (SQ_VALU_MFMA_BUSY_CYCLES against GRBM_GUI_ACTIVE; scripts/pmc_mfma.py)."""
-    v = _recorded("round4_pmc_mfma%s.json" % ("" if dtype == "f32" else "_" + dtype), "mfma_busy_fraction")
+    v = _recorded("round5_pmc_mfma%s.json" % ("" if dtype == "f32" else "_" + dtype), "mfma_busy_fraction")
     return None if v is None else round(v, 4)
 
 
 def torch_kernel_share():
     """Share of the GPU time of one iteration spent in PyTorch's own kernels (autograd's gradient accumulation adds, cat,
     fills, small (N, L) algebra) from the committed kernel trace of this command -- north_star: torch is plumbing."""
-    v = _recorded("round4_torch_share.json", "torch_kernel_time_share")
+    v = _recorded("round5_torch_share.json", "torch_kernel_time_share")
     return None if v is None else round(v, 4)
 
 

@@ -598,7 +598,9 @@ int cn_fwd2_bf16(const CnConvGeom& g, int cfg, int flip, const void* x, const vo
     const float* B = reinterpret_cast<const float*>(wb);
     float* C = reinterpret_cast<float*>(y);
     const long wgs = (long)cn_cdiv(M, cfg == 2 ? 64 : 128) * cn_cdiv(N, cfg == 0 ? 128 : cfg == 4 ? 96 : 64);
-    const int np = g_fwd2_np >= 0 ? g_fwd2_np : 2;
+    // loader waves where a CU holds at most ~three workgroups (as in fp32: above that the other workgroups cover a wave's LDS-DMA
+    // issue and the two extra waves only cost residency: 105 -> 139 us at 4 096 workgroups, 34 -> 28 us at 256)
+    const int np = g_fwd2_np >= 0 ? g_fwd2_np : (wgs <= 768 ? 2 : 0);
     const int ns = g_fwd2_ns ? g_fwd2_ns : ((cfg == 0 || cfg == 4 || wgs >= 2048) ? 3 : 4);
 #define LB(WM, WN, TM, TN, NS_, NP_) \
     return launch2<WM, WN, TM, TN, true, true, 16, NS_, NP_, true>(g, A, B, bias, C, M, N, K, act, slope, 1, 0, par, s, nullptr, ab, bb, flip)

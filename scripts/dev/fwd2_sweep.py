@@ -9,6 +9,7 @@ import numpy as np
 import torch
 import os as _os
 NP = int(_os.environ.get("SWEEP_NP", "-1"))
+KBS = int(_os.environ.get("SWEEP_KB", "0"))
 
 sys.path.insert(0, ".")
 from confignet_amd import ConfigNet, SyntheticFaceDataset, ops, optim
@@ -84,7 +85,7 @@ for kk, cnt in calls.items():
     fn = (lambda: ops.conv_fwd(xin, w, bias, g, 1, 0.3)) if kind == "fwd" else (lambda: ops.conv_dgrad(yout, w, g))
     res = {}
     for loop, ns in ((0, 0), (1, 3), (1, 4)):
-        ops.check(lib.cn_conv_loop_select(loop, 0, ns, NP), "select")
+        ops.check(lib.cn_conv_loop_select(loop, KBS, ns, NP), "select")
         for c in CFGS:
             for s in SPLITS:
                 ops.check(lib.cn_conv_tune(c, s, 0), "tune")

@@ -4,6 +4,7 @@ import sys
 import torch
 import os as _os
 NP = int(_os.environ.get("SWEEP_NP", "-1"))
+KBS = int(_os.environ.get("SWEEP_KB", "0"))
 import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from confignet_amd import ops
@@ -17,7 +18,7 @@ wt = torch.randn(k, k, cin, cout, device="cuda")
 b = torch.randn(cout, device="cuda")
 g = spec.geom(tuple(x.shape), cout)
 gy = torch.randn(n, g.out_h, g.out_w, cout, device="cuda")
-ops.check(lib.cn_conv_loop_select(loop, 0, ns, NP), "select")
+ops.check(lib.cn_conv_loop_select(loop, KBS, ns, NP), "select")
 ops.check(lib.cn_conv_tune(cfg, splits, 0), "tune")
 fn = (lambda: ops.conv_fwd(x, wt, b, g, 1, 0.3)) if kind == "fwd" else (lambda: ops.conv_dgrad(gy, wt, g))
 for _ in range(3):

@@ -1,9 +1,9 @@
 #!/bin/bash
 # Everything the judged profiles/ artifacts are made from, in one GPU-box call:
-#   gpurun --timeout 3000 -- 'bash scripts/make_profiles.sh round4'
+#   gpurun --timeout 3000 -- 'bash scripts/make_profiles.sh round5'
 # writes gpurun_out/profiles_<tag>/ ; copy what is to be judged into profiles/ and commit.
-# `bash scripts/make_profiles.sh round4 pmc` repeats the counter passes (section 3) only.
-TAG=${1:-round4}
+# `bash scripts/make_profiles.sh round5 pmc` repeats the counter passes (section 3) only.
+TAG=${1:-round5}
 ONLY=${2:-all}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/profiles_$TAG
@@ -14,6 +14,9 @@ if [ "$ONLY" = all ]; then
 # 1. the bench lines (default flags), fp32 and bf16
 timeout 900 $PY $R/bench.py > $O/${TAG}_bench.json 2> $O/bench.err
 timeout 300 $PY $R/bench.py --dtype bf16 --no-cpu-baseline > $O/${TAG}_bench_bf16.json 2>> $O/bench.err
+# 1b. 400-step soaks of the same two commands (a 20-step mean is 0.8 s of work)
+timeout 600 $PY $R/bench.py --steps 400 --no-cpu-baseline > $O/${TAG}_bench_400_steps.json 2>> $O/bench.err
+timeout 600 $PY $R/bench.py --steps 400 --dtype bf16 --no-cpu-baseline > $O/${TAG}_bench_bf16_400_steps.json 2>> $O/bench.err
 # 2. kernel traces: the default (concurrent graphs) command and the serial one whose averages the roofline object quotes
 rm -rf /tmp/kt1 /tmp/kt2
 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/kt1 -- $PY $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $O/${TAG}_bench_under_rocprof.json 2>/dev/null
@@ -48,6 +51,8 @@ $PY $R/scripts/pmc_traffic_json.py /tmp/pf /tmp/pw $O/${TAG}_pmc_traffic.json "p
 $PY $R/scripts/pmc_traffic_by_kernel.py /tmp/pf /tmp/pw /tmp/pf_line.json $O/${TAG}_pmc_traffic_by_kernel.txt $O/${TAG}_pmc_traffic_by_kernel.json > /dev/null
 pmc_pass /tmp/pm /dev/null --steps 2 --warmup 1 --no-cpu-baseline --serial -- SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES
 $PY $R/scripts/pmc_mfma.py /tmp/pm $O/${TAG}_pmc_mfma.json > $O/${TAG}_pmc_mfma.txt
+# 3a. one table per kernel: launches | us | MFMA-busy | t_mfma | t_rest | traffic ratio (the overlap claim, checkable in one file)
+$PY $R/scripts/overlap_table.py /tmp/pm $O/${TAG}_pmc_traffic_by_kernel.json $O/${TAG}_overlap_table.txt > /dev/null
 # 3b. the same counters for the bf16 path (configs[2]'s dtype)
 CMDB="bench.py --steps 2 --warmup 1 --no-cpu-baseline --serial --dtype bf16"
 pmc_pass /tmp/pfb /tmp/pfb_line.json --steps 2 --warmup 1 --no-cpu-baseline --serial --dtype bf16 -- FETCH_SIZE
@@ -56,6 +61,7 @@ $PY $R/scripts/pmc_traffic_json.py /tmp/pfb /tmp/pwb $O/${TAG}_pmc_traffic_bf16.
 $PY $R/scripts/pmc_traffic_by_kernel.py /tmp/pfb /tmp/pwb /tmp/pfb_line.json $O/${TAG}_pmc_traffic_by_kernel_bf16.txt $O/${TAG}_pmc_traffic_by_kernel_bf16.json > /dev/null
 pmc_pass /tmp/pmb /dev/null --steps 2 --warmup 1 --no-cpu-baseline --serial --dtype bf16 -- SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES
 $PY $R/scripts/pmc_mfma.py /tmp/pmb $O/${TAG}_pmc_mfma_bf16.json > $O/${TAG}_pmc_mfma_bf16.txt
+$PY $R/scripts/overlap_table.py /tmp/pmb $O/${TAG}_pmc_traffic_by_kernel_bf16.json $O/${TAG}_overlap_table_bf16.txt > /dev/null
 if [ "$ONLY" = all ]; then
 # 4. per-shape tables
 cd $R

@@ -26,6 +26,11 @@ def family(name):
         return "igemm_wgrad<%s>" % TILES.get(t, t)
     if "wino4_fwd_kernel" in name:
         return "wino_fwd"                             # (F(2x2) and F(4x4) are one family in cn_prof_collect_by_family)
+    if "fwd2_kernel<" in name:                        # the LDS-DMA main loop (round 5): fp32 -> igemm_fwd's tile families, bf16 -> igemm_bf16
+        args = [a.strip() for a in name.split("fwd2_kernel<")[1].split(">")[0].split(",")]
+        if args[-1] in ("true", "1"):
+            return "igemm_bf16"
+        return "igemm_fwd<%s>" % TILES.get(", ".join(args[:4]), ", ".join(args[:4]))
     if "gemm1x1_kernel" in name:                      # the plain-GEMM main loop: same tile families as igemm_fwd_kernel
         t = name.split("gemm1x1_kernel<")[1][:10]
         return "igemm_fwd<%s>" % TILES.get(t, t)

@@ -428,13 +428,14 @@ def test_pipelined_loop_at_benchmark_size_stays_finite():
 
 
 # ------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("bs", [128, 4096])
-def test_latent_gan_steps_and_ema_match_oracle(bs):
+@pytest.mark.parametrize("bs,device_sampling", [(128, False), (4096, False), (4096, True)])
+def test_latent_gan_steps_and_ema_match_oracle(bs, device_sampling):
     """bs = 4096: BASELINE.json configs[4] at its own batch size (the skinny-M dense kernels of bs = 128 give way to the MFMA
-    tile and its split-K at 4096 rows)."""
+    tile and its split-K at 4096 rows).  device_sampling: the configuration's fast path (config["device_latent_sampling"]: latents
+    from the device generator, embeddings resident on the device) -- the oracle replays the logged draws."""
     from confignet_amd import LatentGAN, optim
     L = 145
-    gan = LatentGAN({"latent_dim": L, "batch_size": bs}, seed=1)
+    gan = LatentGAN({"latent_dim": L, "batch_size": bs, "device_latent_sampling": device_sampling}, seed=1)
     rng = np.random.default_rng(2)
     for net in (gan.generator, gan.discriminator):
         net.set_weights([(w + rng.normal(size=w.shape) * 0.05).astype(np.float32) if w.ndim == 1 else w for w in net.get_weights()])
@@ -449,14 +450,20 @@ def test_latent_gan_steps_and_ema_match_oracle(bs):
         # the step functions draw their batches from np.random in the reference's order (latent_gan.py:119-123,152):
         # replay the same draws for the oracle
         state = np.random.get_state()
-        d = gan.discriminator_training_step(emb, opt)
+        gan.latent_log = [] if device_sampling else None
+        d = gan.discriminator_training_step(torch.as_tensor(emb).cuda() if device_sampling else emb, opt)
         g = gan.generator_training_step(opt)
         gan.update_smoothed_weights()
         after = np.random.get_state()
         np.random.set_state(state)
-        z_d = np.random.normal(0, 1, (bs, L))
+        if device_sampling:
+            (z_d, z_g), gan.latent_log = gan.latent_log, None
+            assert z_d.shape == (bs, L) and abs(float(z_d.mean())) < 0.02 and abs(float(z_d.std()) - 1.0) < 0.02 and not np.array_equal(z_d, z_g)
+        else:
+            z_d = np.random.normal(0, 1, (bs, L))
         idx = np.random.randint(0, emb.shape[0], bs)
-        z_g = np.random.normal(0, 1, (bs, L))
+        if not device_sampling:
+            z_g = np.random.normal(0, 1, (bs, L))
         np.random.set_state(after)
         g0, d0 = [w.detach().clone() for w in g_w], [w.detach().clone() for w in d_w]
         rd = S.latent_gan_discriminator_step(g_w, d_w, t64(emb[idx]), t64(z_d), ropt)
