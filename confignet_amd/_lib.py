@@ -42,6 +42,7 @@ SIGNATURES = {
     "cn_version": [],
     "cn_conv_fwd": [_G, _p, _p, _p, _p, _i, _f, _p],
     "cn_conv_fwd_res": [_G, _p, _p, _p, _p, _p, _i, _f, _p],
+    "cn_conv_fwd_stats": [_G, _p, _p, _p, _p, _i, _f, _p, _i, _f, _p],
     "cn_scale_columns_segments": [_p, _p, _p, _p, _i, _z, _p],
     "cn_conv_weight_tflip": [_p, _p, _i, _i, _i, _p],
     "cn_conv_dgrad": [_G, _p, _p, _p, _p],

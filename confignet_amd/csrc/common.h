@@ -55,7 +55,8 @@ int cn_gemm1x1(const CnConvGeom* gp, int cfg, int bt, const float* A, const floa
 // fwd2.hip: the same contract on the LDS-DMA main loop (both operands straight into LDS, NS stages deep); x_elems / w_elems size the
 // buffer descriptors
 int cn_fwd2(const CnConvGeom* gp, int cfg, int bt, const float* A, const float* B, const float* bias, float* C, long M, int N, int K,
-            int act, float slope, int splits, long part_stride, int par, hipStream_t s, const float* res, double x_elems, double w_elems);
+            int act, float slope, int splits, long part_stride, int par, hipStream_t s, const float* res, double x_elems, double w_elems,
+            float* stats = nullptr, int stats_mode = 0, float stats_slope = 0.f, int srows = 1, int sper = 1);
 void cn_fwd2_tune(int kb, int ns, int np);
 int cn_fwd2_bf16(const CnConvGeom& g, int cfg, int flip, const void* x, const void* wb, const float* bias, void* y, int act, float slope,
                  int par, hipStream_t s);

@@ -86,7 +86,8 @@ template <int WM, int WN, int TM, int TN, bool BT, bool GATHER, int KB, int NS, 
 __device__ __forceinline__ void fwd2_body(const CnConvGeom& g, const float* __restrict__ A, const float* __restrict__ B,
                                           const float* __restrict__ bias, float* __restrict__ C, int M, int N, int K,
                                           int act, float slope, int ntm, int ntn, long part_stride, int par,
-                                          const float* __restrict__ res, unsigned a_bytes, unsigned b_bytes, int flip) {
+                                          const float* __restrict__ res, unsigned a_bytes, unsigned b_bytes, int flip,
+                                          float* __restrict__ stats, int stats_mode, float stats_slope, int srows, int sper) {
     static_assert(!BF || BT, "bf16: both operands are K-contiguous rows");
     constexpr int ES = BF ? 2 : 4;                   // bytes per element
     constexpr int KE = KB * 4 / ES;                  // elements of the reduction axis per stage
@@ -468,7 +469,29 @@ __device__ __forceinline__ void fwd2_body(const CnConvGeom& g, const float* __re
         return;
     }
     // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    // stats (unsplit forward launches whose tiles lie inside one sample; reference building_blocks.py:37-44,97-106): the
+    // per-(sample, channel) sums the FOLLOWING normalisation layer needs, taken from the values this epilogue holds anyway instead
+    // of a separate pass over the tensor -- mode 1: sum a, sum a^2 of the stored (activated) value (AdaIn after the fused
+    // LeakyReLU); mode 2: sum v, sum v^2, sum l, sum l^2 with l = leaky_relu(v, stats_slope) (DiscrBlock: style statistics of the
+    // pre-activation tensor + instance-norm statistics of its activation).  stats[k][sample][channel], zeroed by the caller.
     const bool split = gridDim.z > 1;
+    float sacc[TN][4];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sacc[j][k] = 0.f;
+    auto stat = [&](int j, float v, float a) __attribute__((always_inline)) {
+        if (stats_mode == 1) {
+            sacc[j][0] += a;
+            sacc[j][1] += a * a;
+        } else {
+            const float l = v > 0.f ? v : v * stats_slope;
+            sacc[j][0] += v;
+            sacc[j][1] += v * v;
+            sacc[j][2] += l;
+            sacc[j][3] += l * l;
+        }
+    };
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -486,7 +509,9 @@ __device__ __forceinline__ void fwd2_body(const CnConvGeom& g, const float* __re
                 else if (split) { unsafeAtomicAdd(dst, v0); unsafeAtomicAdd(dst + 1, v1); }
                 else {
                     if (res) { const f2 rv = *reinterpret_cast<const f2*>(res + (long)row * N + col); v0 += rv.x; v1 += rv.y; }
-                    *reinterpret_cast<f2*>(dst) = f2{cn_apply_act(v0, act, slope), cn_apply_act(v1, act, slope)};
+                    const float a0 = cn_apply_act(v0, act, slope), a1 = cn_apply_act(v1, act, slope);
+                    *reinterpret_cast<f2*>(dst) = f2{a0, a1};
+                    if (stats) { stat(0, v0, a0); stat(TN - 1, v1, a1); }
                 }
             } else {
 #pragma unroll
@@ -497,29 +522,50 @@ __device__ __forceinline__ void fwd2_body(const CnConvGeom& g, const float* __re
                     float* dst = C + (long)row * N + col;
                     if (part_stride) dst[(long)blockIdx.z * part_stride] = v;
                     else if (split) unsafeAtomicAdd(dst, v);
-                    else *dst = cn_apply_act(res ? v + res[(long)row * N + col] : v, act, slope);
+                    else {
+                        const float vr = res ? v + res[(long)row * N + col] : v, a = cn_apply_act(vr, act, slope);
+                        *dst = a;
+                        if (stats) stat(j, vr, a);
+                    }
                 }
             }
         }
+    if (stats && !split && !part_stride) {
+        // the two half-waves hold the two row halves of the same columns; then one atomic per (column, sum) and wave
+        const int sample = (m0 - (m0 / sper) * sper) / srows;        // (parity-ordered rows: class-major, samples inside a class)
+        const int nk = stats_mode == 1 ? 2 : 4;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + wn * 32 * TN + (BT ? 32 * j + l31 : TN * l31 + j);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (k >= nk) break;
+                const float t = sacc[j][k] + __shfl_xor(sacc[j][k], 32);
+                if (half == 0 && col < N) unsafeAtomicAdd(stats + ((long)k * g.n + sample) * N + col, t);
+            }
+        }
+    }
 }
 
 template <int WM, int WN, int TM, int TN, bool BT, bool GATHER, int KB, int NS, int NP, bool BF>
 __global__ __launch_bounds__(256 + 64 * NP) void fwd2_kernel(CnConvGeom g, const float* __restrict__ A, const float* __restrict__ B,
                                                    const float* __restrict__ bias, float* __restrict__ C, int M, int N, int K,
                                                    int act, float slope, int ntm, int ntn, long part_stride, int par,
-                                                   const float* __restrict__ res, unsigned a_bytes, unsigned b_bytes, int flip) {
+                                                   const float* __restrict__ res, unsigned a_bytes, unsigned b_bytes, int flip,
+                                                   float* __restrict__ stats, int stats_mode, float stats_slope, int srows, int sper) {
     fwd2_body<WM, WN, TM, TN, BT, GATHER, KB, NS, NP, BF>(g, A, B, bias, C, M, N, K, act, slope, ntm, ntn, part_stride, par, res, a_bytes,
-                                                          b_bytes, flip);
+                                                          b_bytes, flip, stats, stats_mode, stats_slope, srows, sper);
 }
 
 template <int WM, int WN, int TM, int TN, bool BT, bool GATHER, int KB, int NS, int NP, bool BF = false>
 int launch2(const CnConvGeom& g, const float* A, const float* B, const float* bias, float* C, long M, int N, int K, int act, float slope,
-            int splits, long part_stride, int par, hipStream_t s, const float* res, unsigned a_bytes, unsigned b_bytes, int flip = 1) {
+            int splits, long part_stride, int par, hipStream_t s, const float* res, unsigned a_bytes, unsigned b_bytes, int flip = 1,
+            float* stats = nullptr, int stats_mode = 0, float stats_slope = 0.f, int srows = 1, int sper = 1) {
     constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
     const int ntm = cn_cdiv(M, BM), ntn = cn_cdiv(N, BN);
     dim3 grid((unsigned)(par ? ntm * ntn : 8 * cn_cdiv((long)ntm * ntn, 8)), 1, (unsigned)splits);
     hipLaunchKernelGGL((fwd2_kernel<WM, WN, TM, TN, BT, GATHER, KB, NS, NP, BF>), grid, dim3(256 + 64 * NP), 0, s, g, A, B, bias, C, (int)M, N, K, act,
-                       slope, ntm, ntn, part_stride, par, res, a_bytes, b_bytes, flip);
+                       slope, ntm, ntn, part_stride, par, res, a_bytes, b_bytes, flip, stats, stats_mode, stats_slope, srows, sper);
     CN_LAUNCH_CHECK();
     return CN_OK;
 }
@@ -540,8 +586,10 @@ void cn_fwd2_tune(int kb, int ns, int np) {
 // protocol of igemm_fwd_kernel, gp = NULL for the plain 1x1 stride-1 product, else the geometry whose gather builds the rows (par:
 // parity-ordered).  x_elems / w_elems: sizes of the two tensors (the buffer descriptors' ranges).
 int cn_fwd2(const CnConvGeom* gp, int cfg, int bt, const float* A, const float* B, const float* bias, float* C, long M, int N, int K,
-            int act, float slope, int splits, long part_stride, int par, hipStream_t s, const float* res, double x_elems, double w_elems) {
-    if (res && (splits > 1 || part_stride)) return CN_EUNSUPPORTED;
+            int act, float slope, int splits, long part_stride, int par, hipStream_t s, const float* res, double x_elems, double w_elems,
+            float* stats, int stats_mode, float stats_slope, int srows, int sper) {
+    if ((res || stats) && (splits > 1 || part_stride)) return CN_EUNSUPPORTED;
+    if (stats && bt) return CN_EUNSUPPORTED;
     if (K % 16 != 0 || N % 4 != 0 || M <= 0 || M > 0x7fffffffL || (par && !gp)) return CN_EUNSUPPORTED;
     if (gp && (gp->dl_d > 2 || gp->dl_h > 2 || gp->dl_w > 2)) return CN_EUNSUPPORTED;     // (the gather's shift-and-mask form)
     if (x_elems * 4.0 >= 2147483647.0 || w_elems * 4.0 >= 2147483647.0) return CN_EUNSUPPORTED;      // 32-bit byte offsets
@@ -560,10 +608,10 @@ int cn_fwd2(const CnConvGeom* gp, int cfg, int bt, const float* A, const float* 
     int np = g_fwd2_np >= 0 ? g_fwd2_np : ((cfg == 2 && wgs <= 768 && !par) ? 2 : 0);
     if (cfg != 2 || kb == 32) np = 0;
 #define L3(WM, WN, TM, TN, KB_, NS_, NP_)                                                                                                          \
-    return gp ? (bt ? launch2<WM, WN, TM, TN, true, true, KB_, NS_, NP_>(*gp, A, B, bias, C, M, N, K, act, slope, splits, part_stride, par, s, res, ab, bb)   \
-                    : launch2<WM, WN, TM, TN, false, true, KB_, NS_, NP_>(*gp, A, B, bias, C, M, N, K, act, slope, splits, part_stride, par, s, res, ab, bb)) \
-              : (bt ? launch2<WM, WN, TM, TN, true, false, KB_, NS_, NP_>(none, A, B, bias, C, M, N, K, act, slope, splits, part_stride, 0, s, res, ab, bb)   \
-                    : launch2<WM, WN, TM, TN, false, false, KB_, NS_, NP_>(none, A, B, bias, C, M, N, K, act, slope, splits, part_stride, 0, s, res, ab, bb))
+    return gp ? (bt ? launch2<WM, WN, TM, TN, true, true, KB_, NS_, NP_>(*gp, A, B, bias, C, M, N, K, act, slope, splits, part_stride, par, s, res, ab, bb, 1, stats, stats_mode, stats_slope, srows, sper)   \
+                    : launch2<WM, WN, TM, TN, false, true, KB_, NS_, NP_>(*gp, A, B, bias, C, M, N, K, act, slope, splits, part_stride, par, s, res, ab, bb, 1, stats, stats_mode, stats_slope, srows, sper)) \
+              : (bt ? launch2<WM, WN, TM, TN, true, false, KB_, NS_, NP_>(none, A, B, bias, C, M, N, K, act, slope, splits, part_stride, 0, s, res, ab, bb, 1, stats, stats_mode, stats_slope, srows, sper)   \
+                    : launch2<WM, WN, TM, TN, false, false, KB_, NS_, NP_>(none, A, B, bias, C, M, N, K, act, slope, splits, part_stride, 0, s, res, ab, bb, 1, stats, stats_mode, stats_slope, srows, sper))
 #define L2(WM, WN, TM, TN)                 \
     if (ns == 3) { L3(WM, WN, TM, TN, 16, 3, 0); } \
     else { L3(WM, WN, TM, TN, 16, 4, 0); }

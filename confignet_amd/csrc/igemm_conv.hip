@@ -1202,8 +1202,11 @@ int launch_wgrad(const CnConvGeom& g, const float* x, const float* gy, float* gw
 
 // bt = 1: w is the original filter of the convolution whose data gradient g describes (see igemm_fwd_kernel); only the
 // vectorised implicit-GEMM path takes it -- every other path answers CN_EUNSUPPORTED without launching.
+// stats (cn_conv_fwd_stats): the launch must be one that can carry the statistics in its epilogue -- the unsplit LDS-DMA loop with
+// tiles inside one sample -- or NOTHING is launched and the answer is CN_EUNSUPPORTED.
 static int conv_fwd_impl(const CnConvGeom* gp, const float* x, const float* w, const float* bias, float* y, int act,
-                         float slope, void* stream, int bt, const float* res = nullptr) {
+                         float slope, void* stream, int bt, const float* res = nullptr, float* stats = nullptr, int stats_mode = 0,
+                         float stats_slope = 0.f) {
     if (int e = check_geom(gp)) return e;
     CN_CHECK_ARG(x && w && y, "NULL tensor");
     const CnConvGeom g = *gp;
@@ -1211,7 +1214,8 @@ static int conv_fwd_impl(const CnConvGeom* gp, const float* x, const float* w, c
     const long M = (long)g.n * g.out_d * g.out_h * g.out_w;
     // res: only the unsplit implicit-GEMM launches carry the residual add in their epilogue -- anything else answers
     // CN_EUNSUPPORTED before launching (the caller then adds it with a pass of its own)
-    if (res && (g.cout <= 4 || g.cin == 3 || g.cout % 4 != 0)) return CN_EUNSUPPORTED;
+    if ((res || stats) && (g.cout <= 4 || g.cin == 3 || g.cout % 4 != 0)) return CN_EUNSUPPORTED;
+    if (stats && (bt || cn_det() || g.cin % BK != 0)) return CN_EUNSUPPORTED;
     if (bt && (g.cout <= 4 || g.cin % BK != 0 || g.cout % 4 != 0)) return CN_EUNSUPPORTED;
     if (g.cout <= 4) {
         const bool vec = g.cin % 4 == 0;
@@ -1358,7 +1362,10 @@ static int conv_fwd_impl(const CnConvGeom* gp, const float* x, const float* w, c
         long nks = nks_total;
         if (par) nks /= (long)g.dl_d * g.dl_h * g.dl_w;
         splits = 1;
-        if (par && T > 1) {
+        // parity classes with the same number of live taps (k % dl == 0 on every axis: the upsample-folded layers' class filters)
+        // are one balanced launch; the data gradients of the stride-2 3x3 layers mix classes of 1 / 2 / 2 / 4 taps
+        const bool par_balanced = par && g.k_d % g.dl_d == 0 && g.k_h % g.dl_h == 0 && g.k_w % g.dl_w == 0;
+        if (par && T > 1 && !par_balanced) {
             // classes of 1 / 2 / 2 / 4 live taps (a quarter of the rows each): the 64 x 64 tile (128 x 96 for cout = 96 once it fills
             // the chip twice), K slices only for the 64 x 64 tile, where they also even out the load between the classes
             cfg = 2;
@@ -1403,6 +1410,15 @@ static int conv_fwd_impl(const CnConvGeom* gp, const float* x, const float* w, c
     if (g_tune_cfg >= 0) cfg = g_tune_cfg;                        // tuning overrides (cn_conv_tune; scripts/conv_sweep.py)
     if (g_tune_splits > 0) splits = g_tune_splits;
     if (res && splits > 1) return CN_EUNSUPPORTED;
+    int srows = 1, sper = 1;
+    if (stats) {
+        // rows of one sample (inside one parity class for class-major rows); every tile must lie inside one sample
+        const int qd = par ? g.out_d / g.dl_d : g.out_d, qh = par ? g.out_h / g.dl_h : g.out_h, qw = par ? g.out_w / g.dl_w : g.out_w;
+        srows = qd * qh * qw;
+        sper = par ? g.n * srows : (int)M;
+        static const bool no_rows = getenv("CN_NO_GEMM1X1") != nullptr;
+        if (!fwd2_takes || no_rows || splits > 1 || cfg == 3 || nks_total <= 8 || srows % (cfg == 2 ? 64 : 128) != 0) return CN_EUNSUPPORTED;
+    }
     float* parts = nullptr;
     if (cn_det() && splits > 1) {
         // deterministic mode: the K splits write partial outputs into the stream's workspace (as many splits as it holds) and a
@@ -1435,7 +1451,12 @@ static int conv_fwd_impl(const CnConvGeom* gp, const float* x, const float* w, c
                            g.dl_w == 1 && !g.up && g.p_d == 0 && g.p_h == 0 && g.p_w == 0 && g.out_d == g.in_d && g.out_h == g.in_h &&
                            g.out_w == g.in_w;
         const double xe = (double)g.n * g.in_d * g.in_h * g.in_w * g.cin, we = (double)g.k_d * g.k_h * g.k_w * g.cin * g.cout;
-        e = cn_fwd2(plain ? nullptr : &g, cfg, bt, x, w, bias, y, M, g.cout, g.cin, kact, slope, splits, part_stride, plain ? 0 : par, s, res, xe, we);
+        e = cn_fwd2(plain ? nullptr : &g, cfg, bt, x, w, bias, y, M, g.cout, g.cin, kact, slope, splits, part_stride, plain ? 0 : par, s, res, xe, we,
+                    stats, stats_mode, stats_slope, srows, sper);
+        if (stats && e != CN_OK) {                   // (cannot happen after the checks above; never fall through to a kernel without them)
+            cn_prof_end(s);
+            return e == CN_EUNSUPPORTED ? CN_EINVAL : e;
+        }
     }
     if (rows_ok && vec && !par && g.k_d * g.k_h * g.k_w == 1 && g.s_d == 1 && g.s_h == 1 && g.s_w == 1 && g.dl_d == 1 && g.dl_h == 1 &&
         g.dl_w == 1 && !g.up && g.p_d == 0 && g.p_h == 0 && g.p_w == 0 && g.out_d == g.in_d && g.out_h == g.in_h && g.out_w == g.in_w &&
@@ -1471,6 +1492,13 @@ extern "C" int cn_conv_fwd(const CnConvGeom* gp, const float* x, const float* w,
 // y = act(conv(x, w) + bias + res): the residual add of a ResNet block in the convolution's epilogue (real_encoder.py:13 --
 // keras ResNet50's `Add` + `Activation("relu")` behind the block's last 1x1 convolution).  Only unsplit implicit-GEMM launches
 // carry it; CN_EUNSUPPORTED (nothing launched) otherwise.
+extern "C" int cn_conv_fwd_stats(const CnConvGeom* gp, const float* x, const float* w, const float* bias, float* y, int act,
+                                 float slope, float* stats, int stats_mode, float stats_slope, void* stream) {
+    CN_CHECK_ARG(stats && (stats_mode == 1 || stats_mode == 2), "cn_conv_fwd_stats: stats buffer and mode 1 / 2");
+    CN_CHECK_ARG(stats_mode == 1 || act == CN_ACT_NONE, "cn_conv_fwd_stats: mode 2 takes the statistics of the pre-activation output");
+    return conv_fwd_impl(gp, x, w, bias, y, act, slope, stream, 0, nullptr, stats, stats_mode, stats_slope);
+}
+
 extern "C" int cn_conv_fwd_res(const CnConvGeom* gp, const float* x, const float* w, const float* bias, const float* res, float* y,
                                int act, float slope, void* stream) {
     CN_CHECK_ARG(res, "cn_conv_fwd_res: res is NULL");

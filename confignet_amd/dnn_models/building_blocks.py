@@ -3,6 +3,7 @@ import numpy as np
 import torch
 
 from .. import functional as F
+from .. import ops
 from ..nn import Net, glorot_uniform
 from ..ops import ACT_LRELU, ACT_NONE, ConvSpec
 
@@ -57,8 +58,9 @@ def conv_adain(x, z, w6, spec):
     """Conv3dAdaIn / Conv2dAdaIn.call (building_blocks.py:37-44,73-80): conv(same)+bias ->
     LeakyReLU(0.3) [fused epilogue] -> AdaIn with [s|b] = MLP(z) (LeakyReLU 0.2)."""
     ck, cb, m0, b0, m1, b1 = w6
-    x = F.conv(x, ck, cb, spec, ACT_LRELU, KERAS_LRELU)
     sb = F.linear(F.linear(z, m0, b0, ACT_LRELU, TF_LRELU), m1, b1)
+    with ops.request_stats("act"):                   # AdaIn's statistics from the convolution's epilogue where the launch carries them
+        x = F.conv(x, ck, cb, spec, ACT_LRELU, KERAS_LRELU)
     return F.adain(x, sb)
 
 
@@ -72,7 +74,11 @@ def discr_block(x, w4, return_styles, twice_differentiable=False, intermediates=
     the tangent-pass R1).  `intermediates` (a list) receives the primal tensors the tangent pass reuses."""
     ck, cb, gamma, beta = w4
     in_shape = tuple(x.shape)
-    x = F.conv(x, ck, cb, DISCR_CONV)
+    if twice_differentiable:
+        x = F.conv(x, ck, cb, DISCR_CONV)
+    else:
+        with ops.request_stats("pre4", KERAS_LRELU):     # the tail's four sums from the convolution's epilogue where the launch carries them
+            x = F.conv(x, ck, cb, DISCR_CONV)
     if not twice_differentiable:
         y, style, mean, q, smean, ssd = F.DiscrTailFn.apply(x, gamma, beta, return_styles, KERAS_LRELU)
         if intermediates is not None:

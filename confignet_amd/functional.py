@@ -400,7 +400,8 @@ class AdaInFn(Function):
     def forward(ctx, x, scale_bias):
         x, sb = _cg(x), _cg(scale_bias)
         sp = _spatial(x)
-        s1, s2 = ops.nc_reduce(x)
+        st = ops.take_stats(x, "act")                # left by the producing convolution's epilogue (ops.request_stats), else one pass
+        s1, s2 = st if st is not None else ops.nc_reduce(x)
         a, b, mean, r = ops.norm_coef_fwd(ops.NORM_ADAIN, s1, s2, sb, None, sp, 1e-3)
         ctx.save_for_backward(x, sb, mean, r)
         return ops.nc_lin2(tuple(x.shape), x, a, b=b)
@@ -447,7 +448,12 @@ class DiscrTailFn(Function):
         x, gamma, beta = _cg(x), _cg(gamma), _cg(beta)
         sp = _spatial(x)
         style = smean = ssd = None
-        if want_style and FUSED_TAIL_STATS and x.shape[-1] % 4 == 0:
+        st = ops.take_stats(x, "pre4")               # (sum x, sum x^2, sum l, sum l^2) from the producing convolution's epilogue
+        if st is not None:
+            s1, s2, a1, a2 = st
+            if want_style:
+                style, _, smean, ssd = ops.norm_coef_fwd(ops.NORM_STYLE, s1, s2, None, None, sp, 1e-6)
+        elif want_style and FUSED_TAIL_STATS and x.shape[-1] % 4 == 0:
             s1, s2, a1, a2 = ops.nc_reduce4(x, slope)          # style + instance-norm statistics: one pass over x instead of two
             style, _, smean, ssd = ops.norm_coef_fwd(ops.NORM_STYLE, s1, s2, None, None, sp, 1e-6)
         else:

@@ -346,7 +346,42 @@ def _wino_filter(w, dgrad):
     return _weight_cache(w, "_cn_wino_d" if dgrad else "_cn_wino_f", make)
 
 
+# Statistics of a convolution's output taken in its epilogue (cn_conv_fwd_stats) for the normalisation layer that follows:
+# `with request_stats(kind[, slope])` around the convolution, `take_stats(y, kind)` in the consumer.  kind "act": (sum a, sum a^2) of
+# the stored, activated output (AdaIn); kind "pre4": (sum v, sum v^2, sum l, sum l^2), l = leaky_relu(v, slope), of a convolution
+# without activation (DiscrBlock tail).  Only launches that can carry them do (fp32, the unsplit LDS-DMA loop, tiles inside one
+# sample, a zero pool active, not the deterministic mode); everything else leaves no entry and the consumer runs its own pass.
+_stats_request = None
+_stats_ready = None          # (data_ptr, shape, kind, tensors) of the most recent fused launch
+STATS_FUSION = os.environ.get("CN_NO_STATS_FUSION") is None
+
+
+class request_stats:
+    def __init__(self, kind, slope=0.0):
+        self.req = (kind, float(slope))
+
+    def __enter__(self):
+        global _stats_request
+        self.prev, _stats_request = _stats_request, (self.req if STATS_FUSION and not DETERMINISTIC else None)
+
+    def __exit__(self, *exc):
+        global _stats_request
+        _stats_request = self.prev
+
+
+def take_stats(y, kind):
+    """The statistics the producing convolution left for tensor y, or None."""
+    global _stats_ready
+    ent, _stats_ready = _stats_ready, None
+    if ent is not None and ent[0] == y.data_ptr() and ent[1] == tuple(y.shape) and ent[2] == kind:
+        return ent[3]
+    return None
+
+
 def conv_fwd(x, w, bias, g, act=ACT_NONE, slope=0.0):
+    global _stats_request, _stats_ready
+    req, _stats_request = _stats_request, None           # (a request applies to the next convolution only)
+    _stats_ready = None
     out_dtype = _act_out_dtype(g.cout)
     if ACT_DTYPE == torch.float32 and x.dtype == torch.float32 and _wino4_ok(g, g.cin, g.cout):
         y = torch.empty(geom_out_shape(g), device=x.device, dtype=torch.float32)
@@ -376,6 +411,17 @@ def conv_fwd(x, w, bias, g, act=ACT_NONE, slope=0.0):
         if rc != CN_EUNSUPPORTED:
             check(rc, "cn_conv_fwd_dt")
     y = torch.empty(geom_out_shape(g), device=x.device, dtype=torch.float32)
+    if req is not None and out_dtype == torch.float32 and g.cout % 4 == 0 and (req[0] == "act" or act == ACT_NONE):
+        nk = 2 if req[0] == "act" else 4
+        st = zero_pool_alloc((nk, g.n, g.cout), x.device)
+        if st is not None:
+            rc = lib.cn_conv_fwd_stats(ctypes.byref(g), _ptr(_c(x)), _fptr(w), _fptr(bias), _ptr(y), act, slope, _ptr(st), 1 if nk == 2 else 2,
+                                       req[1], _stream())
+            if rc == 0:
+                _stats_ready = (y.data_ptr(), tuple(y.shape), req[0], tuple(st[k] for k in range(nk)))
+                return y
+            if rc != CN_EUNSUPPORTED:
+                check(rc, "cn_conv_fwd_stats")
     check(lib.cn_conv_fwd(ctypes.byref(g), _ptr(x), _fptr(w), _fptr(bias), _ptr(y), act, slope, _stream()), "cn_conv_fwd")
     return cast(y, out_dtype)
 

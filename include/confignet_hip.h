@@ -72,6 +72,15 @@ int cn_version(void);
  * layer; CN_NO_* environment switches, read once, turn a route off for A/B runs) -- the results are the same convolution. */
 int cn_conv_fwd(const CnConvGeom* g, const float* x, const float* w, const float* bias,
                 float* y, int act, float slope, void* stream);
+/* cn_conv_fwd that also returns the per-(sample, channel) sums the FOLLOWING normalisation layer needs, taken in the convolution's
+ * epilogue instead of a separate pass over y (reference: Conv2dAdaIn / Conv3dAdaIn -> AdaIn, building_blocks.py:37-44; DiscrBlock ->
+ * get_layer_style + InstanceNormalization, building_blocks.py:97-106).  stats (caller-zeroed, fp32): mode 1 = [2][n][cout]: sum a,
+ * sum a^2 of the stored value a = act(conv + bias); mode 2 (act must be CN_ACT_NONE) = [4][n][cout]: sum v, sum v^2, sum l, sum l^2
+ * with l = leaky_relu(v, stats_slope).  Sums are added with fp32 atomics (run-dependent last bits; refused in deterministic mode).
+ * Returns CN_EUNSUPPORTED WITHOUT launching anything unless the launch can carry them (the unsplit LDS-DMA loop with every tile
+ * inside one sample): the caller then uses cn_conv_fwd + cn_nc_reduce / cn_nc_reduce4. */
+int cn_conv_fwd_stats(const CnConvGeom* g, const float* x, const float* w, const float* bias, float* y, int act, float slope,
+                      float* stats, int stats_mode, float stats_slope, void* stream);
 /* y = act(conv(x, w) + bias + res), res of y's shape: the residual add + ReLU of a ResNet-50 block
  * (real_encoder.py:13, keras.applications ResNet50 `Add` + `Activation`) in the epilogue of the block's last
  * convolution.  Only launches without a K split carry it: CN_EUNSUPPORTED (nothing launched) otherwise. */

@@ -866,3 +866,53 @@ def test_winograd_f4x4_forward_and_data_gradient(case):
         close(ops.conv_dgrad(dev(gy), dev(w), g), xr.grad, what="winograd F(4x4) dgrad")
     finally:
         ops.WINO4_MIN_WGS = keep
+
+
+@pytest.mark.gpu
+def test_convolution_epilogue_statistics_match_the_separate_passes():
+    """cn_conv_fwd_stats: the sums AdaIn (building_blocks.py:37-44: of the activated output) and the DiscrBlock tail
+    (building_blocks.py:97-106: of the pre-activation output and of its LeakyReLU) need, taken in the convolution's epilogue, against
+    the separate statistics passes over the stored output and against float64 sums; the output itself must be the same bits as
+    the convolution without statistics.  Includes an upsample-folded layer (parity-ordered rows: a tile's sample comes from the
+    class-major index) and a layer whose tiles straddle samples (must NOT fuse)."""
+    from confignet_amd import functional as F, ops
+    rng = np.random.default_rng(7)
+    cases = [  # (x shape, kernel, cout, stride, up, kind, must fuse)
+        ((4, 16, 16, 64), (3, 3), 128, 1, 0, "act", True),
+        ((8, 16, 16, 16, 64), (3, 3, 3), 64, 1, 0, "act", True),    # Conv3dAdaIn at 16^3 (the generator's map_3d_post at batch 8)
+        ((8, 32, 32, 128), (4, 4), 64, 1, 1, "act", None),          # Conv2dAdaIn with the folded upsample (k4: classes of 9 / 6 / 6 / 4 taps -> K slices even them out: may split)
+        ((8, 8, 8, 8, 128), (3, 3, 3), 64, 1, 1, "act", True),      # Conv3dAdaIn with the folded upsample (16^3 outputs: 512 rows per class and sample)
+        ((2, 8, 8, 8, 64), (3, 3, 3), 64, 1, 0, "act", None),       # 16 tiles: the launch splits K -> no statistics (either answer is fine for the caller)
+        ((16, 32, 32, 96), (3, 3), 192, 2, 0, "pre4", True),        # DiscrBlock 2
+        ((5, 64, 64, 48), (3, 3), 96, 2, 0, "pre4", True),          # DiscrBlock 1 (128 x 96 tile or 64 x 64)
+        ((6, 8, 8, 384), (3, 3), 768, 2, 0, "pre4", False),         # 16 rows per sample: tiles straddle samples
+    ]
+    for xs, k, cout, stride, up, kind, must in cases:
+        spec = ops.ConvSpec(k, stride=stride, up=up)
+        x = torch.tensor(rng.normal(size=xs).astype(np.float32)).cuda()
+        w = torch.tensor((rng.normal(size=(*k, xs[-1], cout)) / math.sqrt(np.prod(k) * xs[-1])).astype(np.float32)).cuda()
+        b = torch.tensor(rng.normal(size=cout).astype(np.float32)).cuda()
+        act, slope = (ops.ACT_LRELU, 0.3) if kind == "act" else (ops.ACT_NONE, 0.0)
+        with torch.no_grad():
+            y0 = F.conv(x, w, b, spec, act, slope)
+            ops.zero_pool_begin("stats_test", x.device)
+            try:
+                with ops.request_stats(kind, 0.3):
+                    y1 = F.conv(x, w, b, spec, act, slope)
+                st = ops.take_stats(y1, kind)
+                assert must is None or (st is not None) == must, (xs, kind, st is not None)
+                if st is None:
+                    continue
+                assert torch.equal(y0, y1)           # (a launch that carries statistics has no K split: same bits every time)
+                st = [t.clone() for t in st]
+            finally:
+                ops.zero_pool_end()
+        y64 = y1.double().reshape(xs[0], -1, cout)
+        l64 = torch.where(y64 > 0, y64, 0.3 * y64)
+        ref = [y64.sum(1), (y64 * y64).sum(1)] + ([l64.sum(1), (l64 * l64).sum(1)] if kind == "pre4" else [])
+        for got, r in zip(st, ref):
+            assert tuple(got.shape) == (xs[0], cout)
+            assert float((got.double() - r).abs().max()) <= 1e-5 * float(r.abs().max()) + 1e-4, (xs, kind)
+        sep = ops.nc_reduce(y1) if kind == "act" else ops.nc_reduce4(y1, 0.3)
+        for got, r in zip(st, sep):
+            assert float((got - r).abs().max()) <= 2e-5 * float(r.abs().max()) + 1e-4
