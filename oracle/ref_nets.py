@@ -40,30 +40,30 @@ def generator_forward(w, z, rotation, res, return_intermediates=False):
     inter = {}
     # learned_input: Dense(32768, kernel zeros-init, bias ones-init) on zeros(N,1) (l.24-27,133-136)
     k, b = c.take(2)
-    x = O.dense(torch.zeros(n, 1, dtype=z30.dtype), k, b).reshape(n, 4, 4, 4, 512)
+    x = O.stored(O.dense(torch.zeros(n, 1, dtype=z30.dtype), k, b).reshape(n, 4, 4, 4, 512))
     x = O.upsample2(x)                                                   # l.139
     # map_3d_0 / map_3d_1: Conv3D k3 same -> LeakyReLU(0.3) -> AdaIn (building_blocks.py:37-44)
     ck, cb, *mlp = c.take(6)
-    x = O.adain(O.leaky_relu(O.conv_same(x, ck, cb), 0.3), z30, mlp, 0.2)
+    x = O.stored(O.adain(O.stored(O.leaky_relu(O.conv_same(x, ck, cb), 0.3)), z30, mlp, 0.2))     # (O.stored: identity outside O.bf16_storage)
     inter["a3d0"] = x
     x = O.upsample2(x)                                                   # l.143
     ck, cb, *mlp = c.take(6)
-    x = O.adain(O.leaky_relu(O.conv_same(x, ck, cb), 0.3), z31, mlp, 0.2)
+    x = O.stored(O.adain(O.stored(O.leaky_relu(O.conv_same(x, ck, cb), 0.3)), z31, mlp, 0.2))
     inter["a3d1"] = x
     # rotation (l.147-148)
-    x = O.transform_3d_grid(x, O.euler_angles_to_matrix(rotation))
+    x = O.stored(O.transform_3d_grid(x, O.euler_angles_to_matrix(rotation)))
     inter["rot"] = x
     # map_3d_post: 2x (Conv3D k3 + LeakyReLU(0.3)) (l.49-54,151)
     for _ in range(2):
         ck, cb = c.take(2)
-        x = O.leaky_relu(O.conv_same(x, ck, cb), 0.3)
+        x = O.stored(O.leaky_relu(O.conv_same(x, ck, cb), 0.3))
     inter["post3d"] = x
     # depth collapse (l.153-156): (N,16,16,16,64) -> (N,16,16,1024), channel = d*64+c
     s = x.shape
     x = x.reshape(s[0], s[1], s[2], s[3] * s[4])
     # projection_conv 1x1 + tf.nn.leaky_relu (alpha 0.2) (l.56,157)
     ck, cb = c.take(2)
-    x = O.leaky_relu(O.conv_same(x, ck, cb), 0.2)
+    x = O.stored(O.leaky_relu(O.conv_same(x, ck, cb), 0.2))
     inter["proj"] = x
     zs = [z20, z21, z22]
     if res > 128:
@@ -72,8 +72,8 @@ def generator_forward(w, z, rotation, res, return_intermediates=False):
         zs.append(z22)
     for i, zz in enumerate(zs):                                          # l.159-170
         ck, cb, *mlp = c.take(6)
-        x = O.leaky_relu(O.conv_same(x, ck, cb), 0.3)
-        x = O.adain(x, zz, mlp, 0.2)
+        x = O.stored(O.leaky_relu(O.conv_same(x, ck, cb), 0.3))
+        x = O.stored(O.adain(x, zz, mlp, 0.2))
         inter["a2d%d" % i] = x
         x = O.upsample2(x)
     ck, cb = c.take(2)
@@ -118,13 +118,13 @@ def discr_channels(n_layers=5, f0=48, fmax=512):
 def discr_block(x, ck, cb, gamma, beta, return_styles):
     """DiscrBlock (building_blocks.py:83-111): conv k3 s2 same; styles from the
     pre-activation output; LeakyReLU(0.3) THEN instance norm."""
-    x = O.conv_same(x, ck, cb, stride=2)
+    x = O.stored(O.conv_same(x, ck, cb, stride=2))
     styles = None
     if return_styles:
         mu, std = O.layer_style(x)
         styles = torch.cat([mu, std], dim=-1).reshape(x.shape[0], -1)    # (N, 2C): [mu | std]
     x = O.leaky_relu(x, 0.3)
-    x = O.instance_norm(x, gamma, beta)
+    x = O.stored(O.instance_norm(x, gamma, beta))
     return x, styles
 
 

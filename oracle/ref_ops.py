@@ -32,9 +32,40 @@ def _to_cl(x):   # channels-first -> channels-last
     return x.permute(0, *range(2, nd + 2), 1)
 
 
+# ----------------------------------------------------------------------------
+# bf16-storage emulation (tests of the bf16 compute path, BASELINE.json configs[2]): inside `with bf16_storage():` the network
+# restatements of ref_nets.py round every tensor the product STORES in bf16 -- activations with more than 4 channels at the
+# product's kernel boundaries (`stored`) and the filters of the convolutions that run on the bf16 matrix cores (`conv_same`: both
+# channel counts multiples of 8) -- to bf16 and continue in float64.  What remains between product and oracle is then fp32
+# accumulation, the rounding of pre-summed class filters and values that sit on a bf16 rounding boundary.
+# ----------------------------------------------------------------------------
+_BF16_STORAGE = False
+
+
+class bf16_storage:
+    def __enter__(self):
+        global _BF16_STORAGE
+        self.prev, _BF16_STORAGE = _BF16_STORAGE, True
+
+    def __exit__(self, *exc):
+        global _BF16_STORAGE
+        _BF16_STORAGE = self.prev
+
+
+def _bf16_round(t):
+    return (t.detach().to(torch.float32).to(torch.bfloat16).to(t.dtype) - t.detach()) + t      # (straight-through for autograd)
+
+
+def stored(x):
+    """x as the product keeps it in HBM between two kernels (identity outside bf16_storage)."""
+    return _bf16_round(x) if (_BF16_STORAGE and x.shape[-1] > 4) else x
+
+
 def conv_same(x, w, b=None, stride=1):
     """keras.layers.Conv2D/Conv3D(padding="same") -- cross-correlation, asymmetric
     SAME padding (building_blocks.py:29,65,91; hologan_generator.py:50-56,101)."""
+    if _BF16_STORAGE and w.shape[-2] % 8 == 0 and w.shape[-1] % 8 == 0:
+        w = _bf16_round(w)
     nd = x.dim() - 2
     ks = w.shape[:nd]
     spatial = x.shape[1:1 + nd]

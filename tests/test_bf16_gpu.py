@@ -48,6 +48,15 @@ def t64(a):
     return torch.tensor(np.asarray(a), dtype=torch.float64)
 
 
+# bounds of the comparisons against the oracle that rounds what the product rounds (oracle.ref_ops.bf16_storage).  Measured
+# (round 5): discriminator heads 6.2e-3 of their scale against 2.4e-2 for the plain fp32 oracle -- four times sharper, so a
+# systematic 3 % error of one block no longer passes; generator image rel-L2 9.2e-3 against 1.4e-2 -- only 1.5 times: 15
+# storage points deep, a value on a rounding boundary in one layer moves a whole receptive field in the next, and the emulation
+# does not restate the fp32 coefficient algebra of AdaIn bit for bit.  The generator bound is therefore kept as a record, not as
+# a sharp statement.
+BF16_EMU_GEN_REL = 2e-2
+BF16_EMU_DISCR_ERR = 1.5e-2
+
 BF16_CONV_CASES = [
     # (x shape, kernel, cout, stride, up, act, slope)
     ((2, 16, 16, 64), (4, 4), 32, 1, 1, 1, 0.3),        # k4 + folded upsample, 128x32 tile
@@ -210,6 +219,28 @@ def test_bf16_generator_and_discriminator_loss_against_the_fp32_oracle():
     diff = img.detach().cpu().double() - ref
     rel, err = float(diff.norm() / ref.norm()), float(diff.abs().max())
     assert rel <= 3e-2 and err <= 0.2, "bf16 generator image: rel-L2 %.3e, max abs err %.3e (tanh output in [-1, 1])" % (rel, err)
+    # The same comparison with the oracle ROUNDING WHAT THE PRODUCT ROUNDS (oracle.ref_ops.bf16_storage: every activation tensor
+    # of more than 4 channels at the product's kernel boundaries and the filters of the bf16 convolutions to bf16, arithmetic in
+    # float64): what is left is fp32 accumulation, the rounding of the pre-summed class filters of the upsample-folded layers
+    # and values on a rounding boundary -- an order of magnitude below the storage error itself, so a kernel that is wrong by a
+    # per cent in one layer shows here while the bound above would pass it
+    # (the upsample-folded layers round PRE-SUMMED class filters, which the oracle does not restate: this comparison runs the
+    # product with the collapse off -- the same bf16 kernels on per-tap filters -- and the collapsed product is held to it below)
+    from confignet_amd import ops
+    with O.bf16_storage():
+        ref_b = R.generator_forward(wr, t64(z), t64(rot), 128).detach()
+    upfold, ops.UPFOLD = ops.UPFOLD, False
+    try:
+        with torch.no_grad():
+            img_d = g((z, rot)).detach().cpu().double()
+    finally:
+        ops.UPFOLD = upfold
+    diff_b = img_d - ref_b
+    rel_b, err_b = float(diff_b.norm() / ref_b.norm()), float(diff_b.abs().max())
+    rel_c = float((img.detach().cpu().double() - img_d).norm() / img_d.norm())
+    print("bf16 generator image vs the fp32 oracle: rel-L2 %.3e max %.3e; per-tap filters vs the bf16-storage oracle: rel-L2 %.3e max %.3e; "
+          "class filters vs per-tap filters: rel-L2 %.3e" % (rel, err, rel_b, err_b, rel_c))
+    assert rel_b <= BF16_EMU_GEN_REL and rel_c <= 3e-2, (rel_b, rel_c, rel)
     g.zero_grad()
     cot = rng.normal(size=tuple(ref.shape))
     torch.autograd.backward((img * dev(cot)).sum(), inputs=g.trainable_weights)
@@ -230,6 +261,21 @@ def test_bf16_generator_and_discriminator_loss_against_the_fp32_oracle():
 
     d = HologanDiscriminator((64, 64), 5, 512, 3, 48, True, rng=rng)
     real, fake = rng.uniform(-1, 1, size=(3, 64, 64, 3)), rng.uniform(-1, 1, size=(3, 64, 64, 3))
+    # every head of the discriminator forward against the bf16-storage oracle (and, for scale, against the fp32 oracle)
+    with torch.no_grad():
+        outs = d(d.to_device(real))
+    dw0 = [t64(w) for w in d.get_weights()]
+    ref_f = R.discriminator_forward(dw0, t64(real))
+    with O.bf16_storage():
+        ref_e = R.discriminator_forward(dw0, t64(real))
+    worst_f = worst_e = 0.0
+    for k in ref_f:
+        got = outs[k].detach().cpu().double().reshape(ref_f[k].shape)
+        scale = max(1.0, float(ref_f[k].abs().max()))
+        worst_f = max(worst_f, float((got - ref_f[k]).abs().max()) / scale)
+        worst_e = max(worst_e, float((got - ref_e[k]).abs().max()) / scale)
+    print("bf16 discriminator heads: max err vs the fp32 oracle %.3e, vs the bf16-storage oracle %.3e" % (worst_f, worst_e))
+    assert worst_e <= BF16_EMU_DISCR_ERR, (worst_e, worst_f)
     d.zero_grad()
     losses = compute_discriminator_loss(d, d.to_device(real), d.to_device(fake))
     torch.autograd.backward(losses["loss_sum"], inputs=d.trainable_weights)
