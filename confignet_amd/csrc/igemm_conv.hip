@@ -1120,6 +1120,7 @@ static long g_tune_wg_blocks = getenv("CN_WG_BLOCKS") ? atol(getenv("CN_WG_BLOCK
 static int g_xcd = getenv("CN_NO_XCD") ? 0 : 1;
 static int g_fwd2_env = getenv("CN_FWD2") ? atoi(getenv("CN_FWD2")) : 1;      // the LDS-DMA forward loop (fwd2.hip): on unless CN_FWD2=0
 static int g_fwd2_sel = -1;                                                    // cn_conv_loop_select override
+static int g_fwd2_min_nks = getenv("CN_FWD2_MINK") ? atoi(getenv("CN_FWD2_MINK")) : 1;   // it takes reductions of MORE K steps than this
 static int g_fwd2_min_c = getenv("CN_FWD2_MINC") ? atoi(getenv("CN_FWD2_MINC")) : 48;   // thinnest layer it takes (A/B: 64 = round-5 first form)
 
 template <int WM, int WN, int TM, int TN>
@@ -1352,7 +1353,7 @@ static int conv_fwd_impl(const CnConvGeom* gp, const float* x, const float* w, c
     // register-staged loops are split for -- and every K split it avoids saves the zero pass, a tile of atomics per workgroup and
     // the separate bias / activation pass (13 us of a 60 us launch at M = 4096, K = 2304, N = 256; scripts/dev/fwd2_sweep.py).
     const int fwd2_on = g_fwd2_sel >= 0 ? g_fwd2_sel : g_fwd2_env;
-    const bool fwd2_takes = fwd2_on && vec && nks_total > 8 && g.cin >= g_fwd2_min_c && g.cout >= g_fwd2_min_c && g.dl_d <= 2 && g.dl_h <= 2 && g.dl_w <= 2 &&
+    const bool fwd2_takes = fwd2_on && vec && nks_total > g_fwd2_min_nks && g.cin >= g_fwd2_min_c && g.cout >= g_fwd2_min_c && g.dl_d <= 2 && g.dl_h <= 2 && g.dl_w <= 2 &&
                             (double)g.n * g.in_d * g.in_h * g.in_w * g.cin < 5.3e8 && (double)g.k_d * g.k_h * g.k_w * g.cin * g.cout < 5.3e8;
     if (fwd2_takes) {
         const int T = g.k_d * g.k_h * g.k_w;
@@ -1417,7 +1418,7 @@ static int conv_fwd_impl(const CnConvGeom* gp, const float* x, const float* w, c
         srows = qd * qh * qw;
         sper = par ? g.n * srows : (int)M;
         static const bool no_rows = getenv("CN_NO_GEMM1X1") != nullptr;
-        if (!fwd2_takes || no_rows || splits > 1 || cfg == 3 || nks_total <= 8 || srows % (cfg == 2 ? 64 : 128) != 0) return CN_EUNSUPPORTED;
+        if (!fwd2_takes || no_rows || splits > 1 || cfg == 3 || srows % (cfg == 2 ? 64 : 128) != 0) return CN_EUNSUPPORTED;
     }
     float* parts = nullptr;
     if (cn_det() && splits > 1) {
@@ -1446,7 +1447,7 @@ static int conv_fwd_impl(const CnConvGeom* gp, const float* x, const float* w, c
     static const int no_g1 = (getenv("CN_NO_GEMM1X1") ? 1 : 0);
     const bool rows_ok = !no_g1 && nks_total > 8;
     // the LDS-DMA main loop (fwd2.hip)
-    if (fwd2_takes && rows_ok && cfg != 3) {
+    if (fwd2_takes && !no_g1 && cfg != 3) {
         const bool plain = !par && g.k_d * g.k_h * g.k_w == 1 && g.s_d == 1 && g.s_h == 1 && g.s_w == 1 && g.dl_d == 1 && g.dl_h == 1 &&
                            g.dl_w == 1 && !g.up && g.p_d == 0 && g.p_h == 0 && g.p_w == 0 && g.out_d == g.in_d && g.out_h == g.in_h &&
                            g.out_w == g.in_w;
