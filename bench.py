@@ -191,7 +191,8 @@ def main():
                        "dispatch": ("eager, one stream" if args.serial else "eager" if args.no_graphs else
                                     "hip-graph replay per step function, D-type steps concurrent, G step forked over 2 streams" +
                                     (", real half of the next iteration's discriminator steps" + (" and the generator step's ground-truth VGG passes" if getattr(model, "_targets_ahead", None) is not None else "") + " under the generator tail" if model.overlap_discriminators else "") +
-                                    ("" if not parallel.active() else " (fwd+bwd), eager RCCL all-reduce + Adam"))},
+                                    ("" if not parallel.active() else " (fwd+bwd), eager %s all-reduce + Adam" %
+                                     ("RCCL" if dist.get_backend() == "nccl" else "gloo (through the host: ranks share a device)")))},
             "step_functions_ms": step_ms,
             "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": pmc_traffic(args.dtype),
