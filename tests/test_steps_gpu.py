@@ -940,7 +940,7 @@ def test_two_rank_data_parallel_run_of_the_benchmarked_dispatch(tmp_path, determ
           process that runs rank r's logged batches at batch 8 (same kernels, same launch shapes: the exchange adds nothing but
           the mean);
         * equals the gradient of ONE process that runs the concatenated batch of 16, to what two fp32 runs with different launch
-          shapes (batch 8 / 16 pick different tiles and row splits) can agree on: 1e-3 relative L2 for the discriminator-type
+          shapes (batch 8 / 16 pick different tiles and row splits) can agree on: 2e-3 relative L2 for the discriminator-type
           networks (measured 8e-5 ... 5.5e-4; the latent discriminator, an MLP, 1.2e-7), 4e-2 for the generator step's networks
           with the global batch statistics (measured 2e-3 ... 1.5e-2: the chain generator -> VGG-19 -> ResNet-50 -> six heads
           differs by 1e-2 ... 1e-1 between ANY two summation orders through LeakyReLU / ReLU / max-pool decisions on near-zero
@@ -994,7 +994,7 @@ def test_two_rank_data_parallel_run_of_the_benchmarked_dispatch(tmp_path, determ
     for (gs, k), e in worst.items():
         idx = int(k[len("first_m"):])
         if idx < n_d:
-            assert e <= 1e-3, (gs, k, e)
+            assert e <= 2e-3, (gs, k, e)                  # (measured 4e-5 ... 5.5e-4 over a dozen runs)
         elif gs == 1:
             assert e <= 4e-2, (gs, k, e)
     # loss scalars, first iteration (same weights everywhere): per-sample means agree between the rank mean and the global batch;
