@@ -225,10 +225,22 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(CnConvGeom g, const bf1
 template <int WM, int WN, int TM, int TN>
 __global__ __launch_bounds__(256) void igemm_bf16_wgrad_kernel(CnConvGeom g, const bf16_t* __restrict__ X,
                                                                const bf16_t* __restrict__ GY, float* __restrict__ GW,
-                                                               int rows_per_split) {
+                                                               int rows_per_split, int tiles_x, int tiles_y, int nsplits) {
     static_assert(WM * WN == 4, "4 waves per workgroup");
     constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
     constexpr int IPA = BM / 8, IPB = BN / 8;              // 8-channel pieces per position in each tile
+    // XCD-aware order (tiles_x != 0: 1-D launch; the fp32 kernels' rule, igemm_conv.hip): workgroup id runs on XCD id % 8, and
+    // every tile of ONE row slice goes to the same XCD -- the slice of X and GY they all read enters that XCD's L2 once.
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (tiles_x) {
+        const int TT = tiles_x * tiles_y, id = blockIdx.x;
+        const int grp = id / (8 * TT), r = id - grp * 8 * TT;
+        bz = grp * 8 + (r & 7);
+        if (bz >= nsplits) return;
+        const int t = r >> 3;
+        by = t / tiles_x;
+        bx = t - by * tiles_x;
+    }
     constexpr int AT = (IPA * 16 + 255) / 256, BT = (IPB * 16 + 255) / 256;   // (piece, position pair) tasks per thread
     __shared__ __attribute__((aligned(16))) bf16_t As[2][BM][LDK];
     __shared__ __attribute__((aligned(16))) bf16_t Bs[2][BN][LDK];
@@ -237,8 +249,8 @@ __global__ __launch_bounds__(256) void igemm_bf16_wgrad_kernel(CnConvGeom g, con
     const int M = g.n * g.out_d * g.out_h * g.out_w;
     const int T = g.k_d * g.k_h * g.k_w;
     const int Ktot = T * g.cin;
-    const int i0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-    const int mbeg = blockIdx.z * rows_per_split;
+    const int i0 = bx * BM, n0 = by * BN;
+    const int mbeg = bz * rows_per_split;
     const int mend = min(M, mbeg + rows_per_split);
     if (mbeg >= mend) return;
 
@@ -398,10 +410,22 @@ __global__ __launch_bounds__(256) void igemm_bf16_wgrad_kernel(CnConvGeom g, con
 template <int WM, int WN, int TM, int TN>
 __global__ __launch_bounds__(256) void igemm_bf16_wgrad_tr_kernel(CnConvGeom g, const bf16_t* __restrict__ X,
                                                                const bf16_t* __restrict__ GY, float* __restrict__ GW,
-                                                               int rows_per_split) {
+                                                               int rows_per_split, int tiles_x, int tiles_y, int nsplits) {
     static_assert(WM * WN == 4, "4 waves per workgroup");
     constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
     constexpr int IPA = BM / 8, IPB = BN / 8;              // 8-channel pieces per position in each tile
+    // XCD-aware order (tiles_x != 0: 1-D launch; the fp32 kernels' rule, igemm_conv.hip): workgroup id runs on XCD id % 8, and
+    // every tile of ONE row slice goes to the same XCD -- the slice of X and GY they all read enters that XCD's L2 once.
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (tiles_x) {
+        const int TT = tiles_x * tiles_y, id = blockIdx.x;
+        const int grp = id / (8 * TT), r = id - grp * 8 * TT;
+        bz = grp * 8 + (r & 7);
+        if (bz >= nsplits) return;
+        const int t = r >> 3;
+        by = t / tiles_x;
+        bx = t - by * tiles_x;
+    }
     constexpr int AT = (IPA * 16 + 255) / 256, BT = (IPB * 16 + 255) / 256;   // (piece, position pair) tasks per thread
     // Row-major [reduction row][channel] images exactly as they sit in memory (16-byte stores, no transposition); the MFMA
     // operands -- 8 consecutive reduction rows of ONE channel per lane -- come out of ds_read_b64_tr_b16: the 16 lanes of a
@@ -415,8 +439,8 @@ __global__ __launch_bounds__(256) void igemm_bf16_wgrad_tr_kernel(CnConvGeom g, 
     const int M = g.n * g.out_d * g.out_h * g.out_w;
     const int T = g.k_d * g.k_h * g.k_w;
     const int Ktot = T * g.cin;
-    const int i0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-    const int mbeg = blockIdx.z * rows_per_split;
+    const int i0 = bx * BM, n0 = by * BN;
+    const int mbeg = bz * rows_per_split;
     const int mend = min(M, mbeg + rows_per_split);
     if (mbeg >= mend) return;
 
@@ -619,15 +643,39 @@ int launch_bf16_wgrad(const CnConvGeom& g, const bf16_t* x, const bf16_t* gy, fl
     const long M = (long)g.n * g.out_d * g.out_h * g.out_w;
     const long Ktot = (long)g.k_d * g.k_h * g.k_w * g.cin;
     const long tiles = (long)cn_cdiv(Ktot, BMt) * cn_cdiv(g.cout, BNt);
-    long splits = (2048 + tiles - 1) / tiles;
+    // Row slices (round-5 sweep, profiles/round5_bf16_wgrad_splits.txt).  What the sweep showed: (1) a slice shorter than ~512
+    // rows is mostly prologue + the tile's atomic adds; (2) one workgroup more than the CUs hold at once costs a whole extra
+    // round -- the kernels hold 3 (128 x 128), 4 (128 x 96) or 5 workgroups per CU -- and the narrow tiles like two rounds;
+    // (3) with the XCD order a slice count that is not a multiple of 8 leaves XCDs with one slice more than others.
+    static const long wgs_env = getenv("CN_BF16_WGRAD_WGS") ? atol(getenv("CN_BF16_WGRAD_WGS")) : 0;      // A/B: the old rule
+    static const long min_rows = getenv("CN_BF16_WGRAD_ROWS") ? atol(getenv("CN_BF16_WGRAD_ROWS")) : (wgs_env ? 256 : 512);
+    long splits;
+    if (wgs_env) splits = (wgs_env + tiles - 1) / tiles;
+    else {
+        const long per_cu = BMt * BNt >= 128 * 128 ? 3 : BMt * BNt >= 128 * 96 ? 4 : 5;
+        const long target = 256 * per_cu * (BNt >= 96 ? 1 : 2);
+        splits = target / tiles;
+        if (splits > M / min_rows) splits = M / min_rows;
+        const long fill = std::min<long>(M / 256, (256 + tiles - 1) / tiles);        // ... but at least one workgroup per CU
+        if (splits < fill) splits = fill;
+        if (splits >= 16) splits &= ~7L;
+        if (splits < 1) splits = 1;
+    }
     long rows = (M + splits - 1) / splits;
-    if (rows < 256) rows = 256;
+    if (wgs_env && rows < min_rows) rows = min_rows;
+    if (rows < 256) rows = std::min<long>(256, (M + KS - 1) / KS * KS);
     rows = (rows + KS - 1) / KS * KS;
     splits = (M + rows - 1) / rows;
     dim3 grid(cn_cdiv(Ktot, BMt), cn_cdiv(g.cout, BNt), (unsigned)splits);
     static const bool old = getenv("CN_BF16_WGRAD_OLD") != nullptr;
-    if (old) hipLaunchKernelGGL((igemm_bf16_wgrad_kernel<WM, WN, TM, TN>), grid, dim3(256), 0, s, g, x, gy, gw, (int)rows);
-    else hipLaunchKernelGGL((igemm_bf16_wgrad_tr_kernel<WM, WN, TM, TN>), grid, dim3(256), 0, s, g, x, gy, gw, (int)rows);
+    static const bool xcd = getenv("CN_NO_WGRAD_XCD") == nullptr;
+    int tx = 0, ty = 0;
+    if (xcd && grid.x * grid.y > 1 && splits >= 16) {
+        tx = (int)grid.x; ty = (int)grid.y;
+        grid = dim3((unsigned)(cn_cdiv(splits, 8) * 8 * tx * ty), 1, 1);
+    }
+    if (old) hipLaunchKernelGGL((igemm_bf16_wgrad_kernel<WM, WN, TM, TN>), grid, dim3(256), 0, s, g, x, gy, gw, (int)rows, tx, ty, (int)splits);
+    else hipLaunchKernelGGL((igemm_bf16_wgrad_tr_kernel<WM, WN, TM, TN>), grid, dim3(256), 0, s, g, x, gy, gw, (int)rows, tx, ty, (int)splits);
     CN_LAUNCH_CHECK();
     return CN_OK;
 }

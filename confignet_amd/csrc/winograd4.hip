@@ -83,6 +83,9 @@ __global__ void wino4_filter_kernel(const float* __restrict__ W, float* __restri
     }
 }
 
+#ifndef W4_ABLATE
+#define W4_ABLATE 0      // dev (scripts/dev/wino4_ablate.sh): 1 no MFMA, 2 no input transform, 4 no loads in the loop, 8 no output transform / stores, 16 one K step
+#endif
 constexpr int W4_KC = 4;                 // channels per K step
 constexpr int W4_T = 32;                 // tiles per workgroup (4 rows x 8 columns of 4 x 4 output pixels)
 constexpr int W4_C = 64;                 // output channels per workgroup
@@ -229,14 +232,15 @@ __global__ __launch_bounds__(768) void wino4_fwd_kernel(Wino4Geom g, const float
             _Pragma("unroll") for (int j = 0; j < 6; ++j) a[j] = va[(j * W4_KC + 2 * (kk)) * W4_VP];                           \
             W4_RDU(0, kk, b[0]); W4_RDU(1, kk, b[1]); W4_RDU(2, kk, b[2]); W4_RDU(3, kk, b[3]); W4_RDU(4, kk, b[4]); W4_RDU(5, kk, b[5]); \
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]));     \
-            _Pragma("unroll") for (int j = 0; j < 6; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], acc[j], 0, 0, 0); \
+            if (!(W4_ABLATE & 1)) { _Pragma("unroll") for (int j = 0; j < 6; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], acc[j], 0, 0, 0); } \
+            else { _Pragma("unroll") for (int j = 0; j < 6; ++j) acc[j][0] += a[j] * b[j]; }                                      \
         }
         W4_MUL(0)
         W4_MUL(1)
 #undef W4_MUL
     };
 
-    const int nks = g.cin / W4_KC, nraw = g.cin / 8;
+    const int nks = (W4_ABLATE & 16) ? 1 : g.cin / W4_KC, nraw = g.cin / 8;
     issue_raw(0);
     issue_u(0);
     __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0)
@@ -250,14 +254,14 @@ __global__ __launch_bounds__(768) void wino4_fwd_kernel(Wino4Geom g, const float
     for (int s = 0; s < nks; ++s) {
         __builtin_amdgcn_s_waitcnt(0x0F70);      // the loads issued a step ago have landed ...
         __syncthreads();                         // ... everybody's; everybody is past step s-1 and V(s) is written
-        if (s >= 1) {
+        if (s >= 1 && !(W4_ABLATE & 4)) {
             if (s + 1 < nks) issue_u(s + 1);
             if ((s & 1) && (s + 3) / 2 < nraw) issue_raw((s + 3) / 2);
         }
 #pragma nounroll
         for (int ph = 0; ph < 2; ++ph) {             // (a loop so that each body exists once: two inlined copies spilled accumulators)
             if ((ph == 0) == mul_first) multiply(s);
-            else if (s + 1 < nks) transform(s + 1);
+            else if (s + 1 < nks && !(W4_ABLATE & 2)) transform(s + 1);
         }
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);
@@ -267,6 +271,15 @@ __global__ __launch_bounds__(768) void wino4_fwd_kernel(Wino4Geom g, const float
     // the wave's six positions j) is per-lane arithmetic; its results R[i][y][tile][channel] of one channel half go through LDS
     // (96 KB over the now idle stages), the column pass (over i) is thread-parallel over (tile, channel, y).
     float* E = BUF;
+    if (W4_ABLATE & 8) {
+        float t = 0.f;
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) t += acc[j][r];
+        if (t == 12345.f) Y[tid] = t;
+        return;
+    }
     for (int rb = 0; rb < 2; ++rb) {
         if (cb == rb) {
 #pragma unroll

@@ -1,6 +1,7 @@
 """Collect every distinct implicit-GEMM launch of one second-stage iteration (256x256, batch 16) and time
 each shape in isolation: per-shape TFLOP/s and share of the conv time.  Run on the GPU box."""
 import ctypes
+import os
 import sys
 from collections import OrderedDict
 
@@ -69,8 +70,11 @@ def valid_pairs(out, k, s, dl, p, inn, up):
 
 
 rows = []
+ONLY = os.environ.get("CONV_SHAPES_KIND")          # e.g. "wgrad": time only that kind (A/B runs)
 for kk, cnt in calls.items():
     kind = kk[0]
+    if ONLY and kind != ONLY:
+        continue
     g = ops.CnConvGeom(*kk[1:])
     if kind == "dgrad":
         # effective geometry the kernel sees
