@@ -959,6 +959,7 @@ __global__ __launch_bounds__(256) void c3_fwd_kernel(CnConvGeom g, const float* 
                                                      const float* __restrict__ bias, TO* __restrict__ Y, int act, float slope) {
     constexpr int TH = 8, TW = 32, PR = (TH - 1) * S + 3, PC = ((TW - 1) * S + 3) * 3, PCP = PC + 1;
     __shared__ float patch[PR * PCP];
+    __shared__ __attribute__((aligned(16))) float stage[4][16 * NB * 32];      // per wave: 16 pixels x cout of the epilogue
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, half = lane >> 5;
     const int tiles_w = (g.out_w + TW - 1) / TW, tiles_h = (g.out_h + TH - 1) / TH;
     int b = blockIdx.x;
@@ -966,13 +967,8 @@ __global__ __launch_bounds__(256) void c3_fwd_kernel(CnConvGeom g, const float* 
     const int ti = b % tiles_h;
     const int n = b / tiles_h;
     const int oy0 = ti * TH, ox0 = tj * TW, iy0 = oy0 * S - g.p_h, ix0 = ox0 * S - g.p_w;
-    for (int idx = threadIdx.x; idx < PR * PC; idx += 256) {
-        const int r = idx / PC, c = idx - r * PC;
-        const int iy = iy0 + r, ix = ix0 + c / 3;
-        float v = 0.f;
-        if (iy >= 0 && iy < g.in_h && ix >= 0 && ix < g.in_w) v = X[(((long)n * g.in_h + iy) * g.in_w + ix0) * 3 + c];
-        patch[r * PCP + c] = v;
-    }
+    // 16-byte stores need whole chunks per pixel and an aligned tensor (else: the element-wise epilogue)
+    const bool staged = g.cout % (16 / (int)sizeof(TO)) == 0 && ((uintptr_t)Y & 15) == 0;
     float breg[14][NB];
     int aoff[14];
 #pragma unroll
@@ -984,6 +980,28 @@ __global__ __launch_bounds__(256) void c3_fwd_kernel(CnConvGeom g, const float* 
         for (int nb = 0; nb < NB; ++nb) {
             const int col = nb * 32 + l31;
             breg[q][nb] = (k < 27 && col < g.cout) ? W[k * g.cout + col] : 0.f;
+        }
+    }
+    {
+        // patch rows: a thread owns one column of the patch (PC <= 256 / RPP floats per row) and every RPP-th row; ALL its loads
+        // are issued before the first LDS store (a load -> wait -> store loop serialises PR x PC / 256 memory round trips per
+        // workgroup: that loop, not the MFMA work or the stores, was what the kernel's time consisted of)
+        constexpr int PCC = PC <= 128 ? 128 : 256, RPP = 256 / PCC, NR = (PR + RPP - 1) / RPP;
+        static_assert(PC <= 256, "patch row wider than the workgroup");
+        const int c = threadIdx.x % PCC, rs = threadIdx.x / PCC;
+        const int ix = ix0 + c / 3;
+        const bool cok = c < PC, xin = cok && ix >= 0 && ix < g.in_w;
+        const float* xp = X + ((long)n * g.in_h * g.in_w + ix0) * 3 + c;
+        float pv[NR];
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const int r = rs + RPP * i, iy = iy0 + r;
+            pv[i] = (xin && r < PR && iy >= 0 && iy < g.in_h) ? xp[(long)iy * g.in_w * 3] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const int r = rs + RPP * i;
+            if (cok && r < PR) patch[r * PCP + c] = pv[i];
         }
     }
     __syncthreads();
@@ -1004,6 +1022,50 @@ __global__ __launch_bounds__(256) void c3_fwd_kernel(CnConvGeom g, const float* 
         }
         const int oy = oy0 + r;
         if (oy >= g.out_h) continue;
+        TO* yrow = Y + (((long)n * g.out_h + oy) * g.out_w + ox0) * g.cout;
+        if (staged) {
+            // The 32 pixels x cout values of this wave's row segment are one contiguous run of the NHWC output: pass them through
+            // LDS, 16 pixels at a time ([pixel][channel] = the run's own layout), and write the run with 16-byte stores -- lane c
+            // writes bytes 16 c .. of it.  (Straight from the accumulators a lane owns ONE channel of 16 pixels: 4-byte -- in bf16
+            // 2-byte -- stores, 64 of them per row; the bf16 variant took longer than the fp32 one.)
+            float* st = stage[wave];
+#pragma unroll
+            for (int ph = 0; ph < 2; ++ph) {
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    const int col = nb * 32 + l31;
+                    if (col < g.cout) {
+                        const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+                        for (int qq = 0; qq < 8; ++qq)
+                            st[(4 * half + (qq & 3) + 8 * (qq >> 2)) * g.cout + col] = cn_apply_act(acc[nb][8 * ph + qq] + bv, act, slope);
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                asm volatile("" ::: "memory");
+                constexpr int CH = 16 / (int)sizeof(TO);                    // channels per 16-byte chunk
+                const int cpp = g.cout / CH, nch = 16 * cpp;
+                const int pix_left = g.out_w - ox0 - 16 * ph;               // pixels of this half that exist (>= 16: all)
+                for (int c = lane; c < nch; c += 64) {
+                    if (pix_left < 16 && c / cpp >= pix_left) continue;
+                    const float4 v0 = *reinterpret_cast<const float4*>(st + c * CH);
+                    if constexpr (sizeof(TO) == 4) {
+                        *reinterpret_cast<float4*>(reinterpret_cast<float*>(yrow) + 16 * ph * g.cout + c * 4) = v0;
+                    } else {
+                        const float4 v1 = *reinterpret_cast<const float4*>(st + c * CH + 4);
+                        uint4 o;
+                        o.x = (unsigned)f32_to_bf16(v0.x) | ((unsigned)f32_to_bf16(v0.y) << 16);
+                        o.y = (unsigned)f32_to_bf16(v0.z) | ((unsigned)f32_to_bf16(v0.w) << 16);
+                        o.z = (unsigned)f32_to_bf16(v1.x) | ((unsigned)f32_to_bf16(v1.y) << 16);
+                        o.w = (unsigned)f32_to_bf16(v1.z) | ((unsigned)f32_to_bf16(v1.w) << 16);
+                        *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(yrow) + 16 * ph * g.cout + c * 8) = o;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                asm volatile("" ::: "memory");
+            }
+            continue;
+        }
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
             const int col = nb * 32 + l31;
