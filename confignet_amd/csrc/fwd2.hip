@@ -598,7 +598,7 @@ int cn_fwd2(const CnConvGeom* gp, int cfg, int bt, const float* A, const float* 
     // stage count: three (24 / 36 / 48 KB: more workgroups per CU) unless the launch is so small that a CU holds one or two
     // workgroups anyway -- then the fourth stage's extra step of look-ahead is what hides the fill latency (same-shape A/B: 64 x 64
     // 388 vs 418 us at M = 1 310 720, 84 vs 111 us the other way round at M = 8 192 with two K slices)
-    const long wgs = (long)cn_cdiv(M, cfg == 2 ? 64 : 128) * cn_cdiv(N, cfg == 0 ? 128 : cfg == 4 ? 96 : 64) * splits;
+    const long wgs = (long)cn_cdiv(M, cfg == 2 ? 64 : 128) * cn_cdiv(N, cfg == 0 ? 128 : cfg == 4 ? 96 : cfg == 3 ? 32 : 64) * splits;
     int kb = g_fwd2_kb ? g_fwd2_kb : 16, ns = g_fwd2_ns ? g_fwd2_ns : ((cfg == 0 || cfg == 4 || wgs >= 2048) ? 3 : 4);
     if (kb == 32 && (K % 32 != 0 || cfg != 2)) kb = 16;            // 32-deep stages: the 64 x 64 tile only
     if (kb == 32) ns = 3;
@@ -623,6 +623,7 @@ int cn_fwd2(const CnConvGeom* gp, int cfg, int bt, const float* A, const float* 
             if (np == 1) { if (ns == 3) { L3(2, 2, 1, 1, 16, 3, 1); } else { L3(2, 2, 1, 1, 16, 4, 1); } }
             if (np == 2) { if (ns == 3) { L3(2, 2, 1, 1, 16, 3, 2); } else { L3(2, 2, 1, 1, 16, 4, 2); } }
             L2(2, 2, 1, 1);
+        case 3: L2(4, 1, 1, 1);
         case 4: L2(4, 1, 1, 3);
         default: return CN_EUNSUPPORTED;
     }

@@ -947,6 +947,70 @@ __global__ __launch_bounds__(256) void s1_image_dgrad_kernel(CnConvGeom g, const
 }
 
 // ---------------------------------------------------------------------------------------------
+// Epilogue of the image-side forward kernels below: one wave's 32 output pixels (one row segment) x cout channels, accumulators
+// in the 32 x 32 MFMA layout (lane = channel, register = pixel), -> bias, activation, store.  yrow: the segment's first pixel;
+// pix: pixels of it that exist (>= 32: all).
+// staged: the 32 pixels x cout values are one contiguous run of the NHWC output: pass them through LDS, 16 pixels at a time
+// ([pixel][channel] = the run's own layout; st: 16 * 32 NB floats of this wave's), and write the run with 16-byte stores -- lane c
+// writes bytes 16 c .. of it.  (Straight from the accumulators a lane owns ONE channel of 16 pixels: 4-byte -- in bf16 2-byte --
+// stores, 64 of them per row; the bf16 variant took longer than the fp32 one.)  Needs cout % (16 / sizeof(TO)) == 0 and a
+// 16-byte aligned tensor; otherwise the element-wise form.
+template <int NB, typename TO>
+__device__ __forceinline__ void image_row_epilogue(const f32x16 (&acc)[NB], float* st, bool staged, TO* yrow, int pix, int cout,
+                                                   const float* __restrict__ bias, int act, float slope) {
+    const int lane = threadIdx.x & 63, l31 = lane & 31, half = lane >> 5;
+    if (staged) {
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph) {
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const int col = nb * 32 + l31;
+                if (col < cout) {
+                    const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+                    for (int qq = 0; qq < 8; ++qq)
+                        st[(4 * half + (qq & 3) + 8 * (qq >> 2)) * cout + col] = cn_apply_act(acc[nb][8 * ph + qq] + bv, act, slope);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("" ::: "memory");
+            constexpr int CH = 16 / (int)sizeof(TO);                    // channels per 16-byte chunk
+            const int cpp = cout / CH, nch = 16 * cpp;
+            const int pix_left = pix - 16 * ph;                         // pixels of this half that exist (>= 16: all)
+            for (int c = lane; c < nch; c += 64) {
+                if (pix_left < 16 && c / cpp >= pix_left) continue;
+                const float4 v0 = *reinterpret_cast<const float4*>(st + c * CH);
+                if constexpr (sizeof(TO) == 4) {
+                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(yrow) + 16 * ph * cout + c * 4) = v0;
+                } else {
+                    const float4 v1 = *reinterpret_cast<const float4*>(st + c * CH + 4);
+                    uint4 o;
+                    o.x = (unsigned)f32_to_bf16(v0.x) | ((unsigned)f32_to_bf16(v0.y) << 16);
+                    o.y = (unsigned)f32_to_bf16(v0.z) | ((unsigned)f32_to_bf16(v0.w) << 16);
+                    o.z = (unsigned)f32_to_bf16(v1.x) | ((unsigned)f32_to_bf16(v1.y) << 16);
+                    o.w = (unsigned)f32_to_bf16(v1.z) | ((unsigned)f32_to_bf16(v1.w) << 16);
+                    *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(yrow) + 16 * ph * cout + c * 8) = o;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("" ::: "memory");
+        }
+        return;
+    }
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int col = nb * 32 + l31;
+        if (col >= cout) continue;
+        const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int px = 4 * half + (q & 3) + 8 * (q >> 2);
+            if (px < pix) stf<TO>(yrow + (long)px * cout + col, cn_apply_act(acc[nb][q] + bv, act, slope));
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // First layers: 3x3 convolution of a 3-channel image (DiscrBlock 0 of both discriminators and the latent regressor,
 // VGG conv1_1): K = 27.  The generic kernel gathers those 27 values with per-element integer division (cin = 3 is not
 // a float4).  Here a workgroup stages the input patch of an 8 x 32 output tile in LDS once (coalesced rows), the K
@@ -1022,61 +1086,90 @@ __global__ __launch_bounds__(256) void c3_fwd_kernel(CnConvGeom g, const float* 
         }
         const int oy = oy0 + r;
         if (oy >= g.out_h) continue;
-        TO* yrow = Y + (((long)n * g.out_h + oy) * g.out_w + ox0) * g.cout;
-        if (staged) {
-            // The 32 pixels x cout values of this wave's row segment are one contiguous run of the NHWC output: pass them through
-            // LDS, 16 pixels at a time ([pixel][channel] = the run's own layout), and write the run with 16-byte stores -- lane c
-            // writes bytes 16 c .. of it.  (Straight from the accumulators a lane owns ONE channel of 16 pixels: 4-byte -- in bf16
-            // 2-byte -- stores, 64 of them per row; the bf16 variant took longer than the fp32 one.)
-            float* st = stage[wave];
+        image_row_epilogue<NB, TO>(acc, stage[wave], staged, Y + (((long)n * g.out_h + oy) * g.out_w + ox0) * g.cout, g.out_w - ox0, g.cout,
+                                   bias, act, slope);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// ResNet-50 conv1 (real_encoder.py:13, keras ResNet50: ZeroPadding2D(3) + 7x7 stride-2 convolution of the 3-channel image): K = 147.
+// The generic kernel gathered those with per-element integer division (190 us on 16 images at 256^2 against ~32 us of MFMA work);
+// here, as in c3_fwd_kernel, a workgroup stages the 21 x 69-pixel patch of its 8 x 32 output tile once (every load in flight before
+// the first LDS store), and walks the filter one kernel row (21 values = 11 MFMA steps, the last half-empty) at a time: the next
+// row's filter slice is loaded while this row's MFMAs run, and both of a wave's output rows use it.
+template <int NB, typename TO = float, int RPW = 2>      // RPW: output rows per wave (tile = 4 RPW rows x 32 pixels; 1: 96 -> 87 us at 1024 tiles, 39 -> 44 at 512)
+__global__ __launch_bounds__(256) void c7s2_fwd_kernel(CnConvGeom g, const float* __restrict__ X, const float* __restrict__ W,
+                                                       const float* __restrict__ bias, TO* __restrict__ Y, int act, float slope) {
+    constexpr int S = 2, KS = 7, TH = 4 * RPW, TW = 32, PR = (TH - 1) * S + KS, PC = ((TW - 1) * S + KS) * 3, PCP = PC + 1;
+    constexpr int KR = KS * 3, NQ = (KR + 1) / 2;
+    static_assert(PC <= 256, "patch row wider than the workgroup");
+    __shared__ float patch[PR * PCP];
+    __shared__ __attribute__((aligned(16))) float stage[4][16 * NB * 32];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, half = lane >> 5;
+    const int tiles_w = (g.out_w + TW - 1) / TW, tiles_h = (g.out_h + TH - 1) / TH;
+    int b = blockIdx.x;
+    const int tj = b % tiles_w; b /= tiles_w;
+    const int ti = b % tiles_h;
+    const int n = b / tiles_h;
+    const int oy0 = ti * TH, ox0 = tj * TW, iy0 = oy0 * S - g.p_h, ix0 = ox0 * S - g.p_w;
+    const bool staged = g.cout % (16 / (int)sizeof(TO)) == 0 && ((uintptr_t)Y & 15) == 0;
+    float bq[2][NQ][NB];
+    auto load_b = [&](int kh, float (*dst)[NB]) {
 #pragma unroll
-            for (int ph = 0; ph < 2; ++ph) {
+        for (int q = 0; q < NQ; ++q) {
+            const int k = 2 * q + half;
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb) {
-                    const int col = nb * 32 + l31;
-                    if (col < g.cout) {
-                        const float bv = bias ? bias[col] : 0.f;
-#pragma unroll
-                        for (int qq = 0; qq < 8; ++qq)
-                            st[(4 * half + (qq & 3) + 8 * (qq >> 2)) * g.cout + col] = cn_apply_act(acc[nb][8 * ph + qq] + bv, act, slope);
-                    }
-                }
-                __builtin_amdgcn_wave_barrier();
-                asm volatile("" ::: "memory");
-                constexpr int CH = 16 / (int)sizeof(TO);                    // channels per 16-byte chunk
-                const int cpp = g.cout / CH, nch = 16 * cpp;
-                const int pix_left = g.out_w - ox0 - 16 * ph;               // pixels of this half that exist (>= 16: all)
-                for (int c = lane; c < nch; c += 64) {
-                    if (pix_left < 16 && c / cpp >= pix_left) continue;
-                    const float4 v0 = *reinterpret_cast<const float4*>(st + c * CH);
-                    if constexpr (sizeof(TO) == 4) {
-                        *reinterpret_cast<float4*>(reinterpret_cast<float*>(yrow) + 16 * ph * g.cout + c * 4) = v0;
-                    } else {
-                        const float4 v1 = *reinterpret_cast<const float4*>(st + c * CH + 4);
-                        uint4 o;
-                        o.x = (unsigned)f32_to_bf16(v0.x) | ((unsigned)f32_to_bf16(v0.y) << 16);
-                        o.y = (unsigned)f32_to_bf16(v0.z) | ((unsigned)f32_to_bf16(v0.w) << 16);
-                        o.z = (unsigned)f32_to_bf16(v1.x) | ((unsigned)f32_to_bf16(v1.y) << 16);
-                        o.w = (unsigned)f32_to_bf16(v1.z) | ((unsigned)f32_to_bf16(v1.w) << 16);
-                        *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(yrow) + 16 * ph * g.cout + c * 8) = o;
-                    }
-                }
-                __builtin_amdgcn_wave_barrier();
-                asm volatile("" ::: "memory");
-            }
-            continue;
-        }
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-            const int col = nb * 32 + l31;
-            if (col >= g.cout) continue;
-            const float bv = bias ? bias[col] : 0.f;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int ox = ox0 + 4 * half + (q & 3) + 8 * (q >> 2);
-                if (ox < g.out_w) stf<TO>(Y + (((long)n * g.out_h + oy) * g.out_w + ox) * g.cout + col, cn_apply_act(acc[nb][q] + bv, act, slope));
+            for (int nb = 0; nb < NB; ++nb) {
+                const int col = nb * 32 + l31;
+                dst[q][nb] = (k < KR && col < g.cout) ? W[(kh * KR + k) * g.cout + col] : 0.f;
             }
         }
+    };
+    load_b(0, bq[0]);
+    {
+        const int c = threadIdx.x;
+        const int ix = ix0 + c / 3;
+        const bool cok = c < PC, xin = cok && ix >= 0 && ix < g.in_w;
+        const float* xp = X + ((long)n * g.in_h * g.in_w + ix0) * 3 + c;
+        float pv[PR];
+#pragma unroll
+        for (int r = 0; r < PR; ++r) {
+            const int iy = iy0 + r;
+            pv[r] = (xin && iy >= 0 && iy < g.in_h) ? xp[(long)iy * g.in_w * 3] : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < PR; ++r)
+            if (cok) patch[r * PCP + c] = pv[r];
+    }
+    __syncthreads();
+    f32x16 acc[RPW][NB];
+#pragma unroll
+    for (int rr = 0; rr < RPW; ++rr)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[rr][nb][q] = 0.f;
+#pragma unroll
+    for (int kh = 0; kh < KS; ++kh) {
+        if (kh + 1 < KS) load_b(kh + 1, bq[(kh + 1) & 1]);
+#pragma unroll
+        for (int rr = 0; rr < RPW; ++rr) {
+            const int base = ((wave * RPW + rr) * S + kh) * PCP + l31 * S * 3;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int k = 2 * q + half;
+                const float a = patch[base + (k < KR ? k : 0)];           // (k = 21: its filter value is 0, the address stays inside the row)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) acc[rr][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bq[kh & 1][q][nb], acc[rr][nb], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int rr = 0; rr < RPW; ++rr) {
+        const int oy = oy0 + wave * RPW + rr;
+        if (oy >= g.out_h) continue;
+        image_row_epilogue<NB, TO>(acc[rr], stage[wave], staged, Y + (((long)n * g.out_h + oy) * g.out_w + ox0) * g.cout, g.out_w - ox0, g.cout,
+                                   bias, act, slope);
     }
 }
 
@@ -1370,6 +1463,17 @@ static int conv_fwd_impl(const CnConvGeom* gp, const float* x, const float* w, c
         CN_LAUNCH_CHECK();
         return CN_OK;
     }
+    static const int no_c7 = getenv("CN_NO_C7") ? 1 : 0;
+    if (!bt && !no_c7 && g.nd == 2 && g.cin == 3 && g.k_h == 7 && g.k_w == 7 && g.s_h == 2 && g.s_w == 2 && g.dl_h == 1 && g.dl_w == 1 &&
+        !g.up && g.cout > 4 && g.cout <= 64 && !res) {
+        dim3 grid((unsigned)(g.n * cn_cdiv(g.out_h, 8) * cn_cdiv(g.out_w, 32)));
+        cn_prof_begin(s, conv_flops(g), conv_bytes(g), CN_FAM_C3_FWD);
+        if (g.cout <= 32) hipLaunchKernelGGL((c7s2_fwd_kernel<1>), grid, dim3(256), 0, s, g, x, w, bias, y, act, slope);
+        else hipLaunchKernelGGL((c7s2_fwd_kernel<2>), grid, dim3(256), 0, s, g, x, w, bias, y, act, slope);
+        cn_prof_end(s);
+        CN_LAUNCH_CHECK();
+        return CN_OK;
+    }
     CN_CHECK_ARG(g.cout % 4 == 0, "cout=%d: implicit-GEMM path needs cout %% 4 == 0", g.cout);
     const bool vec = g.cin % BK == 0;
     const int par = parity_ordered(g) && vec;
@@ -1415,7 +1519,10 @@ static int conv_fwd_impl(const CnConvGeom* gp, const float* x, const float* w, c
     // register-staged loops are split for -- and every K split it avoids saves the zero pass, a tile of atomics per workgroup and
     // the separate bias / activation pass (13 us of a 60 us launch at M = 4096, K = 2304, N = 256; scripts/dev/fwd2_sweep.py).
     const int fwd2_on = g_fwd2_sel >= 0 ? g_fwd2_sel : g_fwd2_env;
-    const bool fwd2_takes = fwd2_on && vec && nks_total > g_fwd2_min_nks && g.cin >= g_fwd2_min_c && g.cout >= g_fwd2_min_c && g.dl_d <= 2 && g.dl_h <= 2 && g.dl_w <= 2 &&
+    // (32 output channels: the 128 x 32 tile of the same loop, input channels from 32 up)
+    static const int fwd2_n32 = getenv("CN_FWD2_N32") ? atoi(getenv("CN_FWD2_N32")) : 1;
+    const bool n32 = fwd2_n32 && g.cout == 32 && g.cin >= 32;
+    const bool fwd2_takes = fwd2_on && vec && nks_total > g_fwd2_min_nks && ((g.cin >= g_fwd2_min_c && g.cout >= g_fwd2_min_c) || n32) && g.dl_d <= 2 && g.dl_h <= 2 && g.dl_w <= 2 &&
                             (double)g.n * g.in_d * g.in_h * g.in_w * g.cin < 5.3e8 && (double)g.k_d * g.k_h * g.k_w * g.cin * g.cout < 5.3e8;
     if (fwd2_takes) {
         const int T = g.k_d * g.k_h * g.k_w;
@@ -1428,7 +1535,10 @@ static int conv_fwd_impl(const CnConvGeom* gp, const float* x, const float* w, c
         // parity classes with the same number of live taps (k % dl == 0 on every axis: the upsample-folded layers' class filters)
         // are one balanced launch; the data gradients of the stride-2 3x3 layers mix classes of 1 / 2 / 2 / 4 taps
         const bool par_balanced = par && g.k_d % g.dl_d == 0 && g.k_h % g.dl_h == 0 && g.k_w % g.dl_w == 0;
-        if (par && T > 1 && !par_balanced) {
+        if (n32) {
+            cfg = 3;
+            tiles = cn_cdiv(M, 128);
+        } else if (par && T > 1 && !par_balanced) {
             // classes of 1 / 2 / 2 / 4 live taps (a quarter of the rows each): the 64 x 64 tile (128 x 96 for cout = 96 once it fills
             // the chip twice), K slices only for the 64 x 64 tile, where they also even out the load between the classes
             cfg = 2;
@@ -1509,7 +1619,7 @@ static int conv_fwd_impl(const CnConvGeom* gp, const float* x, const float* w, c
     static const int no_g1 = (getenv("CN_NO_GEMM1X1") ? 1 : 0);
     const bool rows_ok = !no_g1 && nks_total > 8;
     // the LDS-DMA main loop (fwd2.hip)
-    if (fwd2_takes && !no_g1 && cfg != 3) {
+    if (fwd2_takes && !no_g1 && (cfg != 3 || n32)) {
         const bool plain = !par && g.k_d * g.k_h * g.k_w == 1 && g.s_d == 1 && g.s_h == 1 && g.s_w == 1 && g.dl_d == 1 && g.dl_h == 1 &&
                            g.dl_w == 1 && !g.up && g.p_d == 0 && g.p_h == 0 && g.p_w == 0 && g.out_d == g.in_d && g.out_h == g.in_h &&
                            g.out_w == g.in_w;
@@ -1596,6 +1706,16 @@ extern "C" int cn_conv_fwd_dt(const CnConvGeom* gp, const void* x, int x_dt, con
         if (g.s_h == 1) { if (g.cout <= 32) C3F(1, 1); else C3F(1, 2); }
         else { if (g.cout <= 32) C3F(2, 1); else C3F(2, 2); }
 #undef C3F
+        cn_prof_end(s);
+        CN_LAUNCH_CHECK();
+        return CN_OK;
+    }
+    if (x_dt == CN_F32 && y_dt == CN_BF16 && g.nd == 2 && g.cin == 3 && g.k_h == 7 && g.k_w == 7 && g.s_h == 2 && g.s_w == 2 &&
+        g.dl_h == 1 && g.dl_w == 1 && !g.up && g.cout > 4 && g.cout <= 64 && !getenv("CN_NO_C7")) {
+        dim3 grid((unsigned)(g.n * cn_cdiv(g.out_h, 8) * cn_cdiv(g.out_w, 32)));
+        cn_prof_begin(s, conv_flops(g), conv_bytes(g, 4.0, 2.0), CN_FAM_C3_FWD);
+        if (g.cout <= 32) hipLaunchKernelGGL((c7s2_fwd_kernel<1, bf16_t>), grid, dim3(256), 0, s, g, (const float*)x, w, bias, (bf16_t*)y, act, slope);
+        else hipLaunchKernelGGL((c7s2_fwd_kernel<2, bf16_t>), grid, dim3(256), 0, s, g, (const float*)x, w, bias, (bf16_t*)y, act, slope);
         cn_prof_end(s);
         CN_LAUNCH_CHECK();
         return CN_OK;

@@ -43,6 +43,8 @@ CONV_CASES = [
     ((1, 9, 150, 3), (3, 3), 64, 1, 0, None, 0, 0.0),         # K = 27 filter gradient: three 64-pixel tiles per row, the last ragged
     ((1, 11, 301, 3), (3, 3), 20, 2, 0, None, 0, 0.0),        # ... stride 2, 151 outputs per row, cout below one column block
     ((1, 64, 64, 3), (7, 7), 64, 2, 0, 3, 0, 0.0),            # ResNet conv1 (pad 3, valid)
+    ((2, 37, 45, 3), (7, 7), 64, 2, 0, 3, 2, 0.0),            # ... odd extents that do not fill the 8x32 tiles, two images, relu
+    ((1, 70, 130, 3), (7, 7), 24, 2, 0, 3, 0, 0.0),           # ... one column block, a second (ragged) tile column
     ((2, 32, 32, 32), (4, 4), 3, 1, 1, None, 3, 0.0),         # map_final: thin cout + tanh + upsample
     ((1, 20, 13, 32), (4, 4), 3, 1, 1, None, 3, 0.0),         # map_final, extents that do not fill the 8x16 tiles
     ((2, 32, 32, 3), (1, 1), 3, 1, 0, None, 0, 0.0),          # from-RGB 1x1
