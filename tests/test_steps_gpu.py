@@ -305,6 +305,8 @@ def test_whole_second_stage_iteration_under_graph_dispatch_matches_oracle(overla
     ro_d, ro_g = O.KerasAdam(**okw), O.KerasAdam(**okw)
     lr = m.config["optimizer"]["lr"]
 
+    margins = []                                               # (observed / bound, which bound, network, iteration, tensor): printed at the end (-s)
+
     def check_updates(name, it, gl, before, step_len):
         """Post-update weights of iteration `it`.  Iteration 1 (beta_1 = 0, zero moments): |step| = lr*sqrt(1-0.9^t)/sqrt(0.1)
         whatever |g| is, i.e. 1.000 lr for the discriminator (t=1), 1.378 lr for the synthetic-domain discriminator (t=2), 1.646 lr
@@ -328,12 +330,19 @@ def test_whole_second_stage_iteration_under_graph_dispatch_matches_oracle(overla
             # decisions through g1 (single entries of g1 differ by ~10 %: measured up to 0.10 lr on the learned input over runs);
             # a wrong lr_t, a missing half of a split gradient or a stale moment moves EVERY significant entry by O(lr)
             tol = 0.02 if it == 0 else 0.25
+            margins.append((float((step - step_ref)[sig].abs().max()) / lr / tol, "step", name, it, i))
             assert float((step - step_ref)[sig].abs().max()) < tol * lr, (name, it, i, float((step - step_ref)[sig].abs().max()) / lr)
             if step_len is not None:
                 assert abs(float(step[sig].abs().mean()) - step_len * lr) < 0.01 * lr, (name, i, float(step[sig].abs().mean()) / lr, step_len)
             live = g.abs() > 1e-4 * g.abs().max()                # (entries with an exactly-zero true gradient step on fp32 noise)
-            wrong = ((step - step_ref)[live].abs() > 0.1 * lr * (1 if it == 0 else 3)).double().mean()
-            assert float(wrong) < (0.03 if it == 0 else 0.10), (name, it, i, float(wrong))   # ... and below it all but a few per cent do
+            # ... and below it all but a few per cent do.  Counted in entries, with a floor of 3: the 64-entry BatchNorm vectors of
+            # the encoder's first stage have 1.6 % per entry, and which noise-level entries take the other sign changes from run to
+            # run with the order of the filter gradients' atomic adds (six runs: 0 - 1 such entries in those vectors; a second one
+            # failed the former 3 % bound about once in a dozen runs of the whole suite)
+            n_wrong = int(((step - step_ref)[live].abs() > 0.1 * lr * (1 if it == 0 else 3)).sum())
+            allowed = max(3.0, (0.03 if it == 0 else 0.10) * int(live.sum()))
+            margins.append((n_wrong / allowed, "wrong", name, it, i))
+            assert n_wrong < allowed, (name, it, i, n_wrong, int(live.sum()))
 
     for it in range(n_iters):
         before = {k: [w.detach().clone() for w in v] for k, v in W.items()}
@@ -372,6 +381,11 @@ def test_whole_second_stage_iteration_under_graph_dispatch_matches_oracle(overla
             for name in NET_NAMES:
                 for w, a in zip(W[name], after[it][name]):
                     w.copy_(torch.as_tensor(a).double())
+    # how close the statistical bounds of check_updates came (pytest -s): observed / bound, largest first
+    print("update-check margins (observed / bound):", sorted(margins, reverse=True)[:4])
+    loss_m = max(abs(g[k] - float(r[k].detach())) / max(1.0, abs(float(r[k].detach()))) / 1e-3
+                 for g, r in zip(got[-1], (ref["d"], ref["synth_d"], ref["latent_d"], ref["g"])) for k in g)
+    print("last iteration's loss scalars: largest error / bound = %.3f" % loss_m)
 
 
 def test_full_size_iteration_in_the_benchmarked_dispatch_matches_cpu_oracle():
