@@ -23,7 +23,7 @@ def family(name):          # (the family naming of pmc_traffic_by_kernel.py)
         if k + "<" in name:
             t = name.split(k + "<")[1][:10]
             return ("igemm_wgrad<%s>" if "wgrad" in k else "igemm_fwd<%s>") % TILES.get(t, t)
-    for k, f in (("wino4_fwd_kernel", "wino_fwd"), ("wino_fwd_kernel", "wino_fwd"), ("c3_fwd_kernel", "c3_fwd"), ("s2_image_dgrad_kernel", "s2_image_dgrad"),
+    for k, f in (("wino4_fwd_kernel", "wino_fwd"), ("wino_fwd_kernel", "wino_fwd"), ("c3_fwd_kernel", "c3_fwd"), ("c7s2_fwd_kernel", "c3_fwd"), ("s2_image_dgrad_kernel", "s2_image_dgrad"),
                  ("s1_image_dgrad_kernel", "s2_image_dgrad"), ("c3_wgrad_kernel", "c3_wgrad"), ("up2k4_rgb_fwd_kernel", "thin / up2k4_rgb"),
                  ("igemm_bf16_wgrad", "igemm_bf16_wgrad"), ("igemm_bf16_kernel", "igemm_bf16")):
         if k in name:

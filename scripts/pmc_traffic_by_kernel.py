@@ -36,7 +36,7 @@ def family(name):
         return "igemm_fwd<%s>" % TILES.get(t, t)
     if "s1_image_dgrad_kernel" in name:
         return "s2_image_dgrad"                       # (one family in cn_prof_collect_by_family)
-    for k, f in (("wino_fwd_kernel", "wino_fwd"), ("c3_fwd_kernel", "c3_fwd"), ("s2_image_dgrad_kernel", "s2_image_dgrad"),
+    for k, f in (("wino_fwd_kernel", "wino_fwd"), ("c3_fwd_kernel", "c3_fwd"), ("c7s2_fwd_kernel", "c3_fwd"), ("s2_image_dgrad_kernel", "s2_image_dgrad"),
                  ("c3_wgrad_kernel", "c3_wgrad"), ("up2k4_rgb_fwd_kernel", "thin / up2k4_rgb"), ("igemm_bf16_wgrad_tr_kernel", "igemm_bf16_wgrad"), ("igemm_bf16_wgrad_kernel", "igemm_bf16_wgrad"),
                  ("igemm_bf16_kernel", "igemm_bf16")):
         if k in name:
