@@ -599,7 +599,12 @@ int cn_fwd2(const CnConvGeom* gp, int cfg, int bt, const float* A, const float* 
     // workgroups anyway -- then the fourth stage's extra step of look-ahead is what hides the fill latency (same-shape A/B: 64 x 64
     // 388 vs 418 us at M = 1 310 720, 84 vs 111 us the other way round at M = 8 192 with two K slices)
     const long wgs = (long)cn_cdiv(M, cfg == 2 ? 64 : 128) * cn_cdiv(N, cfg == 0 ? 128 : cfg == 4 ? 96 : cfg == 3 ? 32 : 64) * splits;
-    int kb = g_fwd2_kb ? g_fwd2_kb : 16, ns = g_fwd2_ns ? g_fwd2_ns : ((cfg == 0 || cfg == 4 || wgs >= 2048) ? 3 : 4);
+    // stage depth: 32 (half the steps and barriers) for 64 x 64 launches of at most three workgroups per CU -- in place of the loader
+    // waves there: bench.py 391.1 -> 393.8 img/s, 392.6 -> 395.9 with the bound at 512 on another box; every launch: 390.5 --, else 16
+    // (g_fwd2_kb: 0 = this rule, 16 / 32 = forced by cn_conv_loop_select or CN_FWD2_KB)
+    static const long kb_wgs = getenv("CN_FWD2_KB_WGS") ? atol(getenv("CN_FWD2_KB_WGS")) : 768;
+    int kb = g_fwd2_kb ? g_fwd2_kb : ((cfg == 2 && wgs <= kb_wgs && g_fwd2_np < 0) ? 32 : 16);
+    int ns = g_fwd2_ns ? g_fwd2_ns : ((cfg == 0 || cfg == 4 || wgs >= 2048) ? 3 : 4);
     if (kb == 32 && (K % 32 != 0 || cfg != 2)) kb = 16;            // 32-deep stages: the 64 x 64 tile only
     if (kb == 32) ns = 3;
     // loader waves: for 64 x 64 launches of at most three workgroups per CU (above that the other workgroups' MFMAs cover a wave's
@@ -656,6 +661,23 @@ int cn_fwd2_bf16(const CnConvGeom& g, int cfg, int flip, const void* x, const vo
 #define LB2(WM, WN, TM, TN, NP_)   \
     if (ns == 3) { LB(WM, WN, TM, TN, 3, NP_); } \
     else { LB(WM, WN, TM, TN, 4, NP_); }
+    // 32-deep stages (64 bf16 elements): half the steps, hence half the barriers, of a loop whose step holds only two 32-cycle MFMAs
+    // per wave -- for launches of at most ~four workgroups per CU on the 64- and 128 x 64 tiles (M = 4 096, K = 2 304, N = 256:
+    // 26 -> 22 us; 4 096 x 256 x 1 024: 25 -> 19; 8 192 x 4 608 x 512: 65 -> 55).  Larger launches lose (48 / 72 KB of LDS per
+    // workgroup: 524 288 x 576 x 64 84 -> 114 us), so does the 128 x 128 tile (96 KB) and a single-step reduction
+    // (scripts/dev/bf16_kb_ab.sh).
+    static const int kb_env = getenv("CN_FWD2_BF16_KB") ? atoi(getenv("CN_FWD2_BF16_KB")) : 32;
+    static const long kb_wgs = getenv("CN_FWD2_BF16_KB_WGS") ? atol(getenv("CN_FWD2_BF16_KB_WGS")) : 1024;
+#define LB32(WM, WN, TM, TN) \
+    return launch2<WM, WN, TM, TN, true, true, 32, 3, 0, true>(g, A, B, bias, C, M, N, K, act, slope, 1, 0, par, s, nullptr, ab, bb, flip)
+    if (kb_env == 32 && K % 64 == 0 && wgs <= kb_wgs && (long)K * g.k_d * g.k_h * g.k_w >= 128) {
+        switch (cfg) {
+            case 1: LB32(2, 2, 2, 1);
+            case 2: LB32(2, 2, 1, 1);
+            default: break;
+        }
+    }
+#undef LB32
     switch (cfg) {
         case 0: if (np) { LB2(2, 2, 2, 2, 2); } LB2(2, 2, 2, 2, 0);
         case 1: if (np) { LB2(2, 2, 2, 1, 2); } LB2(2, 2, 2, 1, 0);

@@ -72,6 +72,43 @@ def _oracle_conv(x, w, b, stride, up, explicit_pad, act, slope):
     return y
 
 
+LOOP_VARIANTS = [(16, 3, 0), (16, 4, 0), (16, 3, 1), (16, 4, 2), (32, 3, 0)]     # (stage depth, stages, loader waves)
+
+
+@pytest.mark.parametrize("shape", [((2, 16, 16, 64), (3, 3), 128, 1), ((1, 32, 32, 96), (3, 3), 192, 2), ((3, 8, 8, 256), (1, 1), 512, 1),
+                                   ((1, 8, 8, 8, 64), (3, 3, 3), 64, 1)], ids=["k3", "k3s2", "1x1", "3d"])
+def test_every_variant_of_the_lds_dma_loop_gives_the_same_bits(shape):
+    """cn_conv_loop_select: the LDS-DMA main loop (fwd2.hip) with 16- / 32-deep stages, three / four stages and 0 / 1 / 2 loader
+    waves walks the reduction in the same order, so an unsplit launch must give the SAME BITS in every variant -- forward and data
+    gradient (the default rule picks one of them per launch size: small launches of the test suite would otherwise never run the
+    variants the full-size layers use), and agree with the float64 oracle."""
+    from confignet_amd import ops
+    from confignet_amd._lib import lib
+    xs, k, cout, stride = shape
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    x = torch.randn(xs, device="cuda", generator=gen)
+    w = torch.randn(tuple(k) + (xs[-1], cout), device="cuda", generator=gen) * 0.05
+    b = torch.randn(cout, device="cuda", generator=gen)
+    g = ops.ConvSpec(k, stride=stride).geom(xs, cout)
+    gy = torch.randn(ops.geom_out_shape(g), device="cuda", generator=gen)
+    ref = _oracle_conv(x.cpu().double(), w.cpu().double(), b.cpu().double(), stride, 0, None, 1, 0.3)
+    outs = {}
+    try:
+        ops.check(lib.cn_conv_tune(2, 1, 0), "cn_conv_tune")               # 64 x 64 tile (the one every variant exists for), unsplit
+        for kb, ns, np_ in LOOP_VARIANTS:
+            ops.check(lib.cn_conv_loop_select(1, kb, ns, np_), "cn_conv_loop_select")
+            outs[(kb, ns, np_)] = (ops.conv_fwd(x, w, b, g, 1, 0.3).clone(), ops.conv_dgrad(gy, w, g).clone())
+    finally:
+        ops.check(lib.cn_conv_loop_select(-1, 0, 0, -1), "cn_conv_loop_select")
+        ops.check(lib.cn_conv_tune(-1, 0, 0), "cn_conv_tune")
+    torch.cuda.synchronize()
+    y0, d0 = outs[LOOP_VARIANTS[0]]
+    assert float((y0.cpu().double() - ref).abs().max()) <= 2e-4 * float(ref.abs().max())
+    for v, (y, d) in outs.items():
+        assert torch.equal(y, y0), ("forward", v)
+        assert torch.equal(d, d0), ("data gradient", v)
+
+
 @pytest.mark.parametrize("case", CONV_CASES, ids=[str(i) for i in range(len(CONV_CASES))])
 def test_conv_fwd_dgrad_wgrad(case):
     from confignet_amd import ops
