@@ -595,22 +595,21 @@ int cn_fwd2(const CnConvGeom* gp, int cfg, int bt, const float* A, const float* 
     if (x_elems * 4.0 >= 2147483647.0 || w_elems * 4.0 >= 2147483647.0) return CN_EUNSUPPORTED;      // 32-bit byte offsets
     const unsigned ab = (unsigned)(x_elems * 4.0), bb = (unsigned)(w_elems * 4.0);
     static const CnConvGeom none = {};
-    // stage count: three (24 / 36 / 48 KB: more workgroups per CU) unless the launch is so small that a CU holds one or two
-    // workgroups anyway -- then the fourth stage's extra step of look-ahead is what hides the fill latency (same-shape A/B: 64 x 64
-    // 388 vs 418 us at M = 1 310 720, 84 vs 111 us the other way round at M = 8 192 with two K slices)
-    const long wgs = (long)cn_cdiv(M, cfg == 2 ? 64 : 128) * cn_cdiv(N, cfg == 0 ? 128 : cfg == 4 ? 96 : cfg == 3 ? 32 : 64) * splits;
-    // stage depth: 32 (half the steps and barriers) for 64 x 64 launches of at most three workgroups per CU -- in place of the loader
-    // waves there: bench.py 391.1 -> 393.8 img/s, 392.6 -> 395.9 with the bound at 512 on another box; every launch: 390.5 --, else 16
-    // (g_fwd2_kb: 0 = this rule, 16 / 32 = forced by cn_conv_loop_select or CN_FWD2_KB)
-    static const long kb_wgs = getenv("CN_FWD2_KB_WGS") ? atol(getenv("CN_FWD2_KB_WGS")) : 768;
-    int kb = g_fwd2_kb ? g_fwd2_kb : ((cfg == 2 && wgs <= kb_wgs && g_fwd2_np < 0) ? 32 : 16);
-    int ns = g_fwd2_ns ? g_fwd2_ns : ((cfg == 0 || cfg == 4 || wgs >= 2048) ? 3 : 4);
+    // Loop variant.  Defaults: 16-deep stages, FOUR stages, no loader waves.  How they were arrived at (all three are decided by
+    // alternating bench.py runs on one box, scripts/dev/pipe_ab.sh -- isolated timings of one shape say something else for each):
+    //  * stages: in isolation three stages (24 - 48 KB: more workgroups per CU) win for the big tiles and for >= 2048 workgroups
+    //    (64 x 64: 388 vs 418 us at M = 1 310 720) and four for small launches (84 vs 111 us at M = 8 192 with two K slices); in the
+    //    pipelined iteration, where other lines' kernels share the CUs, that rule measured 396.0 against 398.5 images/s for four everywhere;
+    //  * loader waves (NP = 2) for 64 x 64 launches of <= 768 workgroups: 52 -> 48.5 us on the ablation shape, 266 -> 303 us at 8 192
+    //    workgroups; in the pipelined iteration 392.4 -> 394.8 images/s fp32 and 711 -> 719 bf16 WITHOUT them;
+    //  * 32-deep stages (half the steps and barriers; 64 x 64 tile only): +-0 per shape, +0.6 % on the iteration while the small
+    //    launches ran with loader waves, 396.7 against 397.0 once they did not; 32 for every launch loses 1.5 %.  (bf16: cn_fwd2_bf16.)
+    // g_fwd2_kb / _ns / _np: 0 / 0 / -1 = these defaults, else forced by cn_conv_loop_select or CN_FWD2_KB / _NS / _NP.
+    int kb = g_fwd2_kb ? g_fwd2_kb : 16;
+    int ns = g_fwd2_ns ? g_fwd2_ns : 4;
     if (kb == 32 && (K % 32 != 0 || cfg != 2)) kb = 16;            // 32-deep stages: the 64 x 64 tile only
     if (kb == 32) ns = 3;
-    // loader waves: for 64 x 64 launches of at most three workgroups per CU (above that the other workgroups' MFMAs cover a wave's
-    // LDS-DMA issue anyway and the two extra waves only cost residency: 266 -> 303 us at 8 192 workgroups); not for
-    // parity-ordered launches (their tiles differ 4 : 1 in length, the long ones run alone at the end either way: measured slower)
-    int np = g_fwd2_np >= 0 ? g_fwd2_np : ((cfg == 2 && wgs <= 768 && !par) ? 2 : 0);
+    int np = g_fwd2_np >= 0 ? g_fwd2_np : 0;
     if (cfg != 2 || kb == 32) np = 0;
 #define L3(WM, WN, TM, TN, KB_, NS_, NP_)                                                                                                          \
     return gp ? (bt ? launch2<WM, WN, TM, TN, true, true, KB_, NS_, NP_>(*gp, A, B, bias, C, M, N, K, act, slope, splits, part_stride, par, s, res, ab, bb, 1, stats, stats_mode, stats_slope, srows, sper)   \
@@ -652,9 +651,9 @@ int cn_fwd2_bf16(const CnConvGeom& g, int cfg, int flip, const void* x, const vo
     const float* B = reinterpret_cast<const float*>(wb);
     float* C = reinterpret_cast<float*>(y);
     const long wgs = (long)cn_cdiv(M, cfg == 2 ? 64 : 128) * cn_cdiv(N, cfg == 0 ? 128 : cfg == 4 ? 96 : 64);
-    // loader waves where a CU holds at most ~three workgroups (as in fp32: above that the other workgroups cover a wave's LDS-DMA
-    // issue and the two extra waves only cost residency: 105 -> 139 us at 4 096 workgroups, 34 -> 28 us at 256)
-    const int np = g_fwd2_np >= 0 ? g_fwd2_np : (wgs <= 768 ? 2 : 0);
+    // loader waves: none by default (in isolation they pay where a CU holds at most ~three workgroups -- 34 -> 28 us at 256
+    // workgroups, 105 -> 139 us at 4 096 --; in the pipelined iteration 711 -> 719 images/s without them: see cn_fwd2)
+    const int np = g_fwd2_np >= 0 ? g_fwd2_np : 0;
     const int ns = g_fwd2_ns ? g_fwd2_ns : ((cfg == 0 || cfg == 4 || wgs >= 2048) ? 3 : 4);
 #define LB(WM, WN, TM, TN, NS_, NP_) \
     return launch2<WM, WN, TM, TN, true, true, 16, NS_, NP_, true>(g, A, B, bias, C, M, N, K, act, slope, 1, 0, par, s, nullptr, ab, bb, flip)
