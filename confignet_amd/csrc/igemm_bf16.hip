@@ -222,6 +222,22 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(CnConvGeom g, const bf1
 // ---------------------------------------------------------------------------------------------
 // filter gradient:  GW[(t,ci), co] += sum_m X[src(m,t), ci] * GY[m, co]   (fp32 output, split over m, fp32 atomics)
 // ---------------------------------------------------------------------------------------------
+// Filter-gradient launches: (tap-channel tile, cout tile, row slice) of this workgroup.  tiles_x == 0: the 3-D grid as it is.  Else
+// the XCD-aware 1-D order (the fp32 kernels' rule, igemm_conv.hip): workgroup id runs on XCD id % 8, and every tile of ONE row
+// slice goes to the same XCD -- the slice of X and GY they all read enters that XCD's L2 once.  false: a padding workgroup.
+__device__ __forceinline__ bool wgrad_tile_of_workgroup(int tiles_x, int tiles_y, int nsplits, int& bx, int& by, int& bz) {
+    bx = blockIdx.x; by = blockIdx.y; bz = blockIdx.z;
+    if (!tiles_x) return true;
+    const int TT = tiles_x * tiles_y, id = blockIdx.x;
+    const int grp = id / (8 * TT), r = id - grp * 8 * TT;
+    bz = grp * 8 + (r & 7);
+    if (bz >= nsplits) return false;
+    const int t = r >> 3;
+    by = t / tiles_x;
+    bx = t - by * tiles_x;
+    return true;
+}
+
 template <int WM, int WN, int TM, int TN>
 __global__ __launch_bounds__(256) void igemm_bf16_wgrad_kernel(CnConvGeom g, const bf16_t* __restrict__ X,
                                                                const bf16_t* __restrict__ GY, float* __restrict__ GW,
@@ -229,18 +245,8 @@ __global__ __launch_bounds__(256) void igemm_bf16_wgrad_kernel(CnConvGeom g, con
     static_assert(WM * WN == 4, "4 waves per workgroup");
     constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
     constexpr int IPA = BM / 8, IPB = BN / 8;              // 8-channel pieces per position in each tile
-    // XCD-aware order (tiles_x != 0: 1-D launch; the fp32 kernels' rule, igemm_conv.hip): workgroup id runs on XCD id % 8, and
-    // every tile of ONE row slice goes to the same XCD -- the slice of X and GY they all read enters that XCD's L2 once.
-    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
-    if (tiles_x) {
-        const int TT = tiles_x * tiles_y, id = blockIdx.x;
-        const int grp = id / (8 * TT), r = id - grp * 8 * TT;
-        bz = grp * 8 + (r & 7);
-        if (bz >= nsplits) return;
-        const int t = r >> 3;
-        by = t / tiles_x;
-        bx = t - by * tiles_x;
-    }
+    int bx, by, bz;
+    if (!wgrad_tile_of_workgroup(tiles_x, tiles_y, nsplits, bx, by, bz)) return;
     constexpr int AT = (IPA * 16 + 255) / 256, BT = (IPB * 16 + 255) / 256;   // (piece, position pair) tasks per thread
     __shared__ __attribute__((aligned(16))) bf16_t As[2][BM][LDK];
     __shared__ __attribute__((aligned(16))) bf16_t Bs[2][BN][LDK];
@@ -414,18 +420,8 @@ __global__ __launch_bounds__(256) void igemm_bf16_wgrad_tr_kernel(CnConvGeom g, 
     static_assert(WM * WN == 4, "4 waves per workgroup");
     constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
     constexpr int IPA = BM / 8, IPB = BN / 8;              // 8-channel pieces per position in each tile
-    // XCD-aware order (tiles_x != 0: 1-D launch; the fp32 kernels' rule, igemm_conv.hip): workgroup id runs on XCD id % 8, and
-    // every tile of ONE row slice goes to the same XCD -- the slice of X and GY they all read enters that XCD's L2 once.
-    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
-    if (tiles_x) {
-        const int TT = tiles_x * tiles_y, id = blockIdx.x;
-        const int grp = id / (8 * TT), r = id - grp * 8 * TT;
-        bz = grp * 8 + (r & 7);
-        if (bz >= nsplits) return;
-        const int t = r >> 3;
-        by = t / tiles_x;
-        bx = t - by * tiles_x;
-    }
+    int bx, by, bz;
+    if (!wgrad_tile_of_workgroup(tiles_x, tiles_y, nsplits, bx, by, bz)) return;
     constexpr int AT = (IPA * 16 + 255) / 256, BT = (IPB * 16 + 255) / 256;   // (piece, position pair) tasks per thread
     // Row-major [reduction row][channel] images exactly as they sit in memory (16-byte stores, no transposition); the MFMA
     // operands -- 8 consecutive reduction rows of ONE channel per lane -- come out of ds_read_b64_tr_b16: the 16 lanes of a

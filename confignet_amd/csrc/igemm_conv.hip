@@ -1710,8 +1710,9 @@ extern "C" int cn_conv_fwd_dt(const CnConvGeom* gp, const void* x, int x_dt, con
         CN_LAUNCH_CHECK();
         return CN_OK;
     }
+    static const bool no_c7_dt = getenv("CN_NO_C7") != nullptr;
     if (x_dt == CN_F32 && y_dt == CN_BF16 && g.nd == 2 && g.cin == 3 && g.k_h == 7 && g.k_w == 7 && g.s_h == 2 && g.s_w == 2 &&
-        g.dl_h == 1 && g.dl_w == 1 && !g.up && g.cout > 4 && g.cout <= 64 && !getenv("CN_NO_C7")) {
+        g.dl_h == 1 && g.dl_w == 1 && !g.up && g.cout > 4 && g.cout <= 64 && !no_c7_dt) {
         dim3 grid((unsigned)(g.n * cn_cdiv(g.out_h, 8) * cn_cdiv(g.out_w, 32)));
         cn_prof_begin(s, conv_flops(g), conv_bytes(g, 4.0, 2.0), CN_FAM_C3_FWD);
         if (g.cout <= 32) hipLaunchKernelGGL((c7s2_fwd_kernel<1, bf16_t>), grid, dim3(256), 0, s, g, (const float*)x, w, bias, (bf16_t*)y, act, slope);
