@@ -1055,12 +1055,16 @@ __global__ __launch_bounds__(256) void c3_fwd_kernel(CnConvGeom g, const float* 
         const int c = threadIdx.x % PCC, rs = threadIdx.x / PCC;
         const int ix = ix0 + c / 3;
         const bool cok = c < PC, xin = cok && ix >= 0 && ix < g.in_w;
-        const float* xp = X + ((long)n * g.in_h * g.in_w + ix0) * 3 + c;
+        // (branch-free: an out-of-image element loads X[0] and is zeroed afterwards.  As `ok ? X[...] : 0` hipcc put each guarded
+        // load in its own exec-mask region and, in the <2, 2, float> instance, waited for it there: seven round trips were left.)
+        const long xb = ((long)n * g.in_h * g.in_w + ix0) * 3 + c;
         float pv[NR];
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
             const int r = rs + RPP * i, iy = iy0 + r;
-            pv[i] = (xin && r < PR && iy >= 0 && iy < g.in_h) ? xp[(long)iy * g.in_w * 3] : 0.f;
+            const bool ok = xin && r < PR && iy >= 0 && iy < g.in_h;
+            const float v = X[ok ? xb + (long)iy * g.in_w * 3 : 0L];
+            pv[i] = ok ? v : 0.f;
         }
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
@@ -1130,12 +1134,14 @@ __global__ __launch_bounds__(256) void c7s2_fwd_kernel(CnConvGeom g, const float
         const int c = threadIdx.x;
         const int ix = ix0 + c / 3;
         const bool cok = c < PC, xin = cok && ix >= 0 && ix < g.in_w;
-        const float* xp = X + ((long)n * g.in_h * g.in_w + ix0) * 3 + c;
+        const long xb = ((long)n * g.in_h * g.in_w + ix0) * 3 + c;      // (branch-free loads: see c3_fwd_kernel)
         float pv[PR];
 #pragma unroll
         for (int r = 0; r < PR; ++r) {
             const int iy = iy0 + r;
-            pv[r] = (xin && iy >= 0 && iy < g.in_h) ? xp[(long)iy * g.in_w * 3] : 0.f;
+            const bool ok = xin && iy >= 0 && iy < g.in_h;
+            const float v = X[ok ? xb + (long)iy * g.in_w * 3 : 0L];
+            pv[r] = ok ? v : 0.f;
         }
 #pragma unroll
         for (int r = 0; r < PR; ++r)

@@ -71,3 +71,37 @@ def test_no_register_of_an_in_flight_lds_read_is_touched_before_its_wait(tmp_pat
         assert "ds_read" in text and "lds" in text                       # (the check below is not vacuous)
         sys.argv = ["isa_lds_hazard.py", isa]
         assert isa_lds_hazard.main() == 0, "a ds_read destination is read before its s_waitcnt in " + name
+
+
+def test_the_image_kernels_issue_all_their_staging_loads_before_the_first_wait(tmp_path):
+    """c3_fwd_kernel / c7s2_fwd_kernel (3x3 and 7x7 convolutions of the 3-channel image) stage an input patch in LDS.  Written as
+    `patch[i] = in_image ? X[...] : 0` in a loop, hipcc gave every guarded load its own exec-mask region and an `s_waitcnt vmcnt(0)`
+    in front of the LDS store: thirteen dependent memory round trips per workgroup, 27 us of lifetime around 1.5 us of MFMA work
+    (round 5: 213 -> 118 us once the loads were batched; one instance still kept seven of the waits until the loads became
+    branch-free).  The compiled ISA of every instance must show NO wait for vmcnt(0) that is followed by another global load
+    before the workgroup's first barrier."""
+    import re
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        import pytest
+        pytest.skip("no hipcc")
+    csrc = os.path.join(ROOT, "confignet_amd", "csrc")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-save-temps", "-c",
+                    os.path.join(csrc, "igemm_conv.hip"), "-I" + csrc, "-I" + os.path.join(ROOT, "include"), "-o", "igemm_conv.o"],
+                   cwd=tmp_path, check=True, capture_output=True)
+    lines = open(os.path.join(tmp_path, "igemm_conv-hip-amdgcn-amd-amdhsa-gfx950.s")).read().split("\n")
+    starts = [i for i, l in enumerate(lines) if re.match(r"^_Z\S*(c3_fwd_kernel|c7s2_fwd_kernel)\S*:", l)]
+    assert len(starts) >= 12                                        # 4 + 4 instances of the 3x3 kernel, 2 + 2 of the 7x7 one
+    for i in starts:
+        j = i
+        while "s_endpgm" not in lines[j]:
+            j += 1
+        body = lines[i:j]
+        k = next(n for n, l in enumerate(body) if "s_barrier" in l)
+        pre = body[:k]
+        loads = [n for n, l in enumerate(pre) if "global_load_dword" in l]
+        assert len(loads) >= 17, lines[i]                           # filter slice + one patch element per row
+        early = [n for n, l in enumerate(pre) if re.search(r"s_waitcnt.*vmcnt\(0\)", l) and n < loads[-1]]
+        assert not early, "%s: %d waits for vmcnt(0) with staging loads still to be issued" % (lines[i].split(":")[0], len(early))
