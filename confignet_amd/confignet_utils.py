@@ -7,25 +7,19 @@ import numpy as np
 
 
 def merge_configs(default_config, input_config):
-    """Recursively merge configuration dictionaries (confignet_utils.py:39-61)."""
-    result = {}
-    for name in default_config:
-        lhs = default_config[name]
-        if name in input_config:
-            rhs = input_config[name]
-            if isinstance(lhs, dict):
-                assert isinstance(rhs, dict)
-                result[name] = merge_configs(lhs, rhs)
-            else:
-                result[name] = rhs
+    """Overlay `input_config` on `default_config` (semantics of confignet_utils.py:39-61): a key whose default is a dict is
+    merged key by key (the override must be a dict too), every other key present in the input replaces the default -- also when
+    the input holds a dict where the default holds a scalar --, and keys only the input has are carried over.  The result never
+    aliases the defaults' nested dicts (callers mutate their config)."""
+    merged = copy.deepcopy(dict(default_config))
+    for key, override in input_config.items():
+        base = default_config.get(key)
+        if isinstance(base, dict):
+            assert isinstance(override, dict), "config key %r: a dict default needs a dict override" % (key,)
+            merged[key] = merge_configs(base, override)
         else:
-            result[name] = copy.deepcopy(lhs)      # never alias the defaults' nested dicts: callers mutate their config
-    for name in input_config:
-        rhs = input_config[name]
-        if isinstance(rhs, dict) and name in default_config.keys():
-            continue
-        result[name] = rhs
-    return result
+            merged[key] = override
+    return merged
 
 
 def load_confignet(model_path):
@@ -37,20 +31,18 @@ def load_confignet(model_path):
 
 
 def flip_random_subset_of_images(images):
-    """Host version kept for API parity (confignet_utils.py:198-204); the training path draws the same
-    flip flags and applies them on device while gathering the batch."""
-    flip_or_not = np.random.randint(0, 2, size=images.shape[0])
-    for i, flip in enumerate(flip_or_not):
-        if flip == 1:
-            images[i] = np.fliplr(images[i])
+    """Mirror a random half of the batch left-right, in place (confignet_utils.py:198-204).  The draw -- one
+    np.random.randint(0, 2) per image from the global NumPy stream -- is part of the parity contract; the training path takes
+    the same flags and applies them on device while it gathers the batch (neural_renderer_dataset)."""
+    chosen = np.flatnonzero(np.random.randint(0, 2, size=images.shape[0]))
+    images[chosen] = images[chosen, :, ::-1]
     return images
 
 
 def update_loss_dict(main_loss_dict, new_loss_dict):
-    """confignet_utils.py:206-212."""
-    for key, val in new_loss_dict.items():
-        val = float(val)
-        main_loss_dict.setdefault(key, []).append(val)
+    """Append this step's scalars to the per-loss histories (confignet_utils.py:206-212)."""
+    for name in new_loss_dict:
+        main_loss_dict.setdefault(name, []).append(float(new_loss_dict[name]))
 
 
 def log_loss_vals(loss_dict, output_dir, step_number, prefix, aml_run=None, tb_log_writer=None):

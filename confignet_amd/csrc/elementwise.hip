@@ -812,7 +812,7 @@ static int nc_reduce_launch(const void* x1, const void* x2, float* s1, float* s2
     const int TY = 256 / TX;
     const int cblk = cn_cdiv(CG, TX);
     // ~512 workgroups in total, at least 4*TY rows each
-    static const long red_blocks = getenv("CN_RED_BLOCKS") ? atol(getenv("CN_RED_BLOCKS")) : 512;   // sweep: fewer, longer workgroups = shorter same-address atomic tails
+    constexpr long red_blocks = 512;   // sweep: fewer, longer workgroups = shorter same-address atomic tails
     long want = red_blocks / ((long)cblk * n);
     if (cn_det()) {                 // deterministic mode: as many row blocks as the per-stream workspace holds partials for
         const long cap = (long)(CN_DET_WS_FLOATS / (2 * (size_t)n * c));

@@ -533,6 +533,7 @@ __device__ __forceinline__ void fwd2_body(const CnConvGeom& g, const float* __re
     if (stats && !split && !part_stride) {
         // the two half-waves hold the two row halves of the same columns; then one atomic per (column, sum) and wave
         const int sample = (m0 - (m0 / sper) * sper) / srows;        // (parity-ordered rows: class-major, samples inside a class)
+        const int nsamp = sper / srows;                              // (NOT g.n: the plain 1x1 product is launched without a geometry)
         const int nk = stats_mode == 1 ? 2 : 4;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
@@ -541,7 +542,7 @@ __device__ __forceinline__ void fwd2_body(const CnConvGeom& g, const float* __re
             for (int k = 0; k < 4; ++k) {
                 if (k >= nk) break;
                 const float t = sacc[j][k] + __shfl_xor(sacc[j][k], 32);
-                if (half == 0 && col < N) unsafeAtomicAdd(stats + ((long)k * g.n + sample) * N + col, t);
+                if (half == 0 && col < N) unsafeAtomicAdd(stats + ((long)k * nsamp + sample) * N + col, t);
             }
         }
     }
@@ -570,9 +571,9 @@ int launch2(const CnConvGeom& g, const float* A, const float* B, const float* bi
     return CN_OK;
 }
 
-int g_fwd2_kb = getenv("CN_FWD2_KB") ? atoi(getenv("CN_FWD2_KB")) : 0;     // 0: per-tile default
-int g_fwd2_ns = getenv("CN_FWD2_NS") ? atoi(getenv("CN_FWD2_NS")) : 0;
-int g_fwd2_np = getenv("CN_FWD2_NP") ? atoi(getenv("CN_FWD2_NP")) : -1;    // loader waves: -1 = per-tile default
+int g_fwd2_kb = 0;      // cn_conv_loop_select (tests / sweeps): 0 = per-tile default
+int g_fwd2_ns = 0;
+int g_fwd2_np = -1;     // loader waves: -1 = per-tile default
 
 }  // namespace
 
@@ -604,7 +605,7 @@ int cn_fwd2(const CnConvGeom* gp, int cfg, int bt, const float* A, const float* 
     //    workgroups; in the pipelined iteration 392.4 -> 394.8 images/s fp32 and 711 -> 719 bf16 WITHOUT them;
     //  * 32-deep stages (half the steps and barriers; 64 x 64 tile only): +-0 per shape, +0.6 % on the iteration while the small
     //    launches ran with loader waves, 396.7 against 397.0 once they did not; 32 for every launch loses 1.5 %.  (bf16: cn_fwd2_bf16.)
-    // g_fwd2_kb / _ns / _np: 0 / 0 / -1 = these defaults, else forced by cn_conv_loop_select or CN_FWD2_KB / _NS / _NP.
+    // g_fwd2_kb / _ns / _np: 0 / 0 / -1 = these defaults, else forced by cn_conv_loop_select.
     int kb = g_fwd2_kb ? g_fwd2_kb : 16;
     int ns = g_fwd2_ns ? g_fwd2_ns : 4;
     if (kb == 32 && (K % 32 != 0 || cfg != 2)) kb = 16;            // 32-deep stages: the 64 x 64 tile only
@@ -665,8 +666,8 @@ int cn_fwd2_bf16(const CnConvGeom& g, int cfg, int flip, const void* x, const vo
     // 26 -> 22 us; 4 096 x 256 x 1 024: 25 -> 19; 8 192 x 4 608 x 512: 65 -> 55).  Larger launches lose (48 / 72 KB of LDS per
     // workgroup: 524 288 x 576 x 64 84 -> 114 us), so does the 128 x 128 tile (96 KB) and a single-step reduction
     // (scripts/dev/bf16_kb_ab.sh).
-    static const int kb_env = getenv("CN_FWD2_BF16_KB") ? atoi(getenv("CN_FWD2_BF16_KB")) : 32;
-    static const long kb_wgs = getenv("CN_FWD2_BF16_KB_WGS") ? atol(getenv("CN_FWD2_BF16_KB_WGS")) : 1024;
+    constexpr int kb_env = 32;
+    constexpr long kb_wgs = 1024;
 #define LB32(WM, WN, TM, TN) \
     return launch2<WM, WN, TM, TN, true, true, 32, 3, 0, true>(g, A, B, bias, C, M, N, K, act, slope, 1, 0, par, s, nullptr, ab, bb, flip)
     if (kb_env == 32 && K % 64 == 0 && wgs <= kb_wgs && (long)K * g.k_d * g.k_h * g.k_w >= 128) {

@@ -1907,6 +1907,6 @@ extern "C" int cn_conv_tune(int cfg, int splits, long wg_blocks) {
     g_tune_splits = splits;
     g_tune_wg_blocks = wg_blocks;
     // the same hook steers cn_conv_wgrad_ws: tile 0 / 4 / 2 / 3 -> 128x128 / 128x96 / 64x64 / 128x32, wg_blocks = workgroup target
-    cn_wgrad2_tune(cfg == 0 ? 0 : cfg == 4 ? 1 : cfg == 2 ? 2 : cfg == 3 ? 3 : -1, wg_blocks);
+    cn_wgrad2_tune(cfg == 0 ? 0 : cfg == 4 ? 1 : cfg == 2 ? 2 : cfg == 3 ? 3 : cfg == 5 ? 4 : -1, wg_blocks);
     return CN_OK;
 }

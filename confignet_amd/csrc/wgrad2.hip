@@ -20,32 +20,62 @@
 
 #include "mma_tile.h"
 #include "conv_geom.h"
+#include "slots.h"
 
 namespace {
 
 typedef __attribute__((address_space(3))) float lds_float;
+typedef float v2f __attribute__((ext_vector_type(2)));
 
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-    // s_waitcnt vmcnt(N) only (gfx9 encoding: vmcnt = imm[3:0] | imm[15:14] << 4, expcnt imm[6:4], lgkmcnt imm[11:8])
-    __builtin_amdgcn_s_waitcnt((N & 15) | ((N >> 4) << 14) | (7 << 4) | (15 << 8));
+constexpr int w2_task_slot(int q, int nslot, int ntask) { return q * nslot / ntask; }
+// LDS-DMA tasks (A piece j: task 4 j + 3; B piece j: task 4 JA + 2 j + 1) that sit in a slot below `limit`
+constexpr int w2_dma_before(int ja, int jb, int nslot, int ntask, int limit) {
+    int n = 0;
+    for (int j = 0; j < ja; ++j) n += w2_task_slot(4 * j + 3, nslot, ntask) < limit ? 1 : 0;
+    for (int j = 0; j < jb; ++j) n += w2_task_slot(4 * ja + 2 * j + 1, nslot, ntask) < limit ? 1 : 0;
+    return n;
 }
 
 // WM x WN waves, each TM x TN MFMA tiles: workgroup tile BI = 32 WM TM rows of (tap, ci) by BN = 32 WN TN output channels; KB
-// reduction rows per stage.  A lane owns ADJACENT columns of its wave's tiles (column of MFMA lane l, tile t: T * l + t), so the
-// TM (TN) operands of one k row are one ds_read_b64 when T == 2.
-template <int WM, int WN, int TM, int TN, int KB>
-__global__ __launch_bounds__(256) void wgrad2_kernel(CnConvGeom g, const float* __restrict__ X, const float* __restrict__ GY,
-                                                     float* __restrict__ out, long slab_stride, int rows_per_split, int tiles_x,
-                                                     int tiles_y, int nsplits, int accumulate) {
+// reduction rows per stage, NS stages.  A lane owns ADJACENT columns of its wave's tiles when T == 2 (column of MFMA lane l, tile
+// t: 2 l + t), so the two operands of one k row are one ds_read_b64; otherwise tile t is 32 columns further (ds_read_b32 each).
+//
+// Round 6: the step is laid out as MFMA slots (slots.h; the layout that took fwd2's main family from 0.49 to 0.61 MFMA-busy).
+// The round-4 form of this loop put a whole piece's address arithmetic (~35 VALU with integer multiplies) and its LDS-DMA issue
+// (which alone holds the wave's issue ~60 cycles) behind ONE MFMA and started every step with an exposed wait + barrier + LDS
+// round trip.  Now, per step of G groups (a group = the MFMAs of GK k pairs, at least 3):
+//     groups 0 .. G-2 : MFMA | <= 2 operand reads of the NEXT group (behind the first half of the group's MFMAs) | one task
+//     wait: own pieces of step t+1 landed | s_barrier (everybody's landed, everybody done reading stage t)
+//     group G-1       : MFMA | operand reads of group 0 of step t+1
+// where the tasks are the refill of the stage that step t-1 used (= step t + NS - 1) cut into pieces of <= ~16 VALU: per A piece
+// "source offset", "advance w / h", "advance d / n", "issue"; per B piece "offset", "issue" -- spread evenly over the slots in
+// front of the barrier by a constant expression.  The gather coordinates are kept in the (strided, tap-shifted) source frame and
+// advanced by mixed-radix digits with compare / select only; the three products of the offset are 24-bit multiplies (full rate;
+// cn_wgrad2_ok bounds the operands).
+template <int WM, int WN, int TM, int TN, int KB, int NS>
+__device__ __forceinline__ void wgrad2_body(const CnConvGeom& g, const float* __restrict__ X, const float* __restrict__ GY,
+                                            float* __restrict__ out, long slab_stride, int rows_per_split, int tiles_x, int tiles_y,
+                                            int nsplits, int accumulate) {
     static_assert(WM * WN == 4, "4 waves per workgroup");
     constexpr int BI = 32 * WM * TM, BN = 32 * WN * TN;
     constexpr int QA = KB * BI / 256, QB = KB * BN / 256;            // 1 KB wave instructions per stage
     static_assert(QA % 4 == 0, "A pieces divide over the 4 waves");
     constexpr int JA = QA / 4, JB = (QB + 3) / 4, LPW = JA + JB;      // loads per wave per step (dummy pieces keep it uniform)
     constexpr int SA = KB * BI, SB = JB * 4 * 256;                    // floats per stage
-    constexpr int NS = 4;                                             // stages
-    __shared__ __attribute__((aligned(16))) float SM[NS * (SA + SB)];  // stage s: A at s * SA, B at NS * SA + s * SB
+    constexpr int NMT = TM * TN;                                      // MFMAs per k pair
+    constexpr int GK = NMT >= 3 ? 1 : 4 / NMT;                        // k pairs per group
+    constexpr int NM = GK * NMT, G = KB / (2 * GK);                   // MFMAs per group, groups per stage
+    constexpr int RDA = TM == 2 ? 1 : TM, RDB = TN == 2 ? 1 : TN, RD1 = RDA + RDB, RD = GK * RD1;     // DS instructions per k pair / group
+    constexpr int NSL = NM > 1 ? NM / 2 : 1;                          // the reads go behind the first NSL MFMAs of a group
+    constexpr int AHEAD = 2, NSET = 4;                                // operands are read AHEAD groups before their MFMAs, NSET register sets
+    constexpr int NTASK = 4 * JA + 2 * JB, NSLOT = G * NM;            // refill tasks / MFMA slots of a step
+    static_assert(G >= 4 && G % NSET == 0, "operand sets rotate per group and return to set 0 at the step boundary");
+    static_assert((NS - 1) * LPW < 64, "vmcnt range");
+    // task q sits in slot q * NSLOT / NTASK (even spread, order kept).  The barrier of a step stands in front of group G - AHEAD:
+    // LDS-DMA tasks in later slots are issued after the step's wait for "step t+1 has landed" and do not count in it.
+    constexpr int VMW = (NS - 3) * LPW + w2_dma_before(JA, JB, NSLOT, NTASK, (G - AHEAD) * NM);     // vmcnt that proves step t+1's pieces
+    static_assert(NS >= 3, "stages");
+    __shared__ __attribute__((aligned(1024))) float SM[NS * (SA + SB)];  // stage s: A at s * SA, B at NS * SA + s * SB
 
     // XCD-aware 1-D order: workgroup id runs on XCD id % 8; every tile of ONE row slice goes to the same XCD, so the slice of X
     // and GY that all of them read is fetched into that XCD's L2 once.  Placement only affects speed.
@@ -62,7 +92,8 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(CnConvGeom g, const float* 
     }
     const int by = tt / tiles_x, bx = tt - by * tiles_x;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // (an SGPR: LDS-DMA destinations stay scalar)
     const int wm = wave / WN, wn = wave % WN, half = lane >> 5, l31 = lane & 31;
     const int M = g.n * g.out_d * g.out_h * g.out_w;
     const int Ktot = g.k_d * g.k_h * g.k_w * g.cin;
@@ -74,6 +105,7 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(CnConvGeom g, const float* 
     const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(X), 0, (int)((long)g.n * g.in_d * g.in_h * g.in_w * g.cin * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t yres = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(GY), 0, (int)((long)M * g.cout * 4), 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;            // past every descriptor's range: the piece lands as zeros
 
     // A pieces of this lane: piece index (wave + 4 j) * 64 + lane -> row = idx / (BI / 4), float4 column idx % (BI / 4); the
     // column (hence tap and channel) is the same for every j, the rows are KB / JA apart
@@ -85,66 +117,87 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(CnConvGeom g, const float* 
     const int a_tap = a_ok ? a_i / g.cin : 0;
     const int a_ci = a_ok ? a_i - a_tap * g.cin : 0;
     tap_decode(g, a_tap, a_kd, a_kh, a_kw);
-    // Gather addresses without divisions or branches in the loop: the lane's rows are kept as (n, od, oh, ow) and advanced by
-    // the mixed-radix digits of KB with one conditional subtract per digit; a tap's source position is an unsigned range test
-    // per axis (dl == 1 in a filter-gradient geometry; the folded x2 upsample is the shift).
+    // A row is kept as its source coordinates v = o * stride + tap - pad per axis (the folded x2 upsample is a shift at use) plus
+    // the element offset of its sample; a step advances the row by KB, i.e. by the mixed-radix digits of KB, one conditional
+    // subtract per digit.  In bounds <=> an unsigned range test per axis (dl == 1 in a filter-gradient geometry).
+    const int up = g.up;
     const int bw = a_kw - g.p_w, bh = a_kh - g.p_h, bd = a_kd - g.p_d;
-    const unsigned ext_w = (unsigned)(g.in_w << g.up), ext_h = (unsigned)(g.in_h << g.up), ext_d = (unsigned)(g.in_d << g.up);
+    const unsigned ext_w = (unsigned)(g.in_w << up), ext_h = (unsigned)(g.in_h << up), ext_d = (unsigned)(g.in_d << up);
+    const int Sw = g.cin, Sh = g.in_w * g.cin, Sd = g.in_h * Sh, Sn = g.in_d * Sd;
     int dg_w, dg_t, dg_h, dg_u, dg_d, dg_n;
     divmod_pos(KB, g.out_w, dg_t, dg_w);
     divmod_pos(dg_t, g.out_h, dg_u, dg_h);
     divmod_pos(dg_u, g.out_d, dg_n, dg_d);
-    int p_m[JA], p_n[JA], p_d[JA], p_h[JA], p_w[JA];
+    const int st_w = dg_w * g.s_w, st_h = dg_h * g.s_h, st_d = dg_d * g.s_d, st_n = dg_n * Sn;        // a step's advance per axis
+    const int wr_w = g.out_w * g.s_w, wr_h = g.out_h * g.s_h, wr_d = g.out_d * g.s_d;                 // a wrap's subtract
+    const int lim_w = bw + wr_w, lim_h = bh + wr_h, lim_d = bd + wr_d;                                // wrapped <=> v >= lim
+    int p_m[JA], v_w[JA], v_h[JA], v_d[JA], n_off[JA];
 #pragma unroll
     for (int j = 0; j < JA; ++j) {
-        int m = mbeg + ((wave + 4 * j) * 64 + lane) / PA;
+        int m = mbeg + ((wave + 4 * j) * 64 + lane) / PA, pw, ph, pd, pn;
         p_m[j] = m;
-        divmod_pos(m, g.out_w, m, p_w[j]);
-        divmod_pos(m, g.out_h, m, p_h[j]);
-        divmod_pos(m, g.out_d, p_n[j], p_d[j]);
+        divmod_pos(m, g.out_w, m, pw);
+        divmod_pos(m, g.out_h, m, ph);
+        divmod_pos(m, g.out_d, pn, pd);
+        v_w[j] = pw * g.s_w + bw;
+        v_h[j] = ph * g.s_h + bh;
+        v_d[j] = pd * g.s_d + bd;
+        n_off[j] = pn * Sn + a_ci;
     }
     // B pieces: row = idx / (BN / 4), float4 column idx % (BN / 4); pieces past the tile (QB not a multiple of 4) and columns
     // past the filter are dummies (offset out of range: they land as zeros in the stage's padding / unused columns)
     constexpr int PB = BN / 4;
-    int b_row[JB], b_col[JB];
+    int b_m[JB], b_col[JB];
+    unsigned b_dead[JB];                             // OOB for a dummy piece, else 0 (ORed into the offset: no branch, no select)
 #pragma unroll
     for (int j = 0; j < JB; ++j) {
         const int idx = (wave + 4 * j) * 64 + lane;
         const int col = n0 + 4 * (idx % PB);
-        b_row[j] = idx / PB;
-        b_col[j] = (wave + 4 * j < QB && col < g.cout) ? col : -1;
+        const bool live = wave + 4 * j < QB && col < g.cout;
+        b_m[j] = mbeg + idx / PB;
+        b_col[j] = live ? col : 0;
+        b_dead[j] = live ? 0u : OOB;
     }
 
-    // one stage's loads for K step ks, piece by piece (always issued -- steps past the slice read nothing but keep the vmcnt
-    // bookkeeping uniform).  Piece p < JA: the lane's p-th A row; p >= JA: its (p - JA)-th B piece.
-    auto issue_piece = [&](int ks, int p) {
-        const int st = ks & (NS - 1);
-        if (p < JA) {
-            const int j = p;
-            float* as = SM + st * SA;
-            const int vw = p_w[j] * g.s_w + bw, vh = p_h[j] * g.s_h + bh, vd = p_d[j] * g.s_d + bd;
-            const bool ok = a_ok & (p_m[j] < mend) & ((unsigned)vw < ext_w) & ((unsigned)vh < ext_h) & ((unsigned)vd < ext_d);
-            const int off = (((p_n[j] * g.in_d + (vd >> g.up)) * g.in_h + (vh >> g.up)) * g.in_w + (vw >> g.up)) * g.cin + a_ci;
-            const unsigned vo = ok ? (unsigned)off * 4u : 0x80000000u;
-            p_m[j] += KB;
-            int c;
-            p_w[j] += dg_w; c = p_w[j] >= g.out_w; p_w[j] -= c ? g.out_w : 0;
-            p_h[j] += dg_h + c; c = p_h[j] >= g.out_h; p_h[j] -= c ? g.out_h : 0;
-            p_d[j] += dg_d + c; c = p_d[j] >= g.out_d; p_d[j] -= c ? g.out_d : 0;
-            p_n[j] += dg_n + c;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(xres, (lds_float*)(as + (wave + 4 * j) * 256), 16, vo, 0, 0, 0);
+    // ---- the refill tasks of one step (always run -- steps past the slice read nothing but keep the vmcnt bookkeeping uniform).
+    // q < 4 JA: A piece q / 4, part q % 4; then B piece (q - 4 JA) / 2, part (q - 4 JA) % 2.  rs = stage to fill.
+    unsigned vo[LPW];
+    auto task = [&](auto qc, int rs) __attribute__((always_inline)) {
+        constexpr int q = decltype(qc)::value;
+        (void)vo; (void)p_m; (void)v_w; (void)v_h; (void)v_d; (void)n_off; (void)b_m; (void)b_col; (void)b_dead;
+        if constexpr (q < 4 * JA) {
+            constexpr int j = q / 4, part = q % 4;
+            if constexpr (part == 0) {
+                const bool ok = a_ok & (p_m[j] < mend) & ((unsigned)v_w[j] < ext_w) & ((unsigned)v_h[j] < ext_h) & ((unsigned)v_d[j] < ext_d);
+                const int off = n_off[j] + __mul24(v_d[j] >> up, Sd) + __mul24(v_h[j] >> up, Sh) + __mul24(v_w[j] >> up, Sw);
+                vo[j] = ok ? (unsigned)off * 4u : OOB;
+            } else if constexpr (part == 1) {
+                p_m[j] += KB;
+                v_w[j] += st_w;
+                const bool cw = v_w[j] >= lim_w;
+                v_w[j] -= cw ? wr_w : 0;
+                v_h[j] += st_h + (cw ? g.s_h : 0);
+            } else if constexpr (part == 2) {
+                const bool ch = v_h[j] >= lim_h;
+                v_h[j] -= ch ? wr_h : 0;
+                v_d[j] += st_d + (ch ? g.s_d : 0);
+                const bool cd = v_d[j] >= lim_d;
+                v_d[j] -= cd ? wr_d : 0;
+                n_off[j] += st_n + (cd ? Sn : 0);
+            } else {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xres, (lds_float*)(SM + rs * SA + (wave + 4 * j) * 256), 16, vo[j], 0, 0, 0);
+            }
         } else {
-            const int j = p - JA;
-            float* bs = SM + NS * SA + st * SB;
-            const int m = mbeg + ks * KB + b_row[j];
-            // rows past the slice meet zero rows of A (their values only have to be readable: clamp); dummy pieces read as zero
-            const unsigned vo = b_col[j] >= 0 ? (unsigned)(min(m, M - 1) * g.cout + b_col[j]) * 4u : 0x80000000u;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(yres, (lds_float*)(bs + (wave + 4 * j) * 256), 16, vo, 0, 0, 0);
+            constexpr int j = (q - 4 * JA) / 2, part = (q - 4 * JA) % 2;
+            if constexpr (part == 0) {
+                // rows past the slice meet zero rows of A (their values only have to be readable: clamp); dummy pieces read as zero
+                const int m = min(b_m[j], M - 1);
+                b_m[j] += KB;
+                vo[JA + j] = ((unsigned)(__mul24(m, g.cout) + b_col[j]) * 4u) | b_dead[j];
+            } else {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(yres, (lds_float*)(SM + NS * SA + rs * SB + (wave + 4 * j) * 256), 16, vo[JA + j], 0, 0, 0);
+            }
         }
-    };
-    auto issue = [&](int ks) {
-#pragma unroll
-        for (int p = 0; p < LPW; ++p) issue_piece(ks, p);
     };
 
     f32x16 acc[TM][TN];
@@ -157,90 +210,92 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(CnConvGeom g, const float* 
 
     // The operand reads are inline asm: the compiler cannot tell a ds_read of stage s from the LDS-DMA destination of stage s+3
     // and would drain every outstanding load (s_waitcnt vmcnt(0)) before each of them; likewise __syncthreads() -- a release of
-    // LDS -- waits for every pending LDS-DMA, so the loop uses the bare s_barrier.  Ordering is done by hand: s_waitcnt vmcnt(2
-    // steps) + s_barrier before a stage is read, lgkmcnt before an operand set is used.
+    // LDS -- waits for every pending LDS-DMA, so the loop uses the bare s_barrier.  Ordering is done by hand: s_waitcnt vmcnt +
+    // s_barrier before a stage is read, lgkmcnt(0) + a scheduling barrier before an operand set is used.  The destination
+    // registers are plain asm OUTPUTS that the MFMAs read directly (no tied operands, no temporaries: a copy the register
+    // allocator places between a read and its wait would see the register before the LDS data has landed -- the round-4 form of
+    // this loop did that under LDS contention; scripts/isa_lds_hazard.py checks the compiled loops, tests/test_abi_cpu.py runs it).
     const int ac = wm * 32 * TM + (TM == 2 ? 2 * l31 : l31), bc = wn * 32 * TN + (TN == 2 ? 2 * l31 : l31);
     const unsigned lds0 = (unsigned)(unsigned long long)(lds_float*)SM;
     const unsigned a_lane = lds0 + 4u * (unsigned)(half * BI + ac), b_lane = lds0 + 4u * (unsigned)(NS * SA + half * BN + bc);
-    typedef float v2f __attribute__((ext_vector_type(2)));
-    constexpr int RD = (TM == 2 ? 1 : TM) + (TN == 2 ? 1 : TN);      // DS instructions per operand set
-    static_assert(KB / 2 >= LPW, "one load piece behind each MFMA group");
-    auto compute = [&](int st, int ks_next) {
-        float a[2][TM], b[2][TN];
-        const unsigned ab = a_lane + 4u * (unsigned)(st * SA), bb = b_lane + 4u * (unsigned)(st * SB);
-        auto fetch = [&](int kk, int set) {
-            const unsigned ap = ab + 4u * (unsigned)(kk * BI), bp = bb + 4u * (unsigned)(kk * BN);
-            if (TM == 2) {
-                v2f v;
-                asm volatile("ds_read_b64 %0, %1" : "=v"(v) : "v"(ap));
-                a[set][0] = v.x; a[set][TM - 1] = v.y;
-            } else {
-#pragma unroll
-                for (int i = 0; i < TM; ++i) asm volatile("ds_read_b32 %0, %1" : "=v"(a[set][i]) : "v"(ap + 128u * i));
-            }
-            if (TN == 2) {
-                v2f v;
-                asm volatile("ds_read_b64 %0, %1" : "=v"(v) : "v"(bp));
-                b[set][0] = v.x; b[set][TN - 1] = v.y;
-            } else {
-#pragma unroll
-                for (int j = 0; j < TN; ++j) asm volatile("ds_read_b32 %0, %1" : "=v"(b[set][j]) : "v"(bp + 128u * j));
-            }
-        };
-        // wait until at most RD DS instructions (the next operand set's) are outstanding.  The set's registers are plain INPUTS of the
-        // wait and a scheduling barrier follows it, so that the MFMAs that use them stay behind it.  NOT "+v" (read-write) operands:
-        // a tied operand that the register allocator does not coalesce becomes a v_mov from the ds_read's destination IN FRONT of
-        // the asm, i.e. before the wait -- the copy reads the register before the LDS data has landed.  That was the round-4 form of
-        // this loop; right as long as LDS answered within the ~100 cycles between the read and the copy, wrong under LDS contention
-        // (another kernel's workgroups on the CU): tile-shaped errors of a few per cent, NaN when the stale register held one.
-        // scripts/isa_lds_hazard.py checks the compiled loops for exactly this (tests/test_abi_cpu.py runs it).
-        auto ready = [&](int set, bool more) {
-            if (TM == 1 && TN == 1) {
-                if (more) asm volatile("s_waitcnt lgkmcnt(%2)" : : "v"(a[set][0]), "v"(b[set][0]), "n"(RD));
-                else asm volatile("s_waitcnt lgkmcnt(0)" : : "v"(a[set][0]), "v"(b[set][0]));
-            } else if (TM == 2 && TN == 2) {
-                if (more) asm volatile("s_waitcnt lgkmcnt(%4)" : : "v"(a[set][0]), "v"(a[set][TM - 1]), "v"(b[set][0]), "v"(b[set][TN - 1]), "n"(RD));
-                else asm volatile("s_waitcnt lgkmcnt(0)" : : "v"(a[set][0]), "v"(a[set][TM - 1]), "v"(b[set][0]), "v"(b[set][TN - 1]));
-            } else {      // TM == 1, TN == 3
-                if (more) asm volatile("s_waitcnt lgkmcnt(%4)" : : "v"(a[set][0]), "v"(b[set][0]), "v"(b[set][1 % TN]), "v"(b[set][2 % TN]), "n"(RD));
-                else asm volatile("s_waitcnt lgkmcnt(0)" : : "v"(a[set][0]), "v"(b[set][0]), "v"(b[set][1 % TN]), "v"(b[set][2 % TN]));
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        };
-        fetch(0, 0);
-#pragma unroll
-        for (int kk = 0; kk < KB; kk += 2) {
-            const int cur = (kk >> 1) & 1;
-            if (kk + 2 < KB) fetch(kk + 2, cur ^ 1);
-            ready(cur, kk + 2 < KB);
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
-            // the refill of the stage that step ks-1 used (K step ks+3), one piece in the shadow of each MFMA group: its address
-            // arithmetic and the DMA issue run while the matrix pipe works off the group
-            if (kk / 2 < LPW) {
-                __builtin_amdgcn_sched_barrier(0);
-                issue_piece(ks_next, kk / 2);
-                __builtin_amdgcn_sched_barrier(0);
-            }
+    v2f a2[NSET][GK], b2[NSET][GK];                  // T == 2: the two adjacent columns of a k pair
+    float a1[NSET][GK][TM], b1[NSET][GK][TN];        // else one register per tile
+    // the r-th DS instruction of group gq's operand set (k pair r / RD1; A tiles first), base addresses of the stage in ab / bb
+    auto read_op = [&](auto rc, auto gc, unsigned ab, unsigned bb) __attribute__((always_inline)) {
+        constexpr int r = decltype(rc)::value, gq = decltype(gc)::value, set = gq % NSET;
+        constexpr int k = r / RD1, q = r % RD1, kk = 2 * (GK * gq + k);
+        (void)a2; (void)b2; (void)a1; (void)b1;
+        if constexpr (q < RDA) {
+            if constexpr (TM == 2) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(a2[set][k]) : "v"(ab), "n"(4 * kk * BI));
+            else asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(a1[set][k][TM == 2 ? 0 : q]) : "v"(ab), "n"(4 * kk * BI + 128 * q));
+        } else {
+            constexpr int qb = q - RDA;
+            if constexpr (TN == 2) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(b2[set][k]) : "v"(bb), "n"(4 * kk * BN));
+            else asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(b1[set][k][TN == 2 ? 0 : qb]) : "v"(bb), "n"(4 * kk * BN + 128 * qb));
         }
     };
+    // the reads of slot m of a group: the m-th of NSL equal shares of the RD instructions
+    auto read_slot = [&](auto mc, auto gc, unsigned ab, unsigned bb) __attribute__((always_inline)) {
+        constexpr int m = decltype(mc)::value;
+        sl_static_for<RD>([&](auto rc) __attribute__((always_inline)) {
+            constexpr int r = decltype(rc)::value;
+            if constexpr (m < NSL && r >= (m * RD + NSL - 1) / NSL && r < ((m + 1) * RD + NSL - 1) / NSL) read_op(rc, gc, ab, bb);
+        });
+    };
+    auto mfma_one = [&](auto mc, auto gc) __attribute__((always_inline)) {
+        constexpr int m = decltype(mc)::value, set = decltype(gc)::value % NSET;
+        constexpr int k = m / NMT, i = (m % NMT) / TN, j = m % TN;
+        float av, bv;
+        if constexpr (TM == 2) av = a2[set][k][i]; else av = a1[set][k][i];
+        if constexpr (TN == 2) bv = b2[set][k][j]; else bv = b1[set][k][j];
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
+    };
 
-    // step ks: wait for its loads (issued three steps ago: two younger steps may stay in flight), barrier (everybody's pieces
-    // have landed, everybody is done with step ks-1), refill the stage step ks-1 used with step ks+3, multiply
-    issue(0);
-    issue(1);
-    issue(2);
-    for (int ks = 0; ks < nks; ++ks) {
-        wait_vmcnt<2 * LPW>();
-        __builtin_amdgcn_s_barrier();
+    if (nks > 0) {
+        // prologue: steps 0 .. NS-2 in flight (stage s holds step s)
+#pragma unroll 1
+        for (int s = 0; s < NS - 1; ++s)
+            sl_static_for<NTASK>([&](auto qc) __attribute__((always_inline)) { task(qc, s); });
+        sl_wait_vmcnt<(NS - 2) * LPW>();             // step 0: own pieces landed
+        __builtin_amdgcn_s_barrier();                //         everybody's
         __builtin_amdgcn_sched_barrier(0);
-        compute(ks & (NS - 1), ks + 3);
-        __builtin_amdgcn_sched_barrier(0);
+        sl_static_for<RD>([&](auto rc) __attribute__((always_inline)) { read_op(rc, SlInt<0>{}, a_lane, b_lane); });
+        sl_static_for<RD>([&](auto rc) __attribute__((always_inline)) { read_op(rc, SlInt<1>{}, a_lane, b_lane); });
+        int st = 0;                                  // stage of step t
+        for (int t = 0; t < nks; ++t) {
+            const int st_next = st + 1 == NS ? 0 : st + 1, rs = st == 0 ? NS - 1 : st - 1;
+            const unsigned a_st = a_lane + 4u * (unsigned)(st * SA), b_st = b_lane + 4u * (unsigned)(st * SB);
+            const unsigned a_nx = a_lane + 4u * (unsigned)(st_next * SA), b_nx = b_lane + 4u * (unsigned)(st_next * SB);
+            sl_static_for<G>([&](auto gc) __attribute__((always_inline)) {
+                constexpr int gq = decltype(gc)::value;
+                if constexpr (gq == G - AHEAD) {
+                    // every operand of stage st is in registers once the reads retire; step t+1 has landed for this wave;
+                    // barrier: for everybody, and everybody is done reading stage st
+                    sl_wait_lgkm<0>();
+                    sl_wait_vmcnt<VMW>();
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                } else if constexpr (gq < G - AHEAD) {
+                    sl_wait_lgkm<(AHEAD - 1) * RD>();    // group gq has landed (LDS reads retire in order; the younger groups may be in flight)
+                }
+                sl_static_for<NM>([&](auto mc) __attribute__((always_inline)) {
+                    constexpr int m = decltype(mc)::value;
+                    mfma_one(mc, gc);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (gq + AHEAD < G) read_slot(mc, SlInt<gq + AHEAD>{}, a_st, b_st);
+                    else read_slot(mc, SlInt<gq + AHEAD - G>{}, a_nx, b_nx);       // (behind the barrier: step t+1 has landed)
+                    sl_static_for<NTASK>([&](auto qc) __attribute__((always_inline)) {
+                        constexpr int q = decltype(qc)::value;
+                        if constexpr (w2_task_slot(q, NSLOT, NTASK) == gq * NM + m) task(qc, rs);
+                    });
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            });
+            st = st_next;
+        }
+        sl_wait_lgkm<0>();                           // (the read-ahead of the step past the end)
+        sl_wait_vmcnt<0>();                          // (the dummy tail loads target LDS: they must not outlive the workgroup's allocation)
     }
-    wait_vmcnt<0>();            // (the dummy tail loads target LDS: they must not outlive the workgroup's allocation)
 
     // epilogue: MFMA lane l31 / tile j holds output channel n0 + wn*32*TN + (TN == 2 ? 2 l31 + j : 32 j + l31); accumulator r of
     // tile i holds MFMA row rho = 4 half + (r & 3) + 8 (r >> 2), i.e. filter row i0 + wm*32*TM + (TM == 2 ? 2 rho + i : 32 i + rho)
@@ -271,8 +326,17 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(CnConvGeom g, const float* 
         }
 }
 
+// (the body is a device function: with generic lambdas directly inside the __global__ template hipcc 7.2 leaves the kernel's
+// host-side launch stub undefined)
+template <int WM, int WN, int TM, int TN, int KB, int NS>
+__global__ __launch_bounds__(256) void wgrad2_kernel(CnConvGeom g, const float* __restrict__ X, const float* __restrict__ GY,
+                                                     float* __restrict__ out, long slab_stride, int rows_per_split, int tiles_x,
+                                                     int tiles_y, int nsplits, int accumulate) {
+    wgrad2_body<WM, WN, TM, TN, KB, NS>(g, X, GY, out, slab_stride, rows_per_split, tiles_x, tiles_y, nsplits, accumulate);
+}
+
 struct Wg2Plan {
-    int cfg;          // 0: 128x128, 1: 128x96, 2: 64x64, 3: 128x32
+    int cfg;          // 0: 128x128, 1: 128x96, 2: 64x64, 3: 128x32, 4: 256x64
     int bi, bn, kb;
     long tiles_x, tiles_y, splits, rows;
 };
@@ -288,14 +352,15 @@ Wg2Plan wg2_plan(const CnConvGeom& g) {
     if (g.cout <= 32) cfg = 3;
     else if (Ktot >= 128 && g.cout % 96 == 0 && g.cout % 128 != 0) cfg = 1;
     else if (Ktot >= 128 && g.cout >= 128) cfg = 0;
+    else if (Ktot >= 256 && g.cout == 64) cfg = 4;
     else cfg = 2;
     // few rows, many filter elements: the small tile gives enough workgroups without (or with fewer) row splits
     if (cfg == 0 && cn_cdiv(Ktot, 128) * cn_cdiv(g.cout, 128) * cn_cdiv(M, 512) < 128) cfg = 2;
     if (g_wg2_cfg >= 0) cfg = g_wg2_cfg;
     p.cfg = cfg;
-    p.bi = cfg == 2 ? 64 : 128;
-    p.bn = cfg == 0 ? 128 : cfg == 1 ? 96 : cfg == 2 ? 64 : 32;
-    p.kb = cfg == 2 ? 32 : 16;
+    p.bi = cfg == 2 ? 64 : cfg == 4 ? 256 : 128;
+    p.bn = cfg == 0 ? 128 : cfg == 1 ? 96 : (cfg == 2 || cfg == 4) ? 64 : 32;
+    p.kb = (cfg == 2 || cfg == 3) ? 32 : 16;
     p.tiles_x = cn_cdiv(Ktot, p.bi);
     p.tiles_y = cn_cdiv(g.cout, p.bn);
     const long tiles = p.tiles_x * p.tiles_y;
@@ -333,8 +398,10 @@ Wg2Plan wg2_plan(const CnConvGeom& g) {
 bool cn_wgrad2_ok(const CnConvGeom& g) {
     const double xb = (double)g.n * g.in_d * g.in_h * g.in_w * g.cin * 4.0;
     const double yb = (double)g.n * g.out_d * g.out_h * g.out_w * g.cout * 4.0;
+    // (24-bit multiplies of the gather: source coordinate x stride of the axis, output row x cout)
+    const double sd = (double)g.in_h * g.in_w * g.cin, rows = (double)g.n * g.out_d * g.out_h * g.out_w;
     return g.cin % 4 == 0 && g.cout % 4 == 0 && g.cout > 4 && xb < 2147483647.0 && yb < 2147483647.0 &&
-           g.dl_d == 1 && g.dl_h == 1 && g.dl_w == 1;
+           g.dl_d == 1 && g.dl_h == 1 && g.dl_w == 1 && sd < 8388608.0 && rows < 8388608.0 && g.cout < 8388608;
 }
 
 size_t cn_wgrad2_workspace_floats(const CnConvGeom& g) {
@@ -351,7 +418,7 @@ void cn_wgrad2_tune(int cfg, long wg_target) {
 
 int cn_wgrad2_family(const CnConvGeom& g) {
     const Wg2Plan p = wg2_plan(g);
-    return p.cfg == 0 ? CN_FAM_WGRAD_128x128 : p.cfg == 1 ? CN_FAM_WGRAD_128x96 : p.cfg == 2 ? CN_FAM_WGRAD_64x64 : CN_FAM_WGRAD_128x32;
+    return p.cfg == 0 ? CN_FAM_WGRAD_128x128 : p.cfg == 1 ? CN_FAM_WGRAD_128x96 : p.cfg == 2 ? CN_FAM_WGRAD_64x64 : p.cfg == 4 ? CN_FAM_WGRAD_256x64 : CN_FAM_WGRAD_128x32;
 }
 
 // gw (+)= filter gradient.  ws: at least cn_wgrad2_workspace_floats(g) floats (may be NULL when that is 0).
@@ -364,13 +431,14 @@ int cn_wgrad2(const CnConvGeom& g, const float* x, const float* gy, float* gw, i
     dim3 grid((unsigned)((p.splits >= 8 ? cn_cdiv(p.splits, 8) * 8 : p.splits) * ntile));
     float* out = p.splits > 1 ? ws : gw;
     const long stride = p.splits > 1 ? count : 0;
-#define WG2(WM, WN, TM, TN, KB_) hipLaunchKernelGGL((wgrad2_kernel<WM, WN, TM, TN, KB_>), grid, dim3(256), 0, s, g, x, gy, out, stride, \
-                                                     (int)p.rows, (int)p.tiles_x, (int)p.tiles_y, (int)p.splits, accumulate)
+#define WG2(WM, WN, TM, TN, KB_, NS_) hipLaunchKernelGGL((wgrad2_kernel<WM, WN, TM, TN, KB_, NS_>), grid, dim3(256), 0, s, g, x, gy, out, stride, \
+                                                          (int)p.rows, (int)p.tiles_x, (int)p.tiles_y, (int)p.splits, accumulate)
     switch (p.cfg) {
-        case 0: WG2(2, 2, 2, 2, 16); break;
-        case 1: WG2(4, 1, 1, 3, 16); break;
-        case 2: WG2(2, 2, 1, 1, 32); break;
-        default: WG2(4, 1, 1, 1, 16); break;
+        case 0: WG2(2, 2, 2, 2, 16, 4); break;
+        case 1: WG2(4, 1, 1, 3, 16, 4); break;
+        case 2: WG2(2, 2, 1, 1, 32, 4); break;
+        case 4: WG2(4, 1, 2, 2, 16, 4); break;
+        default: WG2(4, 1, 1, 1, 32, 3); break;
     }
 #undef WG2
     CN_LAUNCH_CHECK();

@@ -1331,7 +1331,7 @@ def upfold_saved_flops(g):
 
 PROF_FAMILIES = ["igemm_fwd<128x128>", "igemm_fwd<128x64>", "igemm_fwd<64x64>", "igemm_fwd<128x32>", "igemm_fwd<128x96>",
                  "igemm_wgrad<128x128>", "igemm_wgrad<128x96>", "igemm_wgrad<64x64>", "igemm_wgrad<128x32>", "wino_fwd", "c3_fwd",
-                 "s2_image_dgrad", "thin / up2k4_rgb", "c3_wgrad", "igemm_bf16", "igemm_bf16_wgrad"]
+                 "s2_image_dgrad", "thin / up2k4_rgb", "c3_wgrad", "igemm_bf16", "igemm_bf16_wgrad", "igemm_wgrad<256x64>"]
 
 
 def prof_collect_by_family():

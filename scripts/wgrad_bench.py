@@ -1,7 +1,8 @@
 """Filter-gradient shapes of one second-stage iteration (256x256, batch 16), each timed in isolation: the round-3 kernel
 (cn_conv_wgrad: split over rows, fp32 atomics) against cn_conv_wgrad_ws (wgrad2.hip: LDS-DMA main loop, partial slabs + ordered
 reduction), results compared, and -- with `sweep` -- every tile x workgroup target of the new kernel (cn_conv_tune).
-    python scripts/wgrad_bench.py [batch] [sweep]"""
+    python scripts/wgrad_bench.py [batch] [sweep] [geoms=FILE] [dump=FILE]
+geoms=FILE: take the (geometry, count) list from FILE (written by an earlier run with dump=FILE) instead of tracing an iteration."""
 import ctypes
 import sys
 from collections import OrderedDict
@@ -15,9 +16,15 @@ from confignet_amd._lib import lib
 from confignet_amd.confignet_first_stage import DEFAULT_CONFIG
 from confignet_amd.confignet_utils import merge_configs
 
+import json
+import os
+
 FIELDS = [f[0] for f in ops.CnConvGeom._fields_]
 calls = OrderedDict()
 orig = ops.conv_wgrad
+GEOMS = next((a.split("=", 1)[1] for a in sys.argv if a.startswith("geoms=")), None)
+DUMP = next((a.split("=", 1)[1] for a in sys.argv if a.startswith("dump=")), None)
+SWEEPOUT = next((open(a.split("=", 1)[1], "w") for a in sys.argv if a.startswith("sweepout=")), None)     # every sweep point: M K N tile target us
 
 
 def conv_wgrad(x, gy, g, ws, out=None):
@@ -27,20 +34,26 @@ def conv_wgrad(x, gy, g, ws, out=None):
     return orig(x, gy, g, ws, out=out)
 
 
-ops.conv_wgrad = conv_wgrad
 B = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 16
 SWEEP = "sweep" in sys.argv
-np.random.seed(0)
-ds = SyntheticFaceDataset(64, 256, seed=1)
-cfg = merge_configs(DEFAULT_CONFIG, {"batch_size": B, "output_shape": (256, 256, 3)})
-ds.process_metadata(cfg, True)
-m = ConfigNet(cfg, seed=0)
-m.setup_training(None, ds, 0, real_training_set=ds)
-m.training_iteration(ds, ds, optim.Adam(**cfg["optimizer"]), optim.Adam(**cfg["optimizer"]))
-torch.cuda.synchronize()
-ops.conv_wgrad = orig
-del m
-torch.cuda.empty_cache()
+if GEOMS and os.path.exists(GEOMS):
+    for k, cnt in json.load(open(GEOMS)):
+        calls[tuple(k)] = cnt
+else:
+    ops.conv_wgrad = conv_wgrad
+    np.random.seed(0)
+    ds = SyntheticFaceDataset(64, 256, seed=1)
+    cfg = merge_configs(DEFAULT_CONFIG, {"batch_size": B, "output_shape": (256, 256, 3)})
+    ds.process_metadata(cfg, True)
+    m = ConfigNet(cfg, seed=0)
+    m.setup_training(None, ds, 0, real_training_set=ds)
+    m.training_iteration(ds, ds, optim.Adam(**cfg["optimizer"]), optim.Adam(**cfg["optimizer"]))
+    torch.cuda.synchronize()
+    ops.conv_wgrad = orig
+    del m
+    torch.cuda.empty_cache()
+if DUMP:
+    json.dump([[list(k), cnt] for k, cnt in calls.items()], open(DUMP, "w"))
 
 
 def timed(fn, reps=20):
@@ -85,19 +98,23 @@ for k, cnt in calls.items():
     t_old, t_new = timed(run_old), timed(run_new)
     best = (t_new, "default")
     if SWEEP and nbytes >= 0:
-        for tile in (0, 4, 2, 3):
+        for tile in (0, 4, 2, 3, 5):                     # 128x128, 128x96, 64x64, 128x32, 256x64
             if tile == 3 and g.cout > 32:
+                continue
+            if tile == 5 and (g.cout % 64 or Ktot < 128):
                 continue
             if tile == 4 and g.cout % 96:
                 continue
             if tile == 0 and g.cout < 64:
                 continue
-            for target in (128, 256, 512, 768, 1024, 2048):
+            for target in (128, 256, 384, 512, 768, 1024, 1536, 2048):
                 ops.check(lib.cn_conv_tune(tile, 0, target), "tune")
                 try:
                     t = timed(run_new, 10)
                 except Exception as e:
                     t = float("inf")
+                if SWEEPOUT:
+                    SWEEPOUT.write("%d %d %d %d %d %.1f\n" % (M, Ktot, g.cout, tile, target, t))
                 if t < best[0]:
                     best = (t, "tile%d/wg%d" % (tile, target))
         ops.check(lib.cn_conv_tune(-1, 0, 0), "tune")
@@ -111,4 +128,4 @@ rows.sort(reverse=True)
 print("filter gradients per iteration: old %.2f ms, new %.2f ms%s" % (tot_old / 1e3, tot_new / 1e3, ", best of sweep %.2f ms" % (tot_best / 1e3) if SWEEP else ""))
 print("%3s %8s %8s %7s %7s %8s %6s %5s %8s %9s  %s" % ("cnt", "old us", "new us", "old TF", "new TF", "M", "K", "N", "ws MB", "rel err", "best"))
 for _, cnt, t_old, t_new, best, flop, M, K, N, nb, err, k in rows:
-    print("%3d %8.1f %8.1f %7.1f %7.1f %8d %6d %5d %8.1f %9.1e  %s %.1f" % (cnt, t_old, t_new, flop / t_old / 1e6, flop / t_new / 1e6, M, K, N, nb / 1e6, err, best[1], best[0]))
+    print("%3d %8.1f %8.1f %7.1f %7.1f %8d %6d %5d %8.1f %9.1e  %s %.1f  %s" % (cnt, t_old, t_new, flop / t_old / 1e6, flop / t_new / 1e6, M, K, N, nb / 1e6, err, best[1], best[0], dict(zip(FIELDS, k)) if "geom" in sys.argv else ""))

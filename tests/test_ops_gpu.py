@@ -918,6 +918,8 @@ def test_convolution_epilogue_statistics_match_the_separate_passes():
     rng = np.random.default_rng(7)
     cases = [  # (x shape, kernel, cout, stride, up, kind, must fuse)
         ((4, 16, 16, 64), (3, 3), 128, 1, 0, "act", True),
+        ((4, 16, 16, 64), (1, 1), 128, 1, 0, "act", True),          # plain 1x1 product: launched without a geometry (sample count from the row counts)
+        ((4, 16, 16, 64), (1, 1), 128, 1, 0, "pre4", True),
         ((8, 16, 16, 16, 64), (3, 3, 3), 64, 1, 0, "act", True),    # Conv3dAdaIn at 16^3 (the generator's map_3d_post at batch 8)
         ((8, 32, 32, 128), (4, 4), 64, 1, 1, "act", None),          # Conv2dAdaIn with the folded upsample (k4: classes of 9 / 6 / 6 / 4 taps -> K slices even them out: may split)
         ((8, 8, 8, 8, 128), (3, 3, 3), 64, 1, 1, "act", True),      # Conv3dAdaIn with the folded upsample (16^3 outputs: 512 rows per class and sample)
