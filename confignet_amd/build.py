@@ -7,7 +7,7 @@ import sys
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libconfignet_hip.so")
-SOURCES = ["prof.hip", "igemm_conv.hip", "igemm_bf16.hip", "upfold.hip", "winograd.hip", "winograd4.hip", "c3_wgrad.hip", "thin_wgrad.hip", "wgrad2.hip", "gemm1x1.hip", "fwd2.hip", "gemm.hip", "elementwise.hip", "norm_coef.hip", "rotate3d.hip"]
+SOURCES = ["prof.hip", "igemm_conv.hip", "igemm_bf16.hip", "upfold.hip", "winograd.hip", "winograd4.hip", "c3_wgrad.hip", "thin_wgrad.hip", "wgrad2.hip", "fwd2.hip", "gemm.hip", "elementwise.hip", "norm_coef.hip", "rotate3d.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wall"]
 
 

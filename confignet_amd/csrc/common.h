@@ -46,14 +46,10 @@ constexpr size_t CN_DET_WS_FLOATS = (size_t)16 << 20;     // 64 MiB per stream, 
 // dst[i] (+)= scale * sum_{p < parts} src[p * count + i], parts added in index order (one thread per i)
 int cn_sum_parts(const float* src, float* dst, int parts, long count, int accumulate, float scale, hipStream_t s);
 
-// gemm1x1.hip: C[M][N] (+)= A[M][K] B for the 1x1 stride-1 convolutions (gp = NULL) and, with a geometry, the same main loop over
-// the gathered rows of a vec convolution (par: parity-ordered rows); tile cfg 0 / 1 / 2 / 4 of the implicit-GEMM numbering, the
-// same split-K protocol; CN_EUNSUPPORTED for anything else
-int cn_gemm1x1(const CnConvGeom* gp, int cfg, int bt, const float* A, const float* B, const float* bias, float* C, long M, int N, int K,
-               int act, float slope, int splits, long part_stride, int par, hipStream_t s, const float* res = nullptr);
-
-// fwd2.hip: the same contract on the LDS-DMA main loop (both operands straight into LDS, NS stages deep); x_elems / w_elems size the
-// buffer descriptors
+// fwd2.hip: C[M][N] (+)= A[M][K] B for the 1x1 stride-1 convolutions (gp = NULL) and, with a geometry, the same main loop over the
+// gathered rows of a vec convolution (par: parity-ordered rows); tile cfg 0 / 1 / 2 / 3 / 4 of the implicit-GEMM numbering, bt = B is the
+// original filter [N][K] (data gradient), the split-K protocol of igemm_fwd_kernel; both operands go straight into LDS (LDS-DMA), NS
+// stages deep; x_elems / w_elems size the buffer descriptors; CN_EUNSUPPORTED for anything it does not take
 int cn_fwd2(const CnConvGeom* gp, int cfg, int bt, const float* A, const float* B, const float* bias, float* C, long M, int N, int K,
             int act, float slope, int splits, long part_stride, int par, hipStream_t s, const float* res, double x_elems, double w_elems,
             float* stats = nullptr, int stats_mode = 0, float stats_slope = 0.f, int srows = 1, int sper = 1);

@@ -3,7 +3,7 @@
 //
 //   C[m, n] = sum_{t, c} A[src(m, t), c] * B[(t, c), n]          m = output position, (t, c) = (tap, input channel), n = cout
 //
-// gemm1x1.hip stages both tiles through registers (global_load -> VGPR -> ds_write_b128 -> barrier -> ds_read) two steps ahead;
+// The round-3 plain-GEMM loop (gemm1x1.hip, deleted in round 6) staged both tiles through registers (global_load -> VGPR -> ds_write_b128 -> barrier -> ds_read) two steps ahead;
 // the loads, their address arithmetic, the LDS stores and the operand reads all sit in the instruction stream of the waves that
 // issue the MFMAs, and at 2 - 4 waves per SIMD that stream is what the matrix pipe waits for (round 4: the class runs at
 // t_mfma + t_rest).  Here a K step's tiles go from L2 straight into LDS (`buffer_load_dwordx4 ... lds`, 1 KB per wave
@@ -16,7 +16,7 @@
 // 16-byte pieces of a row XOR-swizzled with the row index so that the ds_read_b128 of 16 consecutive rows (one LDS cycle's lane
 // group) covers all 64 banks -- an LDS-DMA instruction writes lane L's 16 bytes at byte 16 L of its 1 KB block, so the swizzle
 // is applied on the SOURCE side: lane L fetches the piece that belongs at slot L.  One ds_read_b128 per lane feeds four MFMAs
-// (K order inside an 8-deep group permuted as in gemm1x1.hip: half-wave h owns k = 4h .. 4h + 3).  Forward: the filter tile
+// (K order inside an 8-deep group permuted: half-wave h owns k = 4h .. 4h + 3).  Forward: the filter tile
 // [KB][BN] is k-major as it lies in memory, a lane owns TN ADJACENT output columns.  Data gradient from the original filter
 // (BT): B^T rows are K-contiguous like A and use A's image.
 //
@@ -124,15 +124,15 @@ __device__ __forceinline__ void fwd2_body(const CnConvGeom& g, const float* __re
     const bool loader = NP == 0 || wave >= 4, worker = wave < 4;      // (NP = 0: every wave is both)
     const int lw = NP > 0 ? wave - 4 : wave;                          // index among the loading waves
     const int wm = (wave & 3) / WN, wn = (wave & 3) % WN;
-    // workgroup order (parity-ordered launches keep the plain order: see gemm1x1_kernel)
+    // workgroup order (parity-ordered launches keep the plain order: their row classes are already dealt out class-major)
     int bx, by;
     if (GATHER && par) {
         divmod_pos((int)blockIdx.x, ntm, by, bx);
         if (by >= ntn) return;
     } else {
         // XCD id % 8 gets a contiguous run of TILES in m-major order (the column tiles of one M tile in consecutive slots: they
-        // read the same A rows from that XCD's L2), balanced to within one tile.  (gemm1x1_kernel deals out whole M tiles: with
-        // fewer than 8 of them -- 128-row tiles at M = 512 -- half of the XCDs got nothing.)
+        // read the same A rows from that XCD's L2), balanced to within one tile.  (Dealing out whole M tiles would leave XCDs
+        // empty when there are fewer than 8 of them -- 128-row tiles at M = 512.)
         const int id = blockIdx.x, xcd = id & 7, j = id >> 3;
         const int nt = ntm * ntn, q = nt >> 3, r = nt & 7;
         if (j >= q + (xcd < r ? 1 : 0)) return;
@@ -583,7 +583,7 @@ void cn_fwd2_tune(int kb, int ns, int np) {
     g_fwd2_np = np;
 }
 
-// Same contract as cn_gemm1x1 (gemm1x1.hip): tile cfg 0 / 1 / 2 / 4, bt = B is the original filter [N][K] (data gradient), split-K
+// The contract stated in common.h: tile cfg 0 / 1 / 2 / 4, bt = B is the original filter [N][K] (data gradient), split-K
 // protocol of igemm_fwd_kernel, gp = NULL for the plain 1x1 stride-1 product, else the geometry whose gather builds the rows (par:
 // parity-ordered).  x_elems / w_elems: sizes of the two tensors (the buffer descriptors' ranges).
 int cn_fwd2(const CnConvGeom* gp, int cfg, int bt, const float* A, const float* B, const float* bias, float* C, long M, int N, int K,

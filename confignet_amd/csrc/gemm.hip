@@ -226,8 +226,7 @@ static int gemm_launch(int ta, int tb, int m, int n, int k, const float* a, int 
     CN_CHECK_ARG(m > 0 && n > 0 && k > 0 && a && b && c, "gemm: bad args m=%d n=%d k=%d", m, n, k);
     CN_CHECK_ARG(lda >= (ta ? m : k) && ldb >= (tb ? k : n) && ldc >= n, "gemm: leading dimension too small");
     hipStream_t s = (hipStream_t)stream;
-    static const int no_small = getenv("CN_NO_SMALL_GEMM") ? 1 : 0;
-    if (!no_small && !accumulate && !ta && m <= 32 && n > 4 && (long)(m <= 8 ? 8 : m <= 16 ? 16 : 32) * k <= 8192) {
+    if (!accumulate && !ta && m <= 32 && n > 4 && (long)(m <= 8 ? 8 : m <= 16 ? 16 : 32) * k <= 8192) {
         const int mt = m <= 8 ? 8 : m <= 16 ? 16 : 32;
         const size_t lds = sizeof(float) * ((size_t)mt * k + 3 * mt * 64);
         dim3 grid(cn_cdiv(n, 64));
@@ -239,7 +238,7 @@ static int gemm_launch(int ta, int tb, int m, int n, int k, const float* a, int 
         CN_LAUNCH_CHECK();
         return CN_OK;
     }
-    if (!no_small && ta && !tb && k <= 32 && !bias && act == CN_ACT_NONE) {
+    if (ta && !tb && k <= 32 && !bias && act == CN_ACT_NONE) {
         dim3 grid(cn_cdiv(m, 16), cn_cdiv(n, 64));
         hipLaunchKernelGGL(gemm_depth_kernel, grid, dim3(256), 0, s, m, n, k, a, lda, b, ldb, c, ldc, accumulate);
         CN_LAUNCH_CHECK();

@@ -239,181 +239,6 @@ __device__ __forceinline__ bool wgrad_tile_of_workgroup(int tiles_x, int tiles_y
 }
 
 template <int WM, int WN, int TM, int TN>
-__global__ __launch_bounds__(256) void igemm_bf16_wgrad_kernel(CnConvGeom g, const bf16_t* __restrict__ X,
-                                                               const bf16_t* __restrict__ GY, float* __restrict__ GW,
-                                                               int rows_per_split, int tiles_x, int tiles_y, int nsplits) {
-    static_assert(WM * WN == 4, "4 waves per workgroup");
-    constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
-    constexpr int IPA = BM / 8, IPB = BN / 8;              // 8-channel pieces per position in each tile
-    int bx, by, bz;
-    if (!wgrad_tile_of_workgroup(tiles_x, tiles_y, nsplits, bx, by, bz)) return;
-    constexpr int AT = (IPA * 16 + 255) / 256, BT = (IPB * 16 + 255) / 256;   // (piece, position pair) tasks per thread
-    __shared__ __attribute__((aligned(16))) bf16_t As[2][BM][LDK];
-    __shared__ __attribute__((aligned(16))) bf16_t Bs[2][BN][LDK];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN, half = lane >> 5, l31 = lane & 31;
-    const int M = g.n * g.out_d * g.out_h * g.out_w;
-    const int T = g.k_d * g.k_h * g.k_w;
-    const int Ktot = T * g.cin;
-    const int i0 = bx * BM, n0 = by * BN;
-    const int mbeg = bz * rows_per_split;
-    const int mend = min(M, mbeg + rows_per_split);
-    if (mbeg >= mend) return;
-
-    // A tasks: piece ip (8 consecutive (tap, ci) rows: one tap, cin % 8 == 0) x position pair mp; fixed per thread
-    int a_ip[AT], a_mp[AT], a_ci[AT], a_kd[AT], a_kh[AT], a_kw[AT];
-    bool a_on[AT];
-    int p_n[AT][2], p_d[AT][2], p_h[AT][2], p_w[AT][2], p_m[AT][2];
-#pragma unroll
-    for (int t = 0; t < AT; ++t) {
-        const int task = tid + 256 * t;
-        a_ip[t] = task % IPA;
-        a_mp[t] = task / IPA;
-        const int i = i0 + a_ip[t] * 8;
-        a_on[t] = a_mp[t] < 16 && i < Ktot;
-        const int tap = a_on[t] ? i / g.cin : 0;
-        a_ci[t] = a_on[t] ? i - tap * g.cin : 0;
-        tap_decode(g, tap, a_kd[t], a_kh[t], a_kw[t]);
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            int m = mbeg + 2 * a_mp[t] + e;
-            p_m[t][e] = m;
-            p_w[t][e] = m % g.out_w; m /= g.out_w;
-            p_h[t][e] = m % g.out_h; m /= g.out_h;
-            p_d[t][e] = m % g.out_d;
-            p_n[t][e] = m / g.out_d;
-        }
-    }
-    int b_ip[BT], b_mp[BT];
-#pragma unroll
-    for (int t = 0; t < BT; ++t) {
-        const int task = tid + 256 * t;
-        b_ip[t] = task % IPB;
-        b_mp[t] = task / IPB;
-    }
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    uint4 ra[AT][2], rb[BT][2];
-    const int nks = (mend - mbeg + KS - 1) / KS;
-
-    auto load_tiles = [&](int ks) {      // called with ks = 0, 1, 2, ... in order (the row coordinates advance by carries)
-#pragma unroll
-        for (int t = 0; t < AT; ++t) {
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                RowInfo r;
-                r.ok = a_on[t] && p_m[t][e] < mend;
-                r.nbase = p_n[t][e] * g.in_d;
-                r.vd = p_d[t][e] * g.s_d - g.p_d;
-                r.vh = p_h[t][e] * g.s_h - g.p_h;
-                r.vw = p_w[t][e] * g.s_w - g.p_w;
-                p_m[t][e] += KS;
-                p_w[t][e] += KS;
-                while (p_w[t][e] >= g.out_w) {
-                    p_w[t][e] -= g.out_w;
-                    if (++p_h[t][e] == g.out_h) {
-                        p_h[t][e] = 0;
-                        if (++p_d[t][e] == g.out_d) {
-                            p_d[t][e] = 0;
-                            ++p_n[t][e];
-                        }
-                    }
-                }
-                const int off = src_off(g, r, a_kd[t], a_kh[t], a_kw[t]);
-                ra[t][e] = off >= 0 ? *reinterpret_cast<const uint4*>(X + off + a_ci[t]) : make_uint4(0, 0, 0, 0);
-            }
-        }
-#pragma unroll
-        for (int t = 0; t < BT; ++t) {
-            const int col = n0 + b_ip[t] * 8;
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const int m = mbeg + ks * KS + 2 * b_mp[t] + e;
-                rb[t][e] = (b_mp[t] < 16 && m < mend && col < g.cout) ? *reinterpret_cast<const uint4*>(GY + (long)m * g.cout + col)
-                                                                       : make_uint4(0, 0, 0, 0);
-            }
-        }
-    };
-    // transposing store: the two positions of a pair become one dword of each of the piece's 8 rows
-    auto store_tiles = [&](int buf) {
-#pragma unroll
-        for (int t = 0; t < AT; ++t) {
-            if (a_mp[t] >= 16) continue;
-            const unsigned lo[4] = {ra[t][0].x, ra[t][0].y, ra[t][0].z, ra[t][0].w};
-            const unsigned hi[4] = {ra[t][1].x, ra[t][1].y, ra[t][1].z, ra[t][1].w};
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                unsigned* d0 = reinterpret_cast<unsigned*>(&As[buf][a_ip[t] * 8 + 2 * q][2 * a_mp[t]]);
-                unsigned* d1 = reinterpret_cast<unsigned*>(&As[buf][a_ip[t] * 8 + 2 * q + 1][2 * a_mp[t]]);
-                *d0 = (lo[q] & 0xffffu) | (hi[q] << 16);
-                *d1 = (lo[q] >> 16) | (hi[q] & 0xffff0000u);
-            }
-        }
-#pragma unroll
-        for (int t = 0; t < BT; ++t) {
-            if (b_mp[t] >= 16) continue;
-            const unsigned lo[4] = {rb[t][0].x, rb[t][0].y, rb[t][0].z, rb[t][0].w};
-            const unsigned hi[4] = {rb[t][1].x, rb[t][1].y, rb[t][1].z, rb[t][1].w};
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                unsigned* d0 = reinterpret_cast<unsigned*>(&Bs[buf][b_ip[t] * 8 + 2 * q][2 * b_mp[t]]);
-                unsigned* d1 = reinterpret_cast<unsigned*>(&Bs[buf][b_ip[t] * 8 + 2 * q + 1][2 * b_mp[t]]);
-                *d0 = (lo[q] & 0xffffu) | (hi[q] << 16);
-                *d1 = (lo[q] >> 16) | (hi[q] & 0xffff0000u);
-            }
-        }
-    };
-
-    load_tiles(0);
-    store_tiles(0);
-    __syncthreads();
-    const int a_row = wm * 32 * TM + l31, b_row = wn * 32 * TN + l31;
-    for (int ks = 0; ks < nks; ++ks) {
-        const int buf = ks & 1;
-        if (ks + 1 < nks) load_tiles(ks + 1);
-        Frag a[2][TM], b[2][TN];
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i) a[s][i].u = *reinterpret_cast<const uint4*>(&As[buf][a_row + 32 * i][16 * s + 8 * half]);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) b[s][j].u = *reinterpret_cast<const uint4*>(&Bs[buf][b_row + 32 * j][16 * s + 8 * half]);
-        }
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s][i].v, b[s][j].v, acc[i][j], 0, 0, 0);
-        if (ks + 1 < nks) store_tiles(buf ^ 1);
-        __syncthreads();
-    }
-
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int col = n0 + wn * 32 * TN + 32 * j + l31;
-        if (col >= g.cout) continue;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int rbase = i0 + wm * 32 * TM + 32 * i + 4 * half;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = rbase + (r & 3) + 8 * (r >> 2);
-                if (row < Ktot) unsafeAtomicAdd(&GW[(long)row * g.cout + col], acc[i][j][r]);
-            }
-        }
-    }
-}
-
-template <int WM, int WN, int TM, int TN>
 __global__ __launch_bounds__(256) void igemm_bf16_wgrad_tr_kernel(CnConvGeom g, const bf16_t* __restrict__ X,
                                                                const bf16_t* __restrict__ GY, float* __restrict__ GW,
                                                                int rows_per_split, int tiles_x, int tiles_y, int nsplits) {
@@ -614,13 +439,10 @@ int conv_bf16(const CnConvGeom& g, int flip, const bf16_t* x, const bf16_t* wb, 
     else if (t128x64 >= 512) cfg = 1;
     else cfg = 2;
     if (g.cout % 96 == 0 && g.cout % 128 != 0 && (long)cn_cdiv(M, 128) * (g.cout / 96) >= 256) cfg = 4;
-    static const int cfg_force = getenv("CN_BF16_CFG") ? atoi(getenv("CN_BF16_CFG")) : -1;      // A/B: force the tile
-    if (cfg_force >= 0) cfg = cfg_force;
     cn_prof_begin(s, conv_flops(g), conv_bytes(g, 2.0, 2.0, 2.0), CN_FAM_BF16_FWD);
     int e = CN_EUNSUPPORTED;
     // the LDS-DMA main loop (fwd2.hip) where the reduction axis is a whole number of 32-element stages per tap
-    static const int fwd2_on = getenv("CN_FWD2_BF16") ? atoi(getenv("CN_FWD2_BF16")) : 1;
-    if (fwd2_on && cfg != 3 && g.cin % 32 == 0 && g.cout >= 48) e = cn_fwd2_bf16(g, cfg, flip, x, wb, bias, y, act, slope, par, s);
+    if (cfg != 3 && g.cin % 32 == 0 && g.cout >= 48) e = cn_fwd2_bf16(g, cfg, flip, x, wb, bias, y, act, slope, par, s);
     if (e == CN_EUNSUPPORTED)
     switch (cfg) {
         case 3: e = launch_bf16<4, 1, 1, 1>(g, par, flip, x, wb, bias, y, act, slope, s); break;   // 128 x 32
@@ -643,11 +465,9 @@ int launch_bf16_wgrad(const CnConvGeom& g, const bf16_t* x, const bf16_t* gy, fl
     // rows is mostly prologue + the tile's atomic adds; (2) one workgroup more than the CUs hold at once costs a whole extra
     // round -- the kernels hold 3 (128 x 128), 4 (128 x 96) or 5 workgroups per CU -- and the narrow tiles like two rounds;
     // (3) with the XCD order a slice count that is not a multiple of 8 leaves XCDs with one slice more than others.
-    static const long wgs_env = getenv("CN_BF16_WGRAD_WGS") ? atol(getenv("CN_BF16_WGRAD_WGS")) : 0;      // A/B: the old rule
-    static const long min_rows = getenv("CN_BF16_WGRAD_ROWS") ? atol(getenv("CN_BF16_WGRAD_ROWS")) : (wgs_env ? 256 : 512);
+    constexpr long min_rows = 512;
     long splits;
-    if (wgs_env) splits = (wgs_env + tiles - 1) / tiles;
-    else {
+    {
         const long per_cu = BMt * BNt >= 128 * 128 ? 3 : BMt * BNt >= 128 * 96 ? 4 : 5;
         const long target = 256 * per_cu * (BNt >= 96 ? 1 : 2);
         splits = target / tiles;
@@ -658,20 +478,16 @@ int launch_bf16_wgrad(const CnConvGeom& g, const bf16_t* x, const bf16_t* gy, fl
         if (splits < 1) splits = 1;
     }
     long rows = (M + splits - 1) / splits;
-    if (wgs_env && rows < min_rows) rows = min_rows;
     if (rows < 256) rows = std::min<long>(256, (M + KS - 1) / KS * KS);
     rows = (rows + KS - 1) / KS * KS;
     splits = (M + rows - 1) / rows;
     dim3 grid(cn_cdiv(Ktot, BMt), cn_cdiv(g.cout, BNt), (unsigned)splits);
-    static const bool old = getenv("CN_BF16_WGRAD_OLD") != nullptr;
-    static const bool xcd = getenv("CN_NO_WGRAD_XCD") == nullptr;
     int tx = 0, ty = 0;
-    if (xcd && grid.x * grid.y > 1 && splits >= 16) {
+    if (grid.x * grid.y > 1 && splits >= 16) {
         tx = (int)grid.x; ty = (int)grid.y;
         grid = dim3((unsigned)(cn_cdiv(splits, 8) * 8 * tx * ty), 1, 1);
     }
-    if (old) hipLaunchKernelGGL((igemm_bf16_wgrad_kernel<WM, WN, TM, TN>), grid, dim3(256), 0, s, g, x, gy, gw, (int)rows, tx, ty, (int)splits);
-    else hipLaunchKernelGGL((igemm_bf16_wgrad_tr_kernel<WM, WN, TM, TN>), grid, dim3(256), 0, s, g, x, gy, gw, (int)rows, tx, ty, (int)splits);
+    hipLaunchKernelGGL((igemm_bf16_wgrad_tr_kernel<WM, WN, TM, TN>), grid, dim3(256), 0, s, g, x, gy, gw, (int)rows, tx, ty, (int)splits);
     CN_LAUNCH_CHECK();
     return CN_OK;
 }

@@ -1274,15 +1274,14 @@ __global__ __launch_bounds__(256) void up2k4_rgb_fwd_kernel(CnConvGeom g, const 
     }
 }
 
-static int g_force_kb16 = -1;
-static int g_tune_cfg = getenv("CN_CFG") ? atoi(getenv("CN_CFG")) : -1;          // read once (not per launch)
-static int g_tune_splits = getenv("CN_SPLITS") ? atoi(getenv("CN_SPLITS")) : 0;
-static long g_tune_wg_blocks = getenv("CN_WG_BLOCKS") ? atol(getenv("CN_WG_BLOCKS")) : 0;
-static int g_xcd = getenv("CN_NO_XCD") ? 0 : 1;
-static int g_fwd2_env = getenv("CN_FWD2") ? atoi(getenv("CN_FWD2")) : 1;      // the LDS-DMA forward loop (fwd2.hip): on unless CN_FWD2=0
+constexpr int g_force_kb16 = 1;      // igemm_fwd_kernel: 16-deep LDS stages (32-deep: measured, no net win)
+static int g_tune_cfg = -1;          // cn_conv_tune (sweeps, tests): forced tile / split-K factor / filter-gradient workgroup target
+static int g_tune_splits = 0;
+static long g_tune_wg_blocks = 0;
+constexpr int g_xcd = 1;             // XCD-aware workgroup order
 static int g_fwd2_sel = -1;                                                    // cn_conv_loop_select override
-static int g_fwd2_min_nks = getenv("CN_FWD2_MINK") ? atoi(getenv("CN_FWD2_MINK")) : 1;   // it takes reductions of MORE K steps than this
-static int g_fwd2_min_c = getenv("CN_FWD2_MINC") ? atoi(getenv("CN_FWD2_MINC")) : 48;   // thinnest layer it takes (A/B: 64 = round-5 first form)
+constexpr int g_fwd2_min_nks = 1;    // the LDS-DMA loop (fwd2.hip) takes reductions of MORE K steps than this
+constexpr int g_fwd2_min_c = 48;     // thinnest layer it takes
 
 template <int WM, int WN, int TM, int TN>
 int launch_fwd(const CnConvGeom& g, bool vec, int par, int splits, const float* x, const float* w, const float* bias,
@@ -1291,7 +1290,7 @@ int launch_fwd(const CnConvGeom& g, bool vec, int par, int splits, const float* 
     dim3 grid(cn_cdiv(M, 32 * WM * TM), cn_cdiv(g.cout, 32 * WN * TN), splits);
     int xcd = g_xcd;
     const int ntm = (int)grid.x, ntn = (int)grid.y;
-    static const int tap_minor_on = getenv("CN_TAP_MINOR") ? atoi(getenv("CN_TAP_MINOR")) : 1;
+    constexpr int tap_minor_on = 1;
     // cout tiles of one M tile grouped per XCD (several cout tiles), taps inside channel chunks (wide layers on the big tiles:
     // that is where the tap re-reads miss L2; the offset table costs LDS the small tiles' occupancy cannot spare)
     const bool wide = TM * TN >= 2 && g.cin >= 128;
@@ -1300,7 +1299,6 @@ int launch_fwd(const CnConvGeom& g, bool vec, int par, int splits, const float* 
         const int per_xcd = (ntm + 7) / 8;
         grid = dim3((unsigned)(per_xcd * ntn * 8), 1, 1);
     }
-    if (g_force_kb16 < 0) g_force_kb16 = getenv("CN_KB32") ? 0 : 1;   // 32-deep stages only on request (A/B: no net win)
     // 32-deep LDS stages: twice the MFMA work per barrier / per global-load round trip, which is what the
     // smaller tiles need to cover the L2/HBM latency of the gathered operand
     const bool kb32 = vec && g.cin % 32 == 0 && !g_force_kb16;
@@ -1343,8 +1341,7 @@ int launch_wgrad(const CnConvGeom& g, const float* x, const float* gy, float* gw
     }
     dim3 grid(cn_cdiv(Ktot, BMt), cn_cdiv(g.cout, BNt), (unsigned)splits);
     int tx = 0, ty = 0;
-    static const int wg_xcd = getenv("CN_NO_WGRAD_XCD") ? 0 : 1;
-    if (wg_xcd && grid.x * grid.y > 1 && splits >= 16) {
+    if (grid.x * grid.y > 1 && splits >= 16) {
         tx = (int)grid.x; ty = (int)grid.y;
         grid = dim3((unsigned)(cn_cdiv(splits, 8) * 8 * tx * ty), 1, 1);
     }
@@ -1386,11 +1383,8 @@ static int conv_fwd_impl(const CnConvGeom* gp, const float* x, const float* w, c
         CN_CHECK_ARG(lds <= 64 * 1024, "thin conv: filter of %zu bytes does not fit the LDS stage", lds);
         const int T = g.k_d * g.k_h * g.k_w, CL = g.cin / 4;
         const bool dl1 = g.dl_d * g.dl_h * g.dl_w == 1;
-        static const bool no_rgb = getenv("CN_NO_RGB") != nullptr, no_s2img = getenv("CN_NO_S2IMG") != nullptr,
-                          no_s1img = getenv("CN_NO_S1IMG") != nullptr;     // read once, like every other switch
         if (g.nd == 2 && g.up == 1 && g.k_h == 4 && g.k_w == 4 && g.s_h == 1 && g.s_w == 1 && g.dl_h == 1 && g.dl_w == 1 &&
-            g.cout == 3 && g.cin == 32 && g.p_h == 1 && g.p_w == 1 && g.out_h <= 2 * g.in_h && g.out_w <= 2 * g.in_w &&
-            !no_rgb) {
+            g.cout == 3 && g.cin == 32 && g.p_h == 1 && g.p_w == 1 && g.out_h <= 2 * g.in_h && g.out_w <= 2 * g.in_w) {
             dim3 grid((unsigned)(g.n * cn_cdiv(g.in_h, 8) * cn_cdiv(g.in_w, 16)));
             cn_prof_begin(s, conv_flops(g), conv_bytes(g), CN_FAM_THIN);
             hipLaunchKernelGGL((up2k4_rgb_fwd_kernel<4>), grid, dim3(256), 0, s, g, x, w, bias, y, act, slope);
@@ -1400,7 +1394,7 @@ static int conv_fwd_impl(const CnConvGeom* gp, const float* x, const float* w, c
         }
         if (g.nd == 2 && g.k_h == 3 && g.k_w == 3 && g.dl_h == 2 && g.dl_w == 2 && g.s_h == 1 && g.s_w == 1 && !g.up &&
             g.cout == 3 && g.cin == 48 && !bias && act == CN_ACT_NONE && g.p_h >= 0 && g.p_h <= 2 && g.p_w >= 0 &&
-            g.p_w <= 2 && g.out_h <= 2 * g.in_h && g.out_w <= 2 * g.in_w && !no_s2img) {
+            g.p_w <= 2 && g.out_h <= 2 * g.in_h && g.out_w <= 2 * g.in_w) {
             dim3 grid((unsigned)(g.n * cn_cdiv(g.in_h, 8) * cn_cdiv(g.in_w, 32)));
             cn_prof_begin(s, conv_flops(g), conv_bytes(g), CN_FAM_S2_IMAGE_DGRAD);
             hipLaunchKernelGGL((s2_image_dgrad_kernel<6>), grid, dim3(256), 0, s, g, x, w, y);
@@ -1409,8 +1403,7 @@ static int conv_fwd_impl(const CnConvGeom* gp, const float* x, const float* w, c
             return CN_OK;
         }
         if (g.nd == 2 && g.k_h == 3 && g.k_w == 3 && g.dl_h == 1 && g.dl_w == 1 && g.s_h == 1 && g.s_w == 1 && !g.up &&
-            g.cout == 3 && g.cin == 64 && !bias && act == CN_ACT_NONE && g.p_h >= 0 && g.p_h <= 2 && g.p_w >= 0 && g.p_w <= 2 &&
-            !no_s1img) {
+            g.cout == 3 && g.cin == 64 && !bias && act == CN_ACT_NONE && g.p_h >= 0 && g.p_h <= 2 && g.p_w >= 0 && g.p_w <= 2) {
             dim3 grid((unsigned)(g.n * cn_cdiv(g.out_h, 8) * cn_cdiv(g.out_w, 32)));
             cn_prof_begin(s, conv_flops(g), conv_bytes(g), CN_FAM_S2_IMAGE_DGRAD);
             hipLaunchKernelGGL((s1_image_dgrad_kernel<8>), grid, dim3(256), 0, s, g, x, w, y);
@@ -1456,8 +1449,7 @@ static int conv_fwd_impl(const CnConvGeom* gp, const float* x, const float* w, c
         CN_LAUNCH_CHECK();
         return CN_OK;
     }
-    static const int no_c3 = getenv("CN_NO_C3") ? 1 : 0;
-    if (!bt && !no_c3 && g.nd == 2 && g.cin == 3 && g.k_h == 3 && g.k_w == 3 && g.s_h == g.s_w && (g.s_h == 1 || g.s_h == 2) &&
+    if (!bt && g.nd == 2 && g.cin == 3 && g.k_h == 3 && g.k_w == 3 && g.s_h == g.s_w && (g.s_h == 1 || g.s_h == 2) &&
         g.dl_h == 1 && g.dl_w == 1 && !g.up && g.cout > 4 && g.cout <= 64) {
         dim3 grid((unsigned)(g.n * cn_cdiv(g.out_h, 8) * cn_cdiv(g.out_w, 32)));
         cn_prof_begin(s, conv_flops(g), conv_bytes(g), CN_FAM_C3_FWD);
@@ -1469,8 +1461,7 @@ static int conv_fwd_impl(const CnConvGeom* gp, const float* x, const float* w, c
         CN_LAUNCH_CHECK();
         return CN_OK;
     }
-    static const int no_c7 = getenv("CN_NO_C7") ? 1 : 0;
-    if (!bt && !no_c7 && g.nd == 2 && g.cin == 3 && g.k_h == 7 && g.k_w == 7 && g.s_h == 2 && g.s_w == 2 && g.dl_h == 1 && g.dl_w == 1 &&
+    if (!bt && g.nd == 2 && g.cin == 3 && g.k_h == 7 && g.k_w == 7 && g.s_h == 2 && g.s_w == 2 && g.dl_h == 1 && g.dl_w == 1 &&
         !g.up && g.cout > 4 && g.cout <= 64 && !res) {
         dim3 grid((unsigned)(g.n * cn_cdiv(g.out_h, 8) * cn_cdiv(g.out_w, 32)));
         cn_prof_begin(s, conv_flops(g), conv_bytes(g), CN_FAM_C3_FWD);
@@ -1494,8 +1485,7 @@ static int conv_fwd_impl(const CnConvGeom* gp, const float* x, const float* w, c
     else { cfg = 2; tiles = (long)cn_cdiv(M, 64) * cn_cdiv(g.cout, 64); }
     // cout = 96 / 192 (discriminator blocks 1-2 and the data gradients of blocks 2-3): a 128 x 96 tile wastes nothing
     // where 128- or 64-wide tiles pad a quarter of their columns
-    static const int no_n96 = getenv("CN_NO_N96") ? 1 : 0;
-    if (!no_n96 && g.cout % 96 == 0 && g.cout % 128 != 0 &&
+    if (g.cout % 96 == 0 && g.cout % 128 != 0 &&
         (long)cn_cdiv(M, 128) * (g.cout / 96) >= (g.cout == 96 ? 256 : 384)) {
         cfg = 4;
         tiles = (long)cn_cdiv(M, 128) * (g.cout / 96);
@@ -1524,10 +1514,9 @@ static int conv_fwd_impl(const CnConvGeom* gp, const float* x, const float* w, c
     // MFMAs and none of its instructions sits outside an MFMA's shadow), so it does not need the 4 workgroups per CU the
     // register-staged loops are split for -- and every K split it avoids saves the zero pass, a tile of atomics per workgroup and
     // the separate bias / activation pass (13 us of a 60 us launch at M = 4096, K = 2304, N = 256; scripts/dev/fwd2_sweep.py).
-    const int fwd2_on = g_fwd2_sel >= 0 ? g_fwd2_sel : g_fwd2_env;
+    const int fwd2_on = g_fwd2_sel >= 0 ? g_fwd2_sel : 1;
     // (32 output channels: the 128 x 32 tile of the same loop, input channels from 32 up)
-    static const int fwd2_n32 = getenv("CN_FWD2_N32") ? atoi(getenv("CN_FWD2_N32")) : 1;
-    const bool n32 = fwd2_n32 && g.cout == 32 && g.cin >= 32;
+    const bool n32 = g.cout == 32 && g.cin >= 32;
     const bool fwd2_takes = fwd2_on && vec && nks_total > g_fwd2_min_nks && ((g.cin >= g_fwd2_min_c && g.cout >= g_fwd2_min_c) || n32) && g.dl_d <= 2 && g.dl_h <= 2 && g.dl_w <= 2 &&
                             (double)g.n * g.in_d * g.in_h * g.in_w * g.cin < 5.3e8 && (double)g.k_d * g.k_h * g.k_w * g.cin * g.cout < 5.3e8;
     if (fwd2_takes) {
@@ -1549,7 +1538,7 @@ static int conv_fwd_impl(const CnConvGeom* gp, const float* x, const float* w, c
             // the chip twice), K slices only for the 64 x 64 tile, where they also even out the load between the classes
             cfg = 2;
             tiles = (long)cn_cdiv(M, 64) * cn_cdiv(g.cout, 64);
-            if (!no_n96 && g.cout % 96 == 0 && g.cout % 64 != 0 && (long)cn_cdiv(M, 128) * (g.cout / 96) >= 512) {
+            if (g.cout % 96 == 0 && g.cout % 64 != 0 && (long)cn_cdiv(M, 128) * (g.cout / 96) >= 512) {
                 cfg = 4;
                 tiles = (long)cn_cdiv(M, 128) * (g.cout / 96);
             }
@@ -1574,7 +1563,7 @@ static int conv_fwd_impl(const CnConvGeom* gp, const float* x, const float* w, c
             double best = 0.0;
             bool have = false;
             for (const Cand& c : cands) {
-                if (c.cfg == 4 && (no_n96 || g.cout % 96 != 0 || g.cout % 64 == 0 || (long)cn_cdiv(Me, 128) * (g.cout / 96) < 256)) continue;
+                if (c.cfg == 4 && (g.cout % 96 != 0 || g.cout % 64 == 0 || (long)cn_cdiv(Me, 128) * (g.cout / 96) < 256)) continue;
                 const long tl = (long)cn_cdiv(Me, c.bm) * cn_cdiv(g.cout, c.bn);
                 const long smax = nks / 8 > 1 ? (nks / 8 > 16 ? 16 : nks / 8) : 1;
                 for (long s_ = 1; s_ <= smax; ++s_) {
@@ -1595,8 +1584,7 @@ static int conv_fwd_impl(const CnConvGeom* gp, const float* x, const float* w, c
         const int qd = par ? g.out_d / g.dl_d : g.out_d, qh = par ? g.out_h / g.dl_h : g.out_h, qw = par ? g.out_w / g.dl_w : g.out_w;
         srows = qd * qh * qw;
         sper = par ? g.n * srows : (int)M;
-        static const bool no_rows = getenv("CN_NO_GEMM1X1") != nullptr;
-        if (!fwd2_takes || no_rows || splits > 1 || cfg == 3 || srows % (cfg == 2 ? 64 : 128) != 0) return CN_EUNSUPPORTED;
+        if (!fwd2_takes || splits > 1 || cfg == 3 || srows % (cfg == 2 ? 64 : 128) != 0) return CN_EUNSUPPORTED;
     }
     float* parts = nullptr;
     if (cn_det() && splits > 1) {
@@ -1620,12 +1608,8 @@ static int conv_fwd_impl(const CnConvGeom* gp, const float* x, const float* w, c
     if (parts) y = parts;
     cn_prof_begin(s, conv_flops(g), conv_bytes(g), cfg == 0 ? CN_FAM_FWD_128x128 : cfg == 1 ? CN_FAM_FWD_128x64 : cfg == 3 ? CN_FAM_FWD_128x32 : cfg == 4 ? CN_FAM_FWD_128x96 : CN_FAM_FWD_64x64);
     int e = CN_EUNSUPPORTED;
-    // 1x1, stride 1, no padding / dilation / upsample: the rows of x ARE the A matrix -- plain GEMM kernel (gemm1x1.hip)
-    // (not for <= 8-step reductions: its three-load prologue is most of such a launch -- 38 -> 45 us on 16 384 x 128 x 512)
-    static const int no_g1 = (getenv("CN_NO_GEMM1X1") ? 1 : 0);
-    const bool rows_ok = !no_g1 && nks_total > 8;
     // the LDS-DMA main loop (fwd2.hip)
-    if (fwd2_takes && !no_g1 && (cfg != 3 || n32)) {
+    if (fwd2_takes && (cfg != 3 || n32)) {
         const bool plain = !par && g.k_d * g.k_h * g.k_w == 1 && g.s_d == 1 && g.s_h == 1 && g.s_w == 1 && g.dl_d == 1 && g.dl_h == 1 &&
                            g.dl_w == 1 && !g.up && g.p_d == 0 && g.p_h == 0 && g.p_w == 0 && g.out_d == g.in_d && g.out_h == g.in_h &&
                            g.out_w == g.in_w;
@@ -1637,17 +1621,7 @@ static int conv_fwd_impl(const CnConvGeom* gp, const float* x, const float* w, c
             return e == CN_EUNSUPPORTED ? CN_EINVAL : e;
         }
     }
-    if (rows_ok && vec && !par && g.k_d * g.k_h * g.k_w == 1 && g.s_d == 1 && g.s_h == 1 && g.s_w == 1 && g.dl_d == 1 && g.dl_h == 1 &&
-        g.dl_w == 1 && !g.up && g.p_d == 0 && g.p_h == 0 && g.p_w == 0 && g.out_d == g.in_d && g.out_h == g.in_h && g.out_w == g.in_w &&
-        e == CN_EUNSUPPORTED)
-        e = cn_gemm1x1(nullptr, cfg, bt, x, w, bias, y, M, g.cout, g.cin, kact, slope, splits, part_stride, 0, s, res);
-    // every other vec layer: the same main loop over gathered rows (parity-ordered ones included)
-    static const int no_g2 = getenv("CN_NO_IGEMM_ROWS") ? 1 : 0;
-    static const int no_g3 = getenv("CN_NO_IGEMM_ROWS_PAR") ? 1 : 0;
-    // (thin layers stay: with 48 channels per tap the offsets are recomputed every third step, and 48 output columns pad a
-    // quarter of either kernel's tile -- same-box A/B 107 vs 109 us, 75 vs 77 us; scripts/dev/par_ab.sh)
-    if (e == CN_EUNSUPPORTED && rows_ok && !no_g2 && vec && !(par && no_g3) && g.cin >= 64 && g.cout >= 64)
-        e = cn_gemm1x1(&g, cfg, bt, x, w, bias, y, M, g.cout, g.cin, kact, slope, splits, part_stride, par, s, res);
+    // everything the LDS-DMA loop does not take (K or cout no multiple of 16 / 4, thin layers, > 2 GiB operands): igemm_fwd_kernel
     if (e == CN_EUNSUPPORTED)
     switch (cfg) {
         case 3: e = launch_fwd<4, 1, 1, 1>(g, vec, par, splits, x, w, bias, y, kact, slope, s, bt, part_stride, res); break;   // 128 x 32
@@ -1716,9 +1690,8 @@ extern "C" int cn_conv_fwd_dt(const CnConvGeom* gp, const void* x, int x_dt, con
         CN_LAUNCH_CHECK();
         return CN_OK;
     }
-    static const bool no_c7_dt = getenv("CN_NO_C7") != nullptr;
     if (x_dt == CN_F32 && y_dt == CN_BF16 && g.nd == 2 && g.cin == 3 && g.k_h == 7 && g.k_w == 7 && g.s_h == 2 && g.s_w == 2 &&
-        g.dl_h == 1 && g.dl_w == 1 && !g.up && g.cout > 4 && g.cout <= 64 && !no_c7_dt) {
+        g.dl_h == 1 && g.dl_w == 1 && !g.up && g.cout > 4 && g.cout <= 64) {
         dim3 grid((unsigned)(g.n * cn_cdiv(g.out_h, 8) * cn_cdiv(g.out_w, 32)));
         cn_prof_begin(s, conv_flops(g), conv_bytes(g, 4.0, 2.0), CN_FAM_C3_FWD);
         if (g.cout <= 32) hipLaunchKernelGGL((c7s2_fwd_kernel<1, bf16_t>), grid, dim3(256), 0, s, g, (const float*)x, w, bias, (bf16_t*)y, act, slope);
@@ -1817,12 +1790,11 @@ extern "C" int cn_conv_wgrad(const CnConvGeom* gp, const float* x, const float* 
         if (parts) return cn_sum_parts(parts, gw, nb, (long)g.cin * g.cout, 1, 1.f, s);
         return CN_OK;
     }
-    static const int no_n96 = getenv("CN_NO_N96") ? 1 : 0;
-    cn_prof_begin(s, conv_flops(g), conv_bytes(g), g.cout <= 32 ? CN_FAM_WGRAD_128x32 : (!no_n96 && Ktot >= 128 && g.cout % 96 == 0 && g.cout % 128 != 0) ? CN_FAM_WGRAD_128x96 : (Ktot >= 128 && g.cout >= 128) ? CN_FAM_WGRAD_128x128 : CN_FAM_WGRAD_64x64);
+    cn_prof_begin(s, conv_flops(g), conv_bytes(g), g.cout <= 32 ? CN_FAM_WGRAD_128x32 : (Ktot >= 128 && g.cout % 96 == 0 && g.cout % 128 != 0) ? CN_FAM_WGRAD_128x96 : (Ktot >= 128 && g.cout >= 128) ? CN_FAM_WGRAD_128x128 : CN_FAM_WGRAD_64x64);
     int e;
     if (g.cout <= 32)
         e = launch_wgrad<4, 1, 1, 1>(g, x, gy, gw, s);       // 128 (tap,ci) x 32 co
-    else if (!no_n96 && Ktot >= 128 && g.cout % 96 == 0 && g.cout % 128 != 0)
+    else if (Ktot >= 128 && g.cout % 96 == 0 && g.cout % 128 != 0)
         e = launch_wgrad<4, 1, 1, 3>(g, x, gy, gw, s);       // 128 x 96: cout 96 / 192 without column padding
     else if (Ktot >= 128 && g.cout >= 128)
         e = launch_wgrad<2, 2, 2, 2>(g, x, gy, gw, s);       // 128 x 128
@@ -1837,20 +1809,15 @@ bool cn_wgrad2_ok(const CnConvGeom& g);
 size_t cn_wgrad2_workspace_floats(const CnConvGeom& g);
 int cn_wgrad2_family(const CnConvGeom& g);
 void cn_wgrad2_tune(int cfg, long wg_target);
+void cn_wgrad2_stages(int ns);
 int cn_wgrad2(const CnConvGeom& g, const float* x, const float* gy, float* gw, int accumulate, float* ws, hipStream_t s);
 
 static bool wgrad2_takes(const CnConvGeom& g) {
-    static const bool off = getenv("CN_NO_WGRAD2") != nullptr;       // A/B: the round-3 kernel (split over rows, fp32 atomics)
-    static const bool all = getenv("CN_WGRAD2_ALL") != nullptr;     // A/B: every geometry the new kernel can take
+    // Every geometry the LDS-DMA kernel can take (round 6: with the slot layout and the XCD-aware slice plan it is at or ahead of
+    // the round-3 kernel -- split over rows, fp32 atomics -- on every shape of the iteration, profiles/round6_wgrad_shapes.txt).
+    // The round-3 kernel keeps the rest: channel counts that are no multiple of 4, K < 64, > 2 GiB operands.
     const long Ktot = (long)g.k_d * g.k_h * g.k_w * g.cin;
-    const long M = (long)g.n * g.out_d * g.out_h * g.out_w;
-    if (off || !cn_wgrad2_ok(g) || Ktot < 64) return false;
-    // Measured per shape (scripts/wgrad_bench.py, profiles/round4_wgrad_shapes.txt): the LDS-DMA kernel wins where the reduction
-    // is short and the filter large (M < 16 384 rows: 40 -> 26 us, 57 -> 42, 134 -> 104, 225 -> 173).  Long reductions into small
-    // filters stay on the round-3 kernel: there the (tap, ci) tiles of a row slice drift apart while they stream it and fall out
-    // of the XCD's L2 (the old kernel's many short workgroups re-synchronise every few hundred rows), and 64-wide tiles at
-    // 16 FLOP per LDS-DMA byte are bound by operand delivery, not by the matrix pipe.
-    return all || (M < 16384 && !(g.cout <= 64 && M >= 8192));
+    return cn_wgrad2_ok(g) && Ktot >= 64;
 }
 
 // Workspace (bytes) that cn_conv_wgrad_ws needs for this geometry: room for the partial filters of its row splits; 0 = none.
@@ -1899,6 +1866,7 @@ extern "C" int cn_conv_loop_select(int loop, int kb, int ns, int np) {
                  "cn_conv_loop_select: bad argument");
     g_fwd2_sel = loop;
     cn_fwd2_tune(kb, ns, np);
+    cn_wgrad2_stages(ns);
     return CN_OK;
 }
 

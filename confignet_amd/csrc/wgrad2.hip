@@ -341,55 +341,76 @@ struct Wg2Plan {
     long tiles_x, tiles_y, splits, rows;
 };
 
-long g_wg2_target = 0;     // cn_conv_tune(wg_blocks): workgroup target of the split (0 = heuristic)
-int g_wg2_cfg = -1;
+long g_wg2_target = 0;     // cn_conv_tune(wg_blocks): workgroup target of the split (0 = the model below)
+int g_wg2_cfg = -1;        // cn_conv_tune(cfg): forced tile
+int g_wg2_ns = 0;          // cn_conv_loop_select(ns): forced stage count
+
+// The tiles: rows of (tap, ci) x output channels, reduction rows per stage, and the share of the matrix pipes a CU sustains on the
+// tile with one / with two workgroups resident (fitted to the per-shape sweep of round 6, profiles/round6_wgrad_sweep_points.txt).
+struct Wg2Tile {
+    int cfg, bi, bn, kb;
+    double e1, e2;
+};
+const Wg2Tile WG2_TILES[5] = {{0, 128, 128, 16, 0.72, 0.84}, {1, 128, 96, 16, 0.62, 0.72}, {2, 64, 64, 32, 0.50, 0.56},
+                              {3, 128, 32, 32, 0.38, 0.42}, {4, 256, 64, 16, 0.55, 0.63}};
+
+// Estimated duration (us) of the launch + the slab reduction for `s` row slices on tile t.  Workgroups of one slice share an XCD
+// (slices dealt round-robin to the 8 XCDs, 32 CUs each, two workgroups resident per CU): the launch lasts as long as the XCD with
+// the most slices.  Checked against the 1 096 points of the sweep: its choice is within 5 % of the best measured point in total.
+double wg2_cost(const Wg2Tile& t, long M, long Ktot, int cout, long s, long& rows_out, long& splits_out) {
+    long rows = (M + s - 1) / s;
+    rows = (rows + t.kb - 1) / t.kb * t.kb;
+    const long splits = (M + rows - 1) / rows;
+    rows_out = rows;
+    splits_out = splits;
+    const long tiles = (long)cn_cdiv(Ktot, t.bi) * cn_cdiv(cout, t.bn);
+    const long per_xcd = splits >= 8 ? (long)cn_cdiv(splits, 8) * tiles : (long)cn_cdiv(tiles * splits, 8);
+    const double cyc_row = 32.0 * (t.bi / 32) * (t.bn / 32) / 4.0;           // MFMA cycles per reduction row (4 waves on 4 SIMDs)
+    const double life = ((double)rows * cyc_row + 9000.0) / 2400.0;         // us at the full pipe, + prologue / epilogue
+    // an XCD holds 64 workgroups at once (two per CU); full rounds run two to a CU, the last one alone if it has at most 32
+    const long rounds = cn_cdiv(per_xcd, 64), rem = per_xcd - 64 * (rounds - 1);
+    double us = (double)(rounds - 1) * 2.0 * life / t.e2 + (rem <= 32 ? life / t.e1 : 2.0 * life / t.e2);
+    if (splits > 1) us += 2.0 * (double)splits * (double)Ktot * cout * 4.0 / 2.5e6 + 5.0;      // slabs written + read back, one more launch
+    return us;
+}
 
 Wg2Plan wg2_plan(const CnConvGeom& g) {
     const long M = (long)g.n * g.out_d * g.out_h * g.out_w;
     const long Ktot = (long)g.k_d * g.k_h * g.k_w * g.cin;
-    Wg2Plan p;
-    int cfg;
-    if (g.cout <= 32) cfg = 3;
-    else if (Ktot >= 128 && g.cout % 96 == 0 && g.cout % 128 != 0) cfg = 1;
-    else if (Ktot >= 128 && g.cout >= 128) cfg = 0;
-    else if (Ktot >= 256 && g.cout == 64) cfg = 4;
-    else cfg = 2;
-    // few rows, many filter elements: the small tile gives enough workgroups without (or with fewer) row splits
-    if (cfg == 0 && cn_cdiv(Ktot, 128) * cn_cdiv(g.cout, 128) * cn_cdiv(M, 512) < 128) cfg = 2;
-    if (g_wg2_cfg >= 0) cfg = g_wg2_cfg;
-    p.cfg = cfg;
-    p.bi = cfg == 2 ? 64 : cfg == 4 ? 256 : 128;
-    p.bn = cfg == 0 ? 128 : cfg == 1 ? 96 : (cfg == 2 || cfg == 4) ? 64 : 32;
-    p.kb = (cfg == 2 || cfg == 3) ? 32 : 16;
-    p.tiles_x = cn_cdiv(Ktot, p.bi);
-    p.tiles_y = cn_cdiv(g.cout, p.bn);
-    const long tiles = p.tiles_x * p.tiles_y;
-    const long max_splits = cn_cdiv(M, 4 * p.kb);                     // a workgroup is at least 4 K steps long
-    long splits;
-    if (g_wg2_target > 0) {
-        splits = tiles >= g_wg2_target ? 1 : (g_wg2_target + tiles / 2) / tiles;
-    } else {
-        // cost of `s` row splits in MFMA cycles of one CU: workgroups run two to a CU sharing its matrix pipes, so the launch takes
-        // ceil(tiles * s / 256) workgroup lifetimes (MFMA time of the slice + a fixed start / drain) -- plus, for s > 1, the slabs:
-        // s partial filters written and read back by the reduction (~3 TB/s through L2 / Infinity Cache) and its launch
-        const double mfma_per_row = 32.0 * (p.bi / 32) * (p.bn / 32) / 4.0;       // cycles per reduction row per wave
-        const double count = (double)Ktot * g.cout;
-        double best = 0.0;
-        splits = 1;
-        for (long s_ = 1; s_ <= max_splits && s_ <= 256; ++s_) {
-            const double rows = (double)cn_cdiv(cn_cdiv(M, s_), p.kb) * p.kb;
-            const double life = rows * mfma_per_row + 6000.0;
-            double cost = (double)cn_cdiv(tiles * s_, 256) * life;
-            if (s_ > 1) cost += 2.0 * s_ * count * 4.0 / 3.0e12 * 2.4e9 / 1.0 + 8000.0;
-            if (s_ == 1 || cost < best) { best = cost; splits = s_; }
+    Wg2Plan p{};
+    double best = -1.0;
+    for (const Wg2Tile& t : WG2_TILES) {
+        if (g_wg2_cfg >= 0 ? t.cfg != g_wg2_cfg
+                           : ((t.cfg == 3) != (g.cout <= 32) || (t.cfg == 1 && g.cout % 96 != 0) || (t.cfg == 0 && g.cout < 96) ||
+                              (t.cfg == 4 && (g.cout % 64 != 0 || Ktot < 256)) || (t.cfg != 2 && t.cfg != 3 && Ktot < 128)))
+            continue;
+        const long tiles = (long)cn_cdiv(Ktot, t.bi) * cn_cdiv(g.cout, t.bn);
+        const long max_splits = cn_cdiv(M, 4 * t.kb);                 // a workgroup is at least 4 K steps long
+        auto consider = [&](long s_) {
+            if (s_ < 1) s_ = 1;
+            if (s_ > max_splits) s_ = max_splits;
+            long rows, splits;
+            const double us = wg2_cost(t, M, Ktot, g.cout, s_, rows, splits);
+            if (best < 0.0 || us < best) {
+                best = us;
+                p.cfg = t.cfg; p.bi = t.bi; p.bn = t.bn; p.kb = t.kb;
+                p.tiles_x = cn_cdiv(Ktot, t.bi); p.tiles_y = cn_cdiv(g.cout, t.bn);
+                p.rows = rows; p.splits = splits;
+            }
+        };
+        if (g_wg2_target > 0) {
+            consider(tiles >= g_wg2_target ? 1 : (g_wg2_target + tiles / 2) / tiles);
+        } else {
+            for (long s_ = 1; s_ < 8 && s_ <= max_splits; ++s_) consider(s_);
+            for (long s_ = 8; s_ <= max_splits && s_ <= 1024; s_ += 8) consider(s_);
         }
     }
-    if (splits > max_splits) splits = max_splits;
-    if (splits < 1) splits = 1;
-    long rows = (M + splits - 1) / splits;
-    rows = (rows + p.kb - 1) / p.kb * p.kb;
-    p.rows = rows;
-    p.splits = (M + rows - 1) / rows;
+    if (best < 0.0) {          // (a forced tile that the shape cannot use: the 64 x 64 tile takes everything)
+        const int keep = g_wg2_cfg;
+        g_wg2_cfg = 2;
+        p = wg2_plan(g);
+        g_wg2_cfg = keep;
+    }
     return p;
 }
 
@@ -416,6 +437,8 @@ void cn_wgrad2_tune(int cfg, long wg_target) {
     g_wg2_target = wg_target;
 }
 
+void cn_wgrad2_stages(int ns) { g_wg2_ns = ns; }     // cn_conv_loop_select: 0 = default, 3 / 4 forced
+
 int cn_wgrad2_family(const CnConvGeom& g) {
     const Wg2Plan p = wg2_plan(g);
     return p.cfg == 0 ? CN_FAM_WGRAD_128x128 : p.cfg == 1 ? CN_FAM_WGRAD_128x96 : p.cfg == 2 ? CN_FAM_WGRAD_64x64 : p.cfg == 4 ? CN_FAM_WGRAD_256x64 : CN_FAM_WGRAD_128x32;
@@ -433,13 +456,16 @@ int cn_wgrad2(const CnConvGeom& g, const float* x, const float* gy, float* gw, i
     const long stride = p.splits > 1 ? count : 0;
 #define WG2(WM, WN, TM, TN, KB_, NS_) hipLaunchKernelGGL((wgrad2_kernel<WM, WN, TM, TN, KB_, NS_>), grid, dim3(256), 0, s, g, x, gy, out, stride, \
                                                           (int)p.rows, (int)p.tiles_x, (int)p.tiles_y, (int)p.splits, accumulate)
+    const int ns = g_wg2_ns ? g_wg2_ns : 4;
+#define WG2N(WM, WN, TM, TN, KB_) do { if (ns == 3) WG2(WM, WN, TM, TN, KB_, 3); else WG2(WM, WN, TM, TN, KB_, 4); } while (0)
     switch (p.cfg) {
-        case 0: WG2(2, 2, 2, 2, 16, 4); break;
-        case 1: WG2(4, 1, 1, 3, 16, 4); break;
-        case 2: WG2(2, 2, 1, 1, 32, 4); break;
-        case 4: WG2(4, 1, 2, 2, 16, 4); break;
+        case 0: WG2N(2, 2, 2, 2, 16); break;
+        case 1: WG2N(4, 1, 1, 3, 16); break;
+        case 2: WG2N(2, 2, 1, 1, 32); break;
+        case 4: WG2N(4, 1, 2, 2, 16); break;
         default: WG2(4, 1, 1, 1, 32, 3); break;
     }
+#undef WG2N
 #undef WG2
     CN_LAUNCH_CHECK();
     if (p.splits > 1) return cn_sum_parts(ws, gw, (int)p.splits, count, accumulate, 1.f, s);

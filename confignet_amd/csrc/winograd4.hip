@@ -190,21 +190,33 @@ __global__ __launch_bounds__(768) void wino4_fwd_kernel(Wino4Geom g, const float
         unsigned ra[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) ra[q] = rbase[q] + so + (sub ^ rsw[q]);
-        float t[6];
-#define W4_COLS(j0, j1)                                                                                                       \
-        {                                                                                                                      \
-            float d[4][2];                                                                                                     \
-            _Pragma("unroll") for (int q = 0; q < 4; ++q) { W4_RD(q, j0, d[q][0]); W4_RD(q, j1, d[q][1]); }                    \
-            /* (the registers pass through the wait so that their uses cannot be scheduled ahead of it) */                     \
-            asm volatile("s_waitcnt lgkmcnt(0)"                                                                                \
-                         : "+v"(d[0][0]), "+v"(d[0][1]), "+v"(d[1][0]), "+v"(d[1][1]), "+v"(d[2][0]), "+v"(d[2][1]), "+v"(d[3][0]), "+v"(d[3][1])); \
-            t[j0] = tco[0] * d[0][0] + tco[1] * d[1][0] + tco[2] * d[2][0] + tco[3] * d[3][0];                                 \
-            t[j1] = tco[0] * d[0][1] + tco[1] * d[1][1] + tco[2] * d[2][1] + tco[3] * d[3][1];                                 \
-        }
-        W4_COLS(0, 1)
-        W4_COLS(2, 3)
-        W4_COLS(4, 5)
-#undef W4_COLS
+        // Round 6: the 24 patch elements of the lane's row are requested ahead of their use, a column at a time, and a column pair is
+        // reduced as soon as ITS reads have retired (LDS reads retire in order) while the younger columns are still in flight --
+        // one exposed LDS round trip per step instead of three back to back (round-5 form: read 8, wait, reduce, read 8, ...).
+        // Never more than 12 reads outstanding (the counter holds 15).  Measured: -1 % (179.5 against 180.8 us on conv1_2, 138.8
+        // against 140.2 on conv3_x): with three waves per SIMD another wave already fills a wave's LDS wait; what bounds the
+        // step is operand delivery from L2 (profiles/round5_wino4_ablation.txt), not latency inside a wave.
+        float d[6][4], t[6];
+#define W4_COL(c) W4_RD(0, c, d[c][0]); W4_RD(1, c, d[c][1]); W4_RD(2, c, d[c][2]); W4_RD(3, c, d[c][3]);
+#define W4_WAIT(pending) asm volatile("s_waitcnt lgkmcnt(" #pending ")"); __builtin_amdgcn_sched_barrier(0);
+#define W4_RED(j0, j1)                                                                                                         \
+        t[j0] = tco[0] * d[j0][0] + tco[1] * d[j0][1] + tco[2] * d[j0][2] + tco[3] * d[j0][3];                                 \
+        t[j1] = tco[0] * d[j1][0] + tco[1] * d[j1][1] + tco[2] * d[j1][2] + tco[3] * d[j1][3];                                 \
+        __builtin_amdgcn_sched_barrier(0);
+        W4_COL(0) W4_COL(1) W4_COL(2)
+        W4_WAIT(4)                 // columns 0, 1 are back (column 2 may be in flight)
+        W4_COL(3) W4_COL(4)
+        __builtin_amdgcn_sched_barrier(0);
+        W4_RED(0, 1)
+        W4_WAIT(4)                 // columns 2, 3 (column 4 may be in flight)
+        W4_COL(5)
+        __builtin_amdgcn_sched_barrier(0);
+        W4_RED(2, 3)
+        W4_WAIT(0)
+        W4_RED(4, 5)
+#undef W4_WAIT
+#undef W4_RED
+#undef W4_COL
         float* vdst = &Vs[s & 1][wi * 6][tk][tt];
         constexpr int VPL = W4_KC * W4_VP;          // floats between two positions
         vdst[0 * VPL] = 4.f * t[0] - 5.f * t[2] + t[4];
@@ -221,23 +233,40 @@ __global__ __launch_bounds__(768) void wino4_fwd_kernel(Wino4Geom g, const float
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
+    // ---- multiply of K step s: the wave's six positions x two k pairs = 12 MFMAs.  Round 6: every operand read is inline asm with an
+    // immediate offset, the 24 reads run as a rolling window in front of the MFMAs (pair j of k pair 0 is waited for with 12 younger
+    // reads in flight; the reads of k pair 1 are issued one pair behind each MFMA of k pair 0) -- the round-5 form read 12, waited for
+    // all of them, multiplied 6, and did that twice per step.  Never more than 14 reads outstanding (the counter holds 15).
 #define W4_RDU(j, kk, dst) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(dst) : "v"(ub), "i"((((j) * W4_KC + 2 * (kk)) * W4_C) * 4))
+#define W4_RDA(j, kk, dst) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(dst) : "v"(vb), "i"((((j) * W4_KC + 2 * (kk)) * W4_VP) * 4))
     const unsigned ubase = buf0 + 4u * (unsigned)((wi * 6 * W4_KC + half) * W4_C + cb * 32 + l31);
+    const unsigned vbase = (unsigned)(unsigned long long)(lds_float4*)&Vs[0][wi * 6][half][l31];
     auto multiply = [&](int s) {
         const unsigned ub = ubase + 4u * (unsigned)((s & 1) * W4_U);
-        const float* va = &Vs[s & 1][wi * 6][half][l31];
-#define W4_MUL(kk)                                                                                                             \
-        {                                                                                                                      \
-            float a[6], b[6];                                                                                                  \
-            _Pragma("unroll") for (int j = 0; j < 6; ++j) a[j] = va[(j * W4_KC + 2 * (kk)) * W4_VP];                           \
-            W4_RDU(0, kk, b[0]); W4_RDU(1, kk, b[1]); W4_RDU(2, kk, b[2]); W4_RDU(3, kk, b[3]); W4_RDU(4, kk, b[4]); W4_RDU(5, kk, b[5]); \
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]));     \
-            if (!(W4_ABLATE & 1)) { _Pragma("unroll") for (int j = 0; j < 6; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], acc[j], 0, 0, 0); } \
-            else { _Pragma("unroll") for (int j = 0; j < 6; ++j) acc[j][0] += a[j] * b[j]; }                                      \
-        }
-        W4_MUL(0)
-        W4_MUL(1)
-#undef W4_MUL
+        const unsigned vb = vbase + 4u * (unsigned)((s & 1) * 36 * W4_KC * W4_VP);
+        float a[2][6], b[2][6];
+#define W4_PAIR(j, kk) W4_RDA(j, kk, a[kk][j]); W4_RDU(j, kk, b[kk][j]);
+#define W4_MFMA(j, kk)                                                                                                         \
+        if (!(W4_ABLATE & 1)) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk][j], b[kk][j], acc[j], 0, 0, 0);              \
+        else acc[j][0] += a[kk][j] * b[kk][j];                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);
+#define W4_WAIT(pending) asm volatile("s_waitcnt lgkmcnt(" #pending ")"); __builtin_amdgcn_sched_barrier(0);
+        W4_PAIR(0, 0) W4_PAIR(1, 0) W4_PAIR(2, 0) W4_PAIR(3, 0) W4_PAIR(4, 0) W4_PAIR(5, 0) W4_PAIR(0, 1)
+        W4_WAIT(12) W4_MFMA(0, 0) W4_PAIR(1, 1)
+        W4_WAIT(12) W4_MFMA(1, 0) W4_PAIR(2, 1)
+        W4_WAIT(12) W4_MFMA(2, 0) W4_PAIR(3, 1)
+        W4_WAIT(12) W4_MFMA(3, 0) W4_PAIR(4, 1)
+        W4_WAIT(12) W4_MFMA(4, 0) W4_PAIR(5, 1)
+        W4_WAIT(12) W4_MFMA(5, 0)
+        W4_WAIT(10) W4_MFMA(0, 1)
+        W4_WAIT(8) W4_MFMA(1, 1)
+        W4_WAIT(6) W4_MFMA(2, 1)
+        W4_WAIT(4) W4_MFMA(3, 1)
+        W4_WAIT(2) W4_MFMA(4, 1)
+        W4_WAIT(0) W4_MFMA(5, 1)
+#undef W4_WAIT
+#undef W4_MFMA
+#undef W4_PAIR
     };
 
     const int nks = (W4_ABLATE & 16) ? 1 : g.cin / W4_KC, nraw = g.cin / 8;

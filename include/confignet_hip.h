@@ -13,11 +13,10 @@
  * or a negative CN_E* code; cn_last_error_string() describes the last failure of the
  * calling thread.  No exceptions cross the ABI.
  * Process-wide state (everything else is per call): the profiling event pool (cn_prof_*); the deterministic-mode flag and
- * its per-stream workspaces (cn_set_deterministic); the tuning overrides of cn_conv_tune (diagnostic: tile / split-K /
- * filter-gradient workgroup target, default = the built-in heuristics); and diagnostic environment switches that are read
- * ONCE at first use (CN_CFG, CN_SPLITS, CN_WG_BLOCKS, CN_NO_XCD, CN_NO_N96, CN_NO_C3, CN_KB32, CN_TAP_MINOR, CN_RED_BLOCKS,
- * CN_NO_SMALL_GEMM, CN_NO_WGRAD_XCD: A/B switches of DESIGN.md section 7, never needed for correct results).  None of them
- * changes WHAT a call computes, only which kernel variant computes it; a host that wants a re-entrant library leaves them unset.
+ * its per-stream workspaces (cn_set_deterministic); and the tuning overrides of cn_conv_tune / cn_conv_loop_select (sweeps and
+ * tests: forced tile / split-K / filter-gradient workgroup target / loop variant; default = the built-in rules).  The library reads
+ * NO environment variables (round 6: the A/B switches of earlier rounds are decided and gone).  None of the overrides changes WHAT
+ * a call computes, only which kernel variant computes it.
  */
 #ifndef CONFIGNET_HIP_H
 #define CONFIGNET_HIP_H
@@ -67,9 +66,9 @@ int cn_version(void);
  * Replaces keras.layers.Conv3D/Conv2D forward (+bias +activation):
  *   building_blocks.py:29,65,91 ; hologan_generator.py:50-56,101 ; hologan_discriminator.py:20,77 ;
  *   keras.applications VGG19/VGG16/ResNet50 convs (perceptual_loss.py:19,35 ; real_encoder.py:13).
- * Which kernel runs is the library's choice by geometry (first-layer / thin-output / image-gradient kernels, the k-major
- * implicit-GEMM loop for parity-ordered launches, the plain-GEMM loop of gemm1x1.hip for 1x1 and every other vectorisable
- * layer; CN_NO_* environment switches, read once, turn a route off for A/B runs) -- the results are the same convolution. */
+ * Which kernel runs is the library's choice by geometry alone (first-layer / thin-output / image-gradient kernels, the LDS-DMA
+ * loop of fwd2.hip for every vectorisable layer, the k-major implicit-GEMM loop for the rest) -- the results are the same
+ * convolution.  The library reads no environment variables; cn_conv_tune / cn_conv_loop_select force a route for sweeps and tests. */
 int cn_conv_fwd(const CnConvGeom* g, const float* x, const float* w, const float* bias,
                 float* y, int act, float slope, void* stream);
 /* cn_conv_fwd that also returns the per-(sample, channel) sums the FOLLOWING normalisation layer needs, taken in the convolution's

@@ -69,6 +69,9 @@ def timed(fn, reps=20):
     return e0.elapsed_time(e1) * 1e3 / reps
 
 
+NS = next((int(a.split("=", 1)[1]) for a in sys.argv if a.startswith("ns=")), 0)
+if NS:
+    ops.check(lib.cn_conv_loop_select(-1, 0, NS, -1), "loop_select")      # stage count of the LDS-DMA loops
 rows = []
 tot_old = tot_new = tot_best = 0.0
 for k, cnt in calls.items():
