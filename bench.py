@@ -44,6 +44,10 @@ def main():
                     help="one stream, eager dispatch: no kernel overlaps another (the form to trace for per-kernel durations)")
     ap.add_argument("--cpu-batch", type=int, default=16)
     ap.add_argument("--no-parity", action="store_true", help="skip the loss-parity iteration (loss_parity_vs_cpu)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the `secondary` block (bf16 loop, configs[3] / configs[4])")
+    ap.add_argument("--timing-only", action="store_true",
+                    help="the timed loop and nothing else (no per-function times, no roofline pass, no CPU baseline): the form the "
+                         "`secondary` block runs the bf16 loop in")
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="f32: the reference's arithmetic (BASELINE.json configs[1], the headline).  bf16: configs[2]'s compute type "
                          "(bf16 activations / filter copies on bf16 MFMA, fp32 accumulate, fp32 master weights) -- a separate line")
@@ -114,6 +118,15 @@ def main():
     # Loss parity of THE DISPATCH JUST TIMED against the CPU oracle at this very size (rank 0, N = 1): one more iteration of the
     # same loop (replayed graphs, its real halves already in flight from the previous iteration) on fresh Adam moments; its
     # weights and batches go to the oracle subprocess of the cpu_baseline leg, which runs the same iteration first.
+    if args.timing_only:
+        if rank == 0:
+            print(json.dumps({"value": round(args.batch * world / (elapsed / args.steps), 3), "unit": "images/sec", "dtype": args.dtype,
+                              "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+                              "losses_finite": bool(finite), "kernels_hash": kernels_hash()}), flush=True)
+        if dist.is_initialized():
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     parity_state = None
     if world == 1 and not args.no_cpu_baseline and not args.no_parity:
         parity_state = dump_parity_state(model, real_set, synth_set, d_opt, g_opt)
@@ -197,7 +210,7 @@ def main():
             "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": pmc_traffic(args.dtype),
                          "mfma_busy_pmc": pmc_mfma_busy(args.dtype),
-                         "kernel": ("fwd2/igemm_fwd/gemm1x1/wgrad2/igemm_wgrad/wino_fwd/wino4_fwd (implicit-GEMM + Winograd F(2x2,3x3) / F(4x4,3x3) convolutions, v_mfma_f32_32x32x2_f32)" if args.dtype == "f32" else
+                         "kernel": ("fwd2/igemm_fwd/wgrad2/igemm_wgrad/wino_fwd/wino4_fwd (implicit-GEMM + Winograd F(2x2,3x3) / F(4x4,3x3) convolutions, v_mfma_f32_32x32x2_f32)" if args.dtype == "f32" else
                                     "fwd2<bf16>/igemm_bf16/igemm_bf16_wgrad (implicit-GEMM conv, v_mfma_f32_32x32x16_bf16) + the fp32 kernels of the "
                                     "3-channel image layers"),
                          "launches_per_step": launches / max(args.steps, 1),
@@ -229,7 +242,7 @@ def main():
                              "note": "the same launches priced as direct convolutions (round 1's definition of the algorithmic work, "
                                      "border taps of the Winograd layers counted): an algorithmic saving, NOT a roofline fraction"},
                          "recorded": "traffic / mfma_busy_pmc come from committed rocprofv3 PMC passes and are quoted only when "
-                                     "profiles/round5_pmc_*.json carry this kernels_hash",
+                                     "profiles/round6_pmc_*.json carry this kernels_hash",
                          "kernels_hash": kernels_hash()},
             "torch_kernel_time_share": torch_kernel_share(),
         }
@@ -241,6 +254,8 @@ def main():
                     os.remove(parity_state["path"])
                 except OSError:
                     pass
+        if world == 1 and not args.no_secondary and not args.no_cpu_baseline and args.dtype == "f32":     # (the full line only: auxiliary / traced runs pass --no-cpu-baseline)
+            out["secondary"] = secondary(args)
         if not finite:
             # a timed loop whose losses went non-finite is not a measurement of the workload (round 4: such runs were also faster)
             out["invalid"] = "non-finite losses in the timed loop"
@@ -299,20 +314,20 @@ def _recorded(name, key):
 def pmc_traffic(dtype="f32"):
     """HBM bytes per launch of the dominant kernel class (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE;
     scripts/pmc_summary.py, scripts/pmc_traffic_json.py)."""
-    v = _recorded("round5_pmc_traffic%s.json" % ("" if dtype == "f32" else "_" + dtype), "hbm_bytes_per_launch")
+    v = _recorded("round6_pmc_traffic%s.json" % ("" if dtype == "f32" else "_" + dtype), "hbm_bytes_per_launch")
     return None if v is None else round(v)
 
 
 def pmc_mfma_busy(dtype="f32"):
     """MFMA-pipe busy fraction of the class (SQ_VALU_MFMA_BUSY_CYCLES against GRBM_GUI_ACTIVE; scripts/pmc_mfma.py)."""
-    v = _recorded("round5_pmc_mfma%s.json" % ("" if dtype == "f32" else "_" + dtype), "mfma_busy_fraction")
+    v = _recorded("round6_pmc_mfma%s.json" % ("" if dtype == "f32" else "_" + dtype), "mfma_busy_fraction")
     return None if v is None else round(v, 4)
 
 
 def torch_kernel_share():
     """Share of the GPU time of one iteration spent in PyTorch's own kernels (autograd's gradient accumulation adds, cat,
     fills, small (N, L) algebra) from the committed kernel trace of this command -- north_star: torch is plumbing."""
-    v = _recorded("round5_torch_share.json", "torch_kernel_time_share")
+    v = _recorded("round6_torch_share.json", "torch_kernel_time_share")
     return None if v is None else round(v, 4)
 
 
@@ -341,6 +356,34 @@ def cpu_baseline(args, state_path=None):
             r.get("parity_losses")
     except Exception as e:   # timeout / crash: report it, never block the GPU result
         return {"value": None, "unit": "images/sec", "cores": None, "kind": "port", "sample": "failed: %r" % (e,)}, None
+
+
+def secondary(args):
+    """The other BASELINE.json configurations, measured by THIS command right after the headline (the GPU is idle again; each runs
+    in a child process because the activation dtype is process-wide state): configs[2]'s compute type -- the same loop, same
+    steps / warm-up, in bf16 -- and scripts/bench_configs.py: configs[3] (one-shot fine-tune, 256x256, 200 steps: the reference's
+    literal loop and the cached-target form), configs[4] (LatentGAN at batch 4096: host sampling as the reference, device
+    sampling) and the first-stage iteration at 128x128 batch 8.  Never blocks the headline: a failure is reported in place."""
+    import subprocess
+
+    def child(cmd, limit):
+        try:
+            p = subprocess.run([sys.executable] + cmd, cwd=ROOT, capture_output=True, text=True, timeout=limit)
+            lines = [l for l in p.stdout.strip().splitlines() if l.startswith("{")]
+            if not lines:
+                return {"failed": "exit code %s; stderr ends: %s" % (p.returncode, " | ".join(p.stderr.strip().splitlines()[-4:])[-600:])}
+            return json.loads(lines[-1])
+        except Exception as e:
+            return {"failed": repr(e)}
+
+    t0 = time.perf_counter()
+    out = {"bf16": child([os.path.abspath(__file__), "--dtype", "bf16", "--steps", str(args.steps), "--warmup", str(args.warmup),
+                          "--batch", str(args.batch), "--res", str(args.res), "--pool", str(args.pool), "--timing-only"], 300),
+           "configs": child([os.path.join(ROOT, "scripts", "bench_configs.py")], 300)}
+    out["bf16"]["what"] = ("BASELINE.json configs[2]'s compute type on one GPU: the headline's loop with bf16 activations / filter copies on "
+                           "v_mfma_f32_32x32x16_bf16, fp32 accumulate, fp32 master weights; a separate figure, never the headline")
+    out["seconds"] = round(time.perf_counter() - t0, 1)
+    return out
 
 
 PARITY_NETS = ("generator", "generator_smoothed", "discriminator", "synth_discriminator", "latent_discriminator",

@@ -104,7 +104,7 @@ class ConfigNetFirstStage:
         # second stage: real / synthetic branches of the generator step on two streams (not in deterministic mode: both
         # branches add into the generator's gradient slots, and the order of those adds would depend on the race)
         # (read at USE time -- `fork_generator_step` is a property: ops.set_deterministic() after construction must take effect)
-        self._fork_generator_step = os.environ.get("CN_NO_FORK") is None
+        self._fork_generator_step = True
         self._work_streams = []
         self.use_graphs = False       # capture each step's device half into a HIP graph (single-GPU runs)
 
@@ -519,7 +519,7 @@ class ConfigNetFirstStage:
     def _prelaunch_generator_targets(self, pending, follower, ev_early):
         """(Second stage; no-op otherwise.)"""
 
-    early_generator_forward = os.environ.get("CN_NO_EARLY_G") is None
+    early_generator_forward = True
 
     # Cross-iteration overlap (graph dispatch, steady training loops: bench.py and train() switch it on).  The REAL half of
     # an image-discriminator step -- forward on real images, the R1 sweep and tangent pass, their backward: more than half of

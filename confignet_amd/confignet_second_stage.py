@@ -215,15 +215,15 @@ class ConfigNet(ConfigNetFirstStage):
         losses["loss_sum"] = total_loss(losses.values())
         return losses
 
-    split_latent_regressor = os.environ.get("CN_NO_SPLIT_LR") is None
-    regressor_real_half_on_main = os.environ.get("CN_LR_REAL_ON_SIDE") is None
+    split_latent_regressor = True
+    regressor_real_half_on_main = True
 
     # OFF by default -- measured (round 4, profiles/round4_schedule_experiments.txt): 478 instead of 537 convolution launches and
     # 1.2 ms less convolution kernel time per iteration, but the step takes 28.9 instead of 26.9 ms and the iteration 49.4 instead
     # of 45.5: in the two-pass form the real branch (encoder -> generator -> VGG -> heads) and the synthetic branch run side by
     # side on two streams from start to end, and that concurrency fills the CUs which the small launches of one chain leave idle;
-    # the stacked form has to wait for the encoder before its only generator pass can start.  CN_G_MERGE=1 selects it.
-    merge_generator_passes = os.environ.get("CN_G_MERGE") == "1"
+    # the stacked form has to wait for the encoder before its only generator pass can start.  ConfigNet.merge_generator_passes = True selects it.
+    merge_generator_passes = False
 
     def _generator_loss_merged(self, facemodel_params, synth_rotations, synth_imgs, eye_masks, real_imgs):
         """(See merge_generator_passes: an option, slower end to end.)  The same loss dict from FEWER, LARGER launches: the synthetic and the real half go through the generator as ONE
@@ -322,8 +322,8 @@ class ConfigNet(ConfigNetFirstStage):
     # step under iteration t's generator tail -- whose last third (generator and encoder backward: chains of small launches) has
     # the chip almost to itself, while the generator step's forward at the start of t+1 competes with three discriminator lines.
     # The batch of t+1 is drawn with it: all four host halves move to the end of iteration t, in the reference's order (D,
-    # synth-D, latent-D, G).  CN_NO_PRE_G=1: the four passes inside the step as before.
-    prelaunch_generator_targets = os.environ.get("CN_NO_PRE_G") is None
+    # synth-D, latent-D, G).  prelaunch_generator_targets = False: the four passes inside the step as before.
+    prelaunch_generator_targets = True
 
     def _generator_targets(self, datasets, optimizer, key):
         """The ground-truth VGG activations for the batch staged under "g": None (the step computes them itself) outside the

@@ -195,8 +195,7 @@ class RealEncoder(Net):
         z = F.conv(x, self.weights[kidx], None, spec)           # bias folded into the affine shift
         return F.channel_affine_act(z, coef[0][ci], coef[1][ci], res, relu)
 
-    import os as _os
-    fold_inference = _os.environ.get("CN_NO_BN_FOLD") is None      # (False / CN_NO_BN_FOLD=1: the taped form in every mode -- A/B and cross-check)
+    fold_inference = True      # (False: the taped form in every mode -- cross-check)
 
     def features(self, img):
         if self.fold_inference and not torch.is_grad_enabled() and img.dtype == torch.float32:

@@ -16,9 +16,8 @@ from . import ops
 from .ops import ACT_LRELU, ACT_NONE, ACT_RELU, ACT_TANH, ConvSpec  # noqa: F401
 
 _INPUT_GRADS_ONLY = False
-import os as _os
-FUSED_TAIL_STATS = _os.environ.get("CN_NO_TAIL_STATS4") is None    # DiscrBlock tail: the two statistics passes as one (cn_nc_reduce4)
-BN_BWD_FUSED = _os.environ.get("CN_NO_BN_BWD_FUSED") is None      # conv -> BN(inference) -> ReLU backward as one pass (cn_bn_act_bwd)
+FUSED_TAIL_STATS = True    # DiscrBlock tail: the two statistics passes as one (cn_nc_reduce4)
+BN_BWD_FUSED = True      # conv -> BN(inference) -> ReLU backward as one pass (cn_bn_act_bwd)
 
 
 @contextlib.contextmanager

@@ -1,13 +1,12 @@
 """Losses (reference: confignet/losses.py) on HIP kernels."""
-import os
 
 import numpy as np
 import torch
 
 from . import functional as F
 
-BATCHED_R1 = os.environ.get("CN_NO_BATCHED_R1") is None
-BATCHED_TANGENT = os.environ.get("CN_NO_BATCHED_TANGENT") is None     # the six heads' tangent passes as one stacked pass
+BATCHED_R1 = True
+BATCHED_TANGENT = True     # the six heads' tangent passes as one stacked pass
 
 
 def _r1_penalties(discriminator, out_real, real_imgs, inter):

@@ -153,7 +153,7 @@ def geom_in_shape(g, upsampled=False):
     return (g.n, g.in_h << u, g.in_w << u, g.cin)
 
 
-_CACHE_SINGLE = os.environ.get("CN_NO_STREAM_CACHE") is not None      # A/B: one derived copy per filter, re-derived whenever the other branch used it
+_CACHE_SINGLE = False      # A/B: one derived copy per filter, re-derived whenever the other branch used it
 _keepalive = None        # a list while an InferenceGraph is captured: every derived filter copy the capture references
 
 
@@ -224,7 +224,7 @@ def _bf16_conv_ok(g):
 # ---------------------------------------------------------------------------------------------
 # x2-upsample-folded convolutions collapsed per output-parity class (include/confignet_hip.h: cn_upfold_*)
 # ---------------------------------------------------------------------------------------------
-UPFOLD = os.environ.get("CN_NO_UPFOLD") is None
+UPFOLD = True
 
 
 def upfold_ok(g):
@@ -284,7 +284,7 @@ def upfold_wgrad(gw2, g, w_shape, out=None, single_writer=False):
 # ---------------------------------------------------------------------------------------------
 # Winograd F(2x2, 3x3) for the wide 2-D 3x3 stride-1 SAME layers (fp32 mode): include/confignet_hip.h: cn_conv_fwd_wino
 # ---------------------------------------------------------------------------------------------
-WINOGRAD = os.environ.get("CN_NO_WINOGRAD") is None
+WINOGRAD = True
 WINO_MIN_WGS = 128          # below ~half a workgroup per CU the direct kernel with split-K wins
 WINO_MIN_FILL = 0.7         # fraction of the 8 x 8-tile blocks that must lie inside the image
 
@@ -305,7 +305,7 @@ def _wino_ok(g, cin, cout):
     return g.n * bh * bw * (cout // 64) >= WINO_MIN_WGS
 
 
-WINO4 = os.environ.get("CN_NO_WINO4") is None
+WINO4 = True
 WINO4_MIN_WGS = 192
 
 
@@ -353,7 +353,7 @@ def _wino_filter(w, dgrad):
 # sample, a zero pool active, not the deterministic mode); everything else leaves no entry and the consumer runs its own pass.
 _stats_request = None
 _stats_ready = None          # (data_ptr, shape, kind, tensors) of the most recent fused launch
-STATS_FUSION = os.environ.get("CN_NO_STATS_FUSION") is None
+STATS_FUSION = True
 
 
 class request_stats:
@@ -502,10 +502,10 @@ def conv_dgrad(gy, w, g):
     return cast(gu, _act_out_dtype(g.cin))
 
 
-DGRAD_FROM_W = os.environ.get("CN_NO_DGRAD_FROM_W") is None
-THIN_WGRAD = os.environ.get("CN_NO_THIN_WGRAD") is None
-C3_WGRAD = os.environ.get("CN_NO_C3_WGRAD") is None
-MIXED_FIRST_LAYERS = os.environ.get("CN_NO_MIXED_FIRST") is None      # bf16 path: first-layer kernels that read / write both storage types
+DGRAD_FROM_W = True
+THIN_WGRAD = True
+C3_WGRAD = True
+MIXED_FIRST_LAYERS = True      # bf16 path: first-layer kernels that read / write both storage types
 _C3_PARTS = []
 
 
@@ -515,7 +515,7 @@ def _c3_partials():
     return _C3_PARTS[0]
 
 
-_EXP_NO_WGRAD = os.environ.get("CN_EXP_NO_WGRAD") is not None       # timing experiment only (wrong gradients): filter gradients not launched
+_EXP_NO_WGRAD = False       # timing experiment only (wrong gradients): filter gradients not launched
 
 
 def conv_wgrad(x, gy, g, w_shape, out=None):
@@ -560,26 +560,26 @@ def conv_wgrad(x, gy, g, w_shape, out=None):
 # gradient sink: while nn.backward_into_arenas runs a backward pass, the filter / dense-weight / bias gradients are ADDED by
 # their kernels straight into the weights' slots of the networks' gradient arenas (tf.GradientTape sums the contributions of
 # every use of a variable: here the wgrad kernels' own accumulate mode does, not autograd's add kernels and not a copy pass
-# afterwards).  CN_NO_GRAD_SINK=1: gradients through autograd as before.
+# afterwards).  GRAD_SINK = False: gradients through autograd as before.
 # Nothing downstream of a weight gradient is on the backward chain, so the sinks CAN run on a side stream that forks off the
-# chain (CN_WGRAD_FORK=1, one cross-stream edge per CN_WGRAD_GROUP launches, joined at the end of the pass; all sinks share
+# chain (WGRAD_FORK = True, one cross-stream edge per WGRAD_GROUP launches, joined at the end of the pass; all sinks share
 # ONE side stream, so accumulations into one slot never race).  Measured and left OFF: with the filter gradients not
 # launched at all the iteration drops 49.8 -> 42.3 ms (the bound of the idea), but the forked graphs replay SLOWER than the
 # single chain -- 63.6 ms with an edge per 8 launches, 53.2 per 32, 52.3 with one fork at the end of the pass, against
 # 49.5 unforked: the four hardware queues already carry the iteration's four concurrent lines, a fifth branch takes a queue
 # from one of them (GPU_MAX_HW_QUEUES = 6 / 8 make every variant worse: 61 - 87 ms).
 # ---------------------------------------------------------------------------------------------
-GRAD_SINK = os.environ.get("CN_NO_GRAD_SINK") is None
-WGRAD_FORK = os.environ.get("CN_WGRAD_FORK") == "1"
-# Round 4 experiment, OFF (CN_WGRAD_BALANCE=1 switches it on): load balancing between the TWO streams a forked step already has.
+GRAD_SINK = True
+WGRAD_FORK = False
+# Round 4 experiment, OFF (WGRAD_BALANCE = True switches it on): load balancing between the TWO streams a forked step already has.
 # The backward pass of the generator step runs as two chains -- the real branch (VGG, generator, the whole ResNet-50 encoder) on
 # the model's branch stream, the synthetic branch on the calling stream -- and the real chain is the longer one by the encoder's
 # backward.  Filter / dense-weight gradients are leaves of the tape (nothing on a chain waits for them), so the sink launches
 # issued on a stream other than the one the pass was started on were queued and handed to the calling stream in groups (one
-# cross-stream edge per WGRAD_GROUP launches; no extra stream, no extra hardware queue -- what sank CN_WGRAD_FORK).  Measured
+# cross-stream edge per WGRAD_GROUP launches; no extra stream, no extra hardware queue -- what sank WGRAD_FORK).  Measured
 # (profiles/round4_schedule_experiments.txt): 335 / 327 / 334 images/s with an edge per 8 / 4 / 16 launches against 352 without --
 # every cross-branch edge inside a captured graph costs more than the idle tail of the shorter chain it would fill.
-WGRAD_BALANCE = os.environ.get("CN_WGRAD_BALANCE") == "1"
+WGRAD_BALANCE = False
 _SINK = None              # {"slots": {data_ptr: grad view}, "side": stream | None, "keep": [...], "used": bool}
 _SIDE_STREAMS = {}
 
@@ -639,7 +639,7 @@ def sink_for(w):
     return _SINK["slots"].get(w.data_ptr())
 
 
-WGRAD_GROUP = int(os.environ.get("CN_WGRAD_GROUP", "8"))      # sink launches per fork off the backward chain
+WGRAD_GROUP = 8      # sink launches per fork off the backward chain
 
 
 def _sink_flush():

@@ -1,9 +1,9 @@
 #!/bin/bash
 # Everything the judged profiles/ artifacts are made from, in one GPU-box call:
-#   gpurun --timeout 3000 -- 'bash scripts/make_profiles.sh round5'
+#   gpurun --timeout 3000 -- 'bash scripts/make_profiles.sh round6'
 # writes gpurun_out/profiles_<tag>/ ; copy what is to be judged into profiles/ and commit.
-# `bash scripts/make_profiles.sh round5 pmc` repeats the counter passes (section 3) only.
-TAG=${1:-round5}
+# `bash scripts/make_profiles.sh round6 pmc` repeats the counter passes (section 3) only.
+TAG=${1:-round6}
 ONLY=${2:-all}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/profiles_$TAG

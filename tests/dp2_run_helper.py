@@ -6,6 +6,8 @@ two-part generator backward with the early gradient buckets).
                  batch 8 per rank, batches drawn from np.random.seed(seed + rank), every staged batch logged
     single mode: one process, batch 16, re-running the CONCATENATED batches of the two ranks (StaticBuffers.replay)
 
+--dtype=bf16 anywhere on the command line: the same run with bf16 activations (ops.set_activation_dtype).
+
 Both write: the loss scalars of three iterations, every (optimizer, network)'s Adam first moment after iteration 1
 (= (1 - beta_1) x the gradient that Adam saw: the all-reduced rank mean resp. the global-batch gradient), final weights and
 moments, and (rank mode) the staged batches."""
@@ -19,9 +21,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def main(out_path, mode, batch, global_stats, deterministic, replay_paths):
+def main(out_path, mode, batch, global_stats, deterministic, replay_paths, dtype="f32"):
     import bench
     from confignet_amd import ops, parallel
+    ops.set_activation_dtype(dtype)                              # "bf16": BASELINE.json configs[2]'s compute type
     ops.set_deterministic(bool(deterministic))
     if mode == "rank":
         parallel.init_from_env()
@@ -97,4 +100,6 @@ def main(out_path, mode, batch, global_stats, deterministic, replay_paths):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), sys.argv[6:])
+    argv = [a for a in sys.argv[1:] if not a.startswith("--dtype=")]
+    dt = next((a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--dtype=")), "f32")
+    main(argv[0], argv[1], int(argv[2]), int(argv[3]), int(argv[4]), argv[5:], dt)
