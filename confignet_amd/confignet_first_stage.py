@@ -880,3 +880,28 @@ class ConfigNetFirstStage:
         with torch.no_grad():
             latents = self.synthetic_encoder(facemodel_params).cpu().numpy()
         return self.generate_images(latents, rotations)
+
+    def fit_facemodel_expression_params_to_latent(self, latent, unused_expr_idxs=None, param_name="blendshape_values",
+                                                  n_iters=2000, learning_rate=0.05, verbose=False):
+        """The face-model parameter vector in [0, 1] whose per-input MLP of the synthetic encoder lands closest (mean squared
+        error) to the `param_name` slice of `latent` (reference confignet_first_stage.py:646-679: plain SGD on one (1, d) variable,
+        clipped to [0, 1] after every step, unused expressions zeroed).  The MLP runs on the HIP kernels; the whole loop stays on
+        the device (the reference round-trips the variable through numpy every step)."""
+        idxs = list(self.get_facemodel_param_idxs_in_latent(param_name))
+        names = list(self.config["facemodel_inputs"].keys())
+        n_in = list(self.config["facemodel_inputs"].values())[names.index(param_name)][0]
+        mlp = self.synthetic_encoder.per_facemodel_input_mlps[param_name]
+        target = self.synthetic_encoder.to_device(np.asarray(latent, dtype=np.float32)[:, idxs])
+        values = torch.zeros((1, n_in), device=target.device, dtype=torch.float32, requires_grad=True)
+        unused = None if unused_expr_idxs is None else torch.as_tensor(list(unused_expr_idxs), device=target.device, dtype=torch.long)
+        for step in range(n_iters):
+            loss = torch.mean(torch.square(target - mlp(values)))
+            (grad,) = torch.autograd.grad(loss, [values])
+            with torch.no_grad():
+                values -= learning_rate * grad
+                values.clamp_(0.0, 1.0)
+                if unused is not None:
+                    values[:, unused] = 0.0
+            if verbose:
+                print("%d: %f" % (step, float(loss)))
+        return values.detach().cpu().numpy()

@@ -88,3 +88,7 @@ __device__ __forceinline__ float cn_apply_act(float v, int act, float slope) {
 }
 
 static inline int cn_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// compute units of the current device (hipDeviceAttributeMultiprocessorCount, read once; 256 on an MI355X): the launch cost models
+// count workgroup rounds with it
+int cn_cu_count();

@@ -1567,9 +1567,13 @@ static int conv_fwd_impl(const CnConvGeom* gp, const float* x, const float* w, c
                 const long tl = (long)cn_cdiv(Me, c.bm) * cn_cdiv(g.cout, c.bn);
                 const long smax = nks / 8 > 1 ? (nks / 8 > 16 ? 16 : nks / 8) : 1;
                 for (long s_ = 1; s_ <= smax; ++s_) {
-                    const double waves = (double)cn_cdiv(tl * s_, 256);
+                    const double waves = (double)cn_cdiv(tl * s_, cn_cu_count());
                     double t = 10.0 + waves * (double)cn_cdiv(nks, s_) * c.step_us * (waves == 1.0 ? 1.06 : 1.0);
                     if (s_ > 1) t += 9.0 + (double)s_ * (double)M * g.cout * 4.0 / 6.0e6;
+                    // a split launch cannot carry the residual add / the statistics in its epilogue: the caller then runs a pass of
+                    // its own over y (read + write at ~3 TB/s, one more launch) -- priced here so that a fused request splits only
+                    // where the split still wins with that pass added
+                    if (s_ > 1 && (res || stats)) t += 5.0 + 2.0 * (double)M * g.cout * 4.0 / 3.0e6;
                     if (!have || t < best) { have = true; best = t; cfg = c.cfg; tiles = tl; splits = (int)s_; }
                 }
             }

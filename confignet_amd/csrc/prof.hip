@@ -131,6 +131,15 @@ __global__ void sum_parts_kernel(const float* __restrict__ src, float* __restric
 }
 }  // namespace
 
+int cn_cu_count() {
+    static const int cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        return n;
+    }();
+    return cus;
+}
+
 extern "C" int cn_set_deterministic(int on) {
     std::lock_guard<std::mutex> lk(g_det_mu);
     if (on && !g_det_buf[0]) {

@@ -367,9 +367,11 @@ double wg2_cost(const Wg2Tile& t, long M, long Ktot, int cout, long s, long& row
     const long per_xcd = splits >= 8 ? (long)cn_cdiv(splits, 8) * tiles : (long)cn_cdiv(tiles * splits, 8);
     const double cyc_row = 32.0 * (t.bi / 32) * (t.bn / 32) / 4.0;           // MFMA cycles per reduction row (4 waves on 4 SIMDs)
     const double life = ((double)rows * cyc_row + 9000.0) / 2400.0;         // us at the full pipe, + prologue / epilogue
-    // an XCD holds 64 workgroups at once (two per CU); full rounds run two to a CU, the last one alone if it has at most 32
-    const long rounds = cn_cdiv(per_xcd, 64), rem = per_xcd - 64 * (rounds - 1);
-    double us = (double)(rounds - 1) * 2.0 * life / t.e2 + (rem <= 32 ? life / t.e1 : 2.0 * life / t.e2);
+    // an XCD (an eighth of the CUs: 32 on an MI355X) holds two workgroups per CU at once; full rounds run two to a CU, the last
+    // one alone if it has at most one workgroup per CU
+    const long xcd_cus = cn_cu_count() >= 8 ? cn_cu_count() / 8 : 1;
+    const long rounds = cn_cdiv(per_xcd, 2 * xcd_cus), rem = per_xcd - 2 * xcd_cus * (rounds - 1);
+    double us = (double)(rounds - 1) * 2.0 * life / t.e2 + (rem <= xcd_cus ? life / t.e1 : 2.0 * life / t.e2);
     if (splits > 1) us += 2.0 * (double)splits * (double)Ktot * cout * 4.0 / 2.5e6 + 5.0;      // slabs written + read back, one more launch
     return us;
 }

@@ -150,6 +150,8 @@ class RealEncoder(Net):
         cache = self.__dict__.setdefault("_fold_cache", {})            # one entry per stream (two streams alternating must not re-fold)
         c = cache.get(stream)
         if c is None or c[0] != key:
+            for k in [k for k, v in cache.items() if v[0] != key]:     # copies of older weights (other streams' included) are dead:
+                del cache[k]                                           # the dict holds at most one packed copy per LIVE stream
             seg, total, views = self._fold_table()
             packed = ops.scale_columns_segments(self.arena, seg, a_cat, total)
             c = cache[stream] = (key, [packed[o:o + int(np.prod(shp))].view(shp) for o, shp in views], packed)

@@ -4,6 +4,7 @@ import contextlib
 import ctypes
 import math
 import os
+import threading
 
 import torch
 
@@ -351,8 +352,12 @@ def _wino_filter(w, dgrad):
 # the stored, activated output (AdaIn); kind "pre4": (sum v, sum v^2, sum l, sum l^2), l = leaky_relu(v, slope), of a convolution
 # without activation (DiscrBlock tail).  Only launches that can carry them do (fp32, the unsplit LDS-DMA loop, tiles inside one
 # sample, a zero pool active, not the deterministic mode); everything else leaves no entry and the consumer runs its own pass.
-_stats_request = None
-_stats_ready = None          # (data_ptr, shape, kind, tensors) of the most recent fused launch
+class _StatsSlot(threading.local):        # per host thread: a request / a result never crosses to a convolution issued by another thread
+    request = None
+    ready = None                          # (data_ptr, shape, kind, tensors) of the most recent fused launch
+
+
+_stats = _StatsSlot()
 STATS_FUSION = True
 
 
@@ -361,27 +366,23 @@ class request_stats:
         self.req = (kind, float(slope))
 
     def __enter__(self):
-        global _stats_request
-        self.prev, _stats_request = _stats_request, (self.req if STATS_FUSION and not DETERMINISTIC else None)
+        self.prev, _stats.request = _stats.request, (self.req if STATS_FUSION and not DETERMINISTIC else None)
 
     def __exit__(self, *exc):
-        global _stats_request
-        _stats_request = self.prev
+        _stats.request = self.prev
 
 
 def take_stats(y, kind):
     """The statistics the producing convolution left for tensor y, or None."""
-    global _stats_ready
-    ent, _stats_ready = _stats_ready, None
+    ent, _stats.ready = _stats.ready, None
     if ent is not None and ent[0] == y.data_ptr() and ent[1] == tuple(y.shape) and ent[2] == kind:
         return ent[3]
     return None
 
 
 def conv_fwd(x, w, bias, g, act=ACT_NONE, slope=0.0):
-    global _stats_request, _stats_ready
-    req, _stats_request = _stats_request, None           # (a request applies to the next convolution only)
-    _stats_ready = None
+    req, _stats.request = _stats.request, None           # (a request applies to the next convolution only)
+    _stats.ready = None
     out_dtype = _act_out_dtype(g.cout)
     if ACT_DTYPE == torch.float32 and x.dtype == torch.float32 and _wino4_ok(g, g.cin, g.cout):
         y = torch.empty(geom_out_shape(g), device=x.device, dtype=torch.float32)
@@ -413,15 +414,17 @@ def conv_fwd(x, w, bias, g, act=ACT_NONE, slope=0.0):
     y = torch.empty(geom_out_shape(g), device=x.device, dtype=torch.float32)
     if req is not None and out_dtype == torch.float32 and g.cout % 4 == 0 and (req[0] == "act" or act == ACT_NONE):
         nk = 2 if req[0] == "act" else 4
+        mark = _active_pool.cur if _active_pool is not None else None
         st = zero_pool_alloc((nk, g.n, g.cout), x.device)
         if st is not None:
             rc = lib.cn_conv_fwd_stats(ctypes.byref(g), _ptr(_c(x)), _fptr(w), _fptr(bias), _ptr(y), act, slope, _ptr(st), 1 if nk == 2 else 2,
                                        req[1], _stream())
             if rc == 0:
-                _stats_ready = (y.data_ptr(), tuple(y.shape), req[0], tuple(st[k] for k in range(nk)))
+                _stats.ready = (y.data_ptr(), tuple(y.shape), req[0], tuple(st[k] for k in range(nk)))
                 return y
             if rc != CN_EUNSUPPORTED:
                 check(rc, "cn_conv_fwd_stats")
+            _active_pool.cur = mark                   # nothing was launched: hand the (untouched, still zero) slab back to the pool
     check(lib.cn_conv_fwd(ctypes.byref(g), _ptr(x), _fptr(w), _fptr(bias), _ptr(y), act, slope, _stream()), "cn_conv_fwd")
     return cast(y, out_dtype)
 

@@ -42,7 +42,9 @@ class Adam:
         self.lr, self.beta_1, self.beta_2, self.epsilon = lr, beta_1, beta_2, epsilon
         self.iterations = 0
         self._state = {}
-        self._checked_lists = {}           # network -> the variable list its last Keras-form call was checked with
+        self._checked_lists = {}           # network -> {variable list: epoch of the network's moments it was checked at}
+        self._ever_listed = {}             # network -> ids of the weights any Keras-form call has listed
+        self._list_epoch = {}              # network -> bumped whenever a call lists a weight for the first time
         self._lr_dev = {}
 
     def lr_t(self):
@@ -92,9 +94,18 @@ class Adam:
             listed = frozenset(id(var) for _, var in pairs)
             for owner in nets:
                 st = self._state.get(id(owner))
-                # (re-checked whenever the list differs from the owner's PREVIOUS call: A, superset B, A again must fail on the
-                # third call -- B's extra weights carry moments by then)
-                if st is None or self._checked_lists.get(id(owner)) == listed:
+                # A list is checked once per STATE of the owner's moments.  The state changes only when a call lists a weight that
+                # no earlier call had listed (new moments appear): that bumps the owner's epoch and every list checked before it is
+                # checked again on its next use -- A, superset B, A again still fails on the third call.  Calls that repeat or
+                # alternate already-seen lists do NOT re-run the masked reduction (a host synchronisation, illegal inside a
+                # HIP-graph capture).
+                oid = id(owner)
+                ever = self._ever_listed.setdefault(oid, set())
+                if not listed <= ever:
+                    ever |= listed
+                    self._list_epoch[oid] = self._list_epoch.get(oid, 0) + 1
+                seen = self._checked_lists.setdefault(oid, {})
+                if st is None or seen.get(listed) == self._list_epoch[oid]:
                     continue
                 # once per (optimizer, variable list): one masked reduction over the SECOND-moment arena (v > 0 wherever a
                 # weight has ever had a non-zero gradient in this optimizer) restricted to the unlisted weights
@@ -105,7 +116,7 @@ class Adam:
                         mask[off:off + w.numel()] = True
                 assert not bool((st[1].ne(0) & mask).any()), \
                     "apply_gradients(zip(grads, vars)): an unlisted weight of a listed network has optimizer state"
-                self._checked_lists[id(owner)] = listed
+                seen[listed] = self._list_epoch[oid]
         if not isinstance(nets, (list, tuple)):
             nets = [nets]
         if _deferred is not None:

@@ -73,7 +73,7 @@ NS = next((int(a.split("=", 1)[1]) for a in sys.argv if a.startswith("ns=")), 0)
 if NS:
     ops.check(lib.cn_conv_loop_select(-1, 0, NS, -1), "loop_select")      # stage count of the LDS-DMA loops
 rows = []
-tot_old = tot_new = tot_best = 0.0
+tot_old = tot_new = tot_best = tot_prod = 0.0
 for k, cnt in calls.items():
     g = ops.CnConvGeom(*k)
     taps = g.k_d * g.k_h * g.k_w
@@ -99,6 +99,12 @@ for k, cnt in calls.items():
     torch.cuda.synchronize()
     err = float((gw_old - gw_new).abs().max() / (gw_old.abs().max() + 1e-30))
     t_old, t_new = timed(run_old), timed(run_new)
+    # what the product launches for this geometry: ops.conv_wgrad (first-layer K = 27 and thin-output shapes have kernels of their own)
+    w_shape = ((g.k_d,) if g.nd == 3 else ()) + (g.k_h, g.k_w, g.cin, g.cout)
+    gw_prod = torch.zeros(w_shape, device="cuda")
+    xp, gyp = (x, gy) if g.nd == 3 else (x[:, 0], gy[:, 0])
+    t_prod = timed(lambda: ops.conv_wgrad(xp, gyp, g, w_shape, out=gw_prod))
+    tot_prod += cnt * t_prod
     best = (t_new, "default")
     if SWEEP and nbytes >= 0:
         for tile in (0, 4, 2, 3, 5):                     # 128x128, 128x96, 64x64, 128x32, 256x64
@@ -122,13 +128,14 @@ for k, cnt in calls.items():
                     best = (t, "tile%d/wg%d" % (tile, target))
         ops.check(lib.cn_conv_tune(-1, 0, 0), "tune")
     flop = 2.0 * M * Ktot * g.cout
-    rows.append((cnt * t_old, cnt, t_old, t_new, best, flop, M, Ktot, g.cout, nbytes, err, k))
+    rows.append((cnt * t_old, cnt, t_old, t_new, best, flop, M, Ktot, g.cout, nbytes, err, k, t_prod))
     tot_old += cnt * t_old
     tot_new += cnt * t_new
     tot_best += cnt * best[0]
     del x, gy, gw_old, gw_new
 rows.sort(reverse=True)
-print("filter gradients per iteration: old %.2f ms, new %.2f ms%s" % (tot_old / 1e3, tot_new / 1e3, ", best of sweep %.2f ms" % (tot_best / 1e3) if SWEEP else ""))
-print("%3s %8s %8s %7s %7s %8s %6s %5s %8s %9s  %s" % ("cnt", "old us", "new us", "old TF", "new TF", "M", "K", "N", "ws MB", "rel err", "best"))
-for _, cnt, t_old, t_new, best, flop, M, K, N, nb, err, k in rows:
-    print("%3d %8.1f %8.1f %7.1f %7.1f %8d %6d %5d %8.1f %9.1e  %s %.1f  %s" % (cnt, t_old, t_new, flop / t_old / 1e6, flop / t_new / 1e6, M, K, N, nb / 1e6, err, best[1], best[0], dict(zip(FIELDS, k)) if "geom" in sys.argv else ""))
+print("filter gradients per iteration: round-3 kernel (cn_conv_wgrad) %.2f ms, cn_conv_wgrad_ws %.2f ms, PRODUCT dispatch (ops.conv_wgrad: + the K = 27 / thin-output kernels) %.2f ms%s"
+      % (tot_old / 1e3, tot_new / 1e3, tot_prod / 1e3, ", best of sweep %.2f ms" % (tot_best / 1e3) if SWEEP else ""))
+print("%3s %8s %8s %8s %7s %7s %8s %6s %5s %8s %9s  %s" % ("cnt", "old us", "new us", "prod us", "old TF", "new TF", "M", "K", "N", "ws MB", "rel err", "best"))
+for _, cnt, t_old, t_new, best, flop, M, K, N, nb, err, k, t_prod in rows:
+    print("%3d %8.1f %8.1f %8.1f %7.1f %7.1f %8d %6d %5d %8.1f %9.1e  %s %.1f  %s" % (cnt, t_old, t_new, t_prod, flop / t_old / 1e6, flop / t_new / 1e6, M, K, N, nb / 1e6, err, best[1], best[0], dict(zip(FIELDS, k)) if "geom" in sys.argv else ""))

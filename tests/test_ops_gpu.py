@@ -957,3 +957,40 @@ def test_convolution_epilogue_statistics_match_the_separate_passes():
         sep = ops.nc_reduce(y1) if kind == "act" else ops.nc_reduce4(y1, 0.3)
         for got, r in zip(st, sep):
             assert float((got - r).abs().max()) <= 2e-5 * float(r.abs().max()) + 1e-4
+
+
+@pytest.mark.gpu
+def test_keras_form_apply_gradients_checks_a_variable_list_once_per_state_of_the_moments():
+    """optim.Adam.apply_gradients(zip(grads, vars)) (the Keras form train scripts use): a variable list that leaves out a weight which
+    already has optimizer state must fail -- and that check, a masked reduction with a host synchronisation, must run once per list
+    and state of the moments, not on every call: A, A, A checks once; A, superset B, A fails on the third call."""
+    from confignet_amd import optim
+    from confignet_amd.nn import Net
+    net = Net()
+    for i in range(3):
+        net.add_weight("w%d" % i, np.ones((8, 4), np.float32) * (i + 1))
+    net.finalize()
+    opt = optim.Adam(lr=1e-3, beta_1=0.0, beta_2=0.9)
+    w = net.trainable_weights
+    g = [torch.ones_like(t) for t in w]
+    syncs = []
+    real_any = torch.Tensor.any
+
+    def counting_any(self, *a, **k):
+        syncs.append(1)
+        return real_any(self, *a, **k)
+
+    torch.Tensor.any = counting_any
+    try:
+        a_list = lambda: list(zip(g[:2], w[:2]))
+        for _ in range(4):
+            opt.apply_gradients(a_list())
+        assert len(syncs) == 1, len(syncs)                # (first call: no state yet; second: checked; then cached)
+        opt.apply_gradients(list(zip(g, w)))              # superset B: lists w2 for the first time -> new moments
+        n = len(syncs)
+        opt.apply_gradients(list(zip(g, w)))
+        assert len(syncs) == n                            # B itself: cached
+        with pytest.raises(AssertionError, match="unlisted weight"):
+            opt.apply_gradients(a_list())                 # A again: w2 has moments now
+    finally:
+        torch.Tensor.any = real_any

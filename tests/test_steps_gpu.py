@@ -523,6 +523,34 @@ def test_set_facemodel_param_in_latents_values():
     assert np.abs(out2[:, 37:40] - ref2).max() < 1e-4
 
 
+def test_fit_facemodel_expression_params_to_latent_follows_the_sgd_loop_of_the_reference():
+    """confignet_first_stage.py:646-679: plain SGD (lr 0.05) on one (1, 62) variable through the blendshape MLP of the synthetic
+    encoder towards a latent's expression slice, clipped to [0, 1] after every step, unused expressions zeroed -- 60 steps against
+    the same loop in float64 on the oracle's MLP (every step of the product runs on the HIP kernels; a clip decision on an entry
+    within rounding of 0 or 1 would show as a jump: none may)."""
+    from confignet_amd import ConfigNetFirstStage
+    cfg = {"output_shape": (128, 128, 3), "batch_size": 2, "facemodel_inputs": dict(MG.FM)}
+    m = ConfigNetFirstStage(cfg, seed=5)
+    rng = np.random.default_rng(6)
+    m.synthetic_encoder.set_weights([(w + rng.normal(size=w.shape) * 0.1).astype(np.float32) for w in m.synthetic_encoder.get_weights()])
+    lat = rng.normal(size=(2, MG.L)).astype(np.float32)
+    unused = [3, 17, 40]
+    got = m.fit_facemodel_expression_params_to_latent(lat, unused_expr_idxs=unused, n_iters=60, learning_rate=0.05)
+    assert got.shape == (1, 62) and got.min() >= 0.0 and got.max() <= 1.0 and np.all(got[:, unused] == 0.0)
+    ws = [t64(w) for w in m.synthetic_encoder.get_weights()][4:8]
+    target = t64(lat[:, 7:37])
+    v = torch.zeros((1, 62), dtype=torch.float64, requires_grad=True)
+    for _ in range(60):
+        loss = torch.mean(torch.square(target - O.mlp_simple(v, ws, 0.3)))
+        (g,) = torch.autograd.grad(loss, [v])
+        with torch.no_grad():
+            v -= 0.05 * g
+            v.clamp_(0.0, 1.0)
+            v[:, unused] = 0.0
+    assert float(np.abs(got - v.detach().numpy()).max()) < 1e-4
+    assert float(got.max()) > 0.0                       # (the fit moved)
+
+
 def test_train_scripts_run_on_the_reference_dataset_files(tmp_path):
     """The reference's own smoke tests (tests/training_test.py:13-31): train_confignet.py with the 2-image dataset, 1 + 1
     steps, batch 4; then train_latent_gan.py on the model it wrote."""
