@@ -10,6 +10,12 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CN_LIB") or os.path.join(_HERE, "libconfignet_hip.so")
 
 
+class CnSumJob(ctypes.Structure):
+    """One ordered slab reduction of cn_sum_parts_grouped (include/confignet_hip.h)."""
+    _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("count", ctypes.c_longlong), ("parts", ctypes.c_int),
+                ("accumulate", ctypes.c_int)]
+
+
 class CnConvGeom(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int) for n in (
         "nd", "n", "in_d", "in_h", "in_w", "cin", "out_d", "out_h", "out_w", "cout",
@@ -52,6 +58,8 @@ SIGNATURES = {
     "cn_conv_wgrad": [_G, _p, _p, _p, _i, _p],
     "cn_conv_wgrad_workspace_bytes": [_G],
     "cn_conv_wgrad_ws": [_G, _p, _p, _p, _i, _p, _z, _p],
+    "cn_conv_wgrad_ws_slabs": [_G, _p, _p, _p, _i, _p, _z, ctypes.POINTER(_i), _p],
+    "cn_sum_parts_grouped": [_p, _i, _p],
     "cn_conv_tune": [_i, _i, ctypes.c_long],
     "cn_conv_loop_select": [_i, _i, _i, _i],
     "cn_conv_fwd_dt": [_p, _p, _i, _p, _p, _p, _i, _i, _f, _p],

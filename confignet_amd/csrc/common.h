@@ -61,7 +61,7 @@ int cn_fwd2_bf16(const CnConvGeom& g, int cfg, int flip, const void* x, const vo
 // family: which kernel of the class is launched (cn_prof_collect_by_family); bytes: the launch's algorithmic HBM bytes
 enum { CN_FAM_FWD_128x128 = 0, CN_FAM_FWD_128x64, CN_FAM_FWD_64x64, CN_FAM_FWD_128x32, CN_FAM_FWD_128x96, CN_FAM_WGRAD_128x128,
        CN_FAM_WGRAD_128x96, CN_FAM_WGRAD_64x64, CN_FAM_WGRAD_128x32, CN_FAM_WINO, CN_FAM_C3_FWD, CN_FAM_S2_IMAGE_DGRAD,
-       CN_FAM_THIN, CN_FAM_C3_WGRAD, CN_FAM_BF16_FWD, CN_FAM_BF16_WGRAD, CN_FAM_WGRAD_256x64 };
+       CN_FAM_THIN, CN_FAM_C3_WGRAD, CN_FAM_BF16_FWD, CN_FAM_BF16_WGRAD, CN_FAM_WGRAD_256x64, CN_FAM_WGRAD_SLAB_SUM };
 void cn_prof_begin(hipStream_t s, double flops, double bytes = 0.0, int family = 31);
 void cn_prof_end(hipStream_t s);
 

@@ -1814,7 +1814,7 @@ size_t cn_wgrad2_workspace_floats(const CnConvGeom& g);
 int cn_wgrad2_family(const CnConvGeom& g);
 void cn_wgrad2_tune(int cfg, long wg_target);
 void cn_wgrad2_stages(int ns);
-int cn_wgrad2(const CnConvGeom& g, const float* x, const float* gy, float* gw, int accumulate, float* ws, hipStream_t s);
+int cn_wgrad2(const CnConvGeom& g, const float* x, const float* gy, float* gw, int accumulate, float* ws, hipStream_t s, int* parts_out = nullptr);
 
 static bool wgrad2_takes(const CnConvGeom& g) {
     // Every geometry the LDS-DMA kernel can take (round 6: with the slot layout and the XCD-aware slice plan it is at or ahead of
@@ -1834,18 +1834,31 @@ extern "C" size_t cn_conv_wgrad_workspace_bytes(const CnConvGeom* gp) {
 // through partial slabs in `workspace` + one ordered reduction -- no atomics on the tile, bit-reproducible (wgrad2.hip).
 // Geometries the new kernel does not take (channel counts that are no multiple of 4, K < 64, > 2 GiB operands) go to
 // cn_conv_wgrad and need no workspace.
-extern "C" int cn_conv_wgrad_ws(const CnConvGeom* gp, const float* x, const float* gy, float* gw, int accumulate, void* workspace,
-                                size_t workspace_bytes, void* stream) {
+static int wgrad_ws_impl(const CnConvGeom* gp, const float* x, const float* gy, float* gw, int accumulate, void* workspace,
+                         size_t workspace_bytes, int* parts, void* stream) {
     if (int e = check_geom(gp)) return e;
     CN_CHECK_ARG(x && gy && gw, "NULL tensor");
+    if (parts) *parts = 0;
     if (!wgrad2_takes(*gp)) return cn_conv_wgrad(gp, x, gy, gw, accumulate, stream);
     const size_t need = sizeof(float) * cn_wgrad2_workspace_floats(*gp);
     CN_CHECK_ARG(workspace_bytes >= need && (need == 0 || workspace), "cn_conv_wgrad_ws: workspace of %zu bytes, %zu needed", workspace_bytes, need);
     hipStream_t s = (hipStream_t)stream;
     cn_prof_begin(s, conv_flops(*gp), conv_bytes(*gp), cn_wgrad2_family(*gp));
-    const int e = cn_wgrad2(*gp, x, gy, gw, accumulate, (float*)workspace, s);
+    const int e = cn_wgrad2(*gp, x, gy, gw, accumulate, (float*)workspace, s, parts);
     cn_prof_end(s);
     return e;
+}
+
+extern "C" int cn_conv_wgrad_ws(const CnConvGeom* gp, const float* x, const float* gy, float* gw, int accumulate, void* workspace,
+                                size_t workspace_bytes, void* stream) {
+    return wgrad_ws_impl(gp, x, gy, gw, accumulate, workspace, workspace_bytes, nullptr, stream);
+}
+
+// cn_conv_wgrad_ws that leaves the slabs to the caller (include/confignet_hip.h): *parts = 0 -> gw is complete
+extern "C" int cn_conv_wgrad_ws_slabs(const CnConvGeom* gp, const float* x, const float* gy, float* gw, int accumulate, void* workspace,
+                                      size_t workspace_bytes, int* parts, void* stream) {
+    CN_CHECK_ARG(parts, "cn_conv_wgrad_ws_slabs: parts is NULL");
+    return wgrad_ws_impl(gp, x, gy, gw, accumulate, workspace, workspace_bytes, parts, stream);
 }
 
 extern "C" int cn_sumpool2(const void* gu, void* gx, int nd, int n, int d, int h, int w, int c, int dt, void* stream) {

@@ -235,6 +235,89 @@ int cn_sum_parts(const float* src, float* dst, int parts, long count, int accumu
     return CN_OK;
 }
 
+// ---- many ordered slab reductions in ONE launch (round 6: the filter gradients of a backward pass leave their row slices' slabs
+// behind and the pass adds all of them at its join -- one launch instead of one per layer on the backward chain).  Every job is
+// reduced exactly as cn_sum_parts would reduce it alone (the same two schemes, the same order): the results are the same bits.
+namespace {
+constexpr int CN_SUM_GROUP = 80;          // jobs per launch (the table travels in the kernel arguments: < 4 KB)
+struct SumJobs {
+    const float* src[CN_SUM_GROUP];
+    float* dst[CN_SUM_GROUP];
+    long count[CN_SUM_GROUP];
+    int parts[CN_SUM_GROUP];
+    int flags[CN_SUM_GROUP];              // bit 0: accumulate, bit 1: the wide scheme
+    int blk0[CN_SUM_GROUP + 1];           // first workgroup of job j
+    int n;
+};
+
+__global__ __launch_bounds__(256) void sum_parts_grouped_kernel(SumJobs J) {
+    __shared__ float red[16][17];
+    const int b = blockIdx.x;
+    int lo = 0, hi = J.n;                 // job of this workgroup: blk0[lo] <= b < blk0[lo + 1]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (J.blk0[mid] <= b) lo = mid;
+        else hi = mid;
+    }
+    const int j = __builtin_amdgcn_readfirstlane(lo), lb = b - J.blk0[j];
+    const float* __restrict__ src = J.src[j];
+    float* __restrict__ dst = J.dst[j];
+    const long count = J.count[j];
+    const int parts = J.parts[j], accumulate = J.flags[j] & 1;
+    if (J.flags[j] & 2) {                 // (sum_parts_wide_kernel)
+        const int o = threadIdx.x & 15, grp = threadIdx.x >> 4;
+        const long i = (long)lb * 16 + o;
+        float t = 0.f;
+        if (i < count)
+            for (int p = grp; p < parts; p += 16) t += src[(long)p * count + i];
+        red[grp][o] = t;
+        __syncthreads();
+        if (grp == 0 && i < count) {
+            float u = 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) u += red[k][o];
+            if (accumulate) unsafeAtomicAdd(&dst[i], u);
+            else dst[i] = u;
+        }
+    } else {                              // (sum_parts_kernel)
+        const long i = (long)lb * 256 + threadIdx.x;
+        if (i >= count) return;
+        float t = 0.f;
+        for (int p = 0; p < parts; ++p) t += src[(long)p * count + i];
+        if (accumulate) unsafeAtomicAdd(&dst[i], t);
+        else dst[i] = t;
+    }
+}
+}  // namespace
+
+extern "C" int cn_sum_parts_grouped(const CnSumJob* jobs, int njobs, void* stream) {
+    CN_CHECK_ARG(njobs >= 0 && (njobs == 0 || jobs), "cn_sum_parts_grouped: bad arguments");
+    for (int first = 0; first < njobs; first += CN_SUM_GROUP) {
+        SumJobs J{};
+        const int n = njobs - first < CN_SUM_GROUP ? njobs - first : CN_SUM_GROUP;
+        long blocks = 0;
+        for (int k = 0; k < n; ++k) {
+            const CnSumJob& q = jobs[first + k];
+            CN_CHECK_ARG(q.src && q.dst && q.count > 0 && q.parts > 0, "cn_sum_parts_grouped: job %d is empty", first + k);
+            const bool wide = q.parts >= 64 && q.count * 16 <= (long)256 * 65536;      // (cn_sum_parts' rule)
+            J.src[k] = q.src; J.dst[k] = q.dst; J.count[k] = q.count; J.parts[k] = q.parts;
+            J.flags[k] = (q.accumulate ? 1 : 0) | (wide ? 2 : 0);
+            J.blk0[k] = (int)blocks;
+            blocks += cn_cdiv(q.count, wide ? 16 : 256);
+            CN_CHECK_ARG(blocks < 0x7fffffffL, "cn_sum_parts_grouped: too many workgroups");
+        }
+        J.blk0[n] = (int)blocks;
+        J.n = n;
+        // (part of the convolution class' time: these are the row slices' reductions of the filter gradients -- no FLOP, the slabs
+        // read + the filters written as algorithmic-free bytes, i.e. counted as time only)
+        cn_prof_begin((hipStream_t)stream, 0.0, 0.0, CN_FAM_WGRAD_SLAB_SUM);
+        hipLaunchKernelGGL(sum_parts_grouped_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, J);
+        cn_prof_end((hipStream_t)stream);
+        CN_LAUNCH_CHECK();
+    }
+    return CN_OK;
+}
+
 namespace {
 __global__ void zero_kernel(float* __restrict__ p, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = 0.f;

@@ -447,7 +447,8 @@ int cn_wgrad2_family(const CnConvGeom& g) {
 }
 
 // gw (+)= filter gradient.  ws: at least cn_wgrad2_workspace_floats(g) floats (may be NULL when that is 0).
-int cn_wgrad2(const CnConvGeom& g, const float* x, const float* gy, float* gw, int accumulate, float* ws, hipStream_t s) {
+// parts_out: NULL = add the slabs here (second launch); else the caller does: *parts_out = slabs written (0: gw is complete).
+int cn_wgrad2(const CnConvGeom& g, const float* x, const float* gy, float* gw, int accumulate, float* ws, hipStream_t s, int* parts_out) {
     const Wg2Plan p = wg2_plan(g);
     const long Ktot = (long)g.k_d * g.k_h * g.k_w * g.cin;
     const long count = Ktot * g.cout;
@@ -470,6 +471,10 @@ int cn_wgrad2(const CnConvGeom& g, const float* x, const float* gy, float* gw, i
 #undef WG2N
 #undef WG2
     CN_LAUNCH_CHECK();
+    if (parts_out) {
+        *parts_out = p.splits > 1 ? (int)p.splits : 0;
+        return CN_OK;
+    }
     if (p.splits > 1) return cn_sum_parts(ws, gw, (int)p.splits, count, accumulate, 1.f, s);
     return CN_OK;
 }

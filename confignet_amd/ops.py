@@ -8,7 +8,7 @@ import threading
 
 import torch
 
-from ._lib import CN_BF16, CN_EUNSUPPORTED, CN_F32, CnConvGeom, check, lib
+from ._lib import CN_BF16, CN_EUNSUPPORTED, CN_F32, CnConvGeom, CnSumJob, check, lib
 
 ACT_NONE, ACT_LRELU, ACT_RELU, ACT_TANH = 0, 1, 2, 3
 
@@ -555,6 +555,15 @@ def conv_wgrad(x, gy, g, w_shape, out=None):
     # caller-owned workspace for the partial filters of the kernel's row splits (0 bytes: a single split / the fall-back kernel)
     nbytes = int(lib.cn_conv_wgrad_workspace_bytes(ctypes.byref(g)))
     ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32) if nbytes else None
+    if nbytes and out is not None and _SINK is not None and DEFER_SLAB_SUMS:
+        # inside a backward pass (grad_sink): the row slices' slabs stay in `ws` and the pass adds the slabs of ALL its filter
+        # gradients with one grouped launch at its join (grad_sink.join) instead of one reduction launch per layer on the chain
+        parts = ctypes.c_int(0)
+        check(lib.cn_conv_wgrad_ws_slabs(ctypes.byref(g), _ptr(x), _ptr(gy), _fptr(gw), int(pre), _ptr(ws), nbytes, ctypes.byref(parts),
+                                         _stream()), "cn_conv_wgrad_ws_slabs")
+        if parts.value:
+            _SINK.setdefault("slabs", []).append((ws, gw, parts.value, gw.numel(), int(pre)))
+        return gw
     check(lib.cn_conv_wgrad_ws(ctypes.byref(g), _ptr(x), _ptr(gy), _fptr(gw), int(pre), _ptr(ws), nbytes, _stream()), "cn_conv_wgrad_ws")
     return gw
 
@@ -573,6 +582,7 @@ def conv_wgrad(x, gy, g, w_shape, out=None):
 # from one of them (GPU_MAX_HW_QUEUES = 6 / 8 make every variant worse: 61 - 87 ms).
 # ---------------------------------------------------------------------------------------------
 GRAD_SINK = True
+DEFER_SLAB_SUMS = True     # the filter gradients' slab reductions of a backward pass as ONE grouped launch at its join (False: one per layer)
 WGRAD_FORK = False
 # Round 4 experiment, OFF (WGRAD_BALANCE = True switches it on): load balancing between the TWO streams a forked step already has.
 # The backward pass of the generator step runs as two chains -- the real branch (VGG, generator, the whole ResNet-50 encoder) on
@@ -615,9 +625,35 @@ class grad_sink:
             torch.cuda.current_stream().wait_stream(st["side"])
         if st is not None:
             cur = torch.cuda.current_stream()
-            for s_ in st.pop("touched", []):            # every stream a sink launched on (a forked step has two) before anything
+            touched = st.pop("touched", [])
+            for s_ in touched:                          # every stream a sink launched on (a forked step has two) before anything
                 if s_ != cur:                           # below reads or adds to the arenas on the calling stream
                     cur.wait_stream(s_)
+            slabs = st.pop("slabs", [])
+            if slabs:
+                # every filter gradient of the pass that split its rows: (slabs, destination, parts, count, accumulate) -> ONE launch
+                # per 80 of them, each reduced in slice order exactly as cn_conv_wgrad_ws would have (same bits)
+                # (a weight used more than once in the pass -- the generator runs twice in the generator step -- has several jobs
+                # with ONE destination: they go into successive launches, in the order of their filter gradients, so that the adds
+                # into one element keep a fixed order; typically two or three launches for ~70 reductions)
+                rounds, seen = [], {}
+                for job in slabs:
+                    r = seen.get(job[1].data_ptr(), 0)
+                    seen[job[1].data_ptr()] = r + 1
+                    if r == len(rounds):
+                        rounds.append([])
+                    rounds[r].append(job)
+                for batch in rounds:
+                    jobs = (CnSumJob * len(batch))()
+                    for q, (ws, dst, parts, count, acc) in zip(jobs, batch):
+                        q.src, q.dst, q.count, q.parts, q.accumulate = ws.data_ptr(), dst.data_ptr(), count, parts, acc
+                    check(lib.cn_sum_parts_grouped(jobs, len(batch), _stream()), "cn_sum_parts_grouped")
+                if not torch.cuda.is_current_stream_capturing():
+                    for ws, *_ in slabs:              # (eager dispatch: the slabs were allocated on the stream of their kernel)
+                        ws.record_stream(cur)
+                for s_ in touched:                    # a stream that wrote slabs must not run ahead of their reduction: a block the
+                    if s_ != cur:                     # allocator hands out again after the join would be overwritten under it
+                        s_.wait_stream(cur)
             for gw2, g, w_shape, slot in st.pop("upfold", {}).values():
                 upfold_wgrad(gw2, g, w_shape, out=slot, single_writer=True)
         if st is not None:
@@ -1334,7 +1370,7 @@ def upfold_saved_flops(g):
 
 PROF_FAMILIES = ["igemm_fwd<128x128>", "igemm_fwd<128x64>", "igemm_fwd<64x64>", "igemm_fwd<128x32>", "igemm_fwd<128x96>",
                  "igemm_wgrad<128x128>", "igemm_wgrad<128x96>", "igemm_wgrad<64x64>", "igemm_wgrad<128x32>", "wino_fwd", "c3_fwd",
-                 "s2_image_dgrad", "thin / up2k4_rgb", "c3_wgrad", "igemm_bf16", "igemm_bf16_wgrad", "igemm_wgrad<256x64>"]
+                 "s2_image_dgrad", "thin / up2k4_rgb", "c3_wgrad", "igemm_bf16", "igemm_bf16_wgrad", "igemm_wgrad<256x64>", "wgrad slab sums (grouped)"]
 
 
 def prof_collect_by_family():

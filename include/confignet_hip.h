@@ -105,6 +105,22 @@ int cn_conv_wgrad(const CnConvGeom* g, const float* x, const float* gy, float* g
 size_t cn_conv_wgrad_workspace_bytes(const CnConvGeom* g);
 int cn_conv_wgrad_ws(const CnConvGeom* g, const float* x, const float* gy, float* gw, int accumulate, void* workspace,
                      size_t workspace_bytes, void* stream);
+/* cn_conv_wgrad_ws that LEAVES THE SLABS to the caller (round 6): *parts = 0: gw is complete (no row splits, or the fall-back
+ * kernel); *parts >= 2: the workspace holds that many partial filters of taps*cin*cout floats each, gw has not been touched, and
+ * the caller adds them in index order (accumulate as passed) -- with cn_sum_parts_grouped, ONE launch for all the filter gradients
+ * of a backward pass instead of one reduction launch per layer.  The sum is the same bits as cn_conv_wgrad_ws's. */
+int cn_conv_wgrad_ws_slabs(const CnConvGeom* g, const float* x, const float* gy, float* gw, int accumulate, void* workspace,
+                           size_t workspace_bytes, int* parts, void* stream);
+typedef struct CnSumJob {
+    const float* src;     /* parts x count floats */
+    float* dst;           /* count floats */
+    long long count;
+    int parts;
+    int accumulate;       /* 0: dst = sum, else dst += sum */
+} CnSumJob;
+/* dst[j][i] (+)= sum_{p < parts[j]} src[j][p * count[j] + i] for every job, parts in index order; `jobs` is a HOST array (its
+ * contents travel in the kernel arguments: nothing is read from it after the call returns).  One launch per 80 jobs. */
+int cn_sum_parts_grouped(const CnSumJob* jobs, int njobs, void* stream);
 /* 3x3 stride-1 SAME 2-D convolution as Winograd F(2x2, 3x3) on the fp32 matrix cores: 16 GEMMs in the transform domain,
  * 4/9 of the multiply-adds of the direct form (exact in real arithmetic).  The same reference lines as cn_conv_fwd /
  * cn_conv_dgrad for the layers it fits (keras.applications VGG19/VGG16 and the 3x3 convolutions of ResNet50:

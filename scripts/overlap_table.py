@@ -19,7 +19,7 @@ def family(name):          # (the family naming of pmc_traffic_by_kernel.py)
     if "fwd2_kernel<" in name:
         args = [a.strip() for a in name.split("fwd2_kernel<")[1].split(">")[0].split(",")]
         return "igemm_bf16" if args[-1] in ("true", "1") else "igemm_fwd<%s>" % TILES.get(", ".join(args[:4]), "?")
-    for k in ("igemm_fwd_kernel", "igemm_wgrad_kernel", "gemm1x1_kernel", "wgrad2_kernel"):
+    for k in ("igemm_fwd_kernel", "igemm_wgrad_kernel", "wgrad2_kernel"):
         if k + "<" in name:
             t = name.split(k + "<")[1][:10]
             return ("igemm_wgrad<%s>" if "wgrad" in k else "igemm_fwd<%s>") % TILES.get(t, t)

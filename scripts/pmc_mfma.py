@@ -21,11 +21,11 @@ for k, c in acc.items():
     gui, busy = c.get("GRBM_GUI_ACTIVE", 0.0), c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0)
     if gui > 0:
         rows.append((busy, k, calls[k], gui, busy / (gui / N_XCD * N_SIMD), c.get("SQ_BUSY_CU_CYCLES", 0.0)))
-tot_busy = sum(r[0] for r in rows if any(t in r[1] for t in ("igemm", "gemm1x1", "fwd2_kernel", "wgrad2", "wino_fwd", "wino4_fwd", "s2_image", "s1_image", "c3_fwd", "c7s2_fwd", "c3_wgrad_kernel", "up2k4")))
-tot_gui = sum(r[3] for r in rows if any(t in r[1] for t in ("igemm", "gemm1x1", "fwd2_kernel", "wgrad2", "wino_fwd", "wino4_fwd", "s2_image", "s1_image", "c3_fwd", "c7s2_fwd", "c3_wgrad_kernel", "up2k4")))
+tot_busy = sum(r[0] for r in rows if any(t in r[1] for t in ("igemm", "fwd2_kernel", "wgrad2", "wino_fwd", "wino4_fwd", "s2_image", "s1_image", "c3_fwd", "c7s2_fwd", "c3_wgrad_kernel", "up2k4")))
+tot_gui = sum(r[3] for r in rows if any(t in r[1] for t in ("igemm", "fwd2_kernel", "wgrad2", "wino_fwd", "wino4_fwd", "s2_image", "s1_image", "c3_fwd", "c7s2_fwd", "c3_wgrad_kernel", "up2k4")))
 for r in sorted(rows, reverse=True)[:14]:
     print("%-66s calls %6d  GUI_ACTIVE %14.0f  MFMA_BUSY %16.0f  MFMA-busy %.3f  SQ_BUSY_CU %14.0f" % (r[1], r[2], r[3], r[0], r[4], r[5]))
-out = {"kernels_hash": kernels_hash(), "kernel_class": "igemm_fwd/gemm1x1/fwd2/igemm_wgrad/wgrad2/wino_fwd/wino4_fwd/s2_image_dgrad/s1_image_dgrad/c3_fwd/c3_wgrad/up2k4_rgb_fwd", "mfma_busy_cycles": tot_busy, "gui_active_cycles": tot_gui,
+out = {"kernels_hash": kernels_hash(), "kernel_class": "igemm_fwd/fwd2/igemm_wgrad/wgrad2/wino_fwd/wino4_fwd/s2_image_dgrad/s1_image_dgrad/c3_fwd/c3_wgrad/up2k4_rgb_fwd", "mfma_busy_cycles": tot_busy, "gui_active_cycles": tot_gui,
        "mfma_busy_fraction": tot_busy / (tot_gui / N_XCD * N_SIMD) if tot_gui else None,
        "normalisation": "SQ_VALU_MFMA_BUSY_CYCLES (sum over SIMDs) / (GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs)"}
 print(json.dumps(out))

@@ -13,7 +13,7 @@ from collections import defaultdict
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import kernels_hash
 
-TILES = {"2, 2, 2, 2": "128x128", "2, 2, 2, 1": "128x64", "2, 2, 1, 1": "64x64", "4, 1, 1, 1": "128x32", "4, 1, 1, 3": "128x96"}
+TILES = {"2, 2, 2, 2": "128x128", "2, 2, 2, 1": "128x64", "2, 2, 1, 1": "64x64", "4, 1, 1, 1": "128x32", "4, 1, 1, 3": "128x96", "4, 1, 2, 2": "256x64"}
 
 
 def family(name):
@@ -31,9 +31,6 @@ def family(name):
         if args[-1] in ("true", "1"):
             return "igemm_bf16"
         return "igemm_fwd<%s>" % TILES.get(", ".join(args[:4]), ", ".join(args[:4]))
-    if "gemm1x1_kernel" in name:                      # the plain-GEMM main loop: same tile families as igemm_fwd_kernel
-        t = name.split("gemm1x1_kernel<")[1][:10]
-        return "igemm_fwd<%s>" % TILES.get(t, t)
     if "s1_image_dgrad_kernel" in name:
         return "s2_image_dgrad"                       # (one family in cn_prof_collect_by_family)
     for k, f in (("wino_fwd_kernel", "wino_fwd"), ("c3_fwd_kernel", "c3_fwd"), ("c7s2_fwd_kernel", "c3_fwd"), ("s2_image_dgrad_kernel", "s2_image_dgrad"),

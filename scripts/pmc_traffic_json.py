@@ -5,8 +5,8 @@ import glob, json, os, sqlite3, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import kernels_hash
 
-CLASS = ("igemm_fwd_kernel", "gemm1x1_kernel", "fwd2_kernel", "igemm_wgrad_kernel", "wgrad2_kernel", "wino_fwd_kernel", "wino4_fwd_kernel", "c3_wgrad_kernel", "s2_image_dgrad_kernel", "s1_image_dgrad_kernel", "c3_fwd_kernel", "c7s2_fwd_kernel", "up2k4_rgb_fwd_kernel",
-         "igemm_bf16_kernel", "igemm_bf16_wgrad_kernel", "igemm_bf16_wgrad_tr_kernel")
+CLASS = ("igemm_fwd_kernel", "fwd2_kernel", "igemm_wgrad_kernel", "wgrad2_kernel", "wino_fwd_kernel", "wino4_fwd_kernel", "c3_wgrad_kernel", "s2_image_dgrad_kernel", "s1_image_dgrad_kernel", "c3_fwd_kernel", "c7s2_fwd_kernel", "up2k4_rgb_fwd_kernel",
+         "igemm_bf16_kernel", "igemm_bf16_wgrad_tr_kernel")
 
 
 def load(d, counter):

@@ -1,4 +1,5 @@
 """GPU parity of the raw HIP ops (through the C ABI) against the CPU oracle (float64)."""
+import ctypes
 import math
 
 import numpy as np
@@ -929,6 +930,8 @@ def test_convolution_epilogue_statistics_match_the_separate_passes():
         ((6, 8, 8, 384), (3, 3), 768, 2, 0, "pre4", False),         # 16 rows per sample: tiles straddle samples
     ]
     for xs, k, cout, stride, up, kind, must in cases:
+        if ops.DETERMINISTIC:
+            must = False                             # (the sums are added with atomics: refused in deterministic mode, the consumer runs its own pass)
         spec = ops.ConvSpec(k, stride=stride, up=up)
         x = torch.tensor(rng.normal(size=xs).astype(np.float32)).cuda()
         w = torch.tensor((rng.normal(size=(*k, xs[-1], cout)) / math.sqrt(np.prod(k) * xs[-1])).astype(np.float32)).cuda()
@@ -994,3 +997,45 @@ def test_keras_form_apply_gradients_checks_a_variable_list_once_per_state_of_the
             opt.apply_gradients(a_list())                 # A again: w2 has moments now
     finally:
         torch.Tensor.any = real_any
+
+
+@pytest.mark.gpu
+def test_slab_reductions_of_a_backward_pass_as_one_grouped_launch_give_the_same_bits():
+    """Round 6: inside a backward pass (ops.grad_sink) a filter gradient that splits its rows leaves its slabs behind
+    (cn_conv_wgrad_ws_slabs) and the pass adds the slabs of ALL its filter gradients at its join with cn_sum_parts_grouped -- one
+    launch per 80 jobs instead of one per layer.  Every job is reduced as cn_conv_wgrad_ws reduces it: SAME BITS, in store and in
+    accumulate mode, for both reduction schemes (< 64 and >= 64 slices), more than 80 jobs in one pass, two streams."""
+    from confignet_amd import ops
+    from confignet_amd._lib import lib
+    gen = torch.Generator(device="cuda").manual_seed(21)
+    shapes = [((8, 32, 32, 128), (3, 3), 128, 1), ((16, 32, 32, 96), (3, 3), 192, 2), ((8, 16, 16, 256), (1, 1), 1024, 1),
+              ((4, 16, 16, 16, 64), (3, 3, 3), 64, 1), ((16, 64, 64, 48), (3, 3), 96, 2)]
+    cases = []
+    for xs, k, cout, stride in shapes:
+        g = ops.ConvSpec(k, stride=stride).geom(xs, cout)
+        assert int(lib.cn_conv_wgrad_workspace_bytes(ctypes.byref(g))) > 0, "the case must split its rows"
+        x = torch.randn(xs, device="cuda", generator=gen)
+        gy = torch.randn(ops.geom_out_shape(g), device="cuda", generator=gen)
+        cases.append((x, gy, g, tuple(k) + (xs[-1], cout)))
+    cases = cases + [cases[2]] * 84                     # > 80 jobs: a second launch of the grouped kernel
+    base = [torch.randn(c[3], device="cuda", generator=gen) for c in cases]
+    ref = []
+    for (x, gy, g, ws), b in zip(cases, base):          # outside a pass: slabs + the per-layer reduction launch
+        ref.append(ops.conv_wgrad(x, gy, g, ws, out=b.clone()).clone())
+    params = []
+    for b in base:
+        p = torch.zeros_like(b).requires_grad_(True)
+        p.grad = b.clone()
+        params.append(p)
+    side = torch.cuda.Stream()
+    with ops.grad_sink(params):
+        for i, ((x, gy, g, ws), p) in enumerate(zip(cases, params)):
+            if i % 2:                                    # every other filter gradient on a second stream (a forked step has two)
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    ops.sink_conv_wgrad(x, gy, g, ws, p.grad)
+            else:
+                ops.sink_conv_wgrad(x, gy, g, ws, p.grad)
+    torch.cuda.synchronize()
+    for i, (p, r) in enumerate(zip(params, ref)):
+        assert torch.equal(p.grad, r), (i, float((p.grad - r).abs().max()))
