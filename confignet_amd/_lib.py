@@ -16,6 +16,12 @@ class CnSumJob(ctypes.Structure):
                 ("accumulate", ctypes.c_int)]
 
 
+class CnDepthJob(ctypes.Structure):
+    """One shallow weight-gradient product of cn_gemm_depth_grouped (include/confignet_hip.h)."""
+    _fields_ = [("a", ctypes.c_void_p), ("b", ctypes.c_void_p), ("c", ctypes.c_void_p), ("m", ctypes.c_int), ("n", ctypes.c_int),
+                ("k", ctypes.c_int), ("lda", ctypes.c_int), ("ldb", ctypes.c_int), ("ldc", ctypes.c_int)]
+
+
 class CnConvGeom(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int) for n in (
         "nd", "n", "in_d", "in_h", "in_w", "cin", "out_d", "out_h", "out_w", "cout",
@@ -60,6 +66,7 @@ SIGNATURES = {
     "cn_conv_wgrad_ws": [_G, _p, _p, _p, _i, _p, _z, _p],
     "cn_conv_wgrad_ws_slabs": [_G, _p, _p, _p, _i, _p, _z, ctypes.POINTER(_i), _p],
     "cn_sum_parts_grouped": [_p, _i, _p],
+    "cn_gemm_depth_grouped": [_p, _i, _p],
     "cn_conv_tune": [_i, _i, ctypes.c_long],
     "cn_conv_loop_select": [_i, _i, _i, _i],
     "cn_conv_fwd_dt": [_p, _p, _i, _p, _p, _p, _i, _i, _f, _p],

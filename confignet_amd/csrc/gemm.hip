@@ -214,6 +214,62 @@ __global__ __launch_bounds__(256) void gemm_depth_kernel(int M, int N, int K, co
     }
 }
 
+// ---- many shallow weight-gradient products in ONE launch (round 6): C_j += A_j^T B_j with K_j <= 32 rows -- the dense layers'
+// weight gradients of a backward pass (batch <= 32 samples: the AdaIN MLPs, the encoders' and the regressor's dense layers) are
+// leaves of the tape; the pass queues them and launches them together at its join.  Per job exactly gemm_depth_kernel's arithmetic.
+constexpr int CN_DEPTH_GROUP = 64;
+struct DepthJobs {
+    const float* a[CN_DEPTH_GROUP];
+    const float* b[CN_DEPTH_GROUP];
+    float* c[CN_DEPTH_GROUP];
+    int m[CN_DEPTH_GROUP], n[CN_DEPTH_GROUP], k[CN_DEPTH_GROUP], lda[CN_DEPTH_GROUP], ldb[CN_DEPTH_GROUP], ldc[CN_DEPTH_GROUP];
+    int blk0[CN_DEPTH_GROUP + 1];
+    int count;
+};
+
+__global__ __launch_bounds__(256) void gemm_depth_grouped_kernel(DepthJobs J) {
+    __shared__ float As[32][16];
+    __shared__ float Bs[32][64];
+    const int bid = blockIdx.x;
+    int lo = 0, hi = J.count;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (J.blk0[mid] <= bid) lo = mid;
+        else hi = mid;
+    }
+    const int j = __builtin_amdgcn_readfirstlane(lo), lb = bid - J.blk0[j];
+    const int M = J.m[j], N = J.n[j], K = J.k[j], lda = J.lda[j], ldb = J.ldb[j], ldc = J.ldc[j];
+    const float* __restrict__ A = J.a[j];
+    const float* __restrict__ B = J.b[j];
+    float* __restrict__ C = J.c[j];
+    const int tx = (M + 15) / 16;
+    const int tid = threadIdx.x, c = tid & 63, r = tid >> 6;
+    const int m0 = (lb % tx) * 16, n0 = (lb / tx) * 64;
+    for (int i = tid; i < K * 16; i += 256) {
+        const int k = i >> 4, m = i & 15;
+        As[k][m] = (m0 + m < M) ? A[(long)k * lda + m0 + m] : 0.f;
+    }
+    for (int i = tid; i < K * 64; i += 256) {
+        const int k = i >> 6, nn = i & 63;
+        Bs[k][nn] = (n0 + nn < N) ? B[(long)k * ldb + n0 + nn] : 0.f;
+    }
+    __syncthreads();
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < K; ++k) {
+        const float b = Bs[k][c];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] += As[k][r * 4 + e] * b;
+    }
+    const int n = n0 + c;
+    if (n >= N) return;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int m = m0 + r * 4 + e;
+        if (m >= M) continue;
+        unsafeAtomicAdd(&C[(long)m * ldc + n], acc[e]);
+    }
+}
+
 __global__ void zero_rows_kernel(float* C, int M, int N, int ldc) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < (long)M * N) C[(i / N) * ldc + i % N] = 0.f;
@@ -302,4 +358,28 @@ extern "C" int cn_gemm(int ta, int tb, int m, int n, int k, const float* a, int 
 extern "C" int cn_gemm_acc(int ta, int tb, int m, int n, int k, const float* a, int lda, const float* b, int ldb, float* c,
                            int ldc, void* stream) {
     return gemm_launch(ta, tb, m, n, k, a, lda, b, ldb, c, ldc, nullptr, CN_ACT_NONE, 0.f, 1, stream);
+}
+
+// C_j += A_j^T B_j (A_j: k x m, B_j: k x n, row-major, k <= 32) for every job in one launch per 64 jobs; `jobs` is a HOST array.
+extern "C" int cn_gemm_depth_grouped(const CnDepthJob* jobs, int njobs, void* stream) {
+    CN_CHECK_ARG(njobs >= 0 && (njobs == 0 || jobs), "cn_gemm_depth_grouped: bad arguments");
+    for (int first = 0; first < njobs; first += CN_DEPTH_GROUP) {
+        DepthJobs J{};
+        const int cnt = njobs - first < CN_DEPTH_GROUP ? njobs - first : CN_DEPTH_GROUP;
+        long blocks = 0;
+        for (int q = 0; q < cnt; ++q) {
+            const CnDepthJob& d = jobs[first + q];
+            CN_CHECK_ARG(d.a && d.b && d.c && d.m > 0 && d.n > 0 && d.k > 0 && d.k <= 32 && d.lda >= d.m && d.ldb >= d.n && d.ldc >= d.n,
+                         "cn_gemm_depth_grouped: job %d: m=%d n=%d k=%d (k <= 32)", first + q, d.m, d.n, d.k);
+            J.a[q] = d.a; J.b[q] = d.b; J.c[q] = d.c;
+            J.m[q] = d.m; J.n[q] = d.n; J.k[q] = d.k; J.lda[q] = d.lda; J.ldb[q] = d.ldb; J.ldc[q] = d.ldc;
+            J.blk0[q] = (int)blocks;
+            blocks += (long)cn_cdiv(d.m, 16) * cn_cdiv(d.n, 64);
+        }
+        J.blk0[cnt] = (int)blocks;
+        J.count = cnt;
+        hipLaunchKernelGGL(gemm_depth_grouped_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, J);
+        CN_LAUNCH_CHECK();
+    }
+    return CN_OK;
 }

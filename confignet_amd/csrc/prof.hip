@@ -299,9 +299,9 @@ extern "C" int cn_sum_parts_grouped(const CnSumJob* jobs, int njobs, void* strea
         for (int k = 0; k < n; ++k) {
             const CnSumJob& q = jobs[first + k];
             CN_CHECK_ARG(q.src && q.dst && q.count > 0 && q.parts > 0, "cn_sum_parts_grouped: job %d is empty", first + k);
-            const bool wide = q.parts >= 64 && q.count * 16 <= (long)256 * 65536;      // (cn_sum_parts' rule)
+            const bool wide = !(q.accumulate & 2) && q.parts >= 64 && q.count * 16 <= (long)256 * 65536;      // (cn_sum_parts' rule)
             J.src[k] = q.src; J.dst[k] = q.dst; J.count[k] = q.count; J.parts[k] = q.parts;
-            J.flags[k] = (q.accumulate ? 1 : 0) | (wide ? 2 : 0);
+            J.flags[k] = ((q.accumulate & 1) ? 1 : 0) | (wide ? 2 : 0);
             J.blk0[k] = (int)blocks;
             blocks += cn_cdiv(q.count, wide ? 16 : 256);
             CN_CHECK_ARG(blocks < 0x7fffffffL, "cn_sum_parts_grouped: too many workgroups");

@@ -8,7 +8,7 @@ import threading
 
 import torch
 
-from ._lib import CN_BF16, CN_EUNSUPPORTED, CN_F32, CnConvGeom, CnSumJob, check, lib
+from ._lib import CN_BF16, CN_EUNSUPPORTED, CN_F32, CnConvGeom, CnDepthJob, CnSumJob, check, lib
 
 ACT_NONE, ACT_LRELU, ACT_RELU, ACT_TANH = 0, 1, 2, 3
 
@@ -648,11 +648,27 @@ class grad_sink:
                     for q, (ws, dst, parts, count, acc) in zip(jobs, batch):
                         q.src, q.dst, q.count, q.parts, q.accumulate = ws.data_ptr(), dst.data_ptr(), count, parts, acc
                     check(lib.cn_sum_parts_grouped(jobs, len(batch), _stream()), "cn_sum_parts_grouped")
-                if not torch.cuda.is_current_stream_capturing():
-                    for ws, *_ in slabs:              # (eager dispatch: the slabs were allocated on the stream of their kernel)
-                        ws.record_stream(cur)
-                for s_ in touched:                    # a stream that wrote slabs must not run ahead of their reduction: a block the
-                    if s_ != cur:                     # allocator hands out again after the join would be overwritten under it
+            depth = st.pop("depth", [])
+            if depth:
+                rounds, seen = [], {}                 # (same-destination jobs in successive launches, as above)
+                for job in depth:
+                    r = seen.get(job[2].data_ptr(), 0)
+                    seen[job[2].data_ptr()] = r + 1
+                    if r == len(rounds):
+                        rounds.append([])
+                    rounds[r].append(job)
+                for batch in rounds:
+                    jobs = (CnDepthJob * len(batch))()
+                    for q, (a, b, slot) in zip(jobs, batch):
+                        q.a, q.b, q.c = a.data_ptr(), b.data_ptr(), slot.data_ptr()
+                        q.m, q.n, q.k, q.lda, q.ldb, q.ldc = a.shape[1], b.shape[1], a.shape[0], a.shape[1], b.shape[1], b.shape[1]
+                    check(lib.cn_gemm_depth_grouped(jobs, len(batch), _stream()), "cn_gemm_depth_grouped")
+            if slabs or depth:
+                if not torch.cuda.is_current_stream_capturing():      # (eager dispatch: the operands were allocated on the stream of
+                    for t in [j[0] for j in slabs] + [t for j in depth for t in j[:2]]:     # their producer, not on this one)
+                        t.record_stream(cur)
+                for s_ in touched:                    # a stream that produced operands must not run ahead of these launches: a block
+                    if s_ != cur:                     # the allocator hands out again after the join would be overwritten under them
                         s_.wait_stream(cur)
             for gw2, g, w_shape, slot in st.pop("upfold", {}).values():
                 upfold_wgrad(gw2, g, w_shape, out=slot, single_writer=True)
@@ -766,6 +782,16 @@ def sink_upfold_wgrad(gy, x, g2, wd_shape, g, w_shape, slot):
 
 
 def sink_gemm(a, b, slot, trans_a=False, trans_b=False):
+    st = _SINK
+    if (st is not None and DEFER_SLAB_SUMS and trans_a and not trans_b and a.shape[0] <= 32 and a.dtype == torch.float32
+            and b.dtype == torch.float32 and a.is_contiguous() and b.is_contiguous() and slot.is_contiguous()):
+        # a dense layer's weight gradient x^T gy over a batch of <= 32 rows: a leaf of the pass -- queued for ONE grouped launch at
+        # the pass' join (grad_sink.join -> cn_gemm_depth_grouped) instead of a launch of its own on the backward chain
+        cur0 = torch.cuda.current_stream()
+        if all(cur0 != s_ for s_ in st.setdefault("touched", [])):
+            st["touched"].append(cur0)
+        st.setdefault("depth", []).append((a, b, slot))
+        return
     _sink_run(lambda: gemm_acc(a, b, slot, trans_a, trans_b), (a, b))
 
 
@@ -1139,6 +1165,15 @@ def act_bwd_bias(gy, y, act, slope=0.0, sink=None):
 def sum_rows_into(partial, dst, accumulate=True, side=True):
     """dst[c] (+)= sum_r partial[r][c] (cn_sum_rows_into); under a grad_sink on its side stream (off the backward chain)."""
     rows, c = partial.shape
+    if side and accumulate and _SINK is not None and DEFER_SLAB_SUMS and partial.dtype == torch.float32 and partial.is_contiguous():
+        # a leaf of the backward pass: joins the pass' grouped reduction launch (grad_sink.join) -- dst[c] += sum_r partial[r][c] is
+        # the ordered slab sum of `rows` parts of c floats; flag 2 keeps the serial order of cn_sum_rows_into for any row count
+        st = _SINK
+        cur0 = torch.cuda.current_stream()
+        if all(cur0 != s_ for s_ in st.setdefault("touched", [])):
+            st["touched"].append(cur0)
+        st.setdefault("slabs", []).append((partial, dst, rows, c, 1 | 2))
+        return
     fn = lambda: check(lib.cn_sum_rows_into(_fptr(partial), _fptr(dst), rows, c, int(accumulate), _stream()), "cn_sum_rows_into")
     if side:
         _sink_run(fn, (partial,))

@@ -116,11 +116,22 @@ typedef struct CnSumJob {
     float* dst;           /* count floats */
     long long count;
     int parts;
-    int accumulate;       /* 0: dst = sum, else dst += sum */
+    int accumulate;       /* bit 0: dst += sum (else dst = sum); bit 1: always the serial order over the parts (the order of
+                             cn_sum_rows_into; default: cn_sum_parts' order, which interleaves 16 sub-sums from 64 parts up) */
 } CnSumJob;
 /* dst[j][i] (+)= sum_{p < parts[j]} src[j][p * count[j] + i] for every job, parts in index order; `jobs` is a HOST array (its
  * contents travel in the kernel arguments: nothing is read from it after the call returns).  One launch per 80 jobs. */
 int cn_sum_parts_grouped(const CnSumJob* jobs, int njobs, void* stream);
+/* Many shallow weight-gradient products in one launch (round 6): c_j (m x n) += a_j^T b_j with a_j (k x m), b_j (k x n) row-major
+ * and k <= 32 (the batch): keras Dense weight gradients of a backward pass (building_blocks.py:152-173 MLPSimple, the AdaIN MLPs of
+ * hologan_generator.py:119-124).  Per job the arithmetic of cn_gemm_acc(ta = 1); `jobs` is a HOST array. */
+typedef struct CnDepthJob {
+    const float* a;
+    const float* b;
+    float* c;
+    int m, n, k, lda, ldb, ldc;
+} CnDepthJob;
+int cn_gemm_depth_grouped(const CnDepthJob* jobs, int njobs, void* stream);
 /* 3x3 stride-1 SAME 2-D convolution as Winograd F(2x2, 3x3) on the fp32 matrix cores: 16 GEMMs in the transform domain,
  * 4/9 of the multiply-adds of the direct form (exact in real arithmetic).  The same reference lines as cn_conv_fwd /
  * cn_conv_dgrad for the layers it fits (keras.applications VGG19/VGG16 and the 3x3 convolutions of ResNet50:

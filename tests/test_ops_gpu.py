@@ -1039,3 +1039,31 @@ def test_slab_reductions_of_a_backward_pass_as_one_grouped_launch_give_the_same_
     torch.cuda.synchronize()
     for i, (p, r) in enumerate(zip(params, ref)):
         assert torch.equal(p.grad, r), (i, float((p.grad - r).abs().max()))
+
+
+@pytest.mark.gpu
+def test_dense_weight_gradients_of_a_backward_pass_as_one_grouped_launch_give_the_same_bits():
+    """Round 6: inside a backward pass the weight gradients of dense layers over <= 32 rows (x^T gy: the AdaIN MLPs, encoders, regressor)
+    are queued and launched together at the pass' join (cn_gemm_depth_grouped); per job the arithmetic of cn_gemm_acc(ta = 1): same
+    bits, more than 64 jobs in one pass, a destination used twice (two launches, fixed order), rows > 32 fall back to cn_gemm_acc."""
+    from confignet_amd import ops
+    gen = torch.Generator(device="cuda").manual_seed(33)
+    dims = [(16, 145, 128), (8, 128, 512), (32, 43, 43), (16, 128, 64), (5, 7, 130), (48, 64, 64)] + [(16, 128, 256)] * 70
+    jobs = [(torch.randn(k, m, device="cuda", generator=gen), torch.randn(k, n, device="cuda", generator=gen)) for k, m, n in dims]
+    base = [torch.randn(m, n, device="cuda", generator=gen) for _, m, n in dims]
+    ref = [ops.gemm_acc(a, b, c.clone(), True, False).clone() for (a, b), c in zip(jobs, base)]
+    params = []
+    for c in base:
+        p = torch.zeros_like(c).requires_grad_(True)
+        p.grad = c.clone()
+        params.append(p)
+    with ops.grad_sink(params):
+        for (a, b), p in zip(jobs, params):
+            ops.sink_gemm(a, b, p.grad, True, False)
+        ops.sink_gemm(jobs[0][0], jobs[0][1], params[0].grad, True, False)       # the first weight used a second time in the pass
+    torch.cuda.synchronize()
+    ref0 = ops.gemm_acc(jobs[0][0], jobs[0][1], ref[0].clone(), True, False)
+    assert torch.equal(params[0].grad, ref0)
+    for i, (p, r) in enumerate(zip(params, ref)):
+        if i:
+            assert torch.equal(p.grad, r), (i, dims[i], float((p.grad - r).abs().max()))
