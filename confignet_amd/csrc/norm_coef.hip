@@ -38,7 +38,23 @@ __global__ void norm_coef_fwd_kernel(int mode, const float* __restrict__ s1, con
 __global__ void norm_coef_bwd_kernel(int mode, const float* __restrict__ t1, const float* __restrict__ t2,
                                      const float* __restrict__ sm, const float* __restrict__ sr,
                                      const float* __restrict__ p1, float* __restrict__ c1, float* __restrict__ c2,
-                                     float* __restrict__ c0, float* __restrict__ gp1, int N, int C, float invS, float eps) {
+                                     float* __restrict__ c0, float* __restrict__ gp1, int N, int C, float invS, float eps,
+                                     int coef_blocks, float* __restrict__ ggamma, float* __restrict__ gbeta) {
+    if ((int)blockIdx.x >= coef_blocks) {
+        // instance norm (mode 1): the workgroups behind the coefficient ones reduce the parameter gradients over n, one channel per
+        // thread in sample order (round 6: was a second launch, inorm_param_grad_kernel -- same arithmetic, same bits)
+        const int c = ((int)blockIdx.x - coef_blocks) * blockDim.x + threadIdx.x;
+        if (c >= C) return;
+        float gg = 0.f, gb = 0.f;
+        for (int n = 0; n < N; ++n) {
+            const int i = n * C + c;
+            gg += sr[i] * (t2[i] - sm[i] * t1[i]);
+            gb += t1[i];
+        }
+        ggamma[c] = gg;
+        gbeta[c] = gb;
+        return;
+    }
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N * C) return;
     const int n = i / C, c = i - n * C;
@@ -74,22 +90,6 @@ __global__ void norm_coef_bwd_kernel(int mode, const float* __restrict__ t1, con
     }
 }
 
-// instance-norm parameter gradients: reduce over n
-__global__ void inorm_param_grad_kernel(const float* __restrict__ t1, const float* __restrict__ t2,
-                                        const float* __restrict__ sm, const float* __restrict__ sr,
-                                        float* __restrict__ ggamma, float* __restrict__ gbeta, int N, int C) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    float gg = 0.f, gb = 0.f;
-    for (int n = 0; n < N; ++n) {
-        const int i = n * C + c;
-        gg += sr[i] * (t2[i] - sm[i] * t1[i]);
-        gb += t1[i];
-    }
-    ggamma[c] = gg;
-    gbeta[c] = gb;
-}
-
 }  // namespace
 
 extern "C" int cn_norm_coef_fwd(int mode, const float* s1, const float* s2, const float* p1, const float* p2, float* A,
@@ -110,13 +110,11 @@ extern "C" int cn_norm_coef_bwd(int mode, const float* t1, const float* t2, cons
     CN_CHECK_ARG(mode == 2 || (t2 && c1 && p1 && gp1), "norm_coef_bwd: missing tensor");
     CN_CHECK_ARG(mode != 1 || gp2, "norm_coef_bwd: instance norm needs dbeta");
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(norm_coef_bwd_kernel, dim3(cn_cdiv((long)n * c, 256)), dim3(256), 0, s, mode, t1, t2, save_mean, save_r,
-                       p1, c1, c2, c0, mode == 0 ? gp1 : nullptr, n, c, 1.f / (float)S, eps);
+    const int coef_blocks = cn_cdiv((long)n * c, 256), param_blocks = mode == 1 ? cn_cdiv(c, 256) : 0;
+    hipLaunchKernelGGL(norm_coef_bwd_kernel, dim3(coef_blocks + param_blocks), dim3(256), 0, s, mode, t1, t2, save_mean, save_r,
+                       p1, c1, c2, c0, mode == 0 ? gp1 : nullptr, n, c, 1.f / (float)S, eps, coef_blocks, mode == 1 ? gp1 : nullptr,
+                       mode == 1 ? gp2 : nullptr);
     CN_LAUNCH_CHECK();
-    if (mode == 1) {
-        hipLaunchKernelGGL(inorm_param_grad_kernel, dim3(cn_cdiv(c, 256)), dim3(256), 0, s, t1, t2, save_mean, save_r, gp1, gp2, n, c);
-        CN_LAUNCH_CHECK();
-    }
     return CN_OK;
 }
 
