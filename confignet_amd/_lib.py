@@ -59,6 +59,8 @@ SIGNATURES = {
     "cn_conv_weight_tflip": [_p, _p, _i, _i, _i, _p],
     "cn_conv_dgrad": [_G, _p, _p, _p, _p],
     "cn_conv_dgrad_w": [_G, _p, _p, _p, _p],
+    "cn_conv_dgrad_w_res": [_G, _p, _p, _p, _p, _p],
+    "cn_bn_fold_bwd": [_p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p],
     "cn_conv_wgrad_thin_partials": [],
     "cn_conv_wgrad_thin": [_G, _p, _p, _p, _p, _i, _p],
     "cn_conv_wgrad": [_G, _p, _p, _p, _i, _p],

@@ -1174,7 +1174,75 @@ __global__ void scale_columns_segments_kernel(const float* __restrict__ src, flo
         *reinterpret_cast<float4*>(dst + e) = make_float4(v.x * c.x, v.y * c.y, v.z * c.z, v.w * c.w);
     }
 }
+
+// The adjoint of the folding above, for every listed filter in one launch (round 6).  The taped ResNet-50 runs on the folded
+// filters w' = w * a[c], shift = beta + a (b - mean), a = gamma * rs, rs = rsqrt(var + eps); its backward pass leaves the folded
+// filters' gradients g' (packed like w') and the shifts' gradients gs (concatenated like a) behind, and this kernel ADDS
+//   d w[k][c] = g'[k][c] a[c],  d gamma[c] = rs[c] (sum_k g'[k][c] w[k][c] + gs[c] (b - mean)[c]),  d beta[c] = gs[c],  d b[c] = a[c] gs[c]
+// into `gout`, which is laid out like the weight arena.  seg: 9 ints per segment -- the five of cn_scale_columns_segments, then
+// the arena offsets of the layer's bias, gamma and beta, then the segment's first workgroup (one workgroup per 64 columns).
+// A workgroup is 16 float4 column lanes x 16 row lanes; the row lanes' partial dot products are added in lane order (no atomics).
+__global__ __launch_bounds__(256) void bn_fold_bwd_kernel(const int* __restrict__ seg, int nseg, const float* __restrict__ gwf,
+                                                          const float* __restrict__ gshift, const float* __restrict__ arena,
+                                                          const float* __restrict__ a, const float* __restrict__ rs,
+                                                          const float* __restrict__ bm, float* __restrict__ gout) {
+    const int b = blockIdx.x;
+    int lo = 0, hi = nseg - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (seg[9 * mid + 8] <= b) lo = mid; else hi = mid - 1;
+    }
+    const int* sg = seg + 9 * lo;
+    const int cout = sg[3], K = sg[2] / cout;
+    const int c4 = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int col = (b - sg[8]) * 64 + c4 * 4;
+    const float4 av = *reinterpret_cast<const float4*>(a + sg[4] + col);
+    float4 dot = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int r = rl; r < K; r += 16) {
+        const long off = (long)r * cout + col;
+        const float4 g = *reinterpret_cast<const float4*>(gwf + sg[1] + off);
+        const float4 w = *reinterpret_cast<const float4*>(arena + sg[0] + off);
+        float4* d = reinterpret_cast<float4*>(gout + sg[0] + off);
+        float4 o = *d;
+        o.x += g.x * av.x; o.y += g.y * av.y; o.z += g.z * av.z; o.w += g.w * av.w;
+        *d = o;
+        dot.x += g.x * w.x; dot.y += g.y * w.y; dot.z += g.z * w.z; dot.w += g.w * w.w;
+    }
+    __shared__ float4 red[16][16];
+    red[rl][c4] = dot;
+    __syncthreads();
+    if (rl == 0) {
+        float4 t = red[0][c4];
+        for (int q = 1; q < 16; ++q) { const float4 u = red[q][c4]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
+        const float4 gs = *reinterpret_cast<const float4*>(gshift + sg[4] + col);
+        const float4 m = *reinterpret_cast<const float4*>(bm + sg[4] + col);
+        const float4 rv = *reinterpret_cast<const float4*>(rs + sg[4] + col);
+        float4* gg = reinterpret_cast<float4*>(gout + sg[6] + col);
+        float4* gbeta = reinterpret_cast<float4*>(gout + sg[7] + col);
+        float4* gbias = reinterpret_cast<float4*>(gout + sg[5] + col);
+        float4 o = *gg;
+        o.x += rv.x * (t.x + gs.x * m.x); o.y += rv.y * (t.y + gs.y * m.y); o.z += rv.z * (t.z + gs.z * m.z); o.w += rv.w * (t.w + gs.w * m.w);
+        *gg = o;
+        o = *gbeta;
+        o.x += gs.x; o.y += gs.y; o.z += gs.z; o.w += gs.w;
+        *gbeta = o;
+        o = *gbias;
+        o.x += av.x * gs.x; o.y += av.y * gs.y; o.z += av.z * gs.z; o.w += av.w * gs.w;
+        *gbias = o;
+    }
+}
 }  // namespace
+
+// The backward of cn_scale_columns_segments together with the BatchNorm coefficient algebra (real_encoder.py:13; see the kernel).
+// seg: nseg x 9 ints on the device, `blocks` = the sum over the segments of cout / 64 (every cout a multiple of 64).
+extern "C" int cn_bn_fold_bwd(const int* seg, int nseg, int blocks, const float* gwf, const float* gshift, const float* arena,
+                              const float* a, const float* rs, const float* bm, float* gout, void* stream) {
+    CN_CHECK_ARG(seg && gwf && gshift && arena && a && rs && bm && gout && nseg > 0 && blocks > 0, "bn_fold_bwd: bad args");
+    hipLaunchKernelGGL(bn_fold_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, seg, nseg, gwf, gshift, arena, a, rs,
+                       bm, gout);
+    CN_LAUNCH_CHECK();
+    return CN_OK;
+}
 
 // BatchNormalization (inference) folded into the preceding convolutions' filters: w'[k][c] = w[k][c] * a[c] for every listed
 // filter of one weight arena in one launch (real_encoder.py:13: keras ResNet50 called without training=).

@@ -1750,6 +1750,24 @@ extern "C" int cn_conv_dgrad_w(const CnConvGeom* gp, const float* gy, const floa
     return conv_fwd_impl(&d, gy, w, nullptr, gu, CN_ACT_NONE, 0.f, stream, 1);
 }
 
+// gu = (data gradient of cn_conv_dgrad_w) + res, res shaped like gu: the SECOND contribution to the gradient of a tensor that
+// feeds a convolution AND a skip connection (a ResNet bottleneck's input, real_encoder.py:13: the gradient of keras' `Add`),
+// added in the data-gradient launch's epilogue instead of by a separate pass.  Stride-1 layers whose launch is an unsplit
+// implicit-GEMM one; CN_EUNSUPPORTED (nothing launched) otherwise -- the caller then adds with a pass of its own.
+extern "C" int cn_conv_dgrad_w_res(const CnConvGeom* gp, const float* gy, const float* w, const float* res, float* gu, void* stream) {
+    if (int e = check_geom(gp)) return e;
+    CN_CHECK_ARG(res, "cn_conv_dgrad_w_res: res is NULL");
+    if (gp->dl_d != 1 || gp->dl_h != 1 || gp->dl_w != 1 || gp->up) return CN_EUNSUPPORTED;
+    if (gp->s_d != 1 || gp->s_h != 1 || gp->s_w != 1) return CN_EUNSUPPORTED;      // (parity-ordered rows: not with a residual)
+    CnConvGeom d = *gp;
+    d.in_d = gp->out_d; d.in_h = gp->out_h; d.in_w = gp->out_w; d.cin = gp->cout;
+    d.out_d = gp->in_d; d.out_h = gp->in_h; d.out_w = gp->in_w;
+    if (gp->nd == 2) d.out_d = 1;
+    d.cout = gp->cin;
+    d.p_d = gp->k_d - 1 - gp->p_d; d.p_h = gp->k_h - 1 - gp->p_h; d.p_w = gp->k_w - 1 - gp->p_w;
+    return conv_fwd_impl(&d, gy, w, nullptr, gu, CN_ACT_NONE, 0.f, stream, 1, res);
+}
+
 extern "C" int cn_conv_dgrad(const CnConvGeom* gp, const float* gy, const float* w_tflip, float* gu, void* stream) {
     if (int e = check_geom(gp)) return e;
     CN_CHECK_ARG(gp->dl_d == 1 && gp->dl_h == 1 && gp->dl_w == 1, "dgrad of a dilated-input geometry is not defined here");

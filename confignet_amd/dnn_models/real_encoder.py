@@ -192,6 +192,46 @@ class RealEncoder(Net):
                 ci += 3
         return F.global_avg_pool(x)
 
+    # ---- taped form on the folded filters (round 6) ---------------------------------------------------------------------------
+    def _fold_table9(self):
+        """(int32 (53, 9) device table, workgroups) for cn_bn_fold_bwd: the five columns of _fold_table, then the arena offsets of
+        the layer's bias, gamma and beta, then the layer's first workgroup (one per 64 output channels)."""
+        if getattr(self, "_fold_tab9", None) is None:
+            seg = self._fold_table()[0].cpu().numpy()
+            base = self.arena.data_ptr()
+            rows, blk = [], 0
+            for (kidx, bidx, _), r in zip(self._convs, seg):
+                cout = int(r[3])
+                assert cout % 64 == 0
+                offs = [(self.weights[i].data_ptr() - base) // 4 for i in (kidx + 1, bidx, bidx + 1)]
+                assert all(o >= 0 and o % 4 == 0 for o in offs)
+                rows.append(list(map(int, r)) + offs + [blk])
+                blk += cout // 64
+            self._fold_tab9 = (torch.tensor(rows, dtype=torch.int32, device=self.device), blk)
+        return self._fold_tab9
+
+    def _fold_coefficients(self):
+        """(a, shift, rs, bm) concatenated over the 53 conv + BN pairs, off the tape: a = gamma rs, rs = rsqrt(var + eps) (a
+        constant: the moving variance is never updated), bm = bias - mean, shift = beta + a bm."""
+        ws = self.weights
+        ks = [k for k, _, _ in self._convs]
+        bs = [b for _, b, _ in self._convs]
+        with torch.no_grad():
+            if getattr(self, "_stat_cache", None) is None:
+                self._stat_cache = (torch.cat([ws[b + 2] for b in bs]), torch.cat([ws[b + 3] for b in bs]))
+            mean, var = self._stat_cache
+            rs = torch.rsqrt(var + BN_EPS)
+            a = torch.cat([ws[b] for b in bs]) * rs
+            bm = torch.cat([ws[k + 1] for k in ks]) - mean
+            shift = torch.addcmul(torch.cat([ws[b + 1] for b in bs]), a, bm)
+        return a, shift, rs, bm
+
+    def _trunk_params(self):
+        """The trainable tensors of the ResNet-50 trunk (everything but the two heads), in weight order."""
+        return [w for w in self.weights[:-4] if w.requires_grad]
+
+    folded_tape = True         # (False: the taped form as convolution + per-channel affine pass per layer -- cross-check)
+
     def _conv_bn(self, ci, x, coef, res=None, relu=True):
         kidx, _, spec = self._convs[ci]
         z = F.conv(x, self.weights[kidx], None, spec)           # bias folded into the affine shift
@@ -204,6 +244,11 @@ class RealEncoder(Net):
             from .. import ops
             if ops.ACT_DTYPE == torch.float32:
                 return self._features_folded(img)
+        if self.folded_tape and torch.is_grad_enabled():
+            params = self._trunk_params()
+            if len(params) == sum(1 for i in self._trainable_idx if i < len(self.weights) - 4) or (not params and img.requires_grad):
+                x = F.caffe_preprocess(img)
+                return F.global_avg_pool(ResNetTrunkFn.apply(self, x, *params))
         coef = self._bn_coefficients()
         x = F.caffe_preprocess(img)                              # real_encoder.py:24-25
         x = self._conv_bn(0, x, coef)
@@ -236,3 +281,146 @@ class RealEncoder(Net):
                 embs.append(e.cpu().numpy())
                 rots.append(r.cpu().numpy())
         return np.concatenate(embs), np.concatenate(rots)
+
+
+class ResNetTrunkFn(torch.autograd.Function):
+    """The ResNet-50 trunk (conv1 .. conv5_block3_out) on the tape as ONE node, forward AND backward on the FOLDED filters
+    (round 6).  BatchNormalization runs in inference mode (R9), so  relu(bn(conv(x, w) + b) [+ shortcut])  is
+    relu(conv(x, w a) + shift [+ shortcut])  with a = gamma rsqrt(var + eps), shift = beta + a (b - mean): one launch per
+    layer with bias / residual / ReLU in its epilogue -- the form the tape-free encoder has used since round 4 -- instead of a
+    convolution plus a per-channel affine pass over its output.  Backward per layer: ReLU mask + shift sums in one pass
+    (cn_act_bwd_bias), data gradient (a block's skip gradient added in the epilogue of its first convolution's data gradient,
+    cn_conv_dgrad_w_res, instead of by autograd's add), filter gradient WRITTEN into a packed scratch; the gradients of
+    kernel / bias / gamma / beta of all 53 pairs then come out of ONE launch at the join of the pass (cn_bn_fold_bwd):
+    d gamma needs sum_k g'[k][c] w[k][c] over the small filter, not a reduction of g z over the activation tensor, so the
+    pre-affine convolution output z is neither kept nor read.  Same function and gradients as the composite form
+    (RealEncoder.folded_tape = False) up to summation order.  First-order only."""
+
+    @staticmethod
+    def forward(ctx, enc, x, *params):
+        from .. import ops
+        from ..ops import ACT_NONE, ACT_RELU
+        a, shift, rs, bm = enc._fold_coefficients()
+        wf = enc._folded_filters(a)
+        sizes = [wf[ci].shape[-1] for ci in range(len(enc._convs))]
+        offs = [0]
+        for c in sizes:
+            offs.append(offs[-1] + c)
+        sh = [shift[offs[i]:offs[i + 1]] for i in range(len(sizes))]
+        x = x.contiguous()
+
+        def conv(ci, t, res=None, relu=True):
+            g = enc._convs[ci][2].geom(tuple(t.shape), sizes[ci])
+            if res is None:
+                return ops.conv_fwd(t, wf[ci], sh[ci], g, ACT_RELU if relu else ACT_NONE)
+            return ops.conv_fwd_res(t, wf[ci], sh[ci], res, g, ACT_RELU)
+
+        saved = [x]
+        y0 = conv(0, x)
+        t = ops.maxpool_fwd(y0, 3, 2, 1)
+        saved += [y0, t]
+        ci = 1
+        for filters, blocks, stride1 in RESNET50_STACKS:
+            for bi in range(blocks):
+                sc = t
+                if bi == 0:
+                    sc = conv(ci, t, relu=False)
+                    ci += 1
+                y1 = conv(ci, t)
+                y2 = conv(ci + 1, y1)
+                t = conv(ci + 2, y2, res=sc)
+                saved += [y1, y2, t]
+                ci += 3
+        ctx.enc, ctx.coef, ctx.wf, ctx.offs = enc, (a, rs, bm), wf, offs
+        ctx.save_for_backward(*saved)
+        return t
+
+    @staticmethod
+    def backward(ctx, gy):
+        from .. import ops
+        from ..ops import ACT_RELU
+        if torch.is_grad_enabled():
+            raise RuntimeError("ResNetTrunkFn is first-order only")
+        enc, wf, offs = ctx.enc, ctx.wf, ctx.offs
+        a, rs, bm = ctx.coef
+        saved = list(ctx.saved_tensors)
+        seg5, total, views = enc._fold_table()
+        seg9, blocks = enc._fold_table9()
+        dev = gy.device
+        params = enc._trunk_params()
+        want_w = any(ctx.needs_input_grad[2:]) and not F._INPUT_GRADS_ONLY
+        sunk = want_w and ops.sink_for(params[0]) is not None
+        # (a pass whose sink does not hold this network: nothing of this node may be deferred to that sink's join)
+        defer_prev, ops.DEFER_SLAB_SUMS = ops.DEFER_SLAB_SUMS, ops.DEFER_SLAB_SUMS and sunk
+        gwf = gsh = None
+        if want_w:
+            gwf = torch.empty(total, device=dev, dtype=torch.float32)    # every layer WRITES its part (accumulate=False)
+            gsh = ops.zero_pool_alloc((offs[-1],), dev)
+            if gsh is None:
+                gsh = torch.zeros(offs[-1], device=dev, dtype=torch.float32)
+
+        def geom(ci, t):
+            return enc._convs[ci][2].geom(tuple(t.shape), wf[ci].shape[-1])
+
+        def wgrad(ci, t_in, gu):
+            o, shp = views[ci]
+            if want_w:
+                ops.sink_conv_wgrad_to(t_in, gu, geom(ci, t_in), shp, gwf[o:o + int(np.prod(shp))].view(shp))
+
+        def relu_bwd(ci, g, y, also=None):
+            """g * (y > 0) and its channel sums into the shift gradient of layer ci (and of layer `also`: a block's shortcut
+            convolution sees the same gradient as its last one)."""
+            if not want_w:
+                return ops.act_bwd(g, y, ACT_RELU)
+            gu, part = ops.act_bwd_partials(g, y, ACT_RELU)
+            ops.sum_rows_into(part, gsh[offs[ci]:offs[ci + 1]])
+            if also is not None:
+                ops.sum_rows_into(part, gsh[offs[also]:offs[also + 1]])
+            return gu
+
+        # walk the blocks backwards; `pos` indexes the saved activations
+        g = gy.contiguous()
+        layout = []                                  # (first conv index of the block, has conv shortcut) in forward order
+        ci = 1
+        for filters, blocks_, stride1 in RESNET50_STACKS:
+            for bi in range(blocks_):
+                layout.append((ci, bi == 0))
+                ci += 4 if bi == 0 else 3
+        pos = len(saved)
+        for first, has_sc in reversed(layout):
+            y1, y2, t_out = saved[pos - 3], saved[pos - 2], saved[pos - 1]
+            pos -= 3
+            t_in = saved[pos - 1]
+            c1 = first + 1 if has_sc else first
+            gu3 = relu_bwd(c1 + 2, g, t_out, also=first if has_sc else None)
+            wgrad(c1 + 2, y2, gu3)
+            gu2 = relu_bwd(c1 + 1, ops.conv_dgrad(gu3, wf[c1 + 2], geom(c1 + 2, y2)), y2)
+            wgrad(c1 + 1, y1, gu2)
+            gu1 = relu_bwd(c1, ops.conv_dgrad(gu2, wf[c1 + 1], geom(c1 + 1, y1)), y1)
+            wgrad(c1, t_in, gu1)
+            if has_sc:
+                wgrad(first, t_in, gu3)
+                skip = ops.conv_dgrad(gu3, wf[first], geom(first, t_in))
+            else:
+                skip = gu3
+            g = ops.conv_dgrad_res(gu1, wf[c1], geom(c1, t_in), skip)
+        x, y0, t = saved[0], saved[1], saved[2]
+        g = ops.maxpool_bwd(y0, g, 3, 2, 1)
+        gu0 = relu_bwd(0, g, y0)
+        wgrad(0, x, gu0)
+        gx = ops.conv_dgrad(gu0, wf[0], geom(0, x)) if ctx.needs_input_grad[1] else None
+        ops.DEFER_SLAB_SUMS = defer_prev
+        if not want_w:
+            return (None, gx) + (None,) * len(params)
+        if sunk:
+            gout = enc.grad_arena
+            ops.sink_post(lambda: ops.bn_fold_bwd(seg9, blocks, gwf, gsh, enc.arena, a, rs, bm, gout), keep=(gwf, gsh, a, rs, bm))
+            return (None, gx) + (None,) * len(params)
+        gout = torch.zeros_like(enc.arena)
+        ops.bn_fold_bwd(seg9, blocks, gwf, gsh, enc.arena, a, rs, bm, gout)
+        base = enc.arena.data_ptr()
+        grads = []
+        for p_ in params:
+            o = (p_.data_ptr() - base) // 4
+            grads.append(gout[o:o + p_.numel()].view(p_.shape))
+        return (None, gx) + tuple(grads)

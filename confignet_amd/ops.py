@@ -505,6 +505,22 @@ def conv_dgrad(gy, w, g):
     return cast(gu, _act_out_dtype(g.cin))
 
 
+def conv_dgrad_res(gy, w, g, res):
+    """conv_dgrad(gy, w, g) + res: the gradient of a tensor that feeds this convolution and a skip connection, the add in the
+    data-gradient launch's epilogue where the launch carries it (cn_conv_dgrad_w_res: fp32, stride 1, unsplit implicit-GEMM
+    launches), else data gradient + one nc_lin2 pass."""
+    if (ACT_DTYPE == torch.float32 and gy.dtype == torch.float32 and res.dtype == torch.float32 and DGRAD_FROM_W and not g.up
+            and not _wino4_ok(g, g.cout, g.cin) and not _wino_ok(g, g.cout, g.cin)):
+        gu = torch.empty(geom_in_shape(g, upsampled=True), device=gy.device, dtype=torch.float32)
+        rc = lib.cn_conv_dgrad_w_res(ctypes.byref(g), _ptr(_c(gy)), _fptr(_c(w)), _ptr(_c(res)), _ptr(gu), _stream())
+        if rc == 0:
+            return gu
+        if rc != CN_EUNSUPPORTED:
+            check(rc, "cn_conv_dgrad_w_res")
+    gu = conv_dgrad(gy, w, g)
+    return nc_lin2(tuple(gu.shape), gu, None, res, None, None)
+
+
 DGRAD_FROM_W = True
 THIN_WGRAD = True
 C3_WGRAD = True
@@ -521,20 +537,21 @@ def _c3_partials():
 _EXP_NO_WGRAD = False       # timing experiment only (wrong gradients): filter gradients not launched
 
 
-def conv_wgrad(x, gy, g, w_shape, out=None):
-    """out: ADD the filter gradient to this tensor (a slot of a gradient arena, see grad_sink) instead of returning a new one."""
+def conv_wgrad(x, gy, g, w_shape, out=None, accumulate=True):
+    """out: ADD the filter gradient to this tensor (a slot of a gradient arena, see grad_sink) instead of returning a new one;
+    out with accumulate=False: WRITE it there (an uninitialised scratch the caller owns: the folded ResNet-50's packed gradients)."""
     if _EXP_NO_WGRAD:
         return out if out is not None else torch.empty(w_shape, device=x.device, dtype=torch.float32)
     gw = out if out is not None else zero_pool_alloc(w_shape, x.device)
-    pre = gw is not None
-    if not pre:
+    pre = gw is not None and (accumulate or out is None)
+    if gw is None:
         gw = torch.empty(w_shape, device=x.device, dtype=torch.float32)
     if C3_WGRAD and g.nd == 2 and g.cin == 3 and g.k_h == 3 and g.k_w == 3 and g.s_h == g.s_w and g.s_h in (1, 2) \
             and g.dl_h == 1 and g.dl_w == 1 and g.up == 0 and g.cout <= 64 and g.cout % 4 == 0 and gy.dtype in (torch.float32, torch.bfloat16):
         # K = 27 first layers: staged-tile kernel without atomics (the generic split-over-rows kernel runs them at 10 TFLOP/s)
         x, gy = _c(f32(x)), _c(gy)
         scratch = torch.empty(_c3_partials() * 27 * g.cout, device=x.device, dtype=torch.float32)
-        check(lib.cn_conv_wgrad_c3(ctypes.byref(g), _ptr(x), _ptr(gy), _dt(gy), _ptr(scratch), _fptr(gw), int(out is not None), _stream()),
+        check(lib.cn_conv_wgrad_c3(ctypes.byref(g), _ptr(x), _ptr(gy), _dt(gy), _ptr(scratch), _fptr(gw), int(out is not None and accumulate), _stream()),
               "cn_conv_wgrad_c3")
         return gw
     if THIN_WGRAD and g.nd == 2 and g.cout <= 4 and 8 <= g.cin <= 64 and g.cin % 4 == 0 and g.s_h == 1 and g.s_w == 1:
@@ -672,6 +689,17 @@ class grad_sink:
                         s_.wait_stream(cur)
             for gw2, g, w_shape, slot in st.pop("upfold", {}).values():
                 upfold_wgrad(gw2, g, w_shape, out=slot, single_writer=True)
+            post = st.pop("post", [])
+            for fn in post:                           # launches that read what the grouped reductions above have just completed
+                fn()                                  # (the folded ResNet-50's parameter gradients: cn_bn_fold_bwd)
+            post_keep = st.pop("post_keep", [])
+            if post:
+                if not torch.cuda.is_current_stream_capturing():
+                    for t in post_keep:
+                        t.record_stream(cur)
+                for s_ in touched:
+                    if s_ != cur:
+                        s_.wait_stream(cur)
         if st is not None:
             st["keep"].clear()
             st["used"] = False
@@ -763,6 +791,31 @@ def _sink_run(fn, keep):
 
 def sink_conv_wgrad(x, gy, g, w_shape, slot):
     _sink_run(lambda: conv_wgrad(x, gy, g, w_shape, out=slot), (x, gy))
+
+
+def sink_conv_wgrad_to(x, gy, g, w_shape, dst):
+    """The filter gradient WRITTEN (not added) into the caller's scratch `dst`, launched like a sink (a leaf of the pass)."""
+    _sink_run(lambda: conv_wgrad(x, gy, g, w_shape, out=dst, accumulate=False), (x, gy))
+
+
+def sink_post(fn, keep=()):
+    """Run fn() once every sink launch of the pass -- the deferred grouped reductions included -- has been issued: at the join of
+    the active gradient sink, on the stream that joins; immediately without one."""
+    st = _SINK
+    if st is None:
+        fn()
+        return
+    cur0 = torch.cuda.current_stream()
+    if all(cur0 != s_ for s_ in st.setdefault("touched", [])):
+        st["touched"].append(cur0)
+    st.setdefault("post_keep", []).extend(t for t in keep if t is not None)
+    st.setdefault("post", []).append(fn)
+
+
+def bn_fold_bwd(seg9, blocks, gwf, gshift, arena, a, rs, bm, gout):
+    """cn_bn_fold_bwd: gout (laid out like `arena`) += the kernel / bias / gamma / beta gradients of every folded conv + BN pair."""
+    check(lib.cn_bn_fold_bwd(_ptr(seg9), seg9.shape[0], blocks, _fptr(gwf), _fptr(gshift), _fptr(arena), _fptr(a), _fptr(rs), _fptr(bm),
+                             _fptr(gout), _stream()), "cn_bn_fold_bwd")
 
 
 def sink_upfold_wgrad(gy, x, g2, wd_shape, g, w_shape, slot):
@@ -1141,9 +1194,9 @@ def act_bwd(gy, y, act, slope=0.0):
     return gx
 
 
-def act_bwd_bias(gy, y, act, slope=0.0, sink=None):
-    """(gx, gb): act_bwd fused with the per-channel sum of its result (the bias gradient) -- one pass instead of two.
-    sink: the bias's slot of a gradient arena (grad_sink) -- the sum is ADDED there and gb is returned as None."""
+def act_bwd_partials(gy, y, act, slope=0.0):
+    """(gx, partial (rep, c)): act_bwd and the per-channel sums of its result over `rep` row slices, in one pass
+    (cn_act_bwd_bias); the caller adds the slices (sum_rows_into)."""
     gy, y = _unify(gy, y)
     _log_mask(y, act)
     _, _, c = _nsc(gy)
@@ -1156,6 +1209,14 @@ def act_bwd_bias(gy, y, act, slope=0.0, sink=None):
         gb, flags = torch.empty((rep, c), device=gy.device, dtype=torch.float32), 0
     check(lib.cn_act_bwd_bias(_ptr(gy), _ptr(y), _ptr(gx), _ptr(gb), rep, rows // rep, c, act, slope, flags, _dt(gy), _stream()),
           "cn_act_bwd_bias")
+    return gx, gb
+
+
+def act_bwd_bias(gy, y, act, slope=0.0, sink=None):
+    """(gx, gb): act_bwd fused with the per-channel sum of its result (the bias gradient) -- one pass instead of two.
+    sink: the bias's slot of a gradient arena (grad_sink) -- the sum is ADDED there and gb is returned as None."""
+    gx, gb = act_bwd_partials(gy, y, act, slope)
+    rep = gb.shape[0]
     if sink is not None:
         sum_rows_into(gb, sink)
         return gx, None

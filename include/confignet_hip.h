@@ -95,6 +95,9 @@ int cn_conv_dgrad(const CnConvGeom* g, const float* gy, const float* w_tflip, fl
  * of by a cn_conv_weight_tflip launch per trainable filter per step.  CN_EUNSUPPORTED (nothing launched) for shapes that do
  * not reach the vectorised implicit-GEMM kernel (thin outputs, cout % 16 != 0): use cn_conv_dgrad there. */
 int cn_conv_dgrad_w(const CnConvGeom* g, const float* gy, const float* w, float* gu, void* stream);
+/* cn_conv_dgrad_w + res (res shaped like gu) in the launch's epilogue: the gradient of a tensor that feeds a convolution and a
+ * skip connection (keras ResNet50's Add, real_encoder.py:13).  Stride-1, unsplit implicit-GEMM launches; else CN_EUNSUPPORTED. */
+int cn_conv_dgrad_w_res(const CnConvGeom* g, const float* gy, const float* w, const float* res, float* gu, void* stream);
 /* Filter gradient (Conv*DBackpropFilter): gw[(t,ci),co] (+)= sum_m x[src(m,t),ci]*gy[m,co]; gw is overwritten,
  * or accumulated into when `accumulate` != 0 (the caller guarantees its previous content, e.g. zeros). */
 int cn_conv_wgrad(const CnConvGeom* g, const float* x, const float* gy, float* gw, int accumulate, void* stream);
@@ -374,6 +377,13 @@ int cn_to_uint8(const float* x, uint8_t* out, size_t numel, void* stream);
  * offset, packed destination offset, element count, columns (cout), offset of the filter's coefficients in `a`; all multiples
  * of 4 floats -- in one launch over `total` destination floats. */
 int cn_scale_columns_segments(const float* src, float* dst, const int* seg, const float* a, int nseg, size_t total, void* stream);
+/* The adjoint of cn_scale_columns_segments together with the BatchNorm coefficient algebra (the taped ResNet-50 of
+ * real_encoder.py:13 runs on the folded filters): from the folded filters' gradients gwf (packed) and the shifts' gradients
+ * gshift, ADD d kernel, d bias, d gamma, d beta into gout (laid out like the weight arena `arena`).  a = gamma rs,
+ * rs = rsqrt(var + eps), bm = bias - mean, concatenated per layer.  seg: nseg x 9 ints on the device -- the five of
+ * cn_scale_columns_segments, the arena offsets of bias / gamma / beta, the segment's first workgroup; blocks = sum cout / 64. */
+int cn_bn_fold_bwd(const int* seg, int nseg, int blocks, const float* gwf, const float* gshift, const float* arena,
+                   const float* a, const float* rs, const float* bm, float* gout, void* stream);
 
 /* ---- profiling of the dominant kernel class (implicit-GEMM convolutions) with HIP events
  * recorded on the launch stream (bench.py roofline object) -----------------------------------*/

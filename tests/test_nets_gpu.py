@@ -330,6 +330,76 @@ def test_real_encoder():
     np.testing.assert_allclose(e2, emb.detach().cpu().numpy(), rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("sink", [False, True])
+def test_real_encoder_folded_tape_equals_the_composite_form(sink):
+    """The taped ResNet-50 as one node on the FOLDED filters (ResNetTrunkFn: bias / residual / ReLU in the convolutions' epilogues,
+    skip gradients in the data gradients' epilogues, every parameter gradient from cn_bn_fold_bwd) against the composite form
+    (convolution + per-channel affine pass per layer, autograd's adds): same outputs, same gradients of every parameter and of
+    the image up to summation order -- through autograd's own accumulation and through a gradient sink (backward_into_arenas)."""
+    from confignet_amd import nn as cnn
+    from confignet_amd.dnn_models.real_encoder import RealEncoder
+    rng = np.random.default_rng(11)
+    enc = RealEncoder(43, (64, 64, 3), ((-30, 30), (-10, 10), (0, 0)), rng=rng)
+    randomize(enc, 7, 0.05)
+    img_np = rng.uniform(-1, 1, size=(3, 64, 64, 3)).astype(np.float32)
+    out = {}
+    for folded in (False, True):
+        enc.folded_tape = folded
+        img = torch.tensor(img_np, device="cuda", requires_grad=True)
+        emb, rot = enc(img)
+        loss = (emb ** 2).sum() + (rot ** 2).sum() * 10
+        if sink:
+            (gi,) = cnn.backward_into_arenas(loss, [enc], extra=[img])
+        else:
+            enc.zero_grad()
+            for p_ in enc.trainable_weights:
+                p_.grad = None
+            grads = torch.autograd.grad(loss, enc.trainable_weights + [img])
+            gi = grads[-1]
+            enc.grad_arena.zero_()
+            base = enc.arena.data_ptr()
+            for p_, g_ in zip(enc.trainable_weights, grads[:-1]):
+                o = (p_.data_ptr() - base) // 4
+                enc.grad_arena[o:o + p_.numel()] += g_.reshape(-1)
+        torch.cuda.synchronize()
+        out[folded] = (emb.detach().clone(), rot.detach().clone(), gi.detach().clone(), enc.grad_arena.clone())
+    enc.folded_tape = True
+    a, b = out[False], out[True]
+    for k, what in enumerate(("embedding", "rotation", "d image", "gradient arena")):
+        ref = a[k].double()
+        err = float((b[k].double() - ref).norm() / ref.norm())
+        print("folded tape vs composite (%s, sink=%s): rel-L2 %.3e" % (what, sink, err))
+        assert err < 2e-4, "%s: rel-L2 %.3e" % (what, err)
+    # per-tensor: every kernel / bias / gamma / beta gradient, not only the arena's norm (which the large filters dominate)
+    base = enc.arena.data_ptr()
+    worst = (0.0, None)
+    for i in enc._trainable_idx:
+        p_ = enc.weights[i]
+        o = (p_.data_ptr() - base) // 4
+        ra, rb = a[3][o:o + p_.numel()].double(), b[3][o:o + p_.numel()].double()
+        e = float((rb - ra).norm() / (ra.norm() + 1e-30))
+        worst = max(worst, (e, enc._entries[i][0]))
+    print("worst per-tensor rel-L2 %.3e (%s)" % worst)
+    assert worst[0] < 2e-3, "per-tensor gradient: %s rel-L2 %.3e" % (worst[1], worst[0])
+
+
+def test_conv_dgrad_with_residual_in_the_epilogue():
+    """cn_conv_dgrad_w_res == cn_conv_dgrad_w followed by an add (same bits where the launch carries the residual), 1x1 and 3x3."""
+    from confignet_amd import ops
+    from confignet_amd.ops import ConvSpec
+    rng = np.random.default_rng(12)
+    for xs, k, cout in (((4, 16, 16, 256), 1, 64), ((2, 32, 32, 64), 1, 256), ((2, 16, 16, 64), 3, 64)):
+        spec = ConvSpec((k, k))
+        g = spec.geom(xs, cout)
+        w = torch.tensor(rng.normal(size=(k, k, xs[-1], cout)) * 0.05, device="cuda", dtype=torch.float32)
+        gy = torch.tensor(rng.normal(size=(xs[0], xs[1], xs[2], cout)), device="cuda", dtype=torch.float32)
+        res = torch.tensor(rng.normal(size=xs), device="cuda", dtype=torch.float32)
+        want = ops.conv_dgrad(gy, w, g) + res
+        got = ops.conv_dgrad_res(gy, w, g, res)
+        err = float((got - want).abs().max())
+        assert err <= 1e-5 * float(want.abs().max()), "case %s k=%d: max-abs %.3e" % (xs, k, err)
+
+
 def _make_model(cls, res, batch, seed=0):
     cfg = {"output_shape": (res, res, 3), "batch_size": batch, "facemodel_inputs": dict(FM)}
     np.random.seed(seed)
