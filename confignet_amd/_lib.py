@@ -22,6 +22,11 @@ class CnDepthJob(ctypes.Structure):
                 ("k", ctypes.c_int), ("lda", ctypes.c_int), ("ldb", ctypes.c_int), ("ldc", ctypes.c_int)]
 
 
+class CnGanJob(ctypes.Structure):
+    """One head of cn_gan_loss_grouped (include/confignet_hip.h)."""
+    _fields_ = [("s", ctypes.c_void_p), ("out", ctypes.c_void_p), ("gout", ctypes.c_void_p), ("n", ctypes.c_int), ("label", ctypes.c_float)]
+
+
 class CnConvGeom(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int) for n in (
         "nd", "n", "in_d", "in_h", "in_w", "cin", "out_d", "out_h", "out_w", "cout",
@@ -69,6 +74,7 @@ SIGNATURES = {
     "cn_conv_wgrad_ws_slabs": [_G, _p, _p, _p, _i, _p, _z, ctypes.POINTER(_i), _p],
     "cn_sum_parts_grouped": [_p, _i, _p],
     "cn_gemm_depth_grouped": [_p, _i, _p],
+    "cn_gan_loss_grouped": [_p, _i, _i, _p],
     "cn_conv_tune": [_i, _i, ctypes.c_long],
     "cn_conv_loop_select": [_i, _i, _i, _i],
     "cn_conv_fwd_dt": [_p, _p, _i, _p, _p, _p, _i, _i, _f, _p],

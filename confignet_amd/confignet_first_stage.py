@@ -18,7 +18,7 @@ from .dnn_models.building_blocks import MLPSimple
 from .dnn_models.hologan_discriminator import HologanDiscriminator, HologanLatentRegressor
 from .dnn_models.hologan_generator import HologanGenerator
 from .dnn_models.synthetic_encoder import SyntheticDataEncoder
-from .losses import (GAN_G_loss, compute_discriminator_loss, compute_latent_discriminator_loss,
+from .losses import (GAN_G_loss, GAN_G_losses, compute_discriminator_loss, compute_latent_discriminator_loss,
                      compute_latent_regression_loss, discriminator_loss_fake, discriminator_loss_real, eye_loss)
 from .neural_renderer_dataset import dump_pickle, load_pickle
 from .losses import total as total_loss
@@ -647,9 +647,9 @@ class ConfigNetFirstStage:
         if side is not main:
             side.wait_stream(main)
         with torch.cuda.stream(side):
-            gan_real = [GAN_G_loss(o) for o in self.discriminator(generator_output_real).values()]
-        for i, o in enumerate(self.synth_discriminator(generator_output_synth).values()):
-            losses["GAN_loss_synth_" + str(i)] = GAN_G_loss(o)
+            gan_real = GAN_G_losses(self.discriminator(generator_output_real).values())
+        for i, l in enumerate(GAN_G_losses(self.synth_discriminator(generator_output_synth).values())):
+            losses["GAN_loss_synth_" + str(i)] = l
         if side is not main:
             main.wait_stream(side)
             if not torch.cuda.is_current_stream_capturing():    # (see ConfigNet._generator_loss: allocator hand-off in eager mode)

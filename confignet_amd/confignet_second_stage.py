@@ -10,7 +10,7 @@ from . import confignet_utils, ops, optim, parallel
 from .confignet_first_stage import DEFAULT_CONFIG, ConfigNetFirstStage, frozen
 from .dnn_models.hologan_generator import HologanGenerator
 from .dnn_models.real_encoder import RealEncoder
-from .losses import GAN_D_loss, GAN_G_loss, compute_latent_discriminator_loss, eye_loss, mean_squared_error, normalized_latent_regression
+from .losses import GAN_D_loss, GAN_G_loss, GAN_G_losses, compute_latent_discriminator_loss, eye_loss, mean_squared_error, normalized_latent_regression
 from .losses import total as total_loss
 from .nn import Net, backward_into_arenas
 from .perceptual_loss import PerceptualLoss
@@ -173,12 +173,12 @@ class ConfigNet(ConfigNetFirstStage):
         split_lr = cfg["latent_regression_weight"] > 0.0 and self.split_latent_regressor
         reg_real = reg_synth = None
         with torch.cuda.stream(side):
-            gan_real = [GAN_G_loss(o) for o in self.discriminator(generator_output_real).values()]
+            gan_real = GAN_G_losses(self.discriminator(generator_output_real).values())
             out_real = self.latent_discriminator(real_latents)
             if split_lr and not self.regressor_real_half_on_main:
                 reg_real = self.latent_regressor(generator_output_real)
-        for i, o in enumerate(self.synth_discriminator(generator_output_synth).values()):
-            losses["GAN_loss_synth_" + str(i)] = GAN_G_loss(o)
+        for i, l in enumerate(GAN_G_losses(self.synth_discriminator(generator_output_synth).values())):
+            losses["GAN_loss_synth_" + str(i)] = l
         out_synth = self.latent_discriminator(synth_latents)
         if split_lr:
             reg_synth = self.latent_regressor(generator_output_synth)
@@ -263,10 +263,10 @@ class ConfigNet(ConfigNetFirstStage):
         if side is not main:
             side.wait_stream(main)
         with torch.cuda.stream(side):
-            gan_real = [GAN_G_loss(o) for o in self.discriminator(generator_output_real).values()]
+            gan_real = GAN_G_losses(self.discriminator(generator_output_real).values())
             out_real = self.latent_discriminator(real_latents)
-        for i, o in enumerate(self.synth_discriminator(generator_output_synth).values()):
-            losses["GAN_loss_synth_" + str(i)] = GAN_G_loss(o)
+        for i, l in enumerate(GAN_G_losses(self.synth_discriminator(generator_output_synth).values())):
+            losses["GAN_loss_synth_" + str(i)] = l
         out_synth = self.latent_discriminator(synth_latents)
         if side is not main:
             main.wait_stream(side)

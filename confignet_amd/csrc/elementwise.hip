@@ -1135,6 +1135,53 @@ extern "C" int cn_gan_loss_bwd(const float* s, const float* gout, float* gs, int
     CN_LAUNCH_CHECK();
     return CN_OK;
 }
+// ---- the GAN losses of every head of one discriminator call in ONE launch (round 6): a workgroup per head -------------------
+namespace {
+constexpr int CN_GAN_GROUP = 16;
+struct GanJobs {
+    const float* s[CN_GAN_GROUP];
+    float* out[CN_GAN_GROUP];            // forward: the head's scalar; backward: the gradient w.r.t. its scores
+    const float* gout[CN_GAN_GROUP];     // backward: the scalar's cotangent (NULL: zero)
+    int n[CN_GAN_GROUP];
+    float label[CN_GAN_GROUP];
+};
+__global__ __launch_bounds__(256) void gan_loss_grouped_fwd_kernel(GanJobs J) {
+    const int j = blockIdx.x;
+    const float* __restrict__ s = J.s[j];
+    const int n = J.n[j];
+    const float label = J.label[j];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) acc += label * softplus_f(-s[i]) + (1.f - label) * softplus_f(s[i]);
+    const float t = block_sum(acc);
+    if (threadIdx.x == 0) J.out[j][0] = t / (float)n;
+}
+__global__ __launch_bounds__(256) void gan_loss_grouped_bwd_kernel(GanJobs J) {
+    const int j = blockIdx.x;
+    const float* __restrict__ s = J.s[j];
+    float* __restrict__ gs = J.out[j];
+    const int n = J.n[j];
+    const float label = J.label[j];
+    const float g = J.gout[j] ? J.gout[j][0] : 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) gs[i] = g * (-label * sigmoid_f(-s[i]) + (1.f - label) * sigmoid_f(s[i])) / (float)n;
+}
+}  // namespace
+// Per job the arithmetic of cn_gan_loss_fwd / cn_gan_loss_bwd (losses.py:7-11); `jobs` is a HOST array, at most 16 jobs per launch.
+extern "C" int cn_gan_loss_grouped(const CnGanJob* jobs, int njobs, int backward, void* stream) {
+    CN_CHECK_ARG(njobs >= 0 && (njobs == 0 || jobs), "cn_gan_loss_grouped: bad arguments");
+    for (int first = 0; first < njobs; first += CN_GAN_GROUP) {
+        GanJobs J{};
+        const int cnt = njobs - first < CN_GAN_GROUP ? njobs - first : CN_GAN_GROUP;
+        for (int q = 0; q < cnt; ++q) {
+            const CnGanJob& d = jobs[first + q];
+            CN_CHECK_ARG(d.s && d.out && d.n > 0, "cn_gan_loss_grouped: job %d: NULL tensor or n = %d", first + q, d.n);
+            J.s[q] = d.s; J.out[q] = d.out; J.gout[q] = d.gout; J.n[q] = d.n; J.label[q] = d.label;
+        }
+        if (backward) hipLaunchKernelGGL(gan_loss_grouped_bwd_kernel, dim3(cnt), dim3(256), 0, (hipStream_t)stream, J);
+        else hipLaunchKernelGGL(gan_loss_grouped_fwd_kernel, dim3(cnt), dim3(256), 0, (hipStream_t)stream, J);
+        CN_LAUNCH_CHECK();
+    }
+    return CN_OK;
+}
 extern "C" int cn_adam_step(float* theta, const float* grad, float* m, float* v, float* ema, size_t numel,
                             const float* lr_t, float beta1, float beta2, float eps, float ema_alpha, void* stream) {
     CN_CHECK_ARG(theta && grad && m && v && lr_t, "adam: NULL");

@@ -868,3 +868,32 @@ class GanLossFn(Function):
 
 def gan_loss(scores, label):
     return GanLossFn.apply(scores, float(label))
+
+
+class GanLossGroupFn(Function):
+    """GanLossFn for every head of one discriminator call (losses.py:20-47: six score tensors per call): one launch forward, one
+    backward (the node runs once the cotangents of all its scalars have arrived)."""
+
+    @staticmethod
+    def forward(ctx, labels, *scores):
+        ctx.set_materialize_grads(False)
+        scores = [_cg(s_) for s_ in scores]
+        ctx.save_for_backward(*scores)
+        ctx.labels = labels
+        res = ops.gan_loss_grouped(scores, labels)
+        return tuple(res[j].reshape(()) for j in range(len(scores)))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        scores = ctx.saved_tensors
+        gouts = [None if g is None else _cg(g.reshape(1)).float() for g in gs]
+        grads = ops.gan_loss_grouped(list(scores), ctx.labels, gouts, backward=True)
+        return (None,) + tuple(g.reshape(s_.shape) for g, s_ in zip(grads, scores))
+
+
+def gan_losses(scores, labels):
+    """[mean(l softplus(-s) + (1 - l) softplus(s))] for the score tensors of several heads and their constant labels."""
+    scores = list(scores)
+    if len(scores) == 1 or any(s_.dtype != torch.float32 for s_ in scores):
+        return [gan_loss(s_, l) for s_, l in zip(scores, labels)]
+    return list(GanLossGroupFn.apply(tuple(float(l) for l in labels), *scores))

@@ -49,6 +49,18 @@ def GAN_G_loss(scores):
     return F.gan_loss(scores, 1.0)
 
 
+def GAN_G_losses(score_tensors):
+    """[GAN_G_loss(s) for s in score_tensors] -- the heads of one discriminator call -- from one launch (F.gan_losses)."""
+    score_tensors = list(score_tensors)
+    return F.gan_losses(score_tensors, [1.0] * len(score_tensors))
+
+
+def GAN_D_losses(label, score_tensors):
+    """[GAN_D_loss(label, s) for s in score_tensors] for one constant label, from one launch."""
+    score_tensors = list(score_tensors)
+    return F.gan_losses(score_tensors, [float(label)] * len(score_tensors))
+
+
 def GAN_D_loss(labels, scores):
     """mean(labels*softplus(-s) + (1-labels)*softplus(s)) (losses.py:10-11).  `labels` is a python
     scalar or an array of 0/1 values (the reference only ever passes those)."""
@@ -98,10 +110,10 @@ def compute_discriminator_loss(discriminator, real_imgs, fake_imgs, second_order
     out_real = discriminator(real_imgs, intermediates=inter)
     out_fake = discriminator(fake_imgs.detach())
     losses = {}
-    for i, o in enumerate(out_real.values()):
-        losses["GAN_loss_real_" + str(i)] = GAN_D_loss(1.0, o)
-    for i, o in enumerate(out_fake.values()):
-        losses["GAN_loss_fake_" + str(i)] = GAN_D_loss(0.0, o)
+    for i, l in enumerate(GAN_D_losses(1.0, out_real.values())):
+        losses["GAN_loss_real_" + str(i)] = l
+    for i, l in enumerate(GAN_D_losses(0.0, out_fake.values())):
+        losses["GAN_loss_fake_" + str(i)] = l
     losses.update(_r1_penalties(discriminator, out_real, real_imgs, inter))
     losses["loss_sum"] = total(losses.values())
     return losses
@@ -112,15 +124,13 @@ def discriminator_loss_real(discriminator, real_imgs):
     real_imgs = real_imgs.detach().requires_grad_(True)
     inter = []
     out_real = discriminator(real_imgs, intermediates=inter)
-    real = {}
-    for i, o in enumerate(out_real.values()):
-        real["GAN_loss_real_" + str(i)] = GAN_D_loss(1.0, o)
+    real = {"GAN_loss_real_" + str(i): l for i, l in enumerate(GAN_D_losses(1.0, out_real.values()))}
     return real, _r1_penalties(discriminator, out_real, real_imgs, inter)
 
 
 def discriminator_loss_fake(discriminator, fake_imgs):
     out_fake = discriminator(fake_imgs.detach())
-    return {"GAN_loss_fake_" + str(i): GAN_D_loss(0.0, o) for i, o in enumerate(out_fake.values())}
+    return {"GAN_loss_fake_" + str(i): l for i, l in enumerate(GAN_D_losses(0.0, out_fake.values()))}
 
 
 def _compute_discriminator_loss_tape(discriminator, real_imgs, fake_imgs):

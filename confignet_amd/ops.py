@@ -8,7 +8,7 @@ import threading
 
 import torch
 
-from ._lib import CN_BF16, CN_EUNSUPPORTED, CN_F32, CnConvGeom, CnDepthJob, CnSumJob, check, lib
+from ._lib import CN_BF16, CN_EUNSUPPORTED, CN_F32, CnConvGeom, CnDepthJob, CnGanJob, CnSumJob, check, lib
 
 ACT_NONE, ACT_LRELU, ACT_RELU, ACT_TANH = 0, 1, 2, 3
 
@@ -307,7 +307,7 @@ def _wino_ok(g, cin, cout):
 
 
 WINO4 = True
-WINO4_MIN_WGS = 192
+WINO4_MIN_WGS = 128
 
 
 def _wino4_ok(g, cin, cout):
@@ -1362,6 +1362,22 @@ def gan_loss_bwd(s, gout, label):
     gs = torch.empty_like(s)
     check(lib.cn_gan_loss_bwd(_ptr(s), _ptr(gout), _ptr(gs), s.numel(), label, _stream()), "cn_gan_loss_bwd")
     return gs
+
+
+def gan_loss_grouped(scores, labels, gouts=None, backward=False):
+    """cn_gan_loss_grouped: the GAN losses of several heads (forward: one (H,) tensor of scalars) or their score gradients
+    (backward: a list shaped like `scores`; gouts[j] = the cotangent scalar of head j or None) in ONE launch."""
+    jobs = (CnGanJob * len(scores))()
+    if backward:
+        outs = [torch.empty_like(s_) for s_ in scores]
+    else:
+        res = torch.empty(len(scores), device=scores[0].device, dtype=torch.float32)
+        outs = [res[j:j + 1] for j in range(len(scores))]
+    for q, s_, o, lab, j in zip(jobs, scores, outs, labels, range(len(scores))):
+        q.s, q.out, q.n, q.label = _fptr(s_).value, o.data_ptr(), s_.numel(), float(lab)
+        q.gout = gouts[j].data_ptr() if (backward and gouts[j] is not None) else None
+    check(lib.cn_gan_loss_grouped(jobs, len(scores), int(backward), _stream()), "cn_gan_loss_grouped")
+    return outs if backward else res
 
 
 def euler_matrix(angles):

@@ -135,6 +135,17 @@ typedef struct CnDepthJob {
     int m, n, k, lda, ldb, ldc;
 } CnDepthJob;
 int cn_gemm_depth_grouped(const CnDepthJob* jobs, int njobs, void* stream);
+/* The GAN losses of every head of one discriminator call in one launch (round 6; losses.py:7-11, 20-47: six heads per call).
+ * backward = 0: out[0] = mean(label softplus(-s) + (1 - label) softplus(s)) over the n scores s.  backward = 1: out[i] = the
+ * gradient w.r.t. s[i] for the scalar's cotangent gout[0] (gout NULL: zero).  `jobs` is a HOST array. */
+typedef struct CnGanJob {
+    const float* s;
+    float* out;
+    const float* gout;
+    int n;
+    float label;
+} CnGanJob;
+int cn_gan_loss_grouped(const CnGanJob* jobs, int njobs, int backward, void* stream);
 /* 3x3 stride-1 SAME 2-D convolution as Winograd F(2x2, 3x3) on the fp32 matrix cores: 16 GEMMs in the transform domain,
  * 4/9 of the multiply-adds of the direct form (exact in real arithmetic).  The same reference lines as cn_conv_fwd /
  * cn_conv_dgrad for the layers it fits (keras.applications VGG19/VGG16 and the 3x3 convolutions of ResNet50:

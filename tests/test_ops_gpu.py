@@ -609,6 +609,32 @@ def test_elementwise_and_losses():
         close(ops.gan_loss_bwd(dev(sc), dev([1.0]), label), sr.grad, tol=1e-5)
 
 
+def test_gan_losses_of_several_heads_in_one_launch():
+    """F.gan_losses (cn_gan_loss_grouped) == one F.gan_loss per head: values and score gradients, with different sizes, labels
+    and cotangents per head, and with a head whose scalar is not used."""
+    from confignet_amd import functional as F
+    rng = np.random.default_rng(21)
+    shapes = [(16, 1), (16, 1), (7, 1), (16, 1), (33, 1), (16, 1)]
+    labels = [1.0, 0.0, 1.0, 1.0, 0.0, 0.0]
+    weights = [1.0, 0.5, -2.0, 0.0, 3.0, 1.0]
+    scs = [rng.normal(size=s) * 3 for s in shapes]
+    a = [dev(s).requires_grad_(True) for s in scs]
+    b = [dev(s).requires_grad_(True) for s in scs]
+    la = F.gan_losses(a, labels)
+    lb = [F.gan_loss(x, l) for x, l in zip(b, labels)]
+    for x, y in zip(la, lb):
+        assert float((x.detach() - y.detach()).abs()) == 0.0
+    used = [0, 1, 2, 4, 5]                                  # head 3 gets no cotangent at all
+    ga = torch.autograd.grad(sum(weights[j] * la[j] for j in used), [a[j] for j in used])
+    gb = torch.autograd.grad(sum(weights[j] * lb[j] for j in used), [b[j] for j in used])
+    for x, y in zip(ga, gb):
+        assert float((x - y).abs().max()) == 0.0             # (the same expression per element as the one-head kernels)
+    for j, (sc, label) in enumerate(zip(scs, labels)):
+        sr = t64(sc)
+        ref = O.gan_d_loss(torch.full(sr.shape, label, dtype=torch.float64), sr)
+        close(la[j].reshape(1), ref.reshape(1), tol=1e-5)
+
+
 def test_pools_preproc_uint8():
     from confignet_amd import ops
     rng = np.random.default_rng(6)
