@@ -22,6 +22,12 @@ class CnDepthJob(ctypes.Structure):
                 ("k", ctypes.c_int), ("lda", ctypes.c_int), ("ldb", ctypes.c_int), ("ldc", ctypes.c_int)]
 
 
+class CnRowsJob(ctypes.Structure):
+    """One row-skinny dense layer of cn_gemm_rows_grouped (include/confignet_hip.h)."""
+    _fields_ = [("a", ctypes.c_void_p), ("b", ctypes.c_void_p), ("c", ctypes.c_void_p), ("bias", ctypes.c_void_p), ("mask", ctypes.c_void_p)] + \
+               [(n_, ctypes.c_int) for n_ in ("m", "n", "k", "lda", "ldb", "ldc", "tb", "act", "accumulate")] + [("slope", ctypes.c_float)]
+
+
 class CnGanJob(ctypes.Structure):
     """One head of cn_gan_loss_grouped (include/confignet_hip.h)."""
     _fields_ = [("s", ctypes.c_void_p), ("out", ctypes.c_void_p), ("gout", ctypes.c_void_p), ("n", ctypes.c_int), ("label", ctypes.c_float)]
@@ -75,6 +81,7 @@ SIGNATURES = {
     "cn_sum_parts_grouped": [_p, _i, _p],
     "cn_gemm_depth_grouped": [_p, _i, _p],
     "cn_gan_loss_grouped": [_p, _i, _i, _p],
+    "cn_gemm_rows_grouped": [_p, _i, _p],
     "cn_conv_tune": [_i, _i, ctypes.c_long],
     "cn_conv_loop_select": [_i, _i, _i, _i],
     "cn_conv_fwd_dt": [_p, _p, _i, _p, _p, _p, _i, _i, _f, _p],

@@ -270,6 +270,98 @@ __global__ __launch_bounds__(256) void gemm_depth_grouped_kernel(DepthJobs J) {
     }
 }
 
+// ---- many row-skinny dense layers in ONE launch (round 6): C_j = epi(A_j op(B_j) + bias_j) with M_j <= 32 rows -- the six AdaIN
+// MLPs of a generator pass layer by layer (hologan_generator.py:119-124), forward and data-gradient side.  Per job exactly
+// gemm_rows_kernel's arithmetic (K quarters combined in the same order); epi = activation, or (mask != NULL) the product with
+// act'(mask) -- the hidden layer's LeakyReLU derivative taken from its stored output --, or (accumulate) an atomic add into C.
+constexpr int CN_ROWS_GROUP = 16;
+struct RowsJobs {
+    const float* a[CN_ROWS_GROUP];
+    const float* b[CN_ROWS_GROUP];
+    float* c[CN_ROWS_GROUP];
+    const float* bias[CN_ROWS_GROUP];
+    const float* mask[CN_ROWS_GROUP];
+    int m[CN_ROWS_GROUP], n[CN_ROWS_GROUP], k[CN_ROWS_GROUP], lda[CN_ROWS_GROUP], ldb[CN_ROWS_GROUP], ldc[CN_ROWS_GROUP];
+    int tb[CN_ROWS_GROUP], act[CN_ROWS_GROUP], accumulate[CN_ROWS_GROUP];
+    float slope[CN_ROWS_GROUP];
+    int blk0[CN_ROWS_GROUP + 1];
+    int count;
+};
+
+template <int MT>
+__global__ __launch_bounds__(256) void gemm_rows_grouped_kernel(RowsJobs J) {
+    extern __shared__ float sm[];                 // A block [MT][K] (rows >= M are zero), then the partial sums [3][MT][64]
+    const int bid = blockIdx.x;
+    int lo = 0, hi = J.count;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (J.blk0[mid] <= bid) lo = mid;
+        else hi = mid;
+    }
+    const int j = __builtin_amdgcn_readfirstlane(lo);
+    const int M = J.m[j], N = J.n[j], K = J.k[j], lda = J.lda[j], ldb = J.ldb[j], ldc = J.ldc[j], tb = J.tb[j];
+    const float* __restrict__ A = J.a[j];
+    const float* __restrict__ B = J.b[j];
+    float* __restrict__ C = J.c[j];
+    float* As = sm;
+    float* red = sm + MT * K;
+    const int tid = threadIdx.x, c = tid & 63, q = tid >> 6;
+    for (int i = tid; i < MT * K; i += 256) {
+        const int m = i / K, k = i - m * K;
+        As[i] = m < M ? A[(long)m * lda + k] : 0.f;
+    }
+    __syncthreads();
+    const int n = (bid - J.blk0[j]) * 64 + c;
+    const int kq = (K + 3) / 4, kbeg = q * kq, kend = min(K, kbeg + kq);
+    float acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[m] = 0.f;
+    if (n < N) {
+        if (tb) {
+#pragma unroll 4
+            for (int k = kbeg; k < kend; ++k) {
+                const float b = B[(long)n * ldb + k];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) acc[m] += As[m * K + k] * b;
+            }
+        } else {
+#pragma unroll 4
+            for (int k = kbeg; k < kend; ++k) {
+                const float b = B[(long)k * ldb + n];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) acc[m] += As[m * K + k] * b;
+            }
+        }
+    }
+    if (q > 0) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) red[((q - 1) * MT + m) * 64 + c] = acc[m];
+    }
+    __syncthreads();
+    if (q == 0 && n < N) {
+        const float bv = J.bias[j] ? J.bias[j][n] : 0.f;
+        const float* __restrict__ mask = J.mask[j];
+        const int act = J.act[j];
+        const float slope = J.slope[j];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const float v = acc[m] + red[(0 * MT + m) * 64 + c] + red[(1 * MT + m) * 64 + c] + red[(2 * MT + m) * 64 + c] + bv;
+            if (m >= M) continue;
+            float* dst = C + (long)m * ldc + n;
+            if (mask) {
+                const float y = mask[(long)m * ldc + n];          // act'(.) from the stored activation output (sign(y) = sign(x))
+                const float d = act == CN_ACT_LRELU ? (y > 0.f ? 1.f : slope) : act == CN_ACT_RELU ? (y > 0.f ? 1.f : 0.f)
+                                : act == CN_ACT_TANH ? 1.f - y * y : 1.f;
+                *dst = v * d;
+            } else if (J.accumulate[j]) {
+                unsafeAtomicAdd(dst, v);
+            } else {
+                *dst = cn_apply_act(v, act, slope);
+            }
+        }
+    }
+}
+
 __global__ void zero_rows_kernel(float* C, int M, int N, int ldc) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < (long)M * N) C[(i / N) * ldc + i % N] = 0.f;
@@ -358,6 +450,41 @@ extern "C" int cn_gemm(int ta, int tb, int m, int n, int k, const float* a, int 
 extern "C" int cn_gemm_acc(int ta, int tb, int m, int n, int k, const float* a, int lda, const float* b, int ldb, float* c,
                            int ldc, void* stream) {
     return gemm_launch(ta, tb, m, n, k, a, lda, b, ldb, c, ldc, nullptr, CN_ACT_NONE, 0.f, 1, stream);
+}
+
+// C_j = epi(A_j op(B_j) + bias_j), m_j <= 32 rows, for every job in one launch per 16 jobs; `jobs` is a HOST array.
+extern "C" int cn_gemm_rows_grouped(const CnRowsJob* jobs, int njobs, void* stream) {
+    CN_CHECK_ARG(njobs >= 0 && (njobs == 0 || jobs), "cn_gemm_rows_grouped: bad arguments");
+    for (int first = 0; first < njobs; first += CN_ROWS_GROUP) {
+        RowsJobs J{};
+        const int cnt = njobs - first < CN_ROWS_GROUP ? njobs - first : CN_ROWS_GROUP;
+        long blocks = 0;
+        int mmax = 0, kmax = 0;
+        for (int q = 0; q < cnt; ++q) {
+            const CnRowsJob& d = jobs[first + q];
+            CN_CHECK_ARG(d.a && d.b && d.c && d.m > 0 && d.m <= 32 && d.n > 0 && d.k > 0 && d.lda >= d.k && d.ldb >= (d.tb ? d.k : d.n) && d.ldc >= d.n,
+                         "cn_gemm_rows_grouped: job %d: m=%d n=%d k=%d (m <= 32)", first + q, d.m, d.n, d.k);
+            CN_CHECK_ARG(!(d.mask && d.accumulate) && !(d.accumulate && (d.bias || d.act != CN_ACT_NONE)),
+                         "cn_gemm_rows_grouped: job %d: accumulate excludes mask / bias / activation", first + q);
+            J.a[q] = d.a; J.b[q] = d.b; J.c[q] = d.c; J.bias[q] = d.bias; J.mask[q] = d.mask;
+            J.m[q] = d.m; J.n[q] = d.n; J.k[q] = d.k; J.lda[q] = d.lda; J.ldb[q] = d.ldb; J.ldc[q] = d.ldc;
+            J.tb[q] = d.tb; J.act[q] = d.act; J.accumulate[q] = d.accumulate; J.slope[q] = d.slope;
+            J.blk0[q] = (int)blocks;
+            blocks += cn_cdiv(d.n, 64);
+            mmax = d.m > mmax ? d.m : mmax;
+            kmax = d.k > kmax ? d.k : kmax;
+        }
+        J.blk0[cnt] = (int)blocks;
+        J.count = cnt;
+        const int mt = mmax <= 8 ? 8 : mmax <= 16 ? 16 : 32;
+        CN_CHECK_ARG((long)mt * kmax <= 8192, "cn_gemm_rows_grouped: %d rows x k = %d do not fit the LDS block", mt, kmax);
+        const size_t lds = sizeof(float) * ((size_t)mt * kmax + 3 * mt * 64);
+        if (mt == 8) hipLaunchKernelGGL((gemm_rows_grouped_kernel<8>), dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, J);
+        else if (mt == 16) hipLaunchKernelGGL((gemm_rows_grouped_kernel<16>), dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, J);
+        else hipLaunchKernelGGL((gemm_rows_grouped_kernel<32>), dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, J);
+        CN_LAUNCH_CHECK();
+    }
+    return CN_OK;
 }
 
 // C_j += A_j^T B_j (A_j: k x m, B_j: k x n, row-major, k <= 32) for every job in one launch per 64 jobs; `jobs` is a HOST array.

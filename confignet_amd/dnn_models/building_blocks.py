@@ -54,11 +54,13 @@ class MLPSimple(Net):
             return self(np.asarray(x, dtype=np.float32)).cpu().numpy()
 
 
-def conv_adain(x, z, w6, spec):
+def conv_adain(x, z, w6, spec, sb=None):
     """Conv3dAdaIn / Conv2dAdaIn.call (building_blocks.py:37-44,73-80): conv(same)+bias ->
-    LeakyReLU(0.3) [fused epilogue] -> AdaIn with [s|b] = MLP(z) (LeakyReLU 0.2)."""
+    LeakyReLU(0.3) [fused epilogue] -> AdaIn with [s|b] = MLP(z) (LeakyReLU 0.2).  sb: the MLP's output when the caller has
+    computed it already (the generator runs the MLPs of all its layers as one bank, F.mlp_bank)."""
     ck, cb, m0, b0, m1, b1 = w6
-    sb = F.linear(F.linear(z, m0, b0, ACT_LRELU, TF_LRELU), m1, b1)
+    if sb is None:
+        sb = F.linear(F.linear(z, m0, b0, ACT_LRELU, TF_LRELU), m1, b1)
     with ops.request_stats("act"):                   # AdaIn's statistics from the convolution's epilogue where the launch carries them
         x = F.conv(x, ck, cb, spec, ACT_LRELU, KERAS_LRELU)
     return F.adain(x, sb)

@@ -62,6 +62,8 @@ class HologanGenerator(Net):
         conv("map_final", (4, 4, last, 3))
         self.finalize()
 
+    mlp_bank = True            # (False: one launch per Dense layer -- cross-check)
+
     def build_input_dict(self, latent_vector, rotation):
         """hologan_generator.py:109-127."""
         d = {}
@@ -80,8 +82,15 @@ class HologanGenerator(Net):
         # learned constant: zeros(N,1) @ kernel + bias (l.133-136)
         zeros = torch.zeros((n, 1), device=self.device, dtype=torch.float32)
         x = F.linear(zeros, w[0], w[1]).reshape(n, *self.const_shape)
-        x = conv_adain(x, inp["z_3d_0"], w[2:8], C3_UP)               # UpSampling3D folded (l.139-142)
-        x = conv_adain(x, inp["z_3d_1"], w[8:14], C3_UP)              # l.143-144
+        zs = [inp["z_2d_0"], inp["z_2d_1"], inp["z_2d_2"], inp["z_2d_2"], inp["z_2d_2"]]
+        sbs = [None] * (2 + self.n_2d)
+        if self.mlp_bank and all(z.dtype == torch.float32 and z.dim() == 2 and z.shape[0] <= 32 for z in [inp["z_3d_0"], inp["z_3d_1"]] + zs):
+            # the AdaIN MLPs of every layer (l.119-124 of the reference build them per layer; they only read the latents): one
+            # grouped launch per MLP layer for the whole pass
+            sets = [w[4:8], w[10:14]] + [w[20 + 6 * j + 2:20 + 6 * j + 6] for j in range(self.n_2d)]
+            sbs = F.mlp_bank([inp["z_3d_0"], inp["z_3d_1"]] + zs[:self.n_2d], sets, TF_LRELU)
+        x = conv_adain(x, inp["z_3d_0"], w[2:8], C3_UP, sbs[0])       # UpSampling3D folded (l.139-142)
+        x = conv_adain(x, inp["z_3d_1"], w[8:14], C3_UP, sbs[1])      # l.143-144
         x = F.rotate3d(x, inp["rotation"])                            # l.147-148
         x = F.conv(x, w[14], w[15], C3, ACT_LRELU, KERAS_LRELU)       # map_3d_post (l.49-54,151)
         x = F.conv(x, w[16], w[17], C3, ACT_LRELU, KERAS_LRELU)
@@ -89,9 +98,8 @@ class HologanGenerator(Net):
         x = x.reshape(s[0], s[1], s[2], s[3] * s[4])                  # depth collapse (l.153-156)
         x = F.conv(x, w[18], w[19], C1, ACT_LRELU, TF_LRELU)          # projection_conv (l.56,157)
         i = 20
-        zs = [inp["z_2d_0"], inp["z_2d_1"], inp["z_2d_2"], inp["z_2d_2"], inp["z_2d_2"]]
         for j in range(self.n_2d):
-            x = conv_adain(x, zs[j], w[i:i + 6], C4 if j == 0 else C4_UP)   # UpSampling2D folded (l.159-170)
+            x = conv_adain(x, zs[j], w[i:i + 6], C4 if j == 0 else C4_UP, sbs[2 + j])   # UpSampling2D folded (l.159-170)
             i += 6
         return F.conv(x, w[i], w[i + 1], C4_UP, ACT_TANH)             # map_final (l.101,172)
 

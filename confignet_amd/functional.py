@@ -267,6 +267,97 @@ def linear(x, w, b=None, act=ACT_NONE, slope=0.0):
     return LinearActFn.apply(x, w, b, act, slope)
 
 
+class MlpBankFn(Function):
+    """Several two-layer MLPs (Dense -> LeakyReLU(slope) -> Dense, building_blocks.py:152-173) as ONE tape node with one grouped
+    launch per layer (cn_gemm_rows_grouped): the AdaIN MLPs of a generator pass (hologan_generator.py:119-124) -- 12 launches
+    forward and ~24 backward become 2 + 2; the gradients of inputs that are the SAME tensor are added by the launch (atomics,
+    <= 6 terms per element; separate outputs + autograd's add in deterministic mode).  The node runs backward once the
+    cotangents of all its outputs have arrived, i.e. at the end of the generator's backward pass -- which is where the latent's
+    gradient is first needed.  Inputs: slope, n, then z_0 .. z_{n-1}, then (w0, b0, w1, b1) per MLP.  First-order only."""
+
+    @staticmethod
+    def forward(ctx, slope, n, *ts):
+        ctx.set_materialize_grads(False)
+        zs = [_cg(z) for z in ts[:n]]
+        ws = ts[n:]
+        hs, outs, j1, j2 = [], [], [], []
+        for i, z in enumerate(zs):
+            w0, b0, w1, b1 = ws[4 * i:4 * i + 4]
+            h = torch.empty((z.shape[0], w0.shape[1]), device=z.device, dtype=torch.float32)
+            o = torch.empty((z.shape[0], w1.shape[1]), device=z.device, dtype=torch.float32)
+            j1.append((z, w0, h, b0, None, False, ACT_LRELU, slope, False))
+            j2.append((h, w1, o, b1, None, False, ACT_NONE, 0.0, False))
+            hs.append(h)
+            outs.append(o)
+        ops.gemm_rows_grouped(j1)
+        ops.gemm_rows_grouped(j2)
+        ctx.save_for_backward(*zs, *hs)
+        ctx.ws, ctx.n, ctx.slope = ws, n, slope
+        # the first input that is this very tensor (same storage, shape and strides: views of one tensor feed one gradient)
+        ctx.same = [next(k for k in range(i + 1) if ts[k].data_ptr() == ts[i].data_ptr() and ts[k].shape == ts[i].shape
+                         and ts[k].stride() == ts[i].stride() and ts[k].dtype == ts[i].dtype) for i in range(n)]
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gos):
+        if torch.is_grad_enabled():
+            raise RuntimeError("MlpBankFn is first-order only")
+        n, ws, slope = ctx.n, ctx.ws, ctx.slope
+        saved = ctx.saved_tensors
+        zs, hs = saved[:n], saved[n:]
+        live = [i for i in range(n) if gos[i] is not None]
+        gos = [None if g is None else _cg(g).float() for g in gos]
+        need_z = [ctx.needs_input_grad[2 + i] for i in range(n)]
+        ghs, j1, j2 = {}, [], []
+        for i in live:
+            gh = torch.empty_like(hs[i])
+            ghs[i] = gh
+            ops._log_mask(hs[i], ACT_LRELU)                                                           # (test instrument: ops.branch_log)
+            j1.append((gos[i], ws[4 * i + 2], gh, None, hs[i], True, ACT_LRELU, slope, False))       # (go w1^T) * lrelu'(h)
+        if j1:
+            ops.gemm_rows_grouped(j1)
+        gzs, shared = [None] * n, {}
+        merged = not ops.DETERMINISTIC
+        for i in live:
+            if not need_z[i]:
+                continue
+            k = ctx.same[i] if merged else i
+            if gzs[k] is None:
+                shared[k] = merged and sum(1 for i2 in live if ctx.same[i2] == k and need_z[i2]) > 1
+                if shared[k]:
+                    gzs[k] = ops.zero_pool_alloc(tuple(zs[i].shape), zs[i].device)
+                    if gzs[k] is None:
+                        gzs[k] = torch.zeros_like(zs[i])
+                else:
+                    gzs[k] = torch.empty_like(zs[i])
+            j2.append((ghs[i], ws[4 * i], gzs[k], None, None, True, ACT_NONE, 0.0, shared[k]))
+        if j2:
+            ops.gemm_rows_grouped(j2)
+        grads = [None, None] + gzs
+        for i in range(n):
+            w0, b0, w1, b1 = ws[4 * i:4 * i + 4]
+            gw = [None] * 4
+            if i in ghs and not _INPUT_GRADS_ONLY:
+                for (w, x_, g_, slot_i) in ((w0, zs[i], ghs[i], 0), (w1, hs[i], gos[i], 2)):
+                    if ctx.needs_input_grad[2 + n + 4 * i + slot_i]:
+                        slot = ops.sink_for(w)
+                        if slot is not None:
+                            ops.sink_gemm(x_, g_, slot, True, False)
+                        else:
+                            gw[slot_i] = ops.gemm(x_, g_, True, False)
+                for (b, g_, slot_i) in ((b0, ghs[i], 1), (b1, gos[i], 3)):
+                    if b is not None and ctx.needs_input_grad[2 + n + 4 * i + slot_i]:
+                        gw[slot_i] = ops.bias_grad(g_, sink=ops.sink_for(b))
+            grads += gw
+        return tuple(grads)
+
+
+def mlp_bank(zs, weight_sets, slope):
+    """[MLP_i(z_i)] for two-layer MLPs with weights (w0, b0, w1, b1)_i: one grouped launch per layer (MlpBankFn)."""
+    flat = [t for ws in weight_sets for t in ws]
+    return list(MlpBankFn.apply(slope, len(zs), *zs, *flat))
+
+
 # =============================================================================================
 # activations
 # =============================================================================================

@@ -8,7 +8,7 @@ import threading
 
 import torch
 
-from ._lib import CN_BF16, CN_EUNSUPPORTED, CN_F32, CnConvGeom, CnDepthJob, CnGanJob, CnSumJob, check, lib
+from ._lib import CN_BF16, CN_EUNSUPPORTED, CN_F32, CnConvGeom, CnDepthJob, CnGanJob, CnRowsJob, CnSumJob, check, lib
 
 ACT_NONE, ACT_LRELU, ACT_RELU, ACT_TANH = 0, 1, 2, 3
 
@@ -286,7 +286,7 @@ def upfold_wgrad(gw2, g, w_shape, out=None, single_writer=False):
 # Winograd F(2x2, 3x3) for the wide 2-D 3x3 stride-1 SAME layers (fp32 mode): include/confignet_hip.h: cn_conv_fwd_wino
 # ---------------------------------------------------------------------------------------------
 WINOGRAD = True
-WINO_MIN_WGS = 128          # below ~half a workgroup per CU the direct kernel with split-K wins
+WINO_MIN_WGS = 32           # (round 6, alternating pipelined runs: 128 -> 64 -> 32 = 409.6 / 411.3 / 411.5 images/s; what counts next to other lines is the work issued, not the isolated latency)
 WINO_MIN_FILL = 0.7         # fraction of the 8 x 8-tile blocks that must lie inside the image
 
 
@@ -1249,6 +1249,11 @@ def bias_grad(gy, sink=None):
         return nc_reduce(gy, None, want_dot=False, per_channel=True)[0].reshape(-1)
     c = gy.shape[-1]
     rows = gy.numel() // c
+    if rows <= 64 and gy.dtype == torch.float32 and _SINK is not None and DEFER_SLAB_SUMS:
+        # a dense layer's bias gradient over a batch of a few rows: the rows ARE the slabs of the pass' grouped reduction
+        # (grad_sink.join) -- no launch of its own
+        sum_rows_into(gy.reshape(rows, c), sink)
+        return None
     rep = _partial_rows(rows)
     part = zero_pool_alloc((rep, c), gy.device)
     flags = 16
@@ -1362,6 +1367,21 @@ def gan_loss_bwd(s, gout, label):
     gs = torch.empty_like(s)
     check(lib.cn_gan_loss_bwd(_ptr(s), _ptr(gout), _ptr(gs), s.numel(), label, _stream()), "cn_gan_loss_bwd")
     return gs
+
+
+def gemm_rows_grouped(jobs):
+    """cn_gemm_rows_grouped: every job (a, b, c, bias | None, mask | None, trans_b, act, slope, accumulate) -- c = epi(a op(b) + bias),
+    a (m <= 32, k), contiguous fp32 2-D tensors -- in ONE launch."""
+    arr = (CnRowsJob * len(jobs))()
+    for q, (a, b, c, bias, mask, tb, act, slope, acc) in zip(arr, jobs):
+        q.a, q.b, q.c = _fptr(a).value, _fptr(b).value, _fptr(c).value
+        q.bias = None if bias is None else _fptr(bias).value
+        q.mask = None if mask is None else _fptr(mask).value
+        q.m, q.k = a.shape
+        q.n = b.shape[0] if tb else b.shape[1]
+        q.lda, q.ldb, q.ldc = a.shape[1], b.shape[1], c.shape[1]
+        q.tb, q.act, q.accumulate, q.slope = int(tb), int(act), int(acc), float(slope)
+    check(lib.cn_gemm_rows_grouped(arr, len(jobs), _stream()), "cn_gemm_rows_grouped")
 
 
 def gan_loss_grouped(scores, labels, gouts=None, backward=False):

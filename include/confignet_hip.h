@@ -135,6 +135,21 @@ typedef struct CnDepthJob {
     int m, n, k, lda, ldb, ldc;
 } CnDepthJob;
 int cn_gemm_depth_grouped(const CnDepthJob* jobs, int njobs, void* stream);
+/* Many row-skinny dense layers in one launch (round 6): c_j (m x n) = epi(a_j op(b_j) + bias_j), m <= 32 rows (the batch), a_j
+ * (m x k) row-major, b_j (k x n), or (n x k) when tb.  epi: the activation `act`; or, with mask (m x n, leading dimension ldc),
+ * the product with act'(mask) -- the LeakyReLU derivative of a hidden layer taken from its stored output --; or, with
+ * accumulate, an atomic add into c_j (no bias / activation).  The six AdaIN MLPs of a generator pass, layer by layer, forward
+ * and data-gradient side (hologan_generator.py:119-124, building_blocks.py:152-173).  `jobs` is a HOST array. */
+typedef struct CnRowsJob {
+    const float* a;
+    const float* b;
+    float* c;
+    const float* bias;
+    const float* mask;
+    int m, n, k, lda, ldb, ldc, tb, act, accumulate;
+    float slope;
+} CnRowsJob;
+int cn_gemm_rows_grouped(const CnRowsJob* jobs, int njobs, void* stream);
 /* The GAN losses of every head of one discriminator call in one launch (round 6; losses.py:7-11, 20-47: six heads per call).
  * backward = 0: out[0] = mean(label softplus(-s) + (1 - label) softplus(s)) over the n scores s.  backward = 1: out[i] = the
  * gradient w.r.t. s[i] for the scalar's cotangent gout[0] (gout NULL: zero).  `jobs` is a HOST array. */

@@ -635,6 +635,45 @@ def test_gan_losses_of_several_heads_in_one_launch():
         close(la[j].reshape(1), ref.reshape(1), tol=1e-5)
 
 
+@pytest.mark.parametrize("deterministic", [False, True])
+def test_mlp_bank_equals_the_separate_dense_layers(deterministic):
+    """F.mlp_bank (cn_gemm_rows_grouped, one launch per MLP layer for six MLPs) == six chains of F.linear: outputs bit for bit
+    (the same per-element arithmetic as gemm_rows_kernel), gradients of the weights, the biases and of the latents -- three of
+    the six inputs are ONE tensor, whose gradient the bank adds itself -- with one output left without a cotangent."""
+    from confignet_amd import functional as F
+    from confignet_amd import ops
+    rng = np.random.default_rng(31)
+    n, latent, hidden = 8, 145, 128
+    outs = [512, 256, 512, 128, 64, 64]
+    za, zb = dev(rng.normal(size=(n, latent))), dev(rng.normal(size=(n, latent)))
+    sets = [[dev(rng.normal(size=(latent, hidden)) * 0.1), dev(rng.normal(size=hidden) * 0.1), dev(rng.normal(size=(hidden, o)) * 0.1),
+             dev(rng.normal(size=o) * 0.1)] for o in outs]
+    cot = [dev(rng.normal(size=(n, o))) for o in outs]
+    res = {}
+    prev = ops.DETERMINISTIC
+    ops.set_deterministic(deterministic)
+    try:
+        for bank in (False, True):
+            z1, z2 = za.clone().requires_grad_(True), zb.clone().requires_grad_(True)
+            zs = [z1, z2, z1, z1, z2, z1]
+            ws = [[t.clone().requires_grad_(True) for t in st] for st in sets]
+            if bank:
+                sb = F.mlp_bank(zs, ws, 0.2)
+            else:
+                sb = [F.linear(F.linear(z, w[0], w[1], ops.ACT_LRELU, 0.2), w[2], w[3]) for z, w in zip(zs, ws)]
+            loss = sum((o * c).sum() for k, (o, c) in enumerate(zip(sb, cot)) if k != 3)          # MLP 3 gets no cotangent
+            leaves = [z1, z2] + [t for k, st in enumerate(ws) if k != 3 for t in st]
+            grads = torch.autograd.grad(loss, leaves)
+            res[bank] = ([o.detach() for o in sb], grads)
+    finally:
+        ops.set_deterministic(prev)
+    for a, b in zip(res[False][0], res[True][0]):
+        assert float((a - b).abs().max()) == 0.0
+    for k, (a, b) in enumerate(zip(res[False][1], res[True][1])):
+        err = float((a - b).norm() / a.norm())
+        assert err < 2e-6, "gradient %d: rel-L2 %.3e" % (k, err)
+
+
 def test_pools_preproc_uint8():
     from confignet_amd import ops
     rng = np.random.default_rng(6)
