@@ -503,6 +503,35 @@ __global__ void row_scale_kernel(const T* __restrict__ x, const float* __restric
     }
 }
 
+// The backward of a tapped, activated layer of a feature loss in ONE pass (round 6): o = (g + (y - target) s[row] k) act'(y) --
+// the squared-difference term's gradient, the gradient arriving from the next layer (g, optional) and the layer's own
+// activation derivative -- instead of cn_row_scale_diff + an add + cn_act_bwd (perceptual_loss.py:74-82: the four VGG taps).
+template <typename T>
+__global__ void tap_bwd_kernel(const T* __restrict__ y, const T* __restrict__ tgt, const T* __restrict__ g, const float* __restrict__ s,
+                               T* __restrict__ o, size_t row, float k, int vec, int act, float slope) {
+    const float f = s[blockIdx.y] * k;
+    const size_t base = (size_t)blockIdx.y * row;
+    const size_t stride = (size_t)gridDim.x * blockDim.x, t0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (vec) {
+        for (size_t i = t0; i < row / 4; i += stride) {
+            const float4 u = ld4<T>(y + base + 4 * i), w = ld4<T>(tgt + base + 4 * i);
+            float4 r = make_float4((u.x - w.x) * f, (u.y - w.y) * f, (u.z - w.z) * f, (u.w - w.w) * f);
+            if (g) {
+                const float4 q = ld4<T>(g + base + 4 * i);
+                r.x += q.x; r.y += q.y; r.z += q.z; r.w += q.w;
+            }
+            st4<T>(o + base + 4 * i, make_float4(r.x * act_deriv(u.x, act, slope), r.y * act_deriv(u.y, act, slope),
+                                                 r.z * act_deriv(u.z, act, slope), r.w * act_deriv(u.w, act, slope)));
+        }
+    } else {
+        for (size_t i = t0; i < row; i += stride) {
+            const float u = ldf<T>(y + base + i);
+            const float r = (u - ldf<T>(tgt + base + i)) * f + (g ? ldf<T>(g + base + i) : 0.f);
+            stf<T>(o + base + i, r * act_deriv(u, act, slope));
+        }
+    }
+}
+
 __global__ void masked_diff_kernel(const float* __restrict__ a, const float* __restrict__ b, const uint8_t* __restrict__ m,
                                    float* __restrict__ o, size_t pixels, int c) {
     for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < pixels; p += (size_t)gridDim.x * blockDim.x) {
@@ -1065,6 +1094,17 @@ extern "C" int cn_row_scale_diff(const void* x, const void* x2, const float* s, 
     int bpr = (int)((row + 256 * 16 - 1) / (256 * 16));
     if (bpr > 512) bpr = 512;
     CN_DISPATCH_DT(dt, hipLaunchKernelGGL((row_scale_kernel<T>), dim3(bpr, n), dim3(256), 0, (hipStream_t)stream, (const T*)x, s, (T*)out, row, k, vec, (const T*)x2));
+    CN_LAUNCH_CHECK();
+    return CN_OK;
+}
+extern "C" int cn_tap_bwd(const void* y, const void* target, const void* g, const float* s, void* out, int n, size_t row, float k,
+                          int act, float slope, int dt, void* stream) {
+    CN_CHECK_ARG(y && target && s && out && n > 0 && row > 0 && (dt == CN_F32 || dt == CN_BF16), "tap_bwd: bad args");
+    const int vec = alv(y, dt) && alv(target, dt) && alv(out, dt) && (!g || alv(g, dt)) && row % 4 == 0;
+    int bpr = (int)((row + 256 * 16 - 1) / (256 * 16));
+    if (bpr > 512) bpr = 512;
+    CN_DISPATCH_DT(dt, hipLaunchKernelGGL((tap_bwd_kernel<T>), dim3(bpr, n), dim3(256), 0, (hipStream_t)stream, (const T*)y, (const T*)target,
+                                          (const T*)g, s, (T*)out, row, k, vec, act, slope));
     CN_LAUNCH_CHECK();
     return CN_OK;
 }

@@ -1307,6 +1307,19 @@ def row_scale_diff(a, b, s, k):
     return out
 
 
+def tap_bwd(y, target, g, s, k, act, slope=0.0):
+    """(g + (y - target) s[row] k) act'(y) in one pass (cn_tap_bwd); g may be None; s: one scale per row (s.numel() rows)."""
+    if g is None:
+        y, target = _unify(y, target)
+    else:
+        y, target, g = _unify(y, target, _c(g))
+    _log_mask(y, act)
+    out = torch.empty_like(y)
+    check(lib.cn_tap_bwd(_ptr(y), _ptr(target), _ptr(g), _fptr(s), _ptr(out), s.numel(), y.numel() // s.numel(), k, act, slope, _dt(y),
+                         _stream()), "cn_tap_bwd")
+    return out
+
+
 def masked_diff(a, b, mask):
     a, b = f32(a), f32(b)
     out = torch.empty_like(a)

@@ -2,7 +2,7 @@
 import torch
 
 from . import functional as F
-from .dnn_models.vgg import VGG16_CFG, VGG16_TAPS, VGG19_CFG, VGG19_TAPS, VGGFeatures
+from .dnn_models.vgg import VGG16_CFG, VGG16_TAPS, VGG19_CFG, VGG19_TAPS, VGGFeatures, VGGLossFn
 
 
 class PerceptualLoss:
@@ -14,6 +14,8 @@ class PerceptualLoss:
             self._pretrained_dnn_activations = VGGFeatures(VGG19_CFG, VGG19_TAPS, rng)
         else:
             raise ValueError(model_type)
+
+    fused_tape = True          # (False: one tape node per layer and per loss term -- cross-check)
 
     def _preprocess_input(self, img):
         return F.vggface_preprocess(img) if self.model_type == "VGGFace" else F.caffe_preprocess(img)
@@ -43,8 +45,18 @@ class PerceptualLoss:
             live, const = predicted, data
         else:
             live, const = data, predicted
-        fl = self._activations(live, torch.is_tensor(live) and live.requires_grad)
-        fc = cached if cached is not None else self._activations(const, torch.is_tensor(const) and const.requires_grad)
+        live_grad = torch.is_tensor(live) and live.requires_grad
+        const_grad = torch.is_tensor(const) and const.requires_grad
+        if self.fused_tape and live_grad and not const_grad and torch.is_grad_enabled():
+            # the whole stack + the four terms as one tape node (VGGLossFn: one elementwise pass per layer in the backward pass)
+            fc = cached if cached is not None else self.features(const)
+            net = self._pretrained_dnn_activations
+            img = net.to_device(live)
+            if img.dim() == 3:
+                img = img.unsqueeze(0)
+            return VGGLossFn.apply(net, self._preprocess_input(img), None, *[f.detach() for f in fc])
+        fl = self._activations(live, live_grad)
+        fc = cached if cached is not None else self._activations(const, const_grad)
         total = 0
         for a, b in zip(fl, fc):
             total = total + F.mse_sum(a, b)
@@ -55,6 +67,10 @@ class PerceptualLoss:
         generated images of all groups, carrying gradient) goes through the feature stack once, `const_features` are the
         activations of the stacked ground-truth images from features().  Returns a (G,) tensor; element g equals
         loss(predicted[group g], data[group g])."""
+        if self.fused_tape and torch.is_tensor(predicted) and predicted.requires_grad and torch.is_grad_enabled():
+            net = self._pretrained_dnn_activations
+            return VGGLossFn.apply(net, self._preprocess_input(net.to_device(predicted)), tuple(int(s) for s in sizes),
+                                   *[f.detach() for f in const_features])
         fl = self._activations(predicted, True)
         total = 0
         for a, b in zip(fl, const_features):

@@ -356,6 +356,10 @@ int cn_row_sumsq(const float* x, float* out, int n, size_t row, void* stream);
 int cn_row_scale(const void* x, const float* s, void* out, int n, size_t row, float k, int dt, void* stream);
 /* out = (x - x2) * s[row] * k: the gradient of a squared-difference loss term (perceptual_loss.py:74-80) in one pass. */
 int cn_row_scale_diff(const void* x, const void* x2, const float* s, void* out, int n, size_t row, float k, int dt, void* stream);
+/* The backward of a tapped, activated layer of a feature loss in one pass (round 6; perceptual_loss.py:74-82, the VGG taps):
+ * out = (g + (y - target) s[r] k) act'(y) over n rows of `row` elements; g (the gradient from the next layer) may be NULL. */
+int cn_tap_bwd(const void* y, const void* target, const void* g, const float* s, void* out, int n, size_t row, float k,
+               int act, float slope, int dt, void* stream);
 /* out = (a - b) * mask[n,h,w] broadcast over c (b optional) (losses.py:14) */
 int cn_masked_diff(const float* a, const float* b, const uint8_t* mask, float* out, size_t pixels, int c, void* stream);
 /* 2-D max pooling, zero padding (keras MaxPooling2D after ZeroPadding2D); bwd: the gradient of a window goes to its

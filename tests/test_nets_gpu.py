@@ -309,6 +309,42 @@ def test_perceptual_loss(model_type):
     assert rel < 2e-2, "d perceptual / d image: rel-L2 %.3e" % rel     # ReLU / max-pool argmax flips, see close_grads
 
 
+@pytest.mark.parametrize("model_type", ["imagenet", "VGGFace"])
+def test_perceptual_loss_as_one_tape_node_equals_the_layerwise_tape(model_type):
+    """VGGLossFn (the stack + its four terms as one tape node, cn_tap_bwd at the taps) against one tape node per layer and term:
+    the same loss and the same image gradient up to summation order, for loss() and for loss_groups() (two sample groups with
+    different cotangents), with cached and with recomputed target features."""
+    from confignet_amd.perceptual_loss import PerceptualLoss
+    rng = np.random.default_rng(19)
+    pl = PerceptualLoss((64, 64, 3), model_type)
+    gt = torch.tensor(rng.uniform(-1, 1, size=(5, 64, 64, 3)), device="cuda", dtype=torch.float32)
+    gen = rng.uniform(-1, 1, size=(5, 64, 64, 3))
+    out = {}
+    # deterministic mode: the K-split atomics of the direct convolutions move the activations by ~1e-6 from run to run, and one
+    # ReLU / arg-max decision taken the other way moves a sample's gradient by ~1e-3 (seen on this very input) -- with ordered
+    # reductions both forms see the same activations and differ by their own summation order only
+    prev = ops_mod().DETERMINISTIC
+    ops_mod().set_deterministic(True)
+    for fused in (False, True):
+        pl.fused_tape = fused
+        a = torch.tensor(gen, device="cuda", dtype=torch.float32, requires_grad=True)
+        l1 = pl.loss(gt, a)
+        (g1,) = torch.autograd.grad(l1 * 3.0, a)
+        b = torch.tensor(gen, device="cuda", dtype=torch.float32, requires_grad=True)
+        l2 = pl.loss(b, gt, cached=pl.features(gt))
+        (g2,) = torch.autograd.grad(l2, b)
+        c = torch.tensor(gen, device="cuda", dtype=torch.float32, requires_grad=True)
+        lg = pl.loss_groups(c, pl.features(gt), (2, 3))
+        (g3,) = torch.autograd.grad(lg[0] * 0.5 + lg[1] * 2.0, c)
+        out[fused] = [t.detach().clone() for t in (l1, g1, l2, g2, lg, g3)]
+    ops_mod().set_deterministic(prev)
+    pl.fused_tape = True
+    for k, (x, y) in enumerate(zip(out[False], out[True])):
+        err = float((x.double() - y.double()).norm() / x.double().norm())
+        print("one node vs layerwise, item %d: rel-L2 %.3e" % (k, err))
+        assert err < 1e-5, "item %d: rel-L2 %.3e" % (k, err)
+
+
 def test_real_encoder():
     from confignet_amd.dnn_models.real_encoder import RealEncoder
     rng = np.random.default_rng(10)
