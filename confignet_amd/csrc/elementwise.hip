@@ -229,6 +229,82 @@ __global__ __launch_bounds__(256) void nc_reduce4_kernel(const T* __restrict__ x
     }
 }
 
+// ---- nc_reduce_hxt: the three reductions of the R1 tangent tail's backward pass in ONE pass over its cotangent (round 6) ----
+// out[0] = sum h, out[1] = sum h lrelu(x), out[2] = sum h ta per (n, c); h and ta hold gridDim.z samples, x `period` samples
+// (read through the sample period); out is (3, N, C), zeroed by the caller unless gridDim.y == 1.  Grid as nc_reduce_kernel<4>.
+template <typename T>
+__global__ __launch_bounds__(256) void nc_reduce_hxt_kernel(const T* __restrict__ h, const T* __restrict__ x, const T* __restrict__ ta,
+                                                            float* __restrict__ out, int S, int C, int rows_per_block, float slope,
+                                                            int period, float* __restrict__ parts) {
+    const int CG = C / 4;
+    const int tx = threadIdx.x, ty = threadIdx.y, TX = blockDim.x, TY = blockDim.y;
+    const int cg = blockIdx.x * TX + tx;
+    const int n = blockIdx.z;
+    const int sbeg = blockIdx.y * rows_per_block, send = min(S, sbeg + rows_per_block);
+    float acc[3][4];
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[q][e] = 0.f;
+    if (cg < CG) {
+        const long base = (long)n * S * C + (long)cg * 4;
+        const long base2 = (long)(n % period) * S * C + (long)cg * 4;
+        int s = sbeg + ty;
+        for (; s + 3 * TY < send; s += 4 * TY) {       // four rows in flight (see nc_reduce_kernel)
+            float4 vh[4], vx[4], vt[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) vh[u] = ld4<T>(h + base + (long)(s + u * TY) * C);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) vx[u] = ld4<T>(x + base2 + (long)(s + u * TY) * C);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) vt[u] = ld4<T>(ta + base + (long)(s + u * TY) * C);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float4 l = lrelu4(vx[u], slope);
+                const float a[4] = {vh[u].x, vh[u].y, vh[u].z, vh[u].w}, b[4] = {l.x, l.y, l.z, l.w},
+                            t[4] = {vt[u].x, vt[u].y, vt[u].z, vt[u].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc[0][e] += a[e];
+                    acc[1][e] += a[e] * b[e];
+                    acc[2][e] += a[e] * t[e];
+                }
+            }
+        }
+        for (; s < send; s += TY) {
+            const float4 vh = ld4<T>(h + base + (long)s * C), l = lrelu4(ld4<T>(x + base2 + (long)s * C), slope),
+                         vt = ld4<T>(ta + base + (long)s * C);
+            const float a[4] = {vh.x, vh.y, vh.z, vh.w}, b[4] = {l.x, l.y, l.z, l.w}, t[4] = {vt.x, vt.y, vt.z, vt.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc[0][e] += a[e];
+                acc[1][e] += a[e] * b[e];
+                acc[2][e] += a[e] * t[e];
+            }
+        }
+    }
+    __shared__ float red[3][256 * 4];
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) red[q][(ty * TX + tx) * 4 + e] = acc[q][e];
+    __syncthreads();
+    if (ty == 0 && cg < CG) {
+        const long nc = (long)gridDim.z * C;
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float t = 0.f;
+                for (int y = 0; y < TY; ++y) t += red[q][(y * TX + tx) * 4 + e];
+                const long o = (long)n * C + (long)cg * 4 + e;
+                if (parts) parts[((long)q * gridDim.y + blockIdx.y) * nc + o] = t;     // deterministic mode: ordered second pass
+                else if (gridDim.y == 1) out[q * nc + o] = t;
+                else unsafeAtomicAdd(&out[q * nc + o], t);
+            }
+    }
+}
+
 // ---- nc_lin2: y = A1*f1(x1) + A2*f2(x2) + B ----
 template <int V, typename T>
 __global__ __launch_bounds__(256) void nc_lin2_kernel(const T* __restrict__ x1, const float* __restrict__ a1,
@@ -875,6 +951,46 @@ static int nc_reduce_launch(const void* x1, const void* x2, float* s1, float* s2
 
 // out (4, n, c) = sum x, sum x^2, sum lrelu(x), sum lrelu(x)^2 over s: the style statistics and the instance-norm statistics of a
 // DiscrBlock's pre-activation tensor in one pass (c % 4 == 0).  flags bit4: `out` is already zero.
+// (sum h, sum h lrelu(x), sum h ta) per (n, c) in one pass: out (3, n, c); x holds `period` samples (n % period == 0); flags & 16:
+// out is already zero.  The backward reductions of the DiscrBlock tail's tangent (losses.py:75-82 through building_blocks.py:100-106).
+extern "C" int cn_nc_reduce_hxt(const void* h, const void* x, const void* ta, float* out, int n, int s, int c, float slope, int period,
+                                int flags, int dt, void* stream) {
+    CN_CHECK_ARG(h && x && ta && out && n > 0 && s > 0 && c > 0 && c % 4 == 0 && period > 0 && n % period == 0 && (dt == CN_F32 || dt == CN_BF16),
+                 "nc_reduce_hxt: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    const int CG = c / 4;
+    int TX = 1;
+    while (TX < CG && TX < 64) TX <<= 1;
+    const int TY = 256 / TX;
+    const int cblk = cn_cdiv(CG, TX);
+    long want = 512 / ((long)cblk * n);
+    if (cn_det()) {
+        const long cap = (long)(CN_DET_WS_FLOATS / (3 * (size_t)n * c));
+        if (want > cap) want = cap;
+    }
+    if (want < 1) want = 1;
+    if (want > 256) want = 256;
+    long rpb = (s + want - 1) / want;
+    if (rpb < 4 * TY) rpb = 4 * TY;
+    const int sblk = cn_cdiv(s, rpb);
+    float* parts = nullptr;
+    if (cn_det() && sblk > 1) {
+        parts = cn_det_ws(st, 3 * (size_t)sblk * n * c);
+        if (!parts) return CN_EINVAL;
+    } else if (sblk > 1 && !(flags & 16)) {
+        if (int ez__ = cn_zero_async(out, sizeof(float) * 3 * (size_t)n * c, st)) return ez__;
+    }
+    dim3 grid(cblk, sblk, n), block(TX, TY);
+    CN_DISPATCH_DT(dt, hipLaunchKernelGGL((nc_reduce_hxt_kernel<T>), grid, block, 0, st, (const T*)h, (const T*)x, (const T*)ta, out, s, c, (int)rpb,
+                                          slope, period, parts));
+    CN_LAUNCH_CHECK();
+    if (parts) {
+        for (int q = 0; q < 3; ++q)
+            if (int e = cn_sum_parts(parts + (size_t)q * sblk * n * c, out + (size_t)q * n * c, sblk, (long)n * c, 0, 1.f, st)) return e;
+    }
+    return CN_OK;
+}
+
 extern "C" int cn_nc_reduce4(const void* x, float* out, int n, int s, int c, float slope, int flags, int dt, void* stream) {
     CN_CHECK_ARG(x && out && n > 0 && s > 0 && c > 0 && c % 4 == 0 && (dt == CN_F32 || dt == CN_BF16), "nc_reduce4: bad args");
     hipStream_t st = (hipStream_t)stream;

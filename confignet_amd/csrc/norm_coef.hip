@@ -227,7 +227,13 @@ __global__ void dual_gx_kernel(const T* __restrict__ h, const T* __restrict__ ta
                                const T* __restrict__ x, const float* __restrict__ kh, const float* __restrict__ kt,
                                const float* __restrict__ ka, const float* __restrict__ kc, const float* __restrict__ et,
                                const float* __restrict__ ex, const float* __restrict__ e0, T* __restrict__ out,
-                               long total4, int S, int C, float slope, int nrep) {
+                               long total4, int S, int C, float slope, int nrep, const float* __restrict__ K1 = nullptr,
+                               const float* __restrict__ K2 = nullptr, const float* __restrict__ K0 = nullptr,
+                               const float* __restrict__ D2 = nullptr, const float* __restrict__ D0 = nullptr,
+                               T* __restrict__ out_tx = nullptr) {
+    // out_tx (round 6, cn_dual_tail_gx_tx): the gradient w.r.t. the stacked tangent input from the SAME pass over h and x --
+    // rows [0, N): D2 x + D0 (the head that left through the style statistics), rows [(1 + j) N, (2 + j) N): lrelu'(x) (K1 h_j + K2
+    // lrelu(x) + K0) -- what two cn_nc_lin2 launches (one more read of h) computed before
     // total4 = N*S*C/4 elements of x / out; h, ta and their coefficients hold nrep*N samples (the heads of a batched tangent
     // pass that share this primal activation): their contributions are summed here, in head order
     const int C4 = C / 4;
@@ -250,6 +256,18 @@ __global__ void dual_gx_kernel(const T* __restrict__ h, const T* __restrict__ ta
                     const float mk = xs[e] > 0.f ? 1.f : slope;
                     r[e] += mk * (kh[cj + e] * hs[e] + kt[cj + e] * ts[e] + ka[cj + e] * xs[e] * mk + kc[cj + e]);
                 }
+                if (out_tx) {
+                    float w[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        // (the operation order of nc_lin2_rows_kernel with flags 2 | 4: bias, + a1 x1, + a2 lrelu(x2), times lrelu'(x2))
+                        float v = K0[cj + e];
+                        v += K1[cj + e] * hs[e];
+                        v += K2[cj + e] * (xs[e] > 0.f ? xs[e] : xs[e] * slope);
+                        w[e] = v * (xs[e] > 0.f ? 1.f : slope);
+                    }
+                    st4<T>(out_tx + 4 * (i + (long)(j + 1) * total4), make_float4(w[0], w[1], w[2], w[3]));
+                }
             }
         }
         if (et) {
@@ -257,6 +275,12 @@ __global__ void dual_gx_kernel(const T* __restrict__ h, const T* __restrict__ ta
             const float ts[4] = {tv.x, tv.y, tv.z, tv.w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) r[e] += et[ci + e] * ts[e] + ex[ci + e] * xs[e] + e0[ci + e];
+        }
+        if (out_tx) {
+            float w[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) w[e] = D0[ci + e] + D2[ci + e] * xs[e];
+            st4<T>(out_tx + 4 * i, make_float4(w[0], w[1], w[2], w[3]));
         }
         st4<T>(out + 4 * i, make_float4(r[0], r[1], r[2], r[3]));
     }
@@ -311,6 +335,26 @@ extern "C" int cn_dual_tail_gx(const void* h, const void* ta, const void* tx, co
     if (blocks > 8192) blocks = 8192;
     CN_DISPATCH_DT(dt, hipLaunchKernelGGL((dual_gx_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const T*)h,
                                           (const T*)ta, (const T*)tx, (const T*)x, kh, kt, ka, kc, et, ex, e0, (T*)out, total4, s, c, slope, nrep));
+    CN_LAUNCH_CHECK();
+    return CN_OK;
+}
+
+// cn_dual_tail_gx + the gradient w.r.t. the stacked tangent input in the same pass (round 6): out_tx holds (1 + nrep) N samples --
+// the style head's rows D2 x + D0 first, then per head lrelu'(x) (K1 h + K2 lrelu(x) + K0) -- instead of two cn_nc_lin2 launches
+// that read h and x again (losses.py:75-82, the R1 penalty's tangent pass through building_blocks.py:100-106).
+extern "C" int cn_dual_tail_gx_tx(const void* h, const void* ta, const void* tx, const void* x, const float* kh, const float* kt,
+                                  const float* ka, const float* kc, const float* et, const float* ex, const float* e0,
+                                  const float* K1, const float* K2, const float* K0, const float* D2, const float* D0, void* out,
+                                  void* out_tx, int n, int s, int c, float slope, int nrep, int dt, void* stream) {
+    CN_CHECK_ARG(h && ta && tx && x && out && out_tx && kh && kt && ka && kc && et && ex && e0 && K1 && K2 && K0 && D2 && D0,
+                 "dual_tail_gx_tx: NULL tensor");
+    CN_CHECK_ARG(n > 0 && s > 0 && c > 0 && c % 4 == 0 && nrep >= 1 && (dt == CN_F32 || dt == CN_BF16), "dual_tail_gx_tx: bad args");
+    const long total4 = (long)n * s * (c / 4);
+    long blocks = (total4 + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    CN_DISPATCH_DT(dt, hipLaunchKernelGGL((dual_gx_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const T*)h,
+                                          (const T*)ta, (const T*)tx, (const T*)x, kh, kt, ka, kc, et, ex, e0, (T*)out, total4, s, c, slope, nrep,
+                                          K1, K2, K0, D2, D0, (T*)out_tx));
     CN_LAUNCH_CHECK();
     return CN_OK;
 }

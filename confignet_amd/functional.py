@@ -17,6 +17,7 @@ from .ops import ACT_LRELU, ACT_NONE, ACT_RELU, ACT_TANH, ConvSpec  # noqa: F401
 
 _INPUT_GRADS_ONLY = False
 FUSED_TAIL_STATS = True    # DiscrBlock tail: the two statistics passes as one (cn_nc_reduce4)
+FUSED_R1_TAIL = True     # tangent tail backward (DualTailBatchedFn): cn_nc_reduce_hxt + cn_dual_tail_gx_tx (two passes over h instead of five launches)
 BN_BWD_FUSED = True      # conv -> BN(inference) -> ReLU backward as one pass (cn_bn_act_bwd)
 
 
@@ -676,6 +677,12 @@ class DualTailBatchedFn(Function):
         if u is None:
             u = torch.zeros((n, 2 * x.shape[-1]), device=x.device, dtype=torch.float32)
         h = _cg(h)
+        if FUSED_R1_TAIL and x.shape[-1] % 4 == 0:
+            # two passes over the stacked cotangent instead of five: the three reductions in one, then both gradients in one
+            H1, H2, E = ops.nc_reduce_hxt(h, x, ta, slope)
+            co = ops.dual_tail_coef_bwd((H1, H2), E, _cg(u), (T1, T2), (U1, U2), mean, q, smean, ssd, gamma, sp)
+            g_x, g_tx = ops.dual_tail_gx_tx(h, ta, tx, x, co, slope)
+            return g_tx, g_x, co["ggamma"], None, None, None, None, None
         H = ops.nc_reduce(h, x, flags=2, slope=slope, x2_period=n)          # sum h, sum h*lrelu(x)
         E = ops.nc_reduce(h, ta, want_sum=False)[1]                          # sum h*ta
         co = ops.dual_tail_coef_bwd(H, E, _cg(u), (T1, T2), (U1, U2), mean, q, smean, ssd, gamma, sp)

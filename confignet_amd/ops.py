@@ -1114,6 +1114,35 @@ def dual_tail_gx(h, ta, tx, x, co, slope):
     return out
 
 
+def dual_tail_gx_tx(h, ta, tx, x, co, slope):
+    """(g_x, g_tx): dual_tail_gx and, from the same pass, the gradient w.r.t. the stacked tangent input tx (its first N samples
+    the style head's D2 x + D0, then per head lrelu'(x) (K1 h + K2 lrelu(x) + K0)): cn_dual_tail_gx_tx."""
+    h, ta, tx, x = _unify(h, ta, tx, x)
+    _log_mask(x)
+    n, s, c = _nsc(x)
+    nrep = h.shape[0] // n
+    assert h.shape[0] == nrep * n and ta.shape[0] == nrep * n and tx.shape[0] == (nrep + 1) * n
+    out = torch.empty_like(x)
+    out_tx = torch.empty_like(tx)
+    check(lib.cn_dual_tail_gx_tx(_ptr(h), _ptr(ta), _ptr(tx), _ptr(x), _ptr(co["kh"]), _ptr(co["kt"]), _ptr(co["ka"]), _ptr(co["kc"]),
+                                 _ptr(co["et"]), _ptr(co["ex"]), _ptr(co["e0"]), _ptr(co["K1"]), _ptr(co["K2"]), _ptr(co["K0"]),
+                                 _ptr(co["D2"]), _ptr(co["D0"]), _ptr(out), _ptr(out_tx), n, s, c, slope, nrep, _dt(x), _stream()),
+          "cn_dual_tail_gx_tx")
+    return out, out_tx
+
+
+def nc_reduce_hxt(h, x, ta, slope):
+    """(sum h, sum h lrelu(x), sum h ta) per (n, c) of h in ONE pass (cn_nc_reduce_hxt); x holds h.shape[0] / k samples."""
+    h, x, ta = _unify(h, x, ta)
+    n, s, c = _nsc(h)
+    out = zero_pool_alloc((3, n, c), h.device)
+    flags = 16
+    if out is None:
+        out, flags = torch.empty((3, n, c), device=h.device, dtype=torch.float32), 0
+    check(lib.cn_nc_reduce_hxt(_ptr(h), _ptr(x), _ptr(ta), _ptr(out), n, s, c, slope, x.shape[0], flags, _dt(h), _stream()), "cn_nc_reduce_hxt")
+    return out[0], out[1], out[2]
+
+
 def bn_act_bwd(gy, y, x, a, act, want_g):
     """(gx, g | None, sum_c g, sum_c g*x): cn_bn_act_bwd -- activation backward, BatchNorm(inference) input gradient and the two
     per-channel parameter sums in one pass over gy / y / x."""
