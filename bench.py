@@ -236,6 +236,13 @@ def main():
                                  "parity-class filters); `frac` is therefore comparable with mfma_busy_pmc -- an algorithm that issues "
                                  "fewer products for the same layer (F(4x4): 2.25 instead of 4 per output) LOWERS this figure while the "
                                  "iteration gets faster: see direct_equivalent",
+                         "pipelined": {
+                             "tflops": round(kernel_flops / nst / (ms_per_step * 1e-3) / 1e12, 3),
+                             "frac": round(kernel_flops / nst / (ms_per_step * 1e-3) / 1e12 / peak, 4),
+                             "note": "the same issued multiply-adds over the TIMED iteration (all lines concurrent, everything else of the "
+                                     "iteration included): the matrix pipes' share of the wall clock.  `frac` above is per launch in "
+                                     "ISOLATION -- since round 6 the Winograd kernels also take launches of 32 - 128 workgroups, which leave CUs "
+                                     "idle when alone (lower `frac`) and are filled by the other lines in the pipelined loop (higher `value`)"},
                          "direct_equivalent": {
                              "gflop_per_step": round((kernel_flops + saved_flops) / max(args.steps, 1) / 1e9, 2),
                              "tflops": round((kernel_flops + saved_flops) / (kernel_ms * 1e-3) / 1e12, 3) if kernel_ms > 0 else 0.0,
