@@ -122,6 +122,7 @@ SIGNATURES = {
     "cn_row_scale": [_p, _p, _p, _i, _z, _f, _i, _p],
     "cn_row_scale_diff": [_p, _p, _p, _p, _i, ctypes.c_size_t, _f, _i, _p],
     "cn_tap_bwd": [_p, _p, _p, _p, _p, _i, ctypes.c_size_t, _f, _i, _f, _i, _p],
+    "cn_maxpool2_bwd_act": [_p, _p, _p, _p, _f, _p, _i, _i, _i, _i, _i, _i, _p],
     "cn_masked_diff": [_p, _p, _p, _p, _z, _i, _p],
     "cn_maxpool_fwd": [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "cn_maxpool_bwd": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],

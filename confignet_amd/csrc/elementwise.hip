@@ -765,7 +765,11 @@ __global__ void maxpool_bwd4_kernel(const T* __restrict__ x, const T* __restrict
 // Same tie rule: the first maximum in (dy, dx) scan order takes the gradient.
 template <typename T>
 __global__ void maxpool2_bwd_kernel(const T* __restrict__ x, const T* __restrict__ gy, T* __restrict__ gx, long windows4,
-                                    int oh, int ow, int c4) {
+                                    int oh, int ow, int c4, int relu = 0, const T* __restrict__ tgt = nullptr,
+                                    const float* __restrict__ sc = nullptr, int sc_rows = 1, float kk = 0.f) {
+    // relu / tgt (round 6, cn_maxpool2_bwd_act): x is the ReLU OUTPUT that was pooled -- the routed gradient (plus, at a tapped
+    // layer, the feature loss' own term (x - tgt) sc[sample] kk) is multiplied by relu'(x) here, so the full-size gradient between
+    // the pool's and the activation's backward is never written
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < windows4; i += (long)gridDim.x * blockDim.x) {
         const int cg = (int)(i % c4);
         long t = i / c4;
@@ -790,6 +794,22 @@ __global__ void maxpool2_bwd_kernel(const T* __restrict__ x, const T* __restrict
                 if (a[e][j] > best) { best = a[e][j]; arg = j; }
 #pragma unroll
             for (int j = 0; j < 4; ++j) o[e][j] = (j == arg && best > -INFINITY) ? gg[e] : 0.f;
+        }
+        if (tgt) {
+            const T* pt = tgt + (px - x);
+            const float4 t00 = ld4<T>(pt), t01 = ld4<T>(pt + c4 * 4), t10 = ld4<T>(pt + row), t11 = ld4<T>(pt + row + c4 * 4);
+            const float tt[4][4] = {{t00.x, t01.x, t10.x, t11.x}, {t00.y, t01.y, t10.y, t11.y}, {t00.z, t01.z, t10.z, t11.z}, {t00.w, t01.w, t10.w, t11.w}};
+            const float f = sc[sc_rows > 1 ? b : 0] * kk;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[e][j] = (a[e][j] - tt[e][j]) * f + o[e][j];
+        }
+        if (relu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[e][j] = a[e][j] > 0.f ? o[e][j] : 0.f;
         }
         st4<T>(pg, make_float4(o[0][0], o[1][0], o[2][0], o[3][0]));
         st4<T>(pg + c4 * 4, make_float4(o[0][1], o[1][1], o[2][1], o[3][1]));
@@ -1266,6 +1286,21 @@ extern "C" int cn_maxpool_bwd(const void* x, const void* gy, void* gx, int n, in
         return CN_OK;
     }
     CN_DISPATCH_DT(dt, hipLaunchKernelGGL((maxpool_bwd_kernel<T>), dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)gy, (T*)gx, n, h, w, c, oh, ow, k, s, pad));
+    CN_LAUNCH_CHECK();
+    return CN_OK;
+}
+// Backward of ReLU -> MaxPooling2D(2, 2) in one pass (round 6): gx = (routed gy [+ (x - target) s[sample] k]) relu'(x), x = the
+// ReLU output that was pooled (perceptual_loss.py:19-41: VGG conv1_2 / conv2_2 / conv3_4; conv1_2 is also a tap).  Windows of
+// 2 x 2 / stride 2 on even extents with c % 4 == 0 and 16-byte aligned tensors; anything else: CN_EUNSUPPORTED, nothing launched.
+extern "C" int cn_maxpool2_bwd_act(const void* x, const void* gy, const void* target, const float* s, float k, void* gx, int n, int h,
+                                   int w, int c, int s_rows, int dt, void* stream) {
+    CN_CHECK_ARG(x && gy && gx && n > 0 && h > 0 && w > 0 && c > 0 && (dt == CN_F32 || dt == CN_BF16) && (!target || (s && (s_rows == 1 || s_rows == n))),
+                 "maxpool2_bwd_act: bad args");
+    if (h % 2 || w % 2 || c % 4 || !alv(x, dt) || !alv(gy, dt) || !alv(gx, dt) || (target && !alv(target, dt))) return CN_EUNSUPPORTED;
+    const int oh = h / 2, ow = w / 2;
+    const long windows4 = (long)n * oh * ow * (c / 4);
+    CN_DISPATCH_DT(dt, hipLaunchKernelGGL((maxpool2_bwd_kernel<T>), dim3(ew_blocks((size_t)windows4)), dim3(256), 0, (hipStream_t)stream,
+                                          (const T*)x, (const T*)gy, (T*)gx, windows4, oh, ow, c / 4, 1, (const T*)target, s, s_rows, k));
     CN_LAUNCH_CHECK();
     return CN_OK;
 }

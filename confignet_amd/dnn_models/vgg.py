@@ -94,15 +94,15 @@ class VGGLossFn(torch.autograd.Function):
         n = x.shape[0]
         g = g.reshape(-1).float()
         tap_of = {ci: k for k, ci in enumerate(net.taps)}
-        gcur, ci, pi = None, ny, npool
+        gcur, ci, pi, pooled = None, ny, npool, None
         for item in reversed(net.cfg):
             if item == "P":
                 pi -= 1
-                if gcur is not None:
-                    gcur = ops.maxpool_bwd(pools[pi], gcur, 2, 2, 0)
+                pooled, gcur = gcur, None             # the pool's backward joins the ReLU backward of the layer in front of it
                 continue
             ci -= 1
             y = ys[ci]
+            s_ = k = None
             if ci in tap_of:
                 per = y.numel() // n
                 if sizes is None:
@@ -110,6 +110,16 @@ class VGGLossFn(torch.autograd.Function):
                 else:
                     s_ = torch.cat([g[i:i + 1].expand(sz) * (1.0 / (sz * per)) for i, sz in enumerate(sizes)]).contiguous()
                     k = 2.0
+            gu = None
+            if pooled is not None:
+                # ReLU -> MaxPooling2D backward in ONE pass (the tap's own term added there too): no full-size gradient in between
+                gu = ops.maxpool2_bwd_relu(y, pooled, targets[tap_of[ci]] if s_ is not None else None, s_, k if s_ is not None else 0.0)
+                if gu is None:
+                    gcur = ops.maxpool_bwd(y, pooled, 2, 2, 0)
+                pooled = None
+            if gu is not None:
+                pass
+            elif s_ is not None:
                 gu = ops.tap_bwd(y, targets[tap_of[ci]], gcur, s_, k, ACT_RELU)
             elif gcur is None:
                 continue                                             # (layers behind the last tap carry no gradient)

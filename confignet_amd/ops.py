@@ -1336,6 +1336,28 @@ def row_scale_diff(a, b, s, k):
     return out
 
 
+def maxpool2_bwd_relu(x, gy, target=None, s=None, k=0.0):
+    """Backward of ReLU -> MaxPooling2D(2, 2) in one pass (cn_maxpool2_bwd_act): (routed gy [+ (x - target) s k]) relu'(x) for the ReLU
+    output x that was pooled; None where the kernel does not take the shape (the caller then runs the two passes)."""
+    n, h, w, c = x.shape
+    if target is None:
+        x, gy = _unify(x, gy)
+    else:
+        x, gy, target = _unify(x, gy, target)
+    if s is not None and s.numel() not in (1, n):
+        return None
+    gx = torch.empty_like(x)
+    rc = lib.cn_maxpool2_bwd_act(_ptr(x), _ptr(_c(gy)), _ptr(target), _fptr(s), k, _ptr(gx), n, h, w, c, 1 if s is None else s.numel(), _dt(x),
+                                 _stream())
+    if rc == CN_EUNSUPPORTED:
+        return None
+    check(rc, "cn_maxpool2_bwd_act")
+    if BRANCH_LOG is not None:                     # (test instrument: the pool's arg-max decisions and the ReLU mask, as the two passes log them)
+        BRANCH_LOG.append(("pool", x.detach().float().cpu(), (2, 2, 0)))
+    _log_mask(x, ACT_RELU)
+    return gx
+
+
 def tap_bwd(y, target, g, s, k, act, slope=0.0):
     """(g + (y - target) s[row] k) act'(y) in one pass (cn_tap_bwd); g may be None; s: one scale per row (s.numel() rows)."""
     if g is None:

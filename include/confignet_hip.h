@@ -370,6 +370,11 @@ int cn_row_scale_diff(const void* x, const void* x2, const float* s, void* out, 
  * out = (g + (y - target) s[r] k) act'(y) over n rows of `row` elements; g (the gradient from the next layer) may be NULL. */
 int cn_tap_bwd(const void* y, const void* target, const void* g, const float* s, void* out, int n, size_t row, float k,
                int act, float slope, int dt, void* stream);
+/* Backward of ReLU -> MaxPooling2D(2, 2) in one pass (round 6; perceptual_loss.py:19-41, VGG conv1_2 / conv2_2 / conv3_4):
+ * gx = (gy routed to each window's first maximum [+ (x - target) s[sample] k]) relu'(x), x = the ReLU output that was pooled;
+ * s_rows = 1 (one scale) or n.  CN_EUNSUPPORTED (nothing launched) unless h, w even, c % 4 == 0, tensors 16-byte aligned. */
+int cn_maxpool2_bwd_act(const void* x, const void* gy, const void* target, const float* s, float k, void* gx, int n, int h,
+                        int w, int c, int s_rows, int dt, void* stream);
 /* out = (a - b) * mask[n,h,w] broadcast over c (b optional) (losses.py:14) */
 int cn_masked_diff(const float* a, const float* b, const uint8_t* mask, float* out, size_t pixels, int c, void* stream);
 /* 2-D max pooling, zero padding (keras MaxPooling2D after ZeroPadding2D); bwd: the gradient of a window goes to its

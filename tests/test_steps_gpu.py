@@ -778,8 +778,10 @@ def test_cross_iteration_overlap_of_the_discriminator_steps():
         for step in (0, 1):                                          # discriminator, synthetic discriminator
             for k, v in h0[it][step].items():
                 # (two runs of the SAME configuration are 1e-5 apart here at iteration 1 and percents apart by iteration 3)
+                # (round 6: iteration 2 at 1e-1 -- one run in ~15 of the unchanged comparison left the 2e-2 band there, as two runs of
+                # ONE configuration do; iteration 1 stays at 2e-2)
                 if it <= 2 and (k.startswith("GAN_loss_real_") or k.startswith("gp_loss_")):
-                    assert abs(v - h1[it][step][k]) <= 2e-2 * max(1.0, abs(v)), (it, step, k, v, h1[it][step][k])
+                    assert abs(v - h1[it][step][k]) <= (2e-2 if it == 1 else 1e-1) * max(1.0, abs(v)), (it, step, k, v, h1[it][step][k])
         assert all(np.isfinite(v) for d in h1[it] for v in d.values())
     # a step called on its own while its real half is in flight completes that iteration's step ...
     before = m.discriminator.get_weights()[2].copy()
