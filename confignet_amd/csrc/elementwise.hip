@@ -416,6 +416,120 @@ __global__ __launch_bounds__(256) void nc_lin2_rows_kernel(const T* __restrict__
     }
 }
 
+// ---- norm_apply: nc_lin2_rows_kernel<4> with the coefficient algebra of cn_norm_coef_fwd / _bwd INLINE (round 6) ----
+// Every thread of the apply pass owns one 4-channel group of one sample and used to LOAD its (n, c) coefficients, which a
+// one-thread-per-(n, c) launch had just computed from the statistics; it now computes them itself (a dozen flops) and the
+// coefficient launch is gone: AdaIn / instance norm apply and backward are reduce + this, two launches instead of three.
+// dir 0 (forward):  y = k1 f1(x1) + kb,  (k1, kb) from (s1, s2, p1, p2) as norm_coef_fwd_kernel modes 0 / 1; the threads of
+//   workgroup column 0 also store mean / r for the backward pass.
+// dir 1 (backward): gx = (k1 gy + k2 f2(x) + kb) [lrelu'(x)] [+ a3 x + b3],  (k1, k2, kb) from (t1, t2, mean, r, p1) as
+//   norm_coef_bwd_kernel; workgroup column 0 stores d[s|b] (mode 0); workgroup (0, 0) reduces d gamma / d beta over the samples
+//   in sample order (mode 1) -- the same arithmetic and order as the separate kernels.
+struct NormApplyArgs {
+    int mode, dir, N, C;
+    float invS, eps;
+    const float* s1; const float* s2;      // dir 0: sum x, sum x^2 (of f1(x1));  dir 1: t1 = sum gy, t2 = sum gy f2(x)
+    const float* p1; const float* p2;      // mode 0: [s | b] (N, 2C);  mode 1: gamma, beta (C)
+    float* sm; float* sr;                  // dir 0: written;  dir 1: read
+    float* gp1; float* gp2;                // dir 1: mode 0 d[s | b] (N, 2C);  mode 1: d gamma, d beta (C)
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void norm_apply_rows_kernel(NormApplyArgs A, const T* __restrict__ x1, const T* __restrict__ x2,
+                                                              const float* __restrict__ a3, const float* __restrict__ b3,
+                                                              T* __restrict__ y, int G, int CG, int flags, float slope, int period2) {
+    constexpr int V = 4;
+    const int t0 = blockIdx.x * 256 + threadIdx.x;
+    const int adv = gridDim.x * 256;
+    const int cg = t0 % CG;
+    const int n = blockIdx.y, C = A.C;
+    const long ci = (long)n * C + (long)cg * V;
+    float k1[V], k2[V], kb[V], k3[V], kb3[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+        const int c = cg * V + e;
+        const long i = ci + e;
+        k2[e] = 0.f;
+        if (A.dir == 0) {
+            const float mu = A.s1[i] * A.invS;
+            const float var = fmaxf(A.s2[i] * A.invS - mu * mu, 0.f);
+            float rr, a;
+            if (A.mode == 0) {
+                rr = rsqrtf(var + A.eps);
+                a = rr * (A.p1[(long)n * 2 * C + c] + 1.f);
+                kb[e] = A.p1[(long)n * 2 * C + C + c] - mu * a;
+            } else {
+                rr = 1.f / (sqrtf(var) + A.eps);
+                a = A.p1[c] * rr;
+                kb[e] = A.p2[c] - mu * a;
+            }
+            k1[e] = a;
+            if (t0 < CG) { A.sm[i] = mu; A.sr[i] = rr; }
+        } else {
+            const float mu = A.sm[i], t1 = A.s1[i], t2 = A.s2[i];
+            if (A.mode == 0) {
+                const float r = A.sr[i], sp1 = A.p1[(long)n * 2 * C + c] + 1.f;
+                const float gs = r * (t2 - mu * t1);
+                const float q1 = r * sp1;
+                const float q2 = -r * r * sp1 * gs * A.invS;
+                k1[e] = q1; k2[e] = q2;
+                kb[e] = -q1 * t1 * A.invS - q2 * mu;
+                if (t0 < CG) { A.gp1[(long)n * 2 * C + c] = gs; A.gp1[(long)n * 2 * C + C + c] = t1; }
+            } else {
+                const float q = A.sr[i], gam = A.p1[c];
+                const float sigma = fmaxf(1.f / q - A.eps, 1e-20f);
+                const float Gm = gam * (t2 - mu * t1);
+                const float q1 = q * gam;
+                const float q2 = -q * q * Gm * A.invS / sigma;
+                k1[e] = q1; k2[e] = q2;
+                kb[e] = -q1 * t1 * A.invS - q2 * mu;
+            }
+        }
+        k3[e] = a3 ? a3[i] : 0.f;
+        kb3[e] = (a3 && b3) ? b3[i] : 0.f;
+    }
+    if (A.dir == 1 && A.mode == 1 && blockIdx.x == 0 && blockIdx.y == 0 && A.gp1) {
+        // d gamma / d beta: one thread per channel, samples in order (norm_coef_bwd_kernel's parameter workgroups)
+        for (int c = threadIdx.x; c < C; c += 256) {
+            float gg = 0.f, gb = 0.f;
+            for (int m = 0; m < A.N; ++m) {
+                const long i = (long)m * C + c;
+                gg += A.sr[i] * (A.s2[i] - A.sm[i] * A.s1[i]);
+                gb += A.s1[i];
+            }
+            A.gp1[c] = gg;
+            A.gp2[c] = gb;
+        }
+    }
+    const long base = (long)blockIdx.y * G;
+    const long base2 = (long)(period2 ? blockIdx.y % period2 : blockIdx.y) * G;
+    const bool f1 = flags & 1, f2 = flags & 2, fm = flags & 4;
+    for (int j = t0; j < G; j += adv) {
+        const long i = (base + j) * V;
+        const long i2 = (base2 + j) * V;
+        float v1[V], v2[V], r[V];
+        {
+            const float4 t = ld4<T>(x1 + i);
+            v1[0] = t.x; v1[1] = t.y; v1[2] = t.z; v1[3] = t.w;
+        }
+        if (x2) {
+            const float4 t = ld4<T>(x2 + i2);
+            v2[0] = t.x; v2[1] = t.y; v2[2] = t.z; v2[3] = t.w;
+        }
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            r[e] = kb[e];
+            r[e] += k1[e] * (f1 ? lrelu(v1[e], slope) : v1[e]);
+            if (x2) {
+                r[e] += k2[e] * (f2 ? lrelu(v2[e], slope) : v2[e]);
+                if (fm) r[e] *= v2[e] > 0.f ? 1.f : slope;
+                if (a3) r[e] += k3[e] * v2[e] + kb3[e];
+            }
+        }
+        st4<T>(y + i, make_float4(r[0], r[1], r[2], r[3]));
+    }
+}
+
 // ---- streaming maps: one float4 per lane per trip when the pointers are 16-byte aligned (they are for every tensor
 // the host side allocates), scalar tail / fallback otherwise.  VEC is decided by the launcher. ----
 
@@ -1130,6 +1244,42 @@ extern "C" int cn_nc_lin2(const void* x1, const float* a1, const void* x2, const
         if (V == 4) hipLaunchKernelGGL((nc_lin2_kernel<4, T>), dim3(ew_blocks(total)), dim3(256), 0, st, (const T*)x1, a1, (const T*)x2, a2, bb, a3, b3, (T*)y, total, s, c, cstride, flags, slope, period2);
         else hipLaunchKernelGGL((nc_lin2_kernel<1, T>), dim3(ew_blocks(total)), dim3(256), 0, st, (const T*)x1, a1, (const T*)x2, a2, bb, a3, b3, (T*)y, total, s, c, cstride, flags, slope, period2);
     });
+    CN_LAUNCH_CHECK();
+    return CN_OK;
+}
+
+// AdaIn (mode 0) / instance norm (mode 1) apply (dir 0) or backward map (dir 1) with the coefficient algebra inline: see
+// norm_apply_rows_kernel.  dir 0: y = k1 f1(x1) + kb from (sa = sum, sb = sum of squares, p1, p2), writes save_mean / save_r.
+// dir 1: y = gx from x1 = gy, x2 = x, (sa, sb) = (sum gy, sum gy f2(x)), reads save_mean / save_r, writes gp1 (/ gp2); a3 / b3: an
+// additional a3 x + b3 (the style statistics' gradient).  flags as cn_nc_lin2 (bits 0, 1, 2; bits 8..: the period of x2).
+// CN_EUNSUPPORTED (nothing launched) unless c % 4 == 0 and the tensor is big enough for the per-sample grid.
+extern "C" int cn_norm_apply(int mode, int dir, const void* x1, const void* x2, const float* sa, const float* sb, const float* p1,
+                             const float* p2, float* save_mean, float* save_r, float* gp1, float* gp2, const float* a3,
+                             const float* b3, void* y, int n, int s, int c, float eps, int flags, float slope, int dt, void* stream) {
+    CN_CHECK_ARG((mode == 0 || mode == 1) && (dir == 0 || dir == 1) && x1 && sa && sb && p1 && save_mean && save_r && y && n > 0 && s > 0 && c > 0 &&
+                 (dt == CN_F32 || dt == CN_BF16), "norm_apply: bad args");
+    CN_CHECK_ARG(mode == 0 || dir == 1 || p2, "norm_apply: instance norm needs beta");
+    CN_CHECK_ARG(dir == 0 || (x2 && gp1 && (mode == 0 || gp2)), "norm_apply: backward needs x and the parameter gradients' tensors");
+    if (c % 4 != 0) return CN_EUNSUPPORTED;
+    const int period2 = flags >> 8;
+    CN_CHECK_ARG(period2 == 0 || (x2 && n % period2 == 0), "norm_apply: bad x2 period %d for n = %d", period2, n);
+    flags &= 255;
+    const int CG = c / 4;
+    const long G = (long)s * CG;
+    int gcd = CG, r256 = 256;
+    while (r256) { const int t = gcd % r256; gcd = r256; r256 = t; }
+    const int q = CG / gcd;
+    if (!(G >= 16384 && G < 2147483647L - 256 * 8192L && q <= 32)) return CN_EUNSUPPORTED;
+    long gx = (G + 256 * 4 - 1) / (256 * 4);
+    if (gx * n > 8192) gx = 8192 / n;
+    if (gx < 1) gx = 1;
+    gx = (gx + q - 1) / q * q;
+    if (gx * 256 < CG) return CN_EUNSUPPORTED;          // (workgroup column 0 must cover every channel group: it writes the side outputs)
+    NormApplyArgs A;
+    A.mode = mode; A.dir = dir; A.N = n; A.C = c; A.invS = 1.f / (float)s; A.eps = eps;
+    A.s1 = sa; A.s2 = sb; A.p1 = p1; A.p2 = p2; A.sm = save_mean; A.sr = save_r; A.gp1 = gp1; A.gp2 = gp2;
+    CN_DISPATCH_DT(dt, hipLaunchKernelGGL((norm_apply_rows_kernel<T>), dim3((unsigned)gx, n), dim3(256), 0, (hipStream_t)stream, A, (const T*)x1,
+                                          (const T*)x2, a3, b3, (T*)y, (int)G, CG, flags, slope, period2));
     CN_LAUNCH_CHECK();
     return CN_OK;
 }

@@ -493,6 +493,11 @@ class AdaInFn(Function):
         sp = _spatial(x)
         st = ops.take_stats(x, "act")                # left by the producing convolution's epilogue (ops.request_stats), else one pass
         s1, s2 = st if st is not None else ops.nc_reduce(x)
+        fused = ops.norm_apply_fwd(ops.NORM_ADAIN, x, s1, s2, sb, None, 1e-3)        # coefficients inline in the apply pass
+        if fused is not None:
+            y, mean, r = fused
+            ctx.save_for_backward(x, sb, mean, r)
+            return y
         a, b, mean, r = ops.norm_coef_fwd(ops.NORM_ADAIN, s1, s2, sb, None, sp, 1e-3)
         ctx.save_for_backward(x, sb, mean, r)
         return ops.nc_lin2(tuple(x.shape), x, a, b=b)
@@ -504,6 +509,9 @@ class AdaInFn(Function):
         x, sb, mean, r = ctx.saved_tensors
         gy = _cg(gy)
         t1, t2 = ops.nc_reduce(gy, x)
+        fused = ops.norm_apply_bwd(ops.NORM_ADAIN, gy, x, t1, t2, mean, r, sb, 1e-3)
+        if fused is not None:
+            return fused[0], fused[1]
         c1, c2, c0, gsb, _ = ops.norm_coef_bwd(ops.NORM_ADAIN, t1, t2, mean, r, sb, _spatial(x), 1e-3)
         return ops.nc_lin2(tuple(x.shape), gy, c1, x, c2, c0), gsb
 
@@ -552,8 +560,12 @@ class DiscrTailFn(Function):
                 s1, s2 = ops.nc_reduce(x)
                 style, _, smean, ssd = ops.norm_coef_fwd(ops.NORM_STYLE, s1, s2, None, None, sp, 1e-6)
             a1, a2 = ops.nc_reduce(x, flags=1, slope=slope)
-        a, b, mean, q = ops.norm_coef_fwd(ops.NORM_INSTANCE, a1, a2, gamma, beta, sp, 1e-3)
-        y = ops.nc_lin2(tuple(x.shape), x, a, b=b, flags=1, slope=slope)
+        fused = ops.norm_apply_fwd(ops.NORM_INSTANCE, x, a1, a2, gamma, beta, 1e-3, flags=1, slope=slope)
+        if fused is not None:
+            y, mean, q = fused
+        else:
+            a, b, mean, q = ops.norm_coef_fwd(ops.NORM_INSTANCE, a1, a2, gamma, beta, sp, 1e-3)
+            y = ops.nc_lin2(tuple(x.shape), x, a, b=b, flags=1, slope=slope)
         ctx.save_for_backward(x, gamma, mean, q, smean, ssd)
         ctx.slope, ctx.want_style = slope, want_style
         nd = [t for t in (mean, q, smean, ssd) if t is not None]
@@ -573,6 +585,9 @@ class DiscrTailFn(Function):
         if have_y:
             gy = _cg(gy)
             t1, t2 = ops.nc_reduce(gy, x, flags=2, slope=ctx.slope)
+            fused = ops.norm_apply_bwd(ops.NORM_INSTANCE, gy, x, t1, t2, mean, q, gamma, 1e-3, flags=2 | 4, slope=ctx.slope, a3=d2, b3=d0)
+            if fused is not None:
+                return fused[0], fused[1], fused[2], None, None
             c1, c2, c0, ggamma, gbeta = ops.norm_coef_bwd(ops.NORM_INSTANCE, t1, t2, mean, q, gamma, sp, 1e-3)
             gx = ops.nc_lin2(tuple(x.shape), gy, c1, x, c2, c0, flags=2 | 4, slope=ctx.slope, a3=d2, b3=d0)
             return gx, ggamma, gbeta, None, None

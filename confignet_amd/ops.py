@@ -1047,6 +1047,49 @@ def norm_coef_bwd(mode, t1, t2, mean, r, p1, spatial, eps):
     return c1, c2, c0, gp1, gp2
 
 
+NORM_APPLY = True        # AdaIn / instance norm: the coefficient algebra inline in the apply / backward pass (cn_norm_apply) where it fits
+
+
+def norm_apply_fwd(mode, x, s1, s2, p1, p2, eps, flags=0, slope=0.0):
+    """(y, mean, r) = the apply pass of AdaIn / instance norm with its coefficients computed inline (cn_norm_apply, dir 0), or None
+    where the launch does not fit (the caller then runs norm_coef_fwd + nc_lin2)."""
+    if not NORM_APPLY or x.shape[-1] % 4:
+        return None
+    n, s, c = _nsc(x)
+    y = torch.empty_like(x)
+    mean = torch.empty((n, c), device=x.device, dtype=torch.float32)
+    r = torch.empty_like(mean)
+    rc = lib.cn_norm_apply(mode, 0, _ptr(x), None, _fptr(s1), _fptr(s2), _fptr(_c(p1)), _fptr(None if p2 is None else _c(p2)), _ptr(mean), _ptr(r),
+                           None, None, None, None, _ptr(y), n, s, c, eps, flags, slope, _dt(x), _stream())
+    if rc == CN_EUNSUPPORTED:
+        return None
+    check(rc, "cn_norm_apply")
+    return y, mean, r
+
+
+def norm_apply_bwd(mode, gy, x, t1, t2, mean, r, p1, eps, flags=0, slope=0.0, a3=None, b3=None):
+    """(gx, gp1, gp2) = the input gradient of AdaIn / instance norm with the coefficients inline (cn_norm_apply, dir 1) and the
+    parameter gradients (mode 0: gp1 = d[s|b] (n, 2c); mode 1: d gamma, d beta), or None where the launch does not fit."""
+    if not NORM_APPLY or x.shape[-1] % 4:
+        return None
+    gy, x = _unify(gy, x)
+    n, s, c = _nsc(x)
+    if flags & 4:
+        _log_mask(x)
+    gx = torch.empty_like(x)
+    if mode == NORM_ADAIN:
+        gp1, gp2 = torch.empty((n, 2 * c), device=x.device, dtype=torch.float32), None
+    else:
+        gp1 = torch.empty((c,), device=x.device, dtype=torch.float32)
+        gp2 = torch.empty_like(gp1)
+    rc = lib.cn_norm_apply(mode, 1, _ptr(gy), _ptr(x), _fptr(t1), _fptr(t2), _fptr(_c(p1)), None, _ptr(mean), _ptr(r), _ptr(gp1), _ptr(gp2),
+                           _fptr(a3), _fptr(b3), _ptr(gx), n, s, c, eps, flags, slope, _dt(x), _stream())
+    if rc == CN_EUNSUPPORTED:
+        return None
+    check(rc, "cn_norm_apply")
+    return gx, gp1, gp2
+
+
 def dual_tail_coef_fwd(T, U, mean, q, sm, ssd, gamma, spatial, eps=1e-3):
     """T = (T1, T2) or None (no ty wanted); U = (U1, U2) or None (no tstyle wanted).  One head at a time: the rows of T / U
     are the samples of the primal statistics.  Batched (both given): U holds the N samples of the head that leaves through the

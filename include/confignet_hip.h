@@ -310,6 +310,16 @@ int cn_norm_coef_fwd(int mode, const float* s1, const float* s2, const float* p1
 int cn_norm_coef_bwd(int mode, const float* t1, const float* t2, const float* save_mean, const float* save_r,
                      const float* p1, float* c1, float* c2, float* c0, float* gp1, float* gp2, int n, int c,
                      int S, float eps, void* stream);
+/* AdaIn (mode 0) / instance norm (mode 1) apply pass (dir 0) or backward map (dir 1) with the coefficient algebra of
+ * cn_norm_coef_fwd / cn_norm_coef_bwd INLINE (round 6): reduce + this instead of reduce + coefficients + cn_nc_lin2
+ * (building_blocks.py:37-44, 97-106, 132-149; instance_normalization.py:108-131).  dir 0: y = k1 f1(x1) + kb from sa = sum,
+ * sb = sum of squares, p1 / p2 as cn_norm_coef_fwd; writes save_mean / save_r.  dir 1: y = the input gradient from x1 = gy,
+ * x2 = x, sa = sum gy, sb = sum gy f2(x); reads save_mean / save_r, writes gp1 = d[s|b] (mode 0) or gp1 / gp2 = d gamma / d beta
+ * (mode 1); a3 / b3 (n, c): an additional a3 x + b3.  flags as cn_nc_lin2.  CN_EUNSUPPORTED (nothing launched) unless
+ * c % 4 == 0 and the tensor is large enough for the per-sample grid -- then the three-launch form. */
+int cn_norm_apply(int mode, int dir, const void* x1, const void* x2, const float* sa, const float* sb, const float* p1,
+                  const float* p2, float* save_mean, float* save_r, float* gp1, float* gp2, const float* a3, const float* b3,
+                  void* y, int n, int s, int c, float eps, int flags, float slope, int dt, void* stream);
 
 /* Tangent ("dual") DiscrBlock tail for the R1 penalty (losses.py:75-82) without a second-order tape: the
  * penalty's weight gradient is 2 d/dtheta JVP_x(out)(v) at v = d out/d x held constant, i.e. a first-order

@@ -17,6 +17,8 @@ timeout 300 $PY $R/bench.py --dtype bf16 --no-cpu-baseline > $O/${TAG}_bench_bf1
 # 1b. 400-step soaks of the same two commands (a 20-step mean is 0.8 s of work)
 timeout 600 $PY $R/bench.py --steps 400 --no-cpu-baseline > $O/${TAG}_bench_400_steps.json 2>> $O/bench.err
 timeout 600 $PY $R/bench.py --steps 400 --dtype bf16 --no-cpu-baseline > $O/${TAG}_bench_bf16_400_steps.json 2>> $O/bench.err
+timeout 600 $PY $R/bench.py --steps 2000 --timing-only > $O/${TAG}_bench_2000_steps.json 2>> $O/bench.err
+timeout 600 $PY $R/bench.py --steps 2000 --timing-only --dtype bf16 > $O/${TAG}_bench_bf16_2000_steps.json 2>> $O/bench.err
 # 2. kernel traces: the default (concurrent graphs) command and the serial one whose averages the roofline object quotes
 rm -rf /tmp/kt1 /tmp/kt2
 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/kt1 -- $PY $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $O/${TAG}_bench_under_rocprof.json 2>/dev/null
