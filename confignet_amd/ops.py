@@ -1047,13 +1047,17 @@ def norm_coef_bwd(mode, t1, t2, mean, r, p1, spatial, eps):
     return c1, c2, c0, gp1, gp2
 
 
-NORM_APPLY = True        # AdaIn / instance norm: the coefficient algebra inline in the apply / backward pass (cn_norm_apply) where it fits
+# AdaIn / instance norm: the coefficient algebra inline in the apply / backward pass (cn_norm_apply) where it fits.  -110 launches per
+# iteration; on the iteration's time it is neutral for fp32 storage (425.8 against 426.1 images/s, alternating runs) and was -0.3 %
+# for bf16 storage (762.4 against 764.8: every workgroup of the short bf16 pass starts with the dependent loads of the statistics),
+# so bf16 tensors keep the separate coefficient launch.
+NORM_APPLY = True
 
 
 def norm_apply_fwd(mode, x, s1, s2, p1, p2, eps, flags=0, slope=0.0):
     """(y, mean, r) = the apply pass of AdaIn / instance norm with its coefficients computed inline (cn_norm_apply, dir 0), or None
     where the launch does not fit (the caller then runs norm_coef_fwd + nc_lin2)."""
-    if not NORM_APPLY or x.shape[-1] % 4:
+    if not NORM_APPLY or x.shape[-1] % 4 or x.dtype != torch.float32:
         return None
     n, s, c = _nsc(x)
     y = torch.empty_like(x)
@@ -1070,7 +1074,7 @@ def norm_apply_fwd(mode, x, s1, s2, p1, p2, eps, flags=0, slope=0.0):
 def norm_apply_bwd(mode, gy, x, t1, t2, mean, r, p1, eps, flags=0, slope=0.0, a3=None, b3=None):
     """(gx, gp1, gp2) = the input gradient of AdaIn / instance norm with the coefficients inline (cn_norm_apply, dir 1) and the
     parameter gradients (mode 0: gp1 = d[s|b] (n, 2c); mode 1: d gamma, d beta), or None where the launch does not fit."""
-    if not NORM_APPLY or x.shape[-1] % 4:
+    if not NORM_APPLY or x.shape[-1] % 4 or x.dtype != torch.float32 or gy.dtype != torch.float32:
         return None
     gy, x = _unify(gy, x)
     n, s, c = _nsc(x)
