@@ -102,7 +102,7 @@ SIGNATURES = {
     "cn_dual_tail_coef_fwd": [_p] * 13 + [_i, _i, _i, _f, _i, _i, _p],
     "cn_dual_tail_coef_bwd": [_p] * 13 + [ctypes.POINTER(ctypes.c_void_p), _i, _i, _i, _f, _i, _i, _p],
     "cn_dual_tail_gx": [_p] * 12 + [_i, _i, _i, _f, _i, _i, _p],
-    "cn_dual_tail_gx_tx": [_p] * 18 + [_i, _i, _i, _f, _i, _i, _p],
+    "cn_dual_tail_gx_tx": [_p] * 18 + [_i, _i, _i, _f, _i, _i, _i, _p],
     "cn_norm_apply": [_i, _i] + [_p] * 13 + [_i, _i, _i, _f, _i, _f, _i, _p],
     "cn_nc_reduce_hxt": [_p, _p, _p, _p, _i, _i, _i, _f, _i, _i, _i, _p],
     "cn_zero": [_p, ctypes.c_size_t, _p],

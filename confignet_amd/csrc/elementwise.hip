@@ -235,7 +235,8 @@ __global__ __launch_bounds__(256) void nc_reduce4_kernel(const T* __restrict__ x
 template <typename T>
 __global__ __launch_bounds__(256) void nc_reduce_hxt_kernel(const T* __restrict__ h, const T* __restrict__ x, const T* __restrict__ ta,
                                                             float* __restrict__ out, int S, int C, int rows_per_block, float slope,
-                                                            int period, float* __restrict__ parts) {
+                                                            int period, float* __restrict__ parts, int ta_is_tx) {
+    // ta_is_tx: the third operand is the tangent INPUT tx; ta = lrelu'(x) tx is formed here (it is never stored)
     const int CG = C / 4;
     const int tx = threadIdx.x, ty = threadIdx.y, TX = blockDim.x, TY = blockDim.y;
     const int cg = blockIdx.x * TX + tx;
@@ -262,7 +263,12 @@ __global__ __launch_bounds__(256) void nc_reduce_hxt_kernel(const T* __restrict_
             for (int u = 0; u < 4; ++u) {
                 const float4 l = lrelu4(vx[u], slope);
                 const float a[4] = {vh[u].x, vh[u].y, vh[u].z, vh[u].w}, b[4] = {l.x, l.y, l.z, l.w},
-                            t[4] = {vt[u].x, vt[u].y, vt[u].z, vt[u].w};
+                            xr[4] = {vx[u].x, vx[u].y, vx[u].z, vx[u].w};
+                float t[4] = {vt[u].x, vt[u].y, vt[u].z, vt[u].w};
+                if (ta_is_tx) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) t[e] *= xr[e] > 0.f ? 1.f : slope;
+                }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     acc[0][e] += a[e];
@@ -272,9 +278,14 @@ __global__ __launch_bounds__(256) void nc_reduce_hxt_kernel(const T* __restrict_
             }
         }
         for (; s < send; s += TY) {
-            const float4 vh = ld4<T>(h + base + (long)s * C), l = lrelu4(ld4<T>(x + base2 + (long)s * C), slope),
+            const float4 vh = ld4<T>(h + base + (long)s * C), vxr = ld4<T>(x + base2 + (long)s * C), l = lrelu4(vxr, slope),
                          vt = ld4<T>(ta + base + (long)s * C);
-            const float a[4] = {vh.x, vh.y, vh.z, vh.w}, b[4] = {l.x, l.y, l.z, l.w}, t[4] = {vt.x, vt.y, vt.z, vt.w};
+            const float a[4] = {vh.x, vh.y, vh.z, vh.w}, b[4] = {l.x, l.y, l.z, l.w}, xr[4] = {vxr.x, vxr.y, vxr.z, vxr.w};
+            float t[4] = {vt.x, vt.y, vt.z, vt.w};
+            if (ta_is_tx) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) t[e] *= xr[e] > 0.f ? 1.f : slope;
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 acc[0][e] += a[e];
@@ -323,18 +334,22 @@ __global__ __launch_bounds__(256) void nc_lin2_kernel(const T* __restrict__ x1, 
 #pragma unroll
         for (int e = 0; e < V; ++e) r[e] = bb ? bb[ci + e] : 0.f;
         float raw2[V];
+        if (x2) {
+#pragma unroll
+            for (int e = 0; e < V; ++e) raw2[e] = ldf<T>(x2 + i2 * V + e);
+        }
         if (x1) {
 #pragma unroll
             for (int e = 0; e < V; ++e) {
                 float v = ldf<T>(x1 + i * V + e);
                 if (flags & 1) v = lrelu(v, slope);
+                if ((flags & 16) && x2) v *= raw2[e] > 0.f ? 1.f : slope;      // x1 lrelu'(x2): a tangent through the activation, not stored
                 r[e] += (a1 ? a1[ci + e] : 1.f) * v;
             }
         }
         if (x2) {
 #pragma unroll
             for (int e = 0; e < V; ++e) {
-                raw2[e] = ldf<T>(x2 + i2 * V + e);
                 float v = raw2[e];
                 if (flags & 2) v = lrelu(v, slope);
                 r[e] += (a2 ? a2[ci + e] : 1.f) * v;
@@ -382,7 +397,7 @@ __global__ __launch_bounds__(256) void nc_lin2_rows_kernel(const T* __restrict__
     }
     const long base = (long)blockIdx.y * G;
     const long base2 = (long)(period2 ? blockIdx.y % period2 : blockIdx.y) * G;      // x2 tiled over samples
-    const bool f1 = flags & 1, f2 = flags & 2, fm = flags & 4, fr = flags & 8;
+    const bool f1 = flags & 1, f2 = flags & 2, fm = flags & 4, fr = flags & 8, fd = flags & 16;
     for (int j = t0; j < G; j += adv) {
         const long i = (base + j) * V;
         const long i2 = (base2 + j) * V;
@@ -403,7 +418,11 @@ __global__ __launch_bounds__(256) void nc_lin2_rows_kernel(const T* __restrict__
 #pragma unroll
         for (int e = 0; e < V; ++e) {
             r[e] = kb[e];
-            if (x1) r[e] += k1[e] * (f1 ? lrelu(v1[e], slope) : v1[e]);
+            if (x1) {
+                float u = f1 ? lrelu(v1[e], slope) : v1[e];
+                if (fd && x2) u *= v2[e] > 0.f ? 1.f : slope;                   // x1 lrelu'(x2)
+                r[e] += k1[e] * u;
+            }
             if (x2) {
                 r[e] += k2[e] * (f2 ? lrelu(v2[e], slope) : v2[e]);
                 if (fm) r[e] *= v2[e] > 0.f ? 1.f : slope;
@@ -1086,7 +1105,7 @@ static int nc_reduce_launch(const void* x1, const void* x2, float* s1, float* s2
 // out (4, n, c) = sum x, sum x^2, sum lrelu(x), sum lrelu(x)^2 over s: the style statistics and the instance-norm statistics of a
 // DiscrBlock's pre-activation tensor in one pass (c % 4 == 0).  flags bit4: `out` is already zero.
 // (sum h, sum h lrelu(x), sum h ta) per (n, c) in one pass: out (3, n, c); x holds `period` samples (n % period == 0); flags & 16:
-// out is already zero.  The backward reductions of the DiscrBlock tail's tangent (losses.py:75-82 through building_blocks.py:100-106).
+// out is already zero; flags & 32: `ta` is the tangent input tx and ta = lrelu'(x) tx is formed in the pass.  The backward reductions of the DiscrBlock tail's tangent (losses.py:75-82 through building_blocks.py:100-106).
 extern "C" int cn_nc_reduce_hxt(const void* h, const void* x, const void* ta, float* out, int n, int s, int c, float slope, int period,
                                 int flags, int dt, void* stream) {
     CN_CHECK_ARG(h && x && ta && out && n > 0 && s > 0 && c > 0 && c % 4 == 0 && period > 0 && n % period == 0 && (dt == CN_F32 || dt == CN_BF16),
@@ -1116,7 +1135,7 @@ extern "C" int cn_nc_reduce_hxt(const void* h, const void* x, const void* ta, fl
     }
     dim3 grid(cblk, sblk, n), block(TX, TY);
     CN_DISPATCH_DT(dt, hipLaunchKernelGGL((nc_reduce_hxt_kernel<T>), grid, block, 0, st, (const T*)h, (const T*)x, (const T*)ta, out, s, c, (int)rpb,
-                                          slope, period, parts));
+                                          slope, period, parts, (flags & 32) ? 1 : 0));
     CN_LAUNCH_CHECK();
     if (parts) {
         for (int q = 0; q < 3; ++q)
@@ -1204,8 +1223,8 @@ extern "C" int cn_bn_act_bwd(const void* gy, const void* y, const void* x, const
 
 extern "C" int cn_nc_reduce_dact(const void* x1, const void* x2, float* s1, float* s2, void* dact_out, int n, int s, int c,
                                  int flags, float slope, int act, int dt, void* stream) {
-    CN_CHECK_ARG(x1 && x2 && s1 && dact_out, "nc_reduce_dact: NULL");
-    return nc_reduce_launch(x1, x2, s1, s2, n, s, c, flags, slope, dt, stream, dact_out, act);
+    CN_CHECK_ARG(x1 && x2 && s1, "nc_reduce_dact: NULL");          // (dact_out may be NULL: the sums only)
+    return nc_reduce_launch(x1, x2, s1, s2, n, s, c, flags, slope, dt, stream, dact_out, act, nullptr, nullptr, nullptr, 1);
 }
 
 extern "C" int cn_nc_lin2(const void* x1, const float* a1, const void* x2, const float* a2, const float* bb,

@@ -230,7 +230,8 @@ __global__ void dual_gx_kernel(const T* __restrict__ h, const T* __restrict__ ta
                                long total4, int S, int C, float slope, int nrep, const float* __restrict__ K1 = nullptr,
                                const float* __restrict__ K2 = nullptr, const float* __restrict__ K0 = nullptr,
                                const float* __restrict__ D2 = nullptr, const float* __restrict__ D0 = nullptr,
-                               T* __restrict__ out_tx = nullptr) {
+                               T* __restrict__ out_tx = nullptr, int ta_is_tx = 0) {
+    // ta_is_tx: `ta` points at the tangent INPUT rows of the heads (tx behind its first N samples); ta = lrelu'(x) tx is formed here
     // out_tx (round 6, cn_dual_tail_gx_tx): the gradient w.r.t. the stacked tangent input from the SAME pass over h and x --
     // rows [0, N): D2 x + D0 (the head that left through the style statistics), rows [(1 + j) N, (2 + j) N): lrelu'(x) (K1 h_j + K2
     // lrelu(x) + K0) -- what two cn_nc_lin2 launches (one more read of h) computed before
@@ -249,7 +250,12 @@ __global__ void dual_gx_kernel(const T* __restrict__ h, const T* __restrict__ ta
             for (int j = 0; j < nrep; ++j) {
                 const float4 hv = ld4<T>(h + 4 * (i + j * total4));
                 const float4 tv = ld4<T>(ta + 4 * (i + j * total4));
-                const float hs[4] = {hv.x, hv.y, hv.z, hv.w}, ts[4] = {tv.x, tv.y, tv.z, tv.w};
+                const float hs[4] = {hv.x, hv.y, hv.z, hv.w};
+                float ts[4] = {tv.x, tv.y, tv.z, tv.w};
+                if (ta_is_tx) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) ts[e] *= xs[e] > 0.f ? 1.f : slope;
+                }
                 const long cj = ci + j * NC;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -341,11 +347,12 @@ extern "C" int cn_dual_tail_gx(const void* h, const void* ta, const void* tx, co
 
 // cn_dual_tail_gx + the gradient w.r.t. the stacked tangent input in the same pass (round 6): out_tx holds (1 + nrep) N samples --
 // the style head's rows D2 x + D0 first, then per head lrelu'(x) (K1 h + K2 lrelu(x) + K0) -- instead of two cn_nc_lin2 launches
-// that read h and x again (losses.py:75-82, the R1 penalty's tangent pass through building_blocks.py:100-106).
+// that read h and x again (losses.py:75-82, the R1 penalty's tangent pass through building_blocks.py:100-106).  ta_is_tx: `ta` holds the
+// heads' tangent INPUT rows and ta = lrelu'(x) tx is formed in the pass (the forward pass then never stores ta).
 extern "C" int cn_dual_tail_gx_tx(const void* h, const void* ta, const void* tx, const void* x, const float* kh, const float* kt,
                                   const float* ka, const float* kc, const float* et, const float* ex, const float* e0,
                                   const float* K1, const float* K2, const float* K0, const float* D2, const float* D0, void* out,
-                                  void* out_tx, int n, int s, int c, float slope, int nrep, int dt, void* stream) {
+                                  void* out_tx, int n, int s, int c, float slope, int nrep, int ta_is_tx, int dt, void* stream) {
     CN_CHECK_ARG(h && ta && tx && x && out && out_tx && kh && kt && ka && kc && et && ex && e0 && K1 && K2 && K0 && D2 && D0,
                  "dual_tail_gx_tx: NULL tensor");
     CN_CHECK_ARG(n > 0 && s > 0 && c > 0 && c % 4 == 0 && nrep >= 1 && (dt == CN_F32 || dt == CN_BF16), "dual_tail_gx_tx: bad args");
@@ -354,7 +361,7 @@ extern "C" int cn_dual_tail_gx_tx(const void* h, const void* ta, const void* tx,
     if (blocks > 8192) blocks = 8192;
     CN_DISPATCH_DT(dt, hipLaunchKernelGGL((dual_gx_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const T*)h,
                                           (const T*)ta, (const T*)tx, (const T*)x, kh, kt, ka, kc, et, ex, e0, (T*)out, total4, s, c, slope, nrep,
-                                          K1, K2, K0, D2, D0, (T*)out_tx));
+                                          K1, K2, K0, D2, D0, (T*)out_tx, ta_is_tx));
     CN_LAUNCH_CHECK();
     return CN_OK;
 }

@@ -669,10 +669,16 @@ class DualTailBatchedFn(Function):
         assert tx.shape[0] % n == 0 and tx.shape[0] >= 2 * n and tx.shape[1:] == x.shape[1:]
         sp = _spatial(x)
         tx_s, tx_r = tx[:n], tx[n:]
-        ta, T1, T2 = ops.nc_reduce_dact(tx_r, x, ACT_LRELU, slope, x2_period=n, flags=2)     # ta = lrelu'(x) tx; sum ta, sum ta*lrelu(x)
+        lazy = FUSED_R1_TAIL and x.shape[-1] % 4 == 0 and tx.dtype == x.dtype
+        # ta = lrelu'(x) tx; sum ta, sum ta*lrelu(x).  lazy: ta is NOT stored -- every later reader forms it from tx and x (one write and
+        # 5 N samples of activation memory per block less)
+        ta, T1, T2 = ops.nc_reduce_dact(tx_r, x, ACT_LRELU, slope, x2_period=n, flags=2, want_a=not lazy)
         U = ops.nc_reduce(tx_s, x)                                                            # sum tx, sum tx*x
         C1, C2, C0, tstyle = ops.dual_tail_coef_fwd((T1, T2), U, mean, q, smean, ssd, gamma, sp)
-        ty = ops.nc_lin2(tuple(tx_r.shape), ta, C1, x, C2, C0, flags=2, slope=slope, x2_period=n)
+        if lazy:
+            ty = ops.nc_lin2(tuple(tx_r.shape), tx_r, C1, x, C2, C0, flags=2 | 16, slope=slope, x2_period=n)
+        else:
+            ty = ops.nc_lin2(tuple(tx_r.shape), ta, C1, x, C2, C0, flags=2, slope=slope, x2_period=n)
         ctx.save_for_backward(tx, x, gamma, mean, q, smean, ssd, ta, T1, T2, U[0], U[1])
         ctx.slope = slope
         return ty, tstyle
@@ -688,15 +694,17 @@ class DualTailBatchedFn(Function):
         if h is None and u is None:
             return torch.zeros_like(tx), torch.zeros_like(x), torch.zeros_like(gamma), None, None, None, None, None
         if h is None:
-            h = torch.zeros_like(ta)
+            h = torch.zeros_like(tx[n:])
         if u is None:
             u = torch.zeros((n, 2 * x.shape[-1]), device=x.device, dtype=torch.float32)
         h = _cg(h)
-        if FUSED_R1_TAIL and x.shape[-1] % 4 == 0:
+        if ta is None or (FUSED_R1_TAIL and x.shape[-1] % 4 == 0):
             # two passes over the stacked cotangent instead of five: the three reductions in one, then both gradients in one
-            H1, H2, E = ops.nc_reduce_hxt(h, x, ta, slope)
+            lazy = ta is None                       # (the forward pass did not store ta: tx[n:] takes its place, times lrelu'(x) in the pass)
+            t_op = tx[n:] if lazy else ta
+            H1, H2, E = ops.nc_reduce_hxt(h, x, t_op, slope, ta_is_tx=lazy)
             co = ops.dual_tail_coef_bwd((H1, H2), E, _cg(u), (T1, T2), (U1, U2), mean, q, smean, ssd, gamma, sp)
-            g_x, g_tx = ops.dual_tail_gx_tx(h, ta, tx, x, co, slope)
+            g_x, g_tx = ops.dual_tail_gx_tx(h, t_op, tx, x, co, slope, ta_is_tx=lazy)
             return g_tx, g_x, co["ggamma"], None, None, None, None, None
         H = ops.nc_reduce(h, x, flags=2, slope=slope, x2_period=n)          # sum h, sum h*lrelu(x)
         E = ops.nc_reduce(h, ta, want_sum=False)[1]                          # sum h*ta

@@ -1161,7 +1161,7 @@ def dual_tail_gx(h, ta, tx, x, co, slope):
     return out
 
 
-def dual_tail_gx_tx(h, ta, tx, x, co, slope):
+def dual_tail_gx_tx(h, ta, tx, x, co, slope, ta_is_tx=False):
     """(g_x, g_tx): dual_tail_gx and, from the same pass, the gradient w.r.t. the stacked tangent input tx (its first N samples
     the style head's D2 x + D0, then per head lrelu'(x) (K1 h + K2 lrelu(x) + K0)): cn_dual_tail_gx_tx."""
     h, ta, tx, x = _unify(h, ta, tx, x)
@@ -1173,19 +1173,20 @@ def dual_tail_gx_tx(h, ta, tx, x, co, slope):
     out_tx = torch.empty_like(tx)
     check(lib.cn_dual_tail_gx_tx(_ptr(h), _ptr(ta), _ptr(tx), _ptr(x), _ptr(co["kh"]), _ptr(co["kt"]), _ptr(co["ka"]), _ptr(co["kc"]),
                                  _ptr(co["et"]), _ptr(co["ex"]), _ptr(co["e0"]), _ptr(co["K1"]), _ptr(co["K2"]), _ptr(co["K0"]),
-                                 _ptr(co["D2"]), _ptr(co["D0"]), _ptr(out), _ptr(out_tx), n, s, c, slope, nrep, _dt(x), _stream()),
+                                 _ptr(co["D2"]), _ptr(co["D0"]), _ptr(out), _ptr(out_tx), n, s, c, slope, nrep, int(ta_is_tx), _dt(x), _stream()),
           "cn_dual_tail_gx_tx")
     return out, out_tx
 
 
-def nc_reduce_hxt(h, x, ta, slope):
-    """(sum h, sum h lrelu(x), sum h ta) per (n, c) of h in ONE pass (cn_nc_reduce_hxt); x holds h.shape[0] / k samples."""
+def nc_reduce_hxt(h, x, ta, slope, ta_is_tx=False):
+    """(sum h, sum h lrelu(x), sum h ta) per (n, c) of h in ONE pass (cn_nc_reduce_hxt); x holds h.shape[0] / k samples.
+    ta_is_tx: `ta` is the tangent input tx, ta = lrelu'(x) tx is formed in the pass."""
     h, x, ta = _unify(h, x, ta)
     n, s, c = _nsc(h)
     out = zero_pool_alloc((3, n, c), h.device)
-    flags = 16
+    flags = 16 | (32 if ta_is_tx else 0)
     if out is None:
-        out, flags = torch.empty((3, n, c), device=h.device, dtype=torch.float32), 0
+        out, flags = torch.empty((3, n, c), device=h.device, dtype=torch.float32), flags & 32
     check(lib.cn_nc_reduce_hxt(_ptr(h), _ptr(x), _ptr(ta), _ptr(out), n, s, c, slope, x.shape[0], flags, _dt(h), _stream()), "cn_nc_reduce_hxt")
     return out[0], out[1], out[2]
 
@@ -1213,12 +1214,13 @@ def bn_act_bwd(gy, y, x, a, act, want_g):
     return gx, g, s12[0], s12[1]
 
 
-def nc_reduce_dact(x1, x2, act, slope, x2_period=0, flags=0, want_dot=True):
-    """(a, sum_s a, sum_s a * f2(x2)) with a = x1 * act'(x2): cn_nc_reduce_dact (one pass instead of act_bwd + nc_reduce)."""
+def nc_reduce_dact(x1, x2, act, slope, x2_period=0, flags=0, want_dot=True, want_a=True):
+    """(a, sum_s a, sum_s a * f2(x2)) with a = x1 * act'(x2): cn_nc_reduce_dact (one pass instead of act_bwd + nc_reduce).
+    want_a = False: the sums only (a is not stored: None)."""
     x1, x2 = _unify(x1, x2)
     _log_mask(x2, act)
     n, s, c = _nsc(x1)
-    a = torch.empty_like(x1)
+    a = torch.empty_like(x1) if want_a else None
     flags |= x2_period << 8
     s12 = zero_pool_alloc((2, n, c), x1.device)
     if s12 is not None:

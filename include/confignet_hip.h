@@ -347,12 +347,14 @@ int cn_dual_tail_gx(const void* h, const void* ta, const void* tx, const void* x
                     const float* kt, const float* ka, const float* kc, const float* et, const float* ex,
                     const float* e0, void* out, int n, int s, int c, float slope, int nrep, int dt, void* stream);
 /* cn_dual_tail_gx + the gradient w.r.t. the stacked tangent input in the same pass (round 6): out_tx holds (1 + nrep) n samples,
- * the style head's rows D2 x + D0 first, then per head lrelu'(x) (K1 h + K2 lrelu(x) + K0). */
+ * the style head's rows D2 x + D0 first, then per head lrelu'(x) (K1 h + K2 lrelu(x) + K0).  ta_is_tx: `ta` holds the heads'
+ * tangent INPUT rows; ta = lrelu'(x) tx is formed in the pass. */
 int cn_dual_tail_gx_tx(const void* h, const void* ta, const void* tx, const void* x, const float* kh, const float* kt,
                        const float* ka, const float* kc, const float* et, const float* ex, const float* e0,
                        const float* K1, const float* K2, const float* K0, const float* D2, const float* D0, void* out,
-                       void* out_tx, int n, int s, int c, float slope, int nrep, int dt, void* stream);
-/* (sum h, sum h lrelu(x), sum h ta) per (n, c) in one pass over the three tensors: out (3, n, c); x holds `period` samples.
+                       void* out_tx, int n, int s, int c, float slope, int nrep, int ta_is_tx, int dt, void* stream);
+/* (sum h, sum h lrelu(x), sum h ta) per (n, c) in one pass over the three tensors: out (3, n, c); x holds `period` samples;
+ * flags & 16: out is zero already; flags & 32: `ta` is the tangent input tx (ta = lrelu'(x) tx formed in the pass).
  * The backward reductions of the DiscrBlock tail's tangent (losses.py:75-82 through building_blocks.py:100-106). */
 int cn_nc_reduce_hxt(const void* h, const void* x, const void* ta, float* out, int n, int s, int c, float slope, int period,
                      int flags, int dt, void* stream);

@@ -36,9 +36,9 @@ def conv_dgrad(gy, wt, g):
     return orig["conv_dgrad"](gy, wt, g)
 
 
-def conv_wgrad(x, gy, g, ws, out=None):
+def conv_wgrad(x, gy, g, ws, out=None, **kw):
     rec("wgrad", g)
-    return orig["conv_wgrad"](x, gy, g, ws, out=out)
+    return orig["conv_wgrad"](x, gy, g, ws, out=out, **kw)
 
 
 ops.conv_fwd, ops.conv_dgrad, ops.conv_wgrad = conv_fwd, conv_dgrad, conv_wgrad

@@ -27,11 +27,11 @@ DUMP = next((a.split("=", 1)[1] for a in sys.argv if a.startswith("dump=")), Non
 SWEEPOUT = next((open(a.split("=", 1)[1], "w") for a in sys.argv if a.startswith("sweepout=")), None)     # every sweep point: M K N tile target us
 
 
-def conv_wgrad(x, gy, g, ws, out=None):
+def conv_wgrad(x, gy, g, ws, out=None, **kw):
     if x.dtype == torch.float32 and gy.dtype == torch.float32:
         k = tuple(getattr(g, f) for f in FIELDS)
         calls[k] = calls.get(k, 0) + 1
-    return orig(x, gy, g, ws, out=out)
+    return orig(x, gy, g, ws, out=out, **kw)
 
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 16
