@@ -900,7 +900,7 @@ def test_data_parallel_dispatch_with_overlap_matches_single_process(tmp_path):
     helper = os.path.join(ROOT, "tests", "dp_run_helper.py")
     dp_env = {"CN_FORCE_DP": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29547", "RANK": "0", "WORLD_SIZE": "1"}
     outs = []
-    for tag, extra, flag in (("single", {}, 0), ("dp", dp_env, 0), ("dp_stats", dp_env, 1)):
+    for tag, extra, flag in (("single", {}, 0), ("dp", dp_env, 0), ("dp_stats", dict(dp_env, MASTER_PORT="29549"), 1)):     # (a port of its own per group)
         env = {k: v for k, v in os.environ.items() if k not in ("CN_FORCE_DP",)}
         env.update(extra)
         path = str(tmp_path / (tag + ".npz"))
