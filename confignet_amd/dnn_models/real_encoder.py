@@ -381,6 +381,15 @@ class ResNetTrunkFn(torch.autograd.Function):
                 ops.sum_rows_into(part, gsh[offs[also]:offs[also + 1]])
             return gu
 
+        try:
+            return ResNetTrunkFn._walk(ctx, gy, enc, wf, offs, saved, views, gwf, gsh, want_w, sunk, params, geom, wgrad, relu_bwd,
+                                       seg9, blocks, a, rs, bm)
+        finally:
+            ops.DEFER_SLAB_SUMS = defer_prev
+
+    @staticmethod
+    def _walk(ctx, gy, enc, wf, offs, saved, views, gwf, gsh, want_w, sunk, params, geom, wgrad, relu_bwd, seg9, blocks, a, rs, bm):
+        from .. import ops
         # walk the blocks backwards; `pos` indexes the saved activations
         g = gy.contiguous()
         layout = []                                  # (first conv index of the block, has conv shortcut) in forward order
@@ -412,7 +421,6 @@ class ResNetTrunkFn(torch.autograd.Function):
         gu0 = relu_bwd(0, g, y0)
         wgrad(0, x, gu0)
         gx = ops.conv_dgrad(gu0, wf[0], geom(0, x)) if ctx.needs_input_grad[1] else None
-        ops.DEFER_SLAB_SUMS = defer_prev
         if not want_w:
             return (None, gx) + (None,) * len(params)
         if sunk:

@@ -54,11 +54,10 @@ class VGGLossFn(torch.autograd.Function):
     def forward(ctx, net, x, sizes, *targets):
         from .. import ops
         x = x.contiguous()
-        ys, pools, feats, ci, t = [], [], [], 0, x
+        ys, feats, ci, t = [], [], 0, x
         for item in net.cfg:
             if item == "P":
-                pools.append(t)
-                t = ops.maxpool_fwd(t, 2, 2, 0)
+                t = ops.maxpool_fwd(t, 2, 2, 0)           # (its input is the previous convolution's output: ys[ci - 1])
             else:
                 w, b = net.weights[2 * ci], net.weights[2 * ci + 1]
                 t = ops.conv_fwd(t, w, b, C3.geom(tuple(t.shape), w.shape[-1]), ACT_RELU)
@@ -78,8 +77,8 @@ class VGGLossFn(torch.autograd.Function):
             terms.append(torch.cat(row) if len(row) > 1 else row[0])
         total = torch.stack(terms).sum(0)
         ctx.net, ctx.sizes, ctx.x_shape = net, sizes, tuple(x.shape)
-        ctx.save_for_backward(x, *ys, *pools, *targets)
-        ctx.counts = (len(ys), len(pools))
+        ctx.save_for_backward(x, *ys, *targets)
+        ctx.counts = (len(ys),)
         return total.reshape(()) if sizes is None else total
 
     @staticmethod
@@ -89,15 +88,14 @@ class VGGLossFn(torch.autograd.Function):
             raise RuntimeError("VGGLossFn is first-order only")
         net, sizes = ctx.net, ctx.sizes
         saved = ctx.saved_tensors
-        ny, npool = ctx.counts
-        x, ys, pools, targets = saved[0], saved[1:1 + ny], saved[1 + ny:1 + ny + npool], saved[1 + ny + npool:]
+        (ny,) = ctx.counts
+        x, ys, targets = saved[0], saved[1:1 + ny], saved[1 + ny:]
         n = x.shape[0]
         g = g.reshape(-1).float()
         tap_of = {ci: k for k, ci in enumerate(net.taps)}
-        gcur, ci, pi, pooled = None, ny, npool, None
+        gcur, ci, pooled = None, ny, None
         for item in reversed(net.cfg):
             if item == "P":
-                pi -= 1
                 pooled, gcur = gcur, None             # the pool's backward joins the ReLU backward of the layer in front of it
                 continue
             ci -= 1
