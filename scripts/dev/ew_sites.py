@@ -12,7 +12,8 @@ for _ in range(2):
 torch.cuda.synchronize()
 agg = collections.defaultdict(lambda: [0, 0])
 NAMES = ["nc_reduce", "nc_reduce4", "nc_lin2", "act_bwd", "act_bwd_partials", "act_fwd", "nc_reduce_dact", "dual_tail_gx", "dual_tail_gx_tx", "nc_reduce_hxt",
-         "bn_act_bwd", "maxpool_fwd", "maxpool_bwd", "sqdiff_sum", "row_scale_diff", "tap_bwd", "row_scale", "axpby", "mul", "cast", "sumpool2", "masked_diff", "zero_"]
+         "norm_apply_fwd", "norm_apply_bwd", "maxpool2_bwd_relu", "bn_act_bwd", "maxpool_fwd", "maxpool_bwd", "sqdiff_sum", "row_scale_diff", "tap_bwd", "row_scale",
+         "axpby", "mul", "sumpool2", "masked_diff", "zero_"]
 def wrap(name):
     fn = getattr(ops, name)
     def w(*a, **k):
@@ -34,5 +35,5 @@ model.training_iteration(real_set, synth_set, d_opt, g_opt)
 torch.cuda.synchronize()
 tot = sum(v[1] for v in agg.values())
 print("total %.2f GB in %d calls" % (tot / 1e9, sum(v[0] for v in agg.values())))
-for (name, site), (c, nb) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:45]:
+for (name, site), (c, nb) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:int(sys.argv[1]) if len(sys.argv) > 1 else 45]:
     print("%7.1f MB %4d  %-18s %s" % (nb / 1e6, c, name, site))
