@@ -1132,3 +1132,198 @@ def test_dense_weight_gradients_of_a_backward_pass_as_one_grouped_launch_give_th
     for i, (p, r) in enumerate(zip(params, ref)):
         if i:
             assert torch.equal(p.grad, r), (i, dims[i], float((p.grad - r).abs().max()))
+
+
+# ---------------------------------------------------------------------------------------------
+# round 6 (second half): the entry points behind the restructured tape, each against a float64 statement of what it computes
+# ---------------------------------------------------------------------------------------------
+def _lrelu64(x, slope):
+    return torch.where(x > 0, x, slope * x)
+
+
+@pytest.mark.parametrize("with_g,rows", [(True, 1), (False, 1), (True, 3)])
+def test_tap_backward_in_one_pass(with_g, rows):
+    """cn_tap_bwd: (g + (y - target) s[row] k) relu'(y) -- the feature-loss term's gradient, the gradient from the next layer and
+    the layer's own ReLU derivative (perceptual_loss.py:74-82) -- with one scale for the whole tensor and with one per sample."""
+    from confignet_amd import ops
+    rng = np.random.default_rng(41)
+    shape = (3, 10, 12, 8)
+    y = np.maximum(rng.normal(size=shape), 0.0)
+    tgt, g = rng.normal(size=shape), rng.normal(size=shape)
+    s = rng.uniform(0.5, 2.0, size=rows)
+    k = 0.37
+    out = ops.tap_bwd(dev(y), dev(tgt), dev(g) if with_g else None, dev(s), k, ops.ACT_RELU)
+    sb = t64(s).reshape(rows, 1, 1, 1) if rows > 1 else t64(s)
+    ref = ((t64(g) if with_g else 0.0) + (t64(y) - t64(tgt)) * sb * k) * (t64(y) > 0)
+    close(out, ref, tol=1e-6, what="tap_bwd")
+
+
+@pytest.mark.parametrize("tap", [False, True])
+def test_relu_maxpool_backward_in_one_pass(tap):
+    """cn_maxpool2_bwd_act: the gradient of ReLU -> MaxPooling2D(2, 2) w.r.t. the ReLU's input side (the routed gradient times
+    relu'(x)), with the tap's own term added before the mask, against autograd on the float64 composite."""
+    from confignet_amd import ops
+    rng = np.random.default_rng(42)
+    n, h, w, c = 2, 12, 16, 8
+    x = np.maximum(rng.normal(size=(n, h, w, c)), 0.0)             # a ReLU output (zeros included)
+    gy = rng.normal(size=(n, h // 2, w // 2, c))
+    tgt = rng.normal(size=(n, h, w, c))
+    s, k = rng.uniform(0.5, 2.0, size=n), 0.21
+    out = ops.maxpool2_bwd_relu(dev(x), dev(gy), dev(tgt) if tap else None, dev(s) if tap else None, k if tap else 0.0)
+    assert out is not None
+    xr = t64(x).requires_grad_(True)
+    pooled = torch.nn.functional.max_pool2d(xr.permute(0, 3, 1, 2), 2, 2).permute(0, 2, 3, 1)
+    (routed,) = torch.autograd.grad((pooled * t64(gy)).sum(), xr)
+    ref = routed + ((t64(x) - t64(tgt)) * t64(s).reshape(n, 1, 1, 1) * k if tap else 0.0)
+    ref = ref * (t64(x) > 0)
+    # (ties inside a window can only occur between zeros of the ReLU output, and those positions are masked out)
+    close(out, ref, tol=1e-6, what="maxpool2_bwd_relu")
+    assert ops.maxpool2_bwd_relu(dev(x[:, :11]), dev(gy[:, :5]), None, None, 0.0) is None       # odd extent: the caller's two passes
+
+
+@pytest.mark.parametrize("lazy", [False, True])
+def test_r1_tail_backward_reductions_and_gradients_in_two_passes(lazy):
+    """cn_nc_reduce_hxt (sum h, sum h lrelu(x), sum h ta per (n, c) over a stack of heads against one copy of x) and
+    cn_dual_tail_gx_tx (the gradient w.r.t. the primal activation AND w.r.t. the stacked tangent input from one pass) against
+    float64 statements of the same sums / maps; lazy: ta = lrelu'(x) tx formed inside the passes from the tangent input."""
+    from confignet_amd import ops
+    rng = np.random.default_rng(43)
+    n, heads, hh, ww, c, slope = 2, 3, 6, 10, 8, 0.3
+    x = rng.normal(size=(n, hh, ww, c))
+    tx = rng.normal(size=((heads + 1) * n, hh, ww, c))
+    h = rng.normal(size=(heads * n, hh, ww, c))
+    x64, tx64, h64 = t64(x), t64(tx), t64(h)
+    xr = x64.repeat(heads, 1, 1, 1)
+    mask = torch.where(xr > 0, 1.0, slope)
+    ta64 = mask * tx64[n:]
+    ta = (dev(tx)[n:] if lazy else dev(ta64.numpy()))
+    H1, H2, E = ops.nc_reduce_hxt(dev(h), dev(x), ta, slope, ta_is_tx=lazy)
+    close(H1, h64.sum((1, 2)), tol=1e-5, what="sum h")
+    close(H2, (h64 * _lrelu64(xr, slope)).sum((1, 2)), tol=1e-5, what="sum h lrelu(x)")
+    close(E, (h64 * ta64).sum((1, 2)), tol=1e-5, what="sum h ta")
+    names = ("kh", "kt", "ka", "kc", "K1", "K2", "K0")
+    co = {k: rng.normal(size=(heads * n, c)) for k in names}
+    co.update({k: rng.normal(size=(n, c)) for k in ("et", "ex", "e0", "D2", "D0")})
+    cod = {k: dev(v) for k, v in co.items()}
+    gx, gtx = ops.dual_tail_gx_tx(dev(h), ta, dev(tx), dev(x), cod, slope, ta_is_tx=lazy)
+    b = lambda k, rows: t64(co[k]).reshape(rows, 1, 1, c)
+    a64 = _lrelu64(xr, slope)
+    per_head = mask * (b("kh", heads * n) * h64 + b("kt", heads * n) * ta64 + b("ka", heads * n) * a64 + b("kc", heads * n))
+    ref_gx = per_head.reshape(heads, n, hh, ww, c).sum(0) + b("et", n) * tx64[:n] + b("ex", n) * x64 + b("e0", n)
+    ref_gtx = torch.cat([b("D2", n) * x64 + b("D0", n), mask * (b("K1", heads * n) * h64 + b("K2", heads * n) * a64 + b("K0", heads * n))])
+    close(gx, ref_gx, tol=1e-5, what="g_x")
+    close(gtx, ref_gtx, tol=1e-5, what="g_tx")
+
+
+@pytest.mark.parametrize("mode", ["adain", "instance"])
+def test_norm_apply_with_inline_coefficients(mode):
+    """cn_norm_apply (AdaIn / instance norm apply and backward map with the coefficient algebra inline) against float64 autograd
+    on the layer's definition (building_blocks.py:132-149: layer norm over space, eps inside the root, x (s + 1) + b;
+    instance_normalization.py:108-131 behind LeakyReLU: (l - mean) / (std + eps) gamma + beta)."""
+    from confignet_amd import ops
+    rng = np.random.default_rng(44)
+    n, hh, ww, c, slope, eps = 2, 64, 64, 16, 0.3, 1e-3
+    x = rng.normal(size=(n, hh, ww, c)) * 2 + 0.5
+    gy = rng.normal(size=(n, hh, ww, c))
+    S = hh * ww
+    xr = t64(x).requires_grad_(True)
+    if mode == "adain":
+        sb = rng.normal(size=(n, 2 * c)) * 0.5
+        sbr = t64(sb).requires_grad_(True)
+        mu = xr.mean((1, 2), keepdim=True)
+        var = ((xr - mu) ** 2).mean((1, 2), keepdim=True)
+        ref = (xr - mu) / torch.sqrt(var + eps) * (sbr[:, :c].reshape(n, 1, 1, c) + 1.0) + sbr[:, c:].reshape(n, 1, 1, c)
+        s1, s2 = ops.nc_reduce(dev(x))
+        fwd = ops.norm_apply_fwd(ops.NORM_ADAIN, dev(x), s1, s2, dev(sb), None, eps)
+        assert fwd is not None
+        y, mean, r = fwd
+        close(y, ref, tol=2e-5, what="adain apply")
+        gxr, gsbr = torch.autograd.grad((ref * t64(gy)).sum(), (xr, sbr))
+        t1, t2 = ops.nc_reduce(dev(gy), dev(x))
+        gx, gsb, _ = ops.norm_apply_bwd(ops.NORM_ADAIN, dev(gy), dev(x), t1, t2, mean, r, dev(sb), eps)
+        close(gx, gxr, tol=5e-5, what="adain d x")
+        close(gsb, gsbr, tol=2e-4, what="adain d [s|b]")
+    else:
+        gamma, beta = rng.normal(size=c) * 0.5 + 1.0, rng.normal(size=c) * 0.1
+        gr, br = t64(gamma).requires_grad_(True), t64(beta).requires_grad_(True)
+        l = _lrelu64(xr, slope)
+        mu = l.mean((1, 2), keepdim=True)
+        sd = torch.sqrt(((l - mu) ** 2).mean((1, 2), keepdim=True))
+        ref = (l - mu) / (sd + eps) * gr + br
+        a1, a2 = ops.nc_reduce(dev(x), flags=1, slope=slope)
+        fwd = ops.norm_apply_fwd(ops.NORM_INSTANCE, dev(x), a1, a2, dev(gamma), dev(beta), eps, flags=1, slope=slope)
+        assert fwd is not None
+        y, mean, q = fwd
+        close(y, ref, tol=2e-5, what="instance norm apply")
+        gxr, ggr, gbr = torch.autograd.grad((ref * t64(gy)).sum(), (xr, gr, br))
+        t1, t2 = ops.nc_reduce(dev(gy), dev(x), flags=2, slope=slope)
+        gx, gg, gb = ops.norm_apply_bwd(ops.NORM_INSTANCE, dev(gy), dev(x), t1, t2, mean, q, dev(gamma), eps, flags=2 | 4, slope=slope)
+        close(gx, gxr, tol=5e-5, what="instance norm d x")
+        close(gg, ggr, tol=2e-4 * S ** 0.5, what="d gamma")
+        close(gb, gbr, tol=2e-4 * S ** 0.5, what="d beta")
+
+
+def test_batchnorm_fold_adjoint():
+    """cn_bn_fold_bwd against float64 autograd through the folding  w' = w a, shift = beta + a (b - mean), a = gamma rsqrt(var + eps)
+    for three filters of different shapes laid out in one arena (offsets as RealEncoder._fold_table9 builds them)."""
+    from confignet_amd import ops
+    rng = np.random.default_rng(45)
+    shapes = [(3, 3, 8, 64), (1, 1, 64, 128), (1, 1, 32, 64)]
+    eps = 1.001e-5
+    arena, offs, rows, packed, aoff, blk = [], {}, [], 0, 0, 0
+    def put(name, a):
+        offs[name] = sum(len(v) for v in arena)
+        arena.append(np.asarray(a, np.float64).reshape(-1))
+    params = []
+    for i, shp in enumerate(shapes):
+        cout = shp[-1]
+        w, b, gam, bet = rng.normal(size=shp) * 0.1, rng.normal(size=cout) * 0.1, rng.uniform(0.5, 1.5, size=cout), rng.normal(size=cout) * 0.1
+        mean, var = rng.normal(size=cout) * 0.1, rng.uniform(0.5, 2.0, size=cout)
+        for nm, a in (("w%d" % i, w), ("b%d" % i, b), ("g%d" % i, gam), ("be%d" % i, bet)):
+            put(nm, a)
+        params.append((w, b, gam, bet, mean, var))
+        rows.append([offs["w%d" % i], packed, w.size, cout, aoff, offs["b%d" % i], offs["g%d" % i], offs["be%d" % i], blk])
+        packed, aoff, blk = packed + w.size, aoff + cout, blk + cout // 64
+    flat = np.concatenate(arena)
+    gwf = rng.normal(size=packed)
+    gsh = rng.normal(size=aoff)
+    a_cat = np.concatenate([p[2] / np.sqrt(p[5] + eps) for p in params])
+    rs_cat = np.concatenate([1.0 / np.sqrt(p[5] + eps) for p in params])
+    bm_cat = np.concatenate([p[1] - p[4] for p in params])
+    gout = torch.zeros(flat.size, device="cuda", dtype=torch.float32)
+    seg9 = torch.tensor(rows, dtype=torch.int32, device="cuda")
+    ops.bn_fold_bwd(seg9, blk, dev(gwf), dev(gsh), dev(flat), dev(a_cat), dev(rs_cat), dev(bm_cat), gout)
+    ref = torch.zeros(flat.size, dtype=torch.float64)
+    po = ao = 0
+    for i, (w, b, gam, bet, mean, var) in enumerate(params):
+        cout = w.shape[-1]
+        wr, br_, gr, ber = (t64(v).requires_grad_(True) for v in (w, b, gam, bet))
+        a = gr / torch.sqrt(t64(var) + eps)
+        obj = (wr * a * t64(gwf[po:po + w.size]).reshape(w.shape)).sum() + ((ber + a * (br_ - t64(mean))) * t64(gsh[ao:ao + cout])).sum()
+        gs = torch.autograd.grad(obj, (wr, br_, gr, ber))
+        for nm, g_ in zip(("w%d" % i, "b%d" % i, "g%d" % i, "be%d" % i), gs):
+            ref[offs[nm]:offs[nm] + g_.numel()] = g_.reshape(-1)
+        po, ao = po + w.size, ao + cout
+    close(gout, ref, tol=1e-5, what="bn_fold_bwd")
+
+
+def test_grouped_rows_gemm_against_float64():
+    """cn_gemm_rows_grouped: four jobs of different shapes in one launch -- plain, transposed B with bias and LeakyReLU, the
+    activation-derivative epilogue (mask), and two jobs accumulating into ONE output."""
+    from confignet_amd import ops
+    rng = np.random.default_rng(46)
+    A = [rng.normal(size=s) for s in ((8, 145), (8, 128), (5, 64), (8, 64), (8, 64))]
+    B = [rng.normal(size=(145, 128)), rng.normal(size=(300, 128)), rng.normal(size=(64, 96)), rng.normal(size=(64, 40)), rng.normal(size=(64, 40))]
+    bias1 = rng.normal(size=300)
+    mask = rng.normal(size=(5, 96))
+    outs = [torch.empty((8, 128), device="cuda"), torch.empty((8, 300), device="cuda"), torch.empty((5, 96), device="cuda"), torch.zeros((8, 40), device="cuda")]
+    jobs = [(dev(A[0]), dev(B[0]), outs[0], None, None, False, ops.ACT_NONE, 0.0, False),
+            (dev(A[1]), dev(B[1]), outs[1], dev(bias1), None, True, ops.ACT_LRELU, 0.2, False),
+            (dev(A[2]), dev(B[2]), outs[2], None, dev(mask), False, ops.ACT_LRELU, 0.2, False),
+            (dev(A[3]), dev(B[3]), outs[3], None, None, False, ops.ACT_NONE, 0.0, True),
+            (dev(A[4]), dev(B[4]), outs[3], None, None, False, ops.ACT_NONE, 0.0, True)]
+    ops.gemm_rows_grouped(jobs)
+    close(outs[0], t64(A[0]) @ t64(B[0]), tol=1e-5, what="plain")
+    close(outs[1], _lrelu64(t64(A[1]) @ t64(B[1]).T + t64(bias1), 0.2), tol=1e-5, what="B^T + bias + lrelu")
+    close(outs[2], (t64(A[2]) @ t64(B[2])) * torch.where(t64(mask) > 0, 1.0, 0.2), tol=1e-5, what="activation-derivative epilogue")
+    close(outs[3], t64(A[3]) @ t64(B[3]) + t64(A[4]) @ t64(B[4]), tol=1e-5, what="two jobs into one output")
