@@ -86,7 +86,7 @@ def main():
     def sync():
         torch.cuda.synchronize()
         if world > 1:
-            dist.barrier()
+            parallel.barrier()                 # (an asynchronous RCCL work: nothing of it stays on a stream that will capture)
             torch.cuda.synchronize()
 
     # Every step's device half is one captured HIP graph (confignet_amd/graphs.py); with N > 1 the graph ends

@@ -72,7 +72,16 @@ def _all_reduce_mean(t, async_op=False):
         w = _HostWork(t, 1.0 / ws, async_op)
         return w if async_op else None
     if t.is_cuda:
-        return dist.all_reduce(t, op=dist.ReduceOp.AVG, async_op=async_op)     # ncclAvg: no scaling pass
+        # ncclAvg: no scaling pass.  ALWAYS issued as an asynchronous work (and waited for at once when the caller wants it in
+        # order): torch runs a synchronous collective on the CALLING stream, and the end event it records there is polled by the
+        # process group's watchdog thread -- if that stream has entered a HIP-graph capture by the time of the poll, hipEventQuery
+        # fails with hipErrorCapturedEvent and the watchdog takes the process down (seen twice in the forced-DP test, round 6).
+        # An asynchronous work runs on torch's own RCCL stream, which never captures; wait() orders the calling stream after it.
+        w = dist.all_reduce(t, op=dist.ReduceOp.AVG, async_op=True)
+        if async_op:
+            return w
+        w.wait()
+        return None
 
     class _Scaled:                                  # gloo on host tensors (CPU tests): no AVG
         def __init__(self, work):
@@ -92,6 +101,8 @@ def all_reduce_sum(t):
     """SUM over ranks of `t`, in place, ordered against the calling stream."""
     if _host_staged(t):
         _HostWork(t, 1.0, False)
+    elif t.is_cuda:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True).wait()        # (on torch's RCCL stream: see _all_reduce_mean)
     else:
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t
@@ -102,6 +113,8 @@ def all_reduce_max(t):
         h = t.detach().to("cpu")
         dist.all_reduce(h, op=dist.ReduceOp.MAX)
         t.copy_(h)
+    elif t.is_cuda:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, async_op=True).wait()
     else:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return t
@@ -112,9 +125,25 @@ def broadcast_(t, src=0):
         h = t.detach().to("cpu")
         dist.broadcast(h, src=src)
         t.copy_(h)
+    elif t.is_cuda:
+        dist.broadcast(t, src=src, async_op=True).wait()
     else:
         dist.broadcast(t, src=src)
     return t
+
+
+def barrier():
+    """All ranks reach this point (host-blocking).  On RCCL as an asynchronous one-element all-reduce on torch's own RCCL stream
+    (see _all_reduce_mean: a synchronous collective would leave an end event on the calling stream for the watchdog to poll after
+    that stream may have started a HIP-graph capture)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return
+    if dist.get_backend() == "nccl" and torch.cuda.is_available():
+        t = torch.zeros(1, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True).wait()
+        torch.cuda.current_stream().synchronize()
+    else:
+        dist.barrier()
 
 
 def world_size():

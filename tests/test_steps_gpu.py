@@ -904,7 +904,15 @@ def test_data_parallel_dispatch_with_overlap_matches_single_process(tmp_path):
         env = {k: v for k, v in os.environ.items() if k not in ("CN_FORCE_DP",)}
         env.update(extra)
         path = str(tmp_path / (tag + ".npz"))
-        r = subprocess.run([sys.executable, helper, path, str(flag)], env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+        for attempt in (0, 1):
+            r = subprocess.run([sys.executable, helper, path, str(flag)], env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+            # torch's RCCL watchdog THREAD polls the end events of collectives with hipEventQuery; next to a HIP-graph capture in the
+            # same process that query has been seen to fail with hipErrorCapturedEvent and take the process down (rc -6, twice in ~8
+            # runs of the whole suite, never in 38 runs of this helper alone: DESIGN.md section 5) -- a runtime race outside the
+            # arithmetic this test compares; one retry with a fresh rendezvous port, anything else fails at once
+            if r.returncode == 0 or attempt == 1 or "last recorded in a capturing stream" not in r.stderr:
+                break
+            env["MASTER_PORT"] = str(int(env.get("MASTER_PORT", "29547")) + 20)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
         outs.append(np.load(path))
     a, b, c = outs
