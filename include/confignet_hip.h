@@ -278,7 +278,8 @@ int cn_nc_reduce(const void* x1, const void* x2, float* sum1, float* sum2, int n
                  int flags, float slope, int dt, void* stream);
 /* a = x1 * act'(f2(x2)) (the activation derivative taken from the sign / value of x2 as in cn_act_bwd), written to dact_out,
  * with sum1[n,c] = sum_s a and (if sum2 != NULL) sum2[n,c] = sum_s a*f2(x2) in the same pass: the tangent of LeakyReLU and its
- * two statistics (cn_dual_tail_*: ta, T1, T2) without a separate cn_act_bwd pass.  flags as cn_nc_reduce (bit1, bit4, period). */
+ * two statistics (cn_dual_tail_*: ta, T1, T2) without a separate cn_act_bwd pass.  flags as cn_nc_reduce (bit1, bit4, period).
+ * dact_out may be NULL (round 6): the two sums only, a is not stored. */
 int cn_nc_reduce_dact(const void* x1, const void* x2, float* sum1, float* sum2, void* dact_out, int n, int s, int c,
                       int flags, float slope, int act, int dt, void* stream);
 /* Backward of conv -> BatchNorm (inference mode: a[c] x + shift[c] (+ residual)) -> activation in one pass (keras ResNet50 blocks
@@ -288,7 +289,8 @@ int cn_bn_act_bwd(const void* gy, const void* y, const void* x, const float* a, 
                   float* sum_gx, int n, int s, int c, int act, int flags, int dt, void* stream);
 /* y = A1*f1(x1) + A2*f2(x2) + B, coefficient tensors indexed [n*cstride + c] (cstride = c, or 0 for
  * per-channel coefficients).  flags: bit0/bit1 as above, bit2: multiply the result by lrelu'(x2),
- * bit3: relu on the result, bits 8..: x2 sample period as in cn_nc_reduce.  x1, x2 and B are each optional (NULL); a NULL coefficient of a present
+ * bit3: relu on the result, bit4 (round 6): f1(x1) is multiplied by lrelu'(x2) before its coefficient -- a tangent through the
+ * activation that is never stored (the R1 tail's ta = lrelu'(x) tx) --, bits 8..: x2 sample period as in cn_nc_reduce.  x1, x2 and B are each optional (NULL); a NULL coefficient of a present
  * x means 1.  If a3 != NULL, a3*x2 + b3 (raw x2) is added after the bit2 mask -- the style-statistics
  * gradient that joins the instance-norm gradient in DiscrBlock (building_blocks.py:100-106). */
 int cn_nc_lin2(const void* x1, const float* a1, const void* x2, const float* a2, const float* bb,
