@@ -252,6 +252,8 @@ def main():
                                      "profiles/round6_pmc_*.json carry this kernels_hash",
                          "kernels_hash": kernels_hash()},
             "torch_kernel_time_share": torch_kernel_share(),
+            # kernel launches of one iteration, from the committed rocprofv3 trace of `bench.py --serial` (recorded, like the PMC fields)
+            "launches_per_iteration": _recorded("round6_torch_share.json", "launches_per_iteration"),
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"], ref_losses = cpu_baseline(args, parity_state["path"] if parity_state else None)
